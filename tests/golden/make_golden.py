@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ FROM THE REAL REFERENCE.
+
+Runs ONLY in the build container (needs /root/reference, which never travels to
+the GPU box).  Usage:  python -B tests/golden/make_golden.py
+
+What it does
+------------
+1. Installs ``sys.modules`` stubs for the third-party packages the reference imports
+   but this image lacks (torchaudio, librosa, dasp_pytorch) - the stub for
+   ``dasp_pytorch.functional`` exposes the oracle's restated ops, i.e. they are
+   patched in exactly at the reference's import seam (mst/modules.py:7-14).
+2. Imports the reference's own ``mst.modules`` / ``mst.mixing`` / ``mst.loss`` /
+   ``mst.filter`` from /root/reference (no bytecode written) and runs
+   ``AdvancedMixConsole.forward`` (+ autograd backward), ``naive_random_mix``,
+   ``AudioFeatureLoss`` and ``barkscale_fbanks`` on seeded inputs.
+3. Asserts the oracle's restatement of the mst-owned logic reproduces those
+   outputs, then writes inputs + expected outputs as small ``.npz`` fixtures.
+
+The fixtures are data (inputs and expected outputs); no reference source is stored.
+"""
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+from oracle import console_restated as oc
+from oracle import dasp_restated as od
+from oracle import loss_restated as ol
+
+REF = "/root/reference"
+
+
+def install_stubs():
+    ta = types.ModuleType("torchaudio")
+    ta.pipelines = types.ModuleType("torchaudio.pipelines")
+    ta.pipelines.HDEMUCS_HIGH_MUSDB_PLUS = None
+    ta.transforms = types.ModuleType("torchaudio.transforms")
+    ta.functional = types.ModuleType("torchaudio.functional")
+    sys.modules["torchaudio"] = ta
+    sys.modules["torchaudio.pipelines"] = ta.pipelines
+    sys.modules["torchaudio.transforms"] = ta.transforms
+    sys.modules["torchaudio.functional"] = ta.functional
+    sys.modules["librosa"] = types.ModuleType("librosa")
+    dp = types.ModuleType("dasp_pytorch")
+    dpf = types.ModuleType("dasp_pytorch.functional")
+    for name in ("gain", "stereo_panner", "compressor", "parametric_eq", "stereo_bus", "noise_shaped_reverberation"):
+        setattr(dpf, name, getattr(od, name))
+    dp.functional = dpf
+    sys.modules["dasp_pytorch"] = dp
+    sys.modules["dasp_pytorch.functional"] = dpf
+
+
+def flat(d):
+    return {f"{e}.{p}": v for e, pd in d.items() for p, v in pd.items()}
+
+
+def console_case(name, bs, T, n, seed, flags, ref_console):
+    torch.manual_seed(seed)
+    tracks = 0.1 * torch.randn(bs, T, n)
+    tp = torch.rand(bs, T, 27, requires_grad=True)
+    fp = torch.rand(bs, 25)
+    mp = torch.rand(bs, 26, requires_grad=True)
+    gmix = torch.randn(bs, 2, n)
+
+    mixed, mix, tpd, fpd, mpd = ref_console(tracks, tp, fp, mp, **flags)
+    (mix * gmix).sum().backward()
+    zg = lambda t: torch.zeros_like(t) if t.grad is None else t.grad.clone()
+    g_tp, g_mp = zg(tp), zg(mp)
+
+    # the oracle's own orchestration must reproduce the reference's
+    tp2 = tp.detach().clone().requires_grad_(True)
+    mp2 = mp.detach().clone().requires_grad_(True)
+    o_mixed, o_mix, o_tpd, _, o_mpd = oc.console_forward(tracks, tp2, fp, mp2, sample_rate=44100, **flags)
+    (o_mix * gmix).sum().backward()
+    assert torch.equal(o_mix, mix), f"{name}: oracle mix != reference orchestration"
+    assert torch.equal(o_mixed, mixed)
+    assert torch.equal(zg(tp2), g_tp) and torch.equal(zg(mp2), g_mp)
+    for k, v in flat(tpd).items():
+        assert torch.equal(v, flat(o_tpd)[k]), k
+    for k, v in flat(mpd).items():
+        assert torch.equal(v, flat(o_mpd)[k]), k
+
+    out = dict(
+        tracks=tracks.numpy(),
+        track_params=tp.detach().numpy(),
+        fx_bus_params=fp.numpy(),
+        master_bus_params=mp.detach().numpy(),
+        grad_mix=gmix.numpy(),
+        mix=mix.detach().numpy(),
+        mixed_tracks_sub=mixed.detach().numpy()[..., ::64],
+        grad_track_params=g_tp.numpy(),
+        grad_master_bus_params=g_mp.numpy(),
+        flags=np.array(sorted(flags.items()), dtype=object).astype(str),
+    )
+    for k, v in flat(tpd).items():
+        out["tp." + k] = v.detach().numpy()
+    for k, v in flat(mpd).items():
+        out["mp." + k] = v.detach().numpy()
+    np.savez_compressed(os.path.join(HERE, f"console_{name}.npz"), **out)
+    print(f"console_{name}: mix rms {mix.pow(2).mean().sqrt():.4e}  |g_tp| {g_tp.abs().max():.3e}")
+
+
+def main():
+    assert os.path.isdir(REF), "golden generation needs /root/reference (build container only)"
+    install_stubs()
+    sys.path.insert(0, REF)
+    import mst.filter as rfilter
+    import mst.loss as rloss
+    import mst.mixing as rmixing
+    import mst.modules as rmodules
+
+    ref_console = rmodules.AdvancedMixConsole(sample_rate=44100)
+    assert ref_console.param_ranges == oc.param_ranges(44100)
+
+    basic = dict(
+        use_track_input_fader=True, use_track_eq=False, use_track_compressor=False, use_track_panner=True,
+        use_fx_bus=False, use_master_bus=False, use_output_fader=False,
+    )
+    full = dict(
+        use_track_input_fader=True, use_track_eq=True, use_track_compressor=True, use_track_panner=True,
+        use_fx_bus=False, use_master_bus=True, use_output_fader=True,
+    )
+    refmix = dict(full, use_track_input_fader=False)  # system.py:162 (reference-mix flags)
+    # cfg #1 shape cut to fixture size (gain+pan only = "BasicMixConsole")
+    console_case("basic_2x4x16384", 2, 4, 16384, 1, basic, ref_console)
+    console_case("full_2x4x16384", 2, 4, 16384, 2, full, ref_console)
+    console_case("full_1x8x32768", 1, 8, 32768, 3, full, ref_console)
+    console_case("refmix_2x3x8192", 2, 3, 8192, 4, refmix, ref_console)
+
+    # naive_random_mix (mixing.py:35-94): RNG draw order and the 8-tuple
+    torch.manual_seed(11)
+    tracks = 0.1 * torch.randn(2, 4, 8192)
+    torch.manual_seed(12)
+    r = rmixing.naive_random_mix(tracks, ref_console, use_fx_bus=False)
+    assert len(r) == 8
+    np.savez_compressed(
+        os.path.join(HERE, "naive_random_mix.npz"),
+        tracks=tracks.numpy(), seed=12, mix=r[1].numpy(), mix_params=r[5].numpy(),
+        fx_bus_params=r[6].numpy(), master_bus_params=r[7].numpy(),
+    )
+
+    # out-of-range parameter => ValueError text (modules.py:86-89)
+    bad = torch.rand(1, 2, 27)
+    bad[0, 1, 25] = 1.5
+    try:
+        ref_console(torch.zeros(1, 2, 4096), bad, torch.rand(1, 25), torch.rand(1, 26), use_fx_bus=False)
+        raise SystemExit("expected ValueError")
+    except ValueError as e:
+        err_text = str(e)
+    print("ValueError text:", err_text)
+
+    # Bark filterbank (filter.py:107-161) - constant table
+    fb = rfilter.barkscale_fbanks(16385, 20.0, 20000.0, 24, 44100)
+    ofb = ol.bark_filterbank(16385, 20.0, 20000.0, 24, 44100)
+    assert torch.equal(fb, ofb), "bark filterbank restatement differs"
+    np.savez_compressed(
+        os.path.join(HERE, "bark_fb.npz"), col_sums=fb.sum(0).numpy(), row_sub=fb[::257].numpy(),
+        argmax=fb.argmax(0).numpy(), nnz=np.array((fb > 0).sum().item()), err_text=np.array(err_text),
+    )
+
+    # AudioFeatureLoss (loss.py:198-260), weights of unpaired+feat.yaml:55-60
+    weights = [0.1, 0.001, 1.0, 1.0, 0.1]
+    torch.manual_seed(21)
+    a = (0.2 * torch.randn(2, 2, 65536)).requires_grad_(True)
+    b = 0.3 * torch.randn(2, 2, 65536) * torch.tensor([1.0, 0.6]).view(1, 2, 1)
+    afl = rloss.AudioFeatureLoss(weights=weights, sample_rate=44100)
+    ld = afl(a, b)
+    sum(v.mean() for v in ld.values()).backward()  # system.py:334-336
+    old = ol.audio_feature_loss(a.detach(), b, weights)
+    assert list(ld.keys()) == list(ol.AF_KEYS)
+    for k in ld:
+        assert torch.allclose(ld[k].detach(), old[k], rtol=1e-6, atol=0), k
+    feats = {
+        "rms": rloss.compute_rms(a.detach()), "crest": rloss.compute_crest_factor(a.detach()),
+        "width": rloss.compute_stereo_width(a.detach()), "imbalance": rloss.compute_stereo_imbalance(a.detach()),
+        "bark": rloss.compute_barkspectrum(a.detach(), sample_rate=44100),
+    }
+    np.savez_compressed(
+        os.path.join(HERE, "af_loss.npz"), input=a.detach().numpy(), target=b.numpy(), weights=np.array(weights),
+        grad_input_sub=a.grad.numpy()[..., ::16], grad_input_l2=np.array(a.grad.pow(2).sum().sqrt().item()),
+        **{"loss." + k: v.detach().numpy() for k, v in ld.items()}, **{"feat." + k: v.numpy() for k, v in feats.items()},
+    )
+
+    # batch_stereo_peak_normalize (utils.py:14-29) cannot be imported (pyloudnorm); its 3 lines of
+    # arithmetic are evaluated literally here to pin the oracle.
+    x = torch.randn(3, 2, 1000)
+    g = x.abs().max(dim=-1, keepdim=True)[0].max(dim=-2, keepdim=True)[0]
+    assert torch.equal(x / g.clamp(1e-8), oc.batch_stereo_peak_normalize(x))
+    print("golden fixtures written to", HERE)
+
+
+if __name__ == "__main__":
+    main()
