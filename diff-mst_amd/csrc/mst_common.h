@@ -1,0 +1,218 @@
+// mst_common.h - shared constants, row-constant layout and small device helpers for the
+// MI355X (gfx950) Diff-MST mix-console kernels.  Wave = 64 lanes, workgroup = 256 lanes
+// unless a kernel says otherwise.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/diffmst_hip.h"
+
+namespace mst {
+
+constexpr int kSections = 6;           // low shelf, 4 peaking, high shelf (reference mst/modules.py:125-143)
+constexpr int kStates = 2 * kSections; // DF2T state of the whole cascade
+constexpr int kWG = 256;               // lanes per workgroup in the streaming kernels
+constexpr int kEqChunk = 64;           // samples one lane filters sequentially (EQ kernels)
+constexpr int kCompChunk = 8;          // samples one lane owns in the compressor kernels
+constexpr int kScanThreads = 1024;     // lanes per row in the carry-scan kernels
+constexpr int kScanLevels = 10;        // log2(kScanThreads)
+constexpr int kPow = 1 + kScanLevels;  // matrices per scan table: M, then M^(K*2^j)
+
+// ---- per-filter-row constants ("rc"), written by k_prep, floats -------------------------------
+constexpr int RC_SOS = 0;      // 6 x {b0 b1 b2 a1 a2}; section 0's b carries the input-fader gain
+constexpr int RC_THR = 30;     // compressor threshold dB
+constexpr int RC_KAPPA = 31;   // 1/ratio - 1
+constexpr int RC_KNEE = 32;    // knee width dB
+constexpr int RC_ALPHA = 33;   // one-pole smoother coefficient
+constexpr int RC_MAKEUP = 34;  // make-up gain dB
+constexpr int RC_ALPHA_C = 35; // alpha^kCompChunk
+constexpr int RC_PANL = 36;    // tracks: left pan gain   | master: output-fader linear gain
+constexpr int RC_PANR = 37;    // tracks: right pan gain  | master: output-fader linear gain
+constexpr int RC_GIN = 38;     // input-fader linear gain (already folded into section 0)
+constexpr int RC_STRIDE = 40;
+
+// partial-sum slots of the compressor backward kernel
+constexpr int CP_THR = 0, CP_KAPPA = 1, CP_KNEE = 2, CP_ALPHA = 3, CP_MAKEUP = 4, CP_PANL = 5, CP_PANR = 6;
+constexpr int CP_COUNT = 8;
+constexpr int EP_COUNT = 30;  // coefficient-gradient partial sums: 6 x {b0 b1 b2 a1 a2}
+
+constexpr float kDbPerLog2 = 6.02059991327962390f;   // 20*log10(2)
+constexpr float kLog2PerDb = 0.16609640474436813f;   // log2(10)/20
+constexpr float kLn10Over20 = 0.11512925464970229f;  // d/dg 10^(g/20) = that * 10^(g/20)
+constexpr float kCompEps = 1e-8f;                     // clamp of |side chain|
+
+__host__ __device__ inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
+
+// ---- one DF2T biquad step: y = b0 x + s1; s1' = b1 x - a1 y + s2; s2' = b2 x - a2 y ---------
+template <typename T>
+__device__ __forceinline__ T biquad_step(T x, const T* c, T& s1, T& s2) {
+    T y = c[0] * x + s1;
+    T n1 = c[1] * x + s2;
+    s1 = n1 - c[3] * y;
+    s2 = c[2] * x - c[4] * y;
+    return y;
+}
+template <>
+__device__ __forceinline__ float biquad_step<float>(float x, const float* c, float& s1, float& s2) {
+    float y = fmaf(c[0], x, s1);
+    float n1 = fmaf(c[1], x, s2);
+    s1 = fmaf(-c[3], y, n1);
+    s2 = fmaf(-c[4], y, c[2] * x);
+    return y;
+}
+
+// forward cascade, state st[2k], st[2k+1] for section k
+template <typename T>
+__device__ __forceinline__ T cascade_step(T x, const T* c, T* st) {
+#pragma unroll
+    for (int k = 0; k < kSections; ++k) x = biquad_step<T>(x, c + 5 * k, st[2 * k], st[2 * k + 1]);
+    return x;
+}
+
+// adjoint of one section, run in REVERSE time: p = g - a1 r1 - a2 r2; xbar = b0 p + b1 r1 + b2 r2
+template <typename T>
+__device__ __forceinline__ T biquad_adj_step(T g, const T* c, T& r1, T& r2) {
+    T p = g - c[3] * r1 - c[4] * r2;
+    T xb = c[0] * p + c[1] * r1 + c[2] * r2;
+    r2 = r1;
+    r1 = p;
+    return xb;
+}
+// adjoint cascade: sections 5..0; state slot j belongs to section 5-j (processing order)
+template <typename T>
+__device__ __forceinline__ T cascade_adj_step(T g, const T* c, T* st) {
+#pragma unroll
+    for (int j = 0; j < kSections; ++j) {
+        const int k = kSections - 1 - j;
+        g = biquad_adj_step<T>(g, c + 5 * k, st[2 * j], st[2 * j + 1]);
+    }
+    return g;
+}
+
+// ---- guarded 4-wide global access (rows are 16-byte aligned; only the tail is ragged) ----------
+__device__ __forceinline__ float4 load4(const float* __restrict__ row, int64_t i, int64_t n) {
+    if (i + 3 < n && !((uintptr_t)(row + i) & 15)) return *reinterpret_cast<const float4*>(row + i);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n) v.x = row[i];
+    if (i + 1 < n) v.y = row[i + 1];
+    if (i + 2 < n) v.z = row[i + 2];
+    if (i + 3 < n) v.w = row[i + 3];
+    return v;
+}
+__device__ __forceinline__ void store4(float* __restrict__ row, int64_t i, int64_t n, float4 v) {
+    if (i + 3 < n && !((uintptr_t)(row + i) & 15)) {
+        *reinterpret_cast<float4*>(row + i) = v;
+        return;
+    }
+    if (i < n) row[i] = v.x;
+    if (i + 1 < n) row[i + 1] = v.y;
+    if (i + 2 < n) row[i + 2] = v.z;
+    if (i + 3 < n) row[i + 3] = v.w;
+}
+// same, with a signed offset that may run off either end (look-ahead delay lines)
+__device__ __forceinline__ float4 load4_shift(const float* __restrict__ row, int64_t i, int64_t n) {
+    if (i >= 0 && i + 3 < n && !((uintptr_t)(row + i) & 15)) return *reinterpret_cast<const float4*>(row + i);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i >= 0 && i < n) v.x = row[i];
+    if (i + 1 >= 0 && i + 1 < n) v.y = row[i + 1];
+    if (i + 2 >= 0 && i + 2 < n) v.z = row[i + 2];
+    if (i + 3 >= 0 && i + 3 < n) v.w = row[i + 3];
+    return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+
+// ---- workspace layout (element offsets in floats), computed on the host ------------------------
+struct Layout {
+    int bs, T, R;            // R = bs*T track rows
+    int64_t N;
+    int ncE, ncE_pad;        // EQ lane-chunks per signal row (pad to kWG)
+    int ncC, ncC_pad;        // compressor lane-chunks per row
+    int nblkE, nblkC;        // workgroups per row in EQ / compressor kernels
+    int KE, KC;              // chunks per scan thread
+    // offsets
+    int64_t rc_t, rc_m;                  // row constants
+    int64_t powF_t, powF_m;              // forward cascade scan tables  rows x kPow x 144
+    int64_t powA_t, powA_m;              // adjoint cascade scan tables
+    int64_t powP_t, powP_m;              // all-pole scan tables rows x 12 x kPow x 4
+    int64_t u_t, gs_t, bus, v_m, gs_m;   // saved signals
+    int64_t zE_t, sE_t, zE_m, sE_m;      // EQ chunk states (z = zero-state end, s = true start)
+    int64_t zS_t, sS_t, zS_m, sS_m;      // smoother chunk states
+    int64_t du_m, dbus, du_t;            // backward signals
+    int64_t zQ_t, sQ_t, zQ_m, sQ_m;      // smoother-adjoint chunk states
+    int64_t zA_t, sA_t, zA_m, sA_m;      // EQ-adjoint chunk states
+    int64_t zP_t, sP_t, zP_m, sP_m;      // all-pole (coefficient-gradient) chunk states
+    int64_t cp_t, cp_m, ep_t, ep_m;      // partial sums
+    int64_t total;                       // floats
+};
+
+inline Layout make_layout(const mst_console_desc* d) {
+    Layout L{};
+    L.bs = d->bs;
+    L.T = d->n_tracks;
+    L.R = d->bs * d->n_tracks;
+    L.N = d->n_samples;
+    L.ncE = (int)((L.N + kEqChunk - 1) / kEqChunk);
+    L.ncE_pad = (int)round_up(L.ncE, kWG);
+    L.ncC = (int)((L.N + kCompChunk - 1) / kCompChunk);
+    L.ncC_pad = (int)round_up(L.ncC, kWG);
+    L.nblkE = L.ncE_pad / kWG;
+    L.nblkC = L.ncC_pad / kWG;
+    L.KE = (L.ncE + kScanThreads - 1) / kScanThreads;
+    L.KC = (L.ncC + kScanThreads - 1) / kScanThreads;
+    int64_t o = 0;
+    auto take = [&](int64_t n) {
+        int64_t at = o;
+        o += round_up(n, 64);  // keep every array 256-byte aligned
+        return at;
+    };
+    const int64_t R = L.R, B = L.bs, N = round_up(L.N, 4);
+    L.rc_t = take(R * RC_STRIDE);
+    L.rc_m = take(B * RC_STRIDE);
+    L.powF_t = take(R * kPow * 144);
+    L.powF_m = take(B * kPow * 144);
+    L.powA_t = take(R * kPow * 144);
+    L.powA_m = take(B * kPow * 144);
+    L.powP_t = take(R * 12 * kPow * 4);
+    L.powP_m = take(B * 12 * kPow * 4);
+    L.u_t = take(R * N);
+    L.gs_t = take(R * N);
+    L.bus = take(B * 2 * N);
+    L.v_m = take(B * 2 * N);
+    L.gs_m = take(B * N);
+    L.zE_t = take(R * 12 * L.ncE_pad);
+    L.sE_t = take(R * 12 * L.ncE_pad);
+    L.zE_m = take(B * 2 * 12 * L.ncE_pad);
+    L.sE_m = take(B * 2 * 12 * L.ncE_pad);
+    L.zS_t = take(R * L.ncC_pad);
+    L.sS_t = take(R * L.ncC_pad);
+    L.zS_m = take(B * L.ncC_pad);
+    L.sS_m = take(B * L.ncC_pad);
+    L.du_m = take(B * 2 * N);
+    L.dbus = take(B * 2 * N);
+    L.du_t = take(R * N);
+    L.zQ_t = take(R * L.ncC_pad);
+    L.sQ_t = take(R * L.ncC_pad);
+    L.zQ_m = take(B * L.ncC_pad);
+    L.sQ_m = take(B * L.ncC_pad);
+    L.zA_t = take(R * 12 * L.ncE_pad);
+    L.sA_t = take(R * 12 * L.ncE_pad);
+    L.zA_m = take(B * 2 * 12 * L.ncE_pad);
+    L.sA_m = take(B * 2 * 12 * L.ncE_pad);
+    L.zP_t = take(R * 24 * L.ncE_pad);
+    L.sP_t = take(R * 24 * L.ncE_pad);
+    L.zP_m = take(B * 2 * 24 * L.ncE_pad);
+    L.sP_m = take(B * 2 * 24 * L.ncE_pad);
+    L.cp_t = take(R * L.nblkC * CP_COUNT);
+    L.cp_m = take(B * L.nblkC * CP_COUNT);
+    L.ep_t = take(R * L.nblkE * EP_COUNT);
+    L.ep_m = take(B * 2 * L.nblkE * EP_COUNT);
+    L.total = o;
+    return L;
+}
+
+}  // namespace mst

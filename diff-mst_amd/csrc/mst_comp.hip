@@ -1,0 +1,360 @@
+// mst_comp.hip - feed-forward compressor, pan and bus-sum kernels (forward and backward).
+//
+// Replaces dasp-pytorch's `compressor` / `stereo_panner` + `tracks.sum(dim=2)` (reference call
+// sites mst/modules.py:246, 263, 272, 300; algorithm SURVEY A.2/A.5):
+//   side = sum_ch x ; x_db = 20 log10(max(|side|,1e-8)) ; soft-knee static curve -> g_c ;
+//   g_s[n] = (1-a) g_c[n] + a g_s[n-1] ; y[n] = x[n-L] * 10^((g_s[n]+makeup)/20) .
+// Every lane owns kCompChunk = 8 consecutive samples (two 16-byte accesses per stream); the
+// one-pole smoother is a first-order linear recurrence handled as zs -> k_scan1 -> run, exactly
+// like the EQ states.  The track "apply" kernel loops over the tracks of one mix so the stereo
+// bus is accumulated in registers and written once (no (bs,2,T,N) intermediate unless asked for).
+#include "mst_kernels.h"
+
+namespace mst {
+
+constexpr int CC = kCompChunk;
+
+struct CompK {
+    float thr, kappa, knee, hw, inv2w, invw, alpha, oma, mk;
+};
+__device__ __forceinline__ CompK load_comp(const float* rc) {
+    CompK k;
+    k.thr = rc[RC_THR];
+    k.kappa = rc[RC_KAPPA];
+    k.knee = rc[RC_KNEE];
+    k.hw = 0.5f * k.knee;
+    k.invw = 1.0f / k.knee;
+    k.inv2w = 0.5f * k.invw;
+    k.alpha = rc[RC_ALPHA];
+    k.oma = 1.0f - k.alpha;
+    k.mk = rc[RC_MAKEUP];
+    return k;
+}
+// static curve: returns g_c = kappa * f(x_db - thr); d = x_db - thr is handed back
+__device__ __forceinline__ float gain_computer(float side, const CompK& k, float& d) {
+    const float ax = fmaxf(fabsf(side), kCompEps);
+    d = kDbPerLog2 * __builtin_amdgcn_logf(ax) - k.thr;
+    float f = 0.0f;
+    if (d > k.hw) f = d;
+    else if (d >= -k.hw) {
+        const float t = d + k.hw;
+        f = t * t * k.inv2w;
+    }
+    return k.kappa * f;
+}
+__device__ __forceinline__ float lin_gain(float gs, const CompK& k) {
+    return __builtin_amdgcn_exp2f((gs + k.mk) * kLog2PerDb);
+}
+__device__ __forceinline__ void ld8(const float* row, int64_t i, int64_t n, float* v) {
+    const float4 a = load4(row, i, n), b = load4(row, i + 4, n);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void ld8s(const float* row, int64_t i, int64_t n, float* v) {
+    const float4 a = load4_shift(row, i, n), b = load4_shift(row, i + 4, n);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void st8(float* row, int64_t i, int64_t n, const float* v) {
+    store4(row, i, n, make_float4(v[0], v[1], v[2], v[3]));
+    store4(row, i + 4, n, make_float4(v[4], v[5], v[6], v[7]));
+}
+
+// ---- forward: zero-state end value of the smoother per lane chunk ------------------------------
+// u: [(row*NCH+ch)][stride]; zs: [row][nc_pad]
+template <int NCH>
+__global__ __launch_bounds__(kWG) void k_comp_zs(const float* __restrict__ u, int64_t stride, const float* __restrict__ rc,
+                                                 float* __restrict__ zs, int nc_pad, int64_t n) {
+    const int row = blockIdx.y, chunk = blockIdx.x * kWG + threadIdx.x;
+    const int64_t i0 = (int64_t)chunk * CC;
+    const CompK k = load_comp(rc + (int64_t)row * RC_STRIDE);
+    float side[CC];
+    ld8(u + (int64_t)(row * NCH) * stride, i0, n, side);
+    if (NCH == 2) {
+        float o[CC];
+        ld8(u + (int64_t)(row * NCH + 1) * stride, i0, n, o);
+#pragma unroll
+        for (int i = 0; i < CC; ++i) side[i] += o[i];
+    }
+    float acc = 0.0f;
+#pragma unroll
+    for (int i = 0; i < CC; ++i) {
+        float d;
+        const float gc = gain_computer(side[i], k, d);
+        // samples past the end contribute nothing (their state is never consumed)
+        acc = fmaf(k.alpha, acc, k.oma * gc);
+    }
+    zs[(int64_t)row * nc_pad + chunk] = acc;
+}
+
+// ---- forward: tracks.  grid (nblk, bs).  Accumulates the stereo bus over the T tracks of mix b.
+__global__ __launch_bounds__(kWG) void k_apply_tracks(TrackApplyArgs a) {
+    const int b = blockIdx.y, chunk = blockIdx.x * kWG + threadIdx.x;
+    const int64_t i0 = (int64_t)chunk * CC;
+    float accL[CC], accR[CC];
+#pragma unroll
+    for (int i = 0; i < CC; ++i) accL[i] = accR[i] = 0.0f;
+    for (int t = 0; t < a.T; ++t) {
+        const int row = b * a.T + t;
+        const float* rc = a.rc + (int64_t)row * RC_STRIDE;
+        const float pl = rc[RC_PANL], pr = rc[RC_PANR];
+        const float* urow = a.u + (int64_t)row * a.stride;
+        float y[CC];
+        if (a.comp_on) {
+            const CompK k = load_comp(rc);
+            float x[CC], xd[CC], g[CC];
+            ld8(urow, i0, a.n, x);
+            ld8s(urow, i0 - a.lookahead, a.n, xd);
+            float s = a.s0[(int64_t)row * a.nc_pad + chunk];
+#pragma unroll
+            for (int i = 0; i < CC; ++i) {
+                float d;
+                const float gc = gain_computer(x[i], k, d);
+                s = fmaf(k.alpha, s, k.oma * gc);
+                g[i] = s;
+                y[i] = xd[i] * lin_gain(s, k);
+            }
+            if (a.gs) st8(a.gs + (int64_t)row * a.stride, i0, a.n, g);
+        } else {
+            ld8(urow, i0, a.n, y);
+        }
+#pragma unroll
+        for (int i = 0; i < CC; ++i) {
+            accL[i] = fmaf(pl, y[i], accL[i]);
+            accR[i] = fmaf(pr, y[i], accR[i]);
+        }
+        if (a.mixed) {
+            float ml[CC], mr[CC];
+#pragma unroll
+            for (int i = 0; i < CC; ++i) {
+                ml[i] = pl * y[i];
+                mr[i] = pr * y[i];
+            }
+            st8(a.mixed + (((int64_t)b * 2 + 0) * a.T + t) * a.n, i0, a.n, ml);
+            st8(a.mixed + (((int64_t)b * 2 + 1) * a.T + t) * a.n, i0, a.n, mr);
+        }
+    }
+    st8(a.bus + ((int64_t)b * 2 + 0) * a.bus_stride, i0, a.n, accL);
+    st8(a.bus + ((int64_t)b * 2 + 1) * a.bus_stride, i0, a.n, accR);
+}
+
+// ---- forward: master bus.  grid (nblk, bs).  out = delay(v) * G * gout  (stereo-linked)
+__global__ __launch_bounds__(kWG) void k_apply_master(MasterApplyArgs a) {
+    const int b = blockIdx.y, chunk = blockIdx.x * kWG + threadIdx.x;
+    const int64_t i0 = (int64_t)chunk * CC;
+    const float* rc = a.rc + (int64_t)b * RC_STRIDE;
+    const float gout = rc[RC_PANL];
+    const float* v0 = a.v + (int64_t)(b * 2) * a.stride;
+    const float* v1 = v0 + a.stride;
+    float yl[CC], yr[CC];
+    if (a.comp_on) {
+        const CompK k = load_comp(rc);
+        float l[CC], r[CC], g[CC];
+        ld8(v0, i0, a.n, l);
+        ld8(v1, i0, a.n, r);
+        ld8s(v0, i0 - a.lookahead, a.n, yl);
+        ld8s(v1, i0 - a.lookahead, a.n, yr);
+        float s = a.s0[(int64_t)b * a.nc_pad + chunk];
+#pragma unroll
+        for (int i = 0; i < CC; ++i) {
+            float d;
+            const float gc = gain_computer(l[i] + r[i], k, d);
+            s = fmaf(k.alpha, s, k.oma * gc);
+            g[i] = s;
+            const float G = lin_gain(s, k) * gout;
+            yl[i] *= G;
+            yr[i] *= G;
+        }
+        if (a.gs) st8(a.gs + (int64_t)b * a.stride, i0, a.n, g);
+    } else {
+        ld8(v0, i0, a.n, yl);
+        ld8(v1, i0, a.n, yr);
+#pragma unroll
+        for (int i = 0; i < CC; ++i) {
+            yl[i] *= gout;
+            yr[i] *= gout;
+        }
+    }
+    st8(a.out + ((int64_t)b * 2 + 0) * a.out_stride, i0, a.n, yl);
+    st8(a.out + ((int64_t)b * 2 + 1) * a.out_stride, i0, a.n, yr);
+}
+
+// ---- backward ------------------------------------------------------------------------------------
+// upstream cotangent of the compressor output y for 8 samples starting at i (may run past either end)
+template <bool MASTER>
+__device__ __forceinline__ void load_gy(const CompBwdArgs& a, int row, const float* rc, int64_t i, float* gl, float* gr) {
+    // raw upstream cotangents per stereo channel: grad_mix (MASTER) or grad_bus (+ grad_mixed_tracks)
+    const int b = MASTER ? row : row / a.T;
+    float l[CC], r[CC];
+    ld8s(a.gup + ((int64_t)b * 2 + 0) * a.gup_stride, i, a.n, l);
+    ld8s(a.gup + ((int64_t)b * 2 + 1) * a.gup_stride, i, a.n, r);
+    if (!MASTER && a.gmixed) {
+        const int t = row % a.T;
+        float ml[CC], mr[CC];
+        ld8s(a.gmixed + (((int64_t)b * 2 + 0) * a.T + t) * a.n, i, a.n, ml);
+        ld8s(a.gmixed + (((int64_t)b * 2 + 1) * a.T + t) * a.n, i, a.n, mr);
+#pragma unroll
+        for (int q = 0; q < CC; ++q) {
+            l[q] += ml[q];
+            r[q] += mr[q];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < CC; ++q) {
+        gl[q] = l[q];
+        gr[q] = r[q];
+    }
+}
+
+// zero-state (from the right) end value of the adjoint smoother q[n] = dgs[n] + a q[n+1]
+template <bool MASTER>
+__global__ __launch_bounds__(kWG) void k_comp_bwd_zs(CompBwdArgs a) {
+    constexpr int NCH = MASTER ? 2 : 1;
+    const int row = blockIdx.y, chunk = blockIdx.x * kWG + threadIdx.x;
+    const int64_t i0 = (int64_t)chunk * CC;
+    const float* rc = a.rc + (int64_t)row * RC_STRIDE;
+    const CompK k = load_comp(rc);
+    float gl[CC], gr[CC], xd0[CC], xd1[CC], g[CC];
+    load_gy<MASTER>(a, row, rc, i0, gl, gr);
+    ld8s(a.u + (int64_t)(row * NCH) * a.stride, i0 - a.lookahead, a.n, xd0);
+    if (MASTER) ld8s(a.u + (int64_t)(row * NCH + 1) * a.stride, i0 - a.lookahead, a.n, xd1);
+    ld8(a.gs + (int64_t)row * a.stride, i0, a.n, g);
+    const float pl = rc[RC_PANL], pr = rc[RC_PANR];  // master: both = output-fader gain
+    float acc = 0.0f;
+#pragma unroll
+    for (int i = CC - 1; i >= 0; --i) {
+        const float G = lin_gain(g[i], k);
+        const float dot = MASTER ? pl * (gl[i] * xd0[i] + gr[i] * xd1[i]) : (pl * gl[i] + pr * gr[i]) * xd0[i];
+        const float dgs = (i0 + i < a.n) ? dot * G * kLn10Over20 : 0.0f;
+        acc = fmaf(k.alpha, acc, dgs);
+    }
+    a.zq[(int64_t)row * a.nc_pad + chunk] = acc;
+}
+
+template <bool MASTER>
+__global__ __launch_bounds__(kWG) void k_comp_bwd_run(CompBwdArgs a) {
+    constexpr int NCH = MASTER ? 2 : 1;
+    __shared__ float red[4][CP_COUNT];
+    const int tid = threadIdx.x, row = blockIdx.y, chunk = blockIdx.x * kWG + tid;
+    const int64_t i0 = (int64_t)chunk * CC;
+    const float* rc = a.rc + (int64_t)row * RC_STRIDE;
+    const float* u0 = a.u + (int64_t)(row * NCH) * a.stride;
+    const float* u1 = u0 + a.stride;
+    float p[CP_COUNT];
+#pragma unroll
+    for (int i = 0; i < CP_COUNT; ++i) p[i] = 0.0f;
+    float gl[CC], gr[CC], du0[CC], du1[CC];
+    load_gy<MASTER>(a, row, rc, i0, gl, gr);
+    const float pl = rc[RC_PANL], pr = rc[RC_PANR];  // master: both = output-fader gain
+
+    if (a.comp_on) {
+        const CompK k = load_comp(rc);
+        float x0[CC], x1[CC], xd0[CC], xd1[CC], g[CC], gF[CC], glF[CC], grF[CC];
+        ld8(u0, i0, a.n, x0);
+        ld8s(u0, i0 - a.lookahead, a.n, xd0);
+        if (MASTER) {
+            ld8(u1, i0, a.n, x1);
+            ld8s(u1, i0 - a.lookahead, a.n, xd1);
+        }
+        ld8(a.gs + (int64_t)row * a.stride, i0, a.n, g);
+        // look-ahead branch: du[i] += gy[i+L] * G[i+L]
+        ld8s(a.gs + (int64_t)row * a.stride, i0 + a.lookahead, a.n, gF);
+        load_gy<MASTER>(a, row, rc, i0 + a.lookahead, glF, grF);
+        const float g_prev0 = (i0 > 0 && i0 - 1 < a.n) ? a.gs[(int64_t)row * a.stride + i0 - 1] : 0.0f;
+        float q = a.s0[(int64_t)row * a.nc_pad + chunk];
+#pragma unroll
+        for (int i = CC - 1; i >= 0; --i) {
+            const bool live = i0 + i < a.n;
+            const float G = lin_gain(g[i], k);
+            const float dot = MASTER ? pl * (gl[i] * xd0[i] + gr[i] * xd1[i]) : (pl * gl[i] + pr * gr[i]) * xd0[i];
+            const float dgs = live ? dot * G * kLn10Over20 : 0.0f;
+            q = fmaf(k.alpha, q, dgs);
+            const float dgc = k.oma * q;
+            const float side = MASTER ? x0[i] + x1[i] : x0[i];
+            float d;
+            const float gc = gain_computer(side, k, d);
+            const float gprev = (i > 0) ? g[i - 1] : g_prev0;
+            float fval = 0.0f, fp = 0.0f, fw = 0.0f;
+            if (d > k.hw) {
+                fval = d;
+                fp = 1.0f;
+            } else if (d >= -k.hw) {
+                const float t = d + k.hw;
+                fval = t * t * k.inv2w;
+                fp = t * k.invw;
+                fw = t * (k.hw - d) * k.inv2w * k.invw;
+            }
+            const float dxdb = dgc * k.kappa * fp;
+            if (live) {
+                p[CP_ALPHA] = fmaf(q, gprev - gc, p[CP_ALPHA]);
+                p[CP_KAPPA] = fmaf(dgc, fval, p[CP_KAPPA]);
+                p[CP_THR] -= dxdb;
+                p[CP_KNEE] = fmaf(dgc * k.kappa, fw, p[CP_KNEE]);
+                p[CP_MAKEUP] += dgs;
+                if (MASTER) {
+                    // cotangent of the output-fader gain: sum(grad_mix * out_before_fader)
+                    p[CP_PANL] = fmaf(gl[i] * xd0[i] + gr[i] * xd1[i], G, p[CP_PANL]);
+                } else {
+                    const float yv = xd0[i] * G;
+                    p[CP_PANL] = fmaf(gl[i], yv, p[CP_PANL]);
+                    p[CP_PANR] = fmaf(gr[i], yv, p[CP_PANR]);
+                }
+            }
+            // side chain: d x_db / d side = (20/ln10) / side, clamp kills it below eps
+            const float ds = (fabsf(side) >= kCompEps) ? dxdb * 8.685889638065035f / side : 0.0f;
+            const float GF = lin_gain(gF[i], k);
+            const bool liveF = i0 + i + a.lookahead < a.n;
+            du0[i] = ds + (liveF ? (MASTER ? pl * glF[i] : pl * glF[i] + pr * grF[i]) * GF : 0.0f);
+            if (MASTER) du1[i] = ds + (liveF ? pr * grF[i] * GF : 0.0f);
+        }
+    } else {
+        float x0[CC], x1[CC];
+        ld8(u0, i0, a.n, x0);
+        if (MASTER) ld8(u1, i0, a.n, x1);
+#pragma unroll
+        for (int i = 0; i < CC; ++i) {
+            du0[i] = MASTER ? pl * gl[i] : pl * gl[i] + pr * gr[i];
+            if (MASTER) du1[i] = pr * gr[i];
+            if (i0 + i < a.n) {
+                if (MASTER) p[CP_PANL] = fmaf(gl[i], x0[i], fmaf(gr[i], x1[i], p[CP_PANL]));
+                else {
+                    p[CP_PANL] = fmaf(gl[i], x0[i], p[CP_PANL]);
+                    p[CP_PANR] = fmaf(gr[i], x0[i], p[CP_PANR]);
+                }
+            }
+        }
+    }
+    st8(a.du + (int64_t)(row * NCH) * a.stride, i0, a.n, du0);
+    if (MASTER) st8(a.du + (int64_t)(row * NCH + 1) * a.stride, i0, a.n, du1);
+
+    const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+    for (int i = 0; i < CP_COUNT; ++i) {
+        const float v = wave_sum(p[i]);
+        if (lane == 0) red[wave][i] = v;
+    }
+    __syncthreads();
+    if (tid < CP_COUNT)
+        a.part[((int64_t)row * gridDim.x + blockIdx.x) * CP_COUNT + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+}
+
+// ---- launch helpers ---------------------------------------------------------------------------------
+void launch_comp_zs(int nch, const float* u, int64_t stride, const float* rc, float* zs, int nc_pad, int64_t n, int rows,
+                    hipStream_t stream) {
+    dim3 grid(nc_pad / kWG, rows), block(kWG);
+    if (nch == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_comp_zs<1>), grid, block, 0, stream, u, stride, rc, zs, nc_pad, n);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_comp_zs<2>), grid, block, 0, stream, u, stride, rc, zs, nc_pad, n);
+}
+void launch_apply_tracks(const TrackApplyArgs& a, int bs, hipStream_t stream) {
+    hipLaunchKernelGGL(k_apply_tracks, dim3(a.nc_pad / kWG, bs), dim3(kWG), 0, stream, a);
+}
+void launch_apply_master(const MasterApplyArgs& a, int bs, hipStream_t stream) {
+    hipLaunchKernelGGL(k_apply_master, dim3(a.nc_pad / kWG, bs), dim3(kWG), 0, stream, a);
+}
+void launch_comp_bwd(bool master, bool run, const CompBwdArgs& a, int rows, hipStream_t stream) {
+    dim3 grid(a.nc_pad / kWG, rows), block(kWG);
+    if (master && !run) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_comp_bwd_zs<true>), grid, block, 0, stream, a);
+    else if (master && run) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_comp_bwd_run<true>), grid, block, 0, stream, a);
+    else if (!master && !run) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_comp_bwd_zs<false>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_comp_bwd_run<false>), grid, block, 0, stream, a);
+}
+
+}  // namespace mst

@@ -1,0 +1,149 @@
+// mst_console.hip - C-ABI entry points of the mix console (include/diffmst_hip.h) and the
+// launch sequences behind them.  No allocation, no host sync: everything is enqueued on the
+// caller's stream over the caller's workspace.
+#include "mst_kernels.h"
+
+namespace mst {
+static int check_desc(const mst_console_desc* d) {
+    if (!d || d->bs <= 0 || d->n_tracks <= 0 || d->n_samples <= 0) return hipErrorInvalidValue;
+    if (d->flags & MST_USE_FX_BUS) return hipErrorInvalidValue;          // SURVEY 8f rank 4, not built yet
+    if (!(d->flags & MST_USE_TRACK_PANNER)) return hipErrorInvalidValue;  // reference branch is broken (mst/modules.py:269)
+    if (d->track_row_stride < d->n_samples || (d->track_row_stride & 3)) return hipErrorInvalidValue;
+    if ((d->track_lookahead & 3) || (d->master_lookahead & 3) || d->track_lookahead < 0 || d->master_lookahead < 0)
+        return hipErrorInvalidValue;
+    return hipSuccess;
+}
+}  // namespace mst
+
+using namespace mst;
+
+extern "C" int mst_abi_version(void) { return 1; }
+
+extern "C" size_t mst_console_workspace_bytes(const mst_console_desc* d) {
+    if (check_desc(d) != hipSuccess) return 0;
+    return (size_t)make_layout(d).total * sizeof(float);
+}
+
+extern "C" int mst_console_forward(const mst_console_desc* d, const float* tracks, const float* track_params,
+                                   const float* fx_bus_params, const float* master_bus_params, float* mix,
+                                   float* mixed_tracks, int32_t* status, void* workspace, size_t workspace_bytes,
+                                   void* stream_) {
+    if (int e = check_desc(d)) return e;
+    const Layout L = make_layout(d);
+    if (!workspace || workspace_bytes < (size_t)L.total * sizeof(float) || ((uintptr_t)workspace & 255)) return hipErrorInvalidValue;
+    if (!tracks || !track_params || !fx_bus_params || !master_bus_params || !mix || !status) return hipErrorInvalidValue;
+    if (((uintptr_t)tracks & 15) || ((uintptr_t)mix & 15)) return hipErrorInvalidValue;
+    hipStream_t stream = (hipStream_t)stream_;
+    float* ws = (float*)workspace;
+    const int64_t n = L.N, Ns = round_up(L.N, 4);
+    const bool save = d->flags & MST_SAVE_FOR_BACKWARD;
+    const bool t_comp = d->flags & MST_USE_TRACK_COMPRESSOR;
+    const bool m_on = d->flags & MST_USE_MASTER_BUS;
+    const bool o_on = d->flags & MST_USE_OUTPUT_FADER;
+
+    hipMemsetAsync(status, 0, sizeof(int32_t), stream);
+    PrepArgs pa{track_params, fx_bus_params, master_bus_params, ws + L.rc_t, ws + L.rc_m,
+                ws + L.powF_t, ws + L.powF_m, ws + L.powA_t, ws + L.powA_m, ws + L.powP_t, ws + L.powP_m,
+                status, L.R, L.bs, L.KE, *d};
+    launch_prep(pa, stream);
+
+    // ---- tracks: EQ (zs -> carry scan -> run), compressor smoother (zs -> scan), apply + pan + bus sum
+    launch_cascade(EQ_FWD, false, tracks, d->track_row_stride, nullptr, 0, ws + L.rc_t, 1, nullptr, ws + L.zE_t, L.ncE_pad, n, L.R, stream);
+    launch_scan12(false, ws + L.zE_t, ws + L.sE_t, ws + L.powF_t, 1, L.ncE, L.ncE_pad, L.KE, L.R, stream);
+    launch_cascade(EQ_FWD, true, tracks, d->track_row_stride, ws + L.u_t, Ns, ws + L.rc_t, 1, ws + L.sE_t, nullptr, L.ncE_pad, n, L.R, stream);
+    if (t_comp) {
+        launch_comp_zs(1, ws + L.u_t, Ns, ws + L.rc_t, ws + L.zS_t, L.ncC_pad, n, L.R, stream);
+        launch_scan1(false, ws + L.zS_t, ws + L.sS_t, ws + L.rc_t, L.ncC, L.ncC_pad, L.KC, L.R, stream);
+    }
+    const bool bus_is_mix = !m_on && !o_on;
+    TrackApplyArgs ta{ws + L.u_t, Ns, ws + L.rc_t, ws + L.sS_t, (save && t_comp) ? ws + L.gs_t : nullptr,
+                      bus_is_mix ? mix : ws + L.bus, bus_is_mix ? n : Ns, mixed_tracks,
+                      L.T, L.ncC_pad, d->track_lookahead, t_comp ? 1 : 0, n};
+    launch_apply_tracks(ta, L.bs, stream);
+
+    // ---- master bus
+    if (m_on) {
+        launch_cascade(EQ_FWD, false, ws + L.bus, Ns, nullptr, 0, ws + L.rc_m, 2, nullptr, ws + L.zE_m, L.ncE_pad, n, 2 * L.bs, stream);
+        launch_scan12(false, ws + L.zE_m, ws + L.sE_m, ws + L.powF_m, 2, L.ncE, L.ncE_pad, L.KE, 2 * L.bs, stream);
+        launch_cascade(EQ_FWD, true, ws + L.bus, Ns, ws + L.v_m, Ns, ws + L.rc_m, 2, ws + L.sE_m, nullptr, L.ncE_pad, n, 2 * L.bs, stream);
+        launch_comp_zs(2, ws + L.v_m, Ns, ws + L.rc_m, ws + L.zS_m, L.ncC_pad, n, L.bs, stream);
+        launch_scan1(false, ws + L.zS_m, ws + L.sS_m, ws + L.rc_m, L.ncC, L.ncC_pad, L.KC, L.bs, stream);
+        MasterApplyArgs ma{ws + L.v_m, Ns, ws + L.rc_m, ws + L.sS_m, save ? ws + L.gs_m : nullptr, mix, n,
+                           L.ncC_pad, d->master_lookahead, 1, n};
+        launch_apply_master(ma, L.bs, stream);
+    } else if (o_on) {
+        MasterApplyArgs ma{ws + L.bus, Ns, ws + L.rc_m, nullptr, nullptr, mix, n, L.ncC_pad, 0, 0, n};
+        launch_apply_master(ma, L.bs, stream);
+    }
+    return (int)hipGetLastError();
+}
+
+extern "C" int mst_console_backward(const mst_console_desc* d, const float* tracks, const float* track_params,
+                                    const float* master_bus_params, const float* grad_mix, const float* grad_mixed_tracks,
+                                    float* grad_track_params, float* grad_master_params, float* grad_tracks,
+                                    void* workspace, size_t workspace_bytes, void* stream_) {
+    if (int e = check_desc(d)) return e;
+    const Layout L = make_layout(d);
+    if (!workspace || workspace_bytes < (size_t)L.total * sizeof(float) || ((uintptr_t)workspace & 255)) return hipErrorInvalidValue;
+    if (!(d->flags & MST_SAVE_FOR_BACKWARD)) return hipErrorInvalidValue;
+    if (!track_params || !master_bus_params || !grad_mix || !grad_track_params || !grad_master_params) return hipErrorInvalidValue;
+    hipStream_t stream = (hipStream_t)stream_;
+    float* ws = (float*)workspace;
+    const int64_t n = L.N, Ns = round_up(L.N, 4);
+    const bool t_comp = d->flags & MST_USE_TRACK_COMPRESSOR;
+    const bool m_on = d->flags & MST_USE_MASTER_BUS;
+    const bool o_on = d->flags & MST_USE_OUTPUT_FADER;
+    (void)tracks;
+
+    // ---- master bus: compressor adjoint, EQ adjoint (-> grad of the stereo bus), coefficient sums
+    const float* gbus = grad_mix;  // cotangent of the stereo bus as seen by the track stage
+    int64_t gbus_stride = n;
+    if (m_on) {
+        CompBwdArgs ca{ws + L.v_m, Ns, ws + L.gs_m, ws + L.rc_m, nullptr, ws + L.zQ_m, ws + L.du_m, ws + L.cp_m,
+                       grad_mix, n, nullptr, 1, L.ncC_pad, d->master_lookahead, 1, n};
+        launch_comp_bwd(true, false, ca, L.bs, stream);
+        launch_scan1(true, ws + L.zQ_m, ws + L.sQ_m, ws + L.rc_m, L.ncC, L.ncC_pad, L.KC, L.bs, stream);
+        ca.s0 = ws + L.sQ_m;
+        launch_comp_bwd(true, true, ca, L.bs, stream);
+        launch_cascade(EQ_ADJ, false, ws + L.du_m, Ns, nullptr, 0, ws + L.rc_m, 2, nullptr, ws + L.zA_m, L.ncE_pad, n, 2 * L.bs, stream);
+        launch_scan12(true, ws + L.zA_m, ws + L.sA_m, ws + L.powA_m, 2, L.ncE, L.ncE_pad, L.KE, 2 * L.bs, stream);
+        launch_cascade(EQ_ADJ, true, ws + L.du_m, Ns, ws + L.dbus, Ns, ws + L.rc_m, 2, ws + L.sA_m, nullptr, L.ncE_pad, n, 2 * L.bs, stream);
+        launch_allpole_zs(ws + L.v_m, Ns, ws + L.rc_m, 2, ws + L.zP_m, L.ncE_pad, n, 2 * L.bs, stream);
+        launch_scan2(ws + L.zP_m, ws + L.sP_m, ws + L.powP_m, 2, L.ncE, L.ncE_pad, L.KE, 2 * L.bs, stream);
+        launch_coefgrad(ws + L.v_m, Ns, ws + L.du_m, Ns, ws + L.rc_m, 2, ws + L.sP_m, L.ncE_pad, ws + L.ep_m, n, 2 * L.bs, stream);
+        gbus = ws + L.dbus;
+        gbus_stride = Ns;
+    } else if (o_on) {
+        CompBwdArgs ca{ws + L.bus, Ns, nullptr, ws + L.rc_m, nullptr, nullptr, ws + L.dbus, ws + L.cp_m,
+                       grad_mix, n, nullptr, 1, L.ncC_pad, 0, 0, n};
+        launch_comp_bwd(true, true, ca, L.bs, stream);
+        gbus = ws + L.dbus;
+        gbus_stride = Ns;
+    } else {
+        hipMemsetAsync(ws + L.cp_m, 0, (size_t)L.bs * L.nblkC * CP_COUNT * sizeof(float), stream);
+    }
+
+    // ---- tracks
+    {
+        CompBwdArgs ca{ws + L.u_t, Ns, ws + L.gs_t, ws + L.rc_t, nullptr, ws + L.zQ_t, ws + L.du_t, ws + L.cp_t,
+                       gbus, gbus_stride, grad_mixed_tracks, L.T, L.ncC_pad, d->track_lookahead, t_comp ? 1 : 0, n};
+        if (t_comp) {
+            launch_comp_bwd(false, false, ca, L.R, stream);
+            launch_scan1(true, ws + L.zQ_t, ws + L.sQ_t, ws + L.rc_t, L.ncC, L.ncC_pad, L.KC, L.R, stream);
+            ca.s0 = ws + L.sQ_t;
+        }
+        launch_comp_bwd(false, true, ca, L.R, stream);
+        launch_allpole_zs(ws + L.u_t, Ns, ws + L.rc_t, 1, ws + L.zP_t, L.ncE_pad, n, L.R, stream);
+        launch_scan2(ws + L.zP_t, ws + L.sP_t, ws + L.powP_t, 1, L.ncE, L.ncE_pad, L.KE, L.R, stream);
+        launch_coefgrad(ws + L.u_t, Ns, ws + L.du_t, Ns, ws + L.rc_t, 1, ws + L.sP_t, L.ncE_pad, ws + L.ep_t, n, L.R, stream);
+        if (grad_tracks) {
+            launch_cascade(EQ_ADJ, false, ws + L.du_t, Ns, nullptr, 0, ws + L.rc_t, 1, nullptr, ws + L.zA_t, L.ncE_pad, n, L.R, stream);
+            launch_scan12(true, ws + L.zA_t, ws + L.sA_t, ws + L.powA_t, 1, L.ncE, L.ncE_pad, L.KE, L.R, stream);
+            launch_cascade(EQ_ADJ, true, ws + L.du_t, Ns, grad_tracks, n, ws + L.rc_t, 1, ws + L.sA_t, nullptr, L.ncE_pad, n, L.R, stream);
+        }
+    }
+    PrepBwdArgs pb{track_params, master_bus_params, ws + L.rc_t, ws + L.rc_m, ws + L.cp_t, ws + L.cp_m, ws + L.ep_t, ws + L.ep_m,
+                   grad_track_params, grad_master_params, L.R, L.bs, L.nblkC, L.nblkE, *d};
+    launch_prep_bwd(pb, stream);
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,265 @@
+// mst_eq.hip - the cascaded-biquad (parametric EQ) kernels.
+//
+// Replaces dasp-pytorch's frequency-sampling `parametric_eq` (reference call sites
+// mst/modules.py:237, 293; SURVEY A.3-A.4: twelve 2^19-point coefficient rFFTs + signal
+// rFFT/irFFT per row) with a time-domain, chunk-parallel linear recurrence:
+//
+//   every lane owns kEqChunk consecutive samples of one signal row; the 256 lanes of a workgroup
+//   cover a 16384-sample tile, staged through LDS in 32-sample slabs so that HBM sees only
+//   coalesced 16-byte accesses while each lane reads its own contiguous slab.
+//     *_zs   : run the chunk from ZERO state, keep only the 12-float end state  (z)
+//     scan   : (mst_scan.hip) s0[c+1] = M s0[c] + z[c] gives every chunk's true start state
+//     *_run  : re-run the chunk from its true start state and emit the output
+//   The adjoint (reverse-time) cascade uses the same skeleton with time reversed.
+//   Coefficient gradients use the forward-only identity  dL/db_kj = <g, S^j (1/B_k) u>,
+//   dL/da_kj = -<g, S^j (1/A_k) u>  (u = EQ output, g = its cotangent): twelve independent 2-state
+//   all-pole recurrences on u, same zs / scan / run structure (k_allpole_zs, k_coefgrad).
+#include "mst_kernels.h"
+
+namespace mst {
+
+constexpr int kSlab = 32;         // samples per lane per LDS stage
+constexpr int kLdw = kSlab + 4;   // padded LDS row: conflict-free ds_read_b128 / ds_write_b128
+constexpr int kNSlab = kEqChunk / kSlab;
+
+// coalesced global -> LDS (lane-major rows).  Tile = kWG lanes x kEqChunk samples; slab j.
+__device__ __forceinline__ void slab_load(float* __restrict__ tile, const float* __restrict__ row, int64_t tile_base,
+                                          int j, int64_t n, int tid) {
+#pragma unroll
+    for (int r = 0; r < (kWG * kSlab / 4) / kWG; ++r) {
+        const int q = tid + kWG * r;       // float4 index inside the slab image
+        const int lane = q / (kSlab / 4);  // owning lane
+        const int i = (q % (kSlab / 4)) * 4;
+        const int64_t g = tile_base + (int64_t)lane * kEqChunk + j * kSlab + i;
+        *reinterpret_cast<float4*>(&tile[lane * kLdw + i]) = load4(row, g, n);
+    }
+}
+__device__ __forceinline__ void slab_store(const float* __restrict__ tile, float* __restrict__ row, int64_t tile_base,
+                                           int j, int64_t n, int tid) {
+#pragma unroll
+    for (int r = 0; r < (kWG * kSlab / 4) / kWG; ++r) {
+        const int q = tid + kWG * r;
+        const int lane = q / (kSlab / 4);
+        const int i = (q % (kSlab / 4)) * 4;
+        const int64_t g = tile_base + (int64_t)lane * kEqChunk + j * kSlab + i;
+        store4(row, g, n, *reinterpret_cast<const float4*>(&tile[lane * kLdw + i]));
+    }
+}
+
+
+// MODE_RUN = false: zero-state pass, writes z[sig][12][nc_pad]
+// MODE_RUN = true : true pass from s0[sig][12][nc_pad], writes out
+template <int DIR, bool MODE_RUN>
+__global__ __launch_bounds__(kWG) void k_cascade(const float* __restrict__ in, int64_t in_stride,
+                                                 float* __restrict__ out, int64_t out_stride,
+                                                 const float* __restrict__ rc, int nch,
+                                                 const float* __restrict__ s0, float* __restrict__ z,
+                                                 int nc_pad, int64_t n) {
+    __shared__ __attribute__((aligned(16))) float tile[kWG * kLdw];
+    const int tid = threadIdx.x, sig = blockIdx.y;
+    const int64_t tile_base = (int64_t)blockIdx.x * kWG * kEqChunk;
+    const int chunk = blockIdx.x * kWG + tid;
+    const float* coef = rc + (int64_t)(sig / nch) * RC_STRIDE + RC_SOS;
+    float c[5 * kSections];
+#pragma unroll
+    for (int i = 0; i < 5 * kSections; ++i) c[i] = coef[i];
+    float st[kStates];
+#pragma unroll
+    for (int i = 0; i < kStates; ++i)
+        st[i] = MODE_RUN ? s0[((int64_t)sig * kStates + i) * nc_pad + chunk] : 0.0f;
+
+    const float* inrow = in + (int64_t)sig * in_stride;
+    float* outrow = MODE_RUN ? out + (int64_t)sig * out_stride : nullptr;
+    float* mine = &tile[tid * kLdw];
+
+    for (int jj = 0; jj < kNSlab; ++jj) {
+        const int j = (DIR == EQ_FWD) ? jj : kNSlab - 1 - jj;
+        slab_load(tile, inrow, tile_base, j, n, tid);
+        __syncthreads();
+        if (DIR == EQ_FWD) {
+#pragma unroll
+            for (int i4 = 0; i4 < kSlab; i4 += 4) {
+                float4 v = *reinterpret_cast<float4*>(&mine[i4]);
+                v.x = cascade_step<float>(v.x, c, st);
+                v.y = cascade_step<float>(v.y, c, st);
+                v.z = cascade_step<float>(v.z, c, st);
+                v.w = cascade_step<float>(v.w, c, st);
+                if (MODE_RUN) *reinterpret_cast<float4*>(&mine[i4]) = v;
+            }
+        } else {
+#pragma unroll
+            for (int i4 = kSlab - 4; i4 >= 0; i4 -= 4) {
+                float4 v = *reinterpret_cast<float4*>(&mine[i4]);
+                v.w = cascade_adj_step<float>(v.w, c, st);
+                v.z = cascade_adj_step<float>(v.z, c, st);
+                v.y = cascade_adj_step<float>(v.y, c, st);
+                v.x = cascade_adj_step<float>(v.x, c, st);
+                if (MODE_RUN) *reinterpret_cast<float4*>(&mine[i4]) = v;
+            }
+        }
+        __syncthreads();
+        if (MODE_RUN) {
+            slab_store(tile, outrow, tile_base, j, n, tid);
+            __syncthreads();
+        }
+    }
+    if (!MODE_RUN) {
+#pragma unroll
+        for (int i = 0; i < kStates; ++i) z[((int64_t)sig * kStates + i) * nc_pad + chunk] = st[i];
+    }
+}
+
+// ---- all-pole bank for the coefficient gradients ------------------------------------------------
+// filter f = 2k : w = u - a1 w1 - a2 w2 (1/A_k);  f = 2k+1 : w = u/b0 - (b1/b0) w1 - (b2/b0) w2 (1/B_k)
+struct ApCoef {
+    float a1[kSections], a2[kSections], ib0[kSections], c1[kSections], c2[kSections];
+};
+__device__ __forceinline__ void load_ap(const float* coef, ApCoef& k) {
+#pragma unroll
+    for (int s = 0; s < kSections; ++s) {
+        const float b0 = coef[5 * s], b1 = coef[5 * s + 1], b2 = coef[5 * s + 2];
+        k.a1[s] = coef[5 * s + 3];
+        k.a2[s] = coef[5 * s + 4];
+        k.ib0[s] = 1.0f / b0;
+        k.c1[s] = b1 / b0;
+        k.c2[s] = b2 / b0;
+    }
+}
+
+// zero-state end states of the 12 all-pole filters per lane chunk: z[sig][24][nc_pad]
+__global__ __launch_bounds__(kWG) void k_allpole_zs(const float* __restrict__ u, int64_t u_stride,
+                                                    const float* __restrict__ rc, int nch, float* __restrict__ z,
+                                                    int nc_pad, int64_t n) {
+    __shared__ __attribute__((aligned(16))) float tile[kWG * kLdw];
+    const int tid = threadIdx.x, sig = blockIdx.y;
+    const int64_t tile_base = (int64_t)blockIdx.x * kWG * kEqChunk;
+    const int chunk = blockIdx.x * kWG + tid;
+    ApCoef k;
+    load_ap(rc + (int64_t)(sig / nch) * RC_STRIDE + RC_SOS, k);
+    float wa1[kSections], wa2[kSections], wb1[kSections], wb2[kSections];
+#pragma unroll
+    for (int s = 0; s < kSections; ++s) wa1[s] = wa2[s] = wb1[s] = wb2[s] = 0.0f;
+    const float* urow = u + (int64_t)sig * u_stride;
+    float* mine = &tile[tid * kLdw];
+    for (int j = 0; j < kNSlab; ++j) {
+        slab_load(tile, urow, tile_base, j, n, tid);
+        __syncthreads();
+#pragma unroll 4
+        for (int i = 0; i < kSlab; ++i) {
+            const float x = mine[i];
+#pragma unroll
+            for (int s = 0; s < kSections; ++s) {
+                const float wa = fmaf(-k.a2[s], wa2[s], fmaf(-k.a1[s], wa1[s], x));
+                wa2[s] = wa1[s];
+                wa1[s] = wa;
+                const float wb = fmaf(-k.c2[s], wb2[s], fmaf(-k.c1[s], wb1[s], x * k.ib0[s]));
+                wb2[s] = wb1[s];
+                wb1[s] = wb;
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int s = 0; s < kSections; ++s) {
+        const int64_t base = ((int64_t)sig * 24 + 4 * s) * nc_pad + chunk;
+        z[base] = wa1[s];
+        z[base + nc_pad] = wa2[s];
+        z[base + 2 * (int64_t)nc_pad] = wb1[s];
+        z[base + 3 * (int64_t)nc_pad] = wb2[s];
+    }
+}
+
+// coefficient-gradient partial sums: part[sig][block][30] = {db0 db1 db2 da1 da2} x 6 sections
+__global__ __launch_bounds__(kWG) void k_coefgrad(const float* __restrict__ u, int64_t u_stride,
+                                                  const float* __restrict__ g, int64_t g_stride,
+                                                  const float* __restrict__ rc, int nch,
+                                                  const float* __restrict__ s0, int nc_pad,
+                                                  float* __restrict__ part, int64_t n) {
+    __shared__ __attribute__((aligned(16))) float tile_u[kWG * kLdw];
+    __shared__ __attribute__((aligned(16))) float tile_g[kWG * kLdw];
+    __shared__ float red[4][EP_COUNT];
+    const int tid = threadIdx.x, sig = blockIdx.y;
+    const int64_t tile_base = (int64_t)blockIdx.x * kWG * kEqChunk;
+    const int chunk = blockIdx.x * kWG + tid;
+    ApCoef k;
+    load_ap(rc + (int64_t)(sig / nch) * RC_STRIDE + RC_SOS, k);
+    float wa1[kSections], wa2[kSections], wb1[kSections], wb2[kSections];
+#pragma unroll
+    for (int s = 0; s < kSections; ++s) {
+        const int64_t base = ((int64_t)sig * 24 + 4 * s) * nc_pad + chunk;
+        wa1[s] = s0[base];
+        wa2[s] = s0[base + nc_pad];
+        wb1[s] = s0[base + 2 * (int64_t)nc_pad];
+        wb2[s] = s0[base + 3 * (int64_t)nc_pad];
+    }
+    float acc[EP_COUNT];
+#pragma unroll
+    for (int i = 0; i < EP_COUNT; ++i) acc[i] = 0.0f;
+    const float* urow = u + (int64_t)sig * u_stride;
+    const float* grow = g + (int64_t)sig * g_stride;
+    float* mu = &tile_u[tid * kLdw];
+    float* mg = &tile_g[tid * kLdw];
+    for (int j = 0; j < kNSlab; ++j) {
+        slab_load(tile_u, urow, tile_base, j, n, tid);
+        slab_load(tile_g, grow, tile_base, j, n, tid);
+        __syncthreads();
+#pragma unroll 2
+        for (int i = 0; i < kSlab; ++i) {
+            const float x = mu[i], gg = mg[i];
+#pragma unroll
+            for (int s = 0; s < kSections; ++s) {
+                const float wa = fmaf(-k.a2[s], wa2[s], fmaf(-k.a1[s], wa1[s], x));
+                const float wb = fmaf(-k.c2[s], wb2[s], fmaf(-k.c1[s], wb1[s], x * k.ib0[s]));
+                acc[5 * s + 0] = fmaf(gg, wb, acc[5 * s + 0]);
+                acc[5 * s + 1] = fmaf(gg, wb1[s], acc[5 * s + 1]);
+                acc[5 * s + 2] = fmaf(gg, wb2[s], acc[5 * s + 2]);
+                acc[5 * s + 3] = fmaf(-gg, wa1[s], acc[5 * s + 3]);
+                acc[5 * s + 4] = fmaf(-gg, wa2[s], acc[5 * s + 4]);
+                wa2[s] = wa1[s];
+                wa1[s] = wa;
+                wb2[s] = wb1[s];
+                wb1[s] = wb;
+            }
+        }
+        __syncthreads();
+    }
+    // deterministic workgroup reduction: wave shuffle tree, then 4 wave partials in fixed order
+    const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+    for (int i = 0; i < EP_COUNT; ++i) {
+        const float v = wave_sum(acc[i]);
+        if (lane == 0) red[wave][i] = v;
+    }
+    __syncthreads();
+    if (tid < EP_COUNT)
+        part[((int64_t)sig * gridDim.x + blockIdx.x) * EP_COUNT + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+}
+
+// ---- host-side launch helpers (called from mst_console.hip) --------------------------------------
+void launch_cascade(int dir, bool run, const float* in, int64_t in_stride, float* out, int64_t out_stride,
+                    const float* rc, int nch, const float* s0, float* z, int nc_pad, int64_t n, int nsig,
+                    hipStream_t stream) {
+    dim3 grid(nc_pad / kWG, nsig), block(kWG);
+    if (dir == EQ_FWD && !run)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cascade<EQ_FWD, false>), grid, block, 0, stream, in, in_stride, out, out_stride, rc, nch, s0, z, nc_pad, n);
+    else if (dir == EQ_FWD && run)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cascade<EQ_FWD, true>), grid, block, 0, stream, in, in_stride, out, out_stride, rc, nch, s0, z, nc_pad, n);
+    else if (dir == EQ_ADJ && !run)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cascade<EQ_ADJ, false>), grid, block, 0, stream, in, in_stride, out, out_stride, rc, nch, s0, z, nc_pad, n);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cascade<EQ_ADJ, true>), grid, block, 0, stream, in, in_stride, out, out_stride, rc, nch, s0, z, nc_pad, n);
+}
+
+void launch_allpole_zs(const float* u, int64_t u_stride, const float* rc, int nch, float* z, int nc_pad, int64_t n,
+                       int nsig, hipStream_t stream) {
+    dim3 grid(nc_pad / kWG, nsig), block(kWG);
+    hipLaunchKernelGGL(k_allpole_zs, grid, block, 0, stream, u, u_stride, rc, nch, z, nc_pad, n);
+}
+
+void launch_coefgrad(const float* u, int64_t u_stride, const float* g, int64_t g_stride, const float* rc, int nch,
+                     const float* s0, int nc_pad, float* part, int64_t n, int nsig, hipStream_t stream) {
+    dim3 grid(nc_pad / kWG, nsig), block(kWG);
+    hipLaunchKernelGGL(k_coefgrad, grid, block, 0, stream, u, u_stride, g, g_stride, rc, nch, s0, nc_pad, part, n);
+}
+
+}  // namespace mst

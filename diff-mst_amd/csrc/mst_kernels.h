@@ -1,0 +1,101 @@
+// mst_kernels.h - argument blocks and host-side launch helpers shared by the console translation
+// units (each kernel is launched only from the file that defines it: no relocatable device code).
+#pragma once
+#include "mst_common.h"
+
+namespace mst {
+
+enum { EQ_FWD = 0, EQ_ADJ = 1 };
+
+// ---- mst_params.hip
+struct PrepArgs {
+    const float* track_params;   // (R, 27)
+    const float* fx_params;      // (bs, 25)
+    const float* master_params;  // (bs, 26)
+    float* rc_t;
+    float* rc_m;
+    float* powF_t; float* powF_m;  // forward-cascade scan tables
+    float* powA_t; float* powA_m;  // adjoint-cascade scan tables
+    float* powP_t; float* powP_m;  // all-pole scan tables
+    int32_t* status;
+    int R, bs;
+    int KE;  // chunks per scan lane (EQ scans)
+    mst_console_desc d;
+};
+struct PrepBwdArgs {
+    const float* track_params;
+    const float* master_params;
+    const float* rc_t;
+    const float* rc_m;
+    const float* cp_t; const float* cp_m;  // compressor partial sums  rows x nblkC x CP_COUNT
+    const float* ep_t; const float* ep_m;  // coefficient partial sums sigrows x nblkE x EP_COUNT
+    float* grad_track_params;              // (R,27)
+    float* grad_master_params;             // (bs,26)
+    int R, bs, nblkC, nblkE;
+    mst_console_desc d;
+};
+void launch_prep(const PrepArgs& a, hipStream_t stream);
+void launch_prep_bwd(const PrepBwdArgs& a, hipStream_t stream);
+
+// ---- mst_eq.hip
+void launch_cascade(int dir, bool run, const float* in, int64_t in_stride, float* out, int64_t out_stride, const float* rc,
+                    int nch, const float* s0, float* z, int nc_pad, int64_t n, int nsig, hipStream_t stream);
+void launch_allpole_zs(const float* u, int64_t u_stride, const float* rc, int nch, float* z, int nc_pad, int64_t n, int nsig,
+                       hipStream_t stream);
+void launch_coefgrad(const float* u, int64_t u_stride, const float* g, int64_t g_stride, const float* rc, int nch,
+                     const float* s0, int nc_pad, float* part, int64_t n, int nsig, hipStream_t stream);
+
+// ---- mst_scan.hip
+void launch_scan12(bool reverse, const float* z, float* s0, const float* tab, int nch, int nc, int nc_pad, int K, int nsig,
+                   hipStream_t stream);
+void launch_scan2(const float* z, float* s0, const float* tab, int nch, int nc, int nc_pad, int K, int nsig, hipStream_t stream);
+void launch_scan1(bool reverse, const float* z, float* s0, const float* rc, int nc, int nc_pad, int K, int nrows,
+                  hipStream_t stream);
+
+// ---- mst_comp.hip
+struct TrackApplyArgs {
+    const float* u;      // (R, stride) EQ output
+    int64_t stride;
+    const float* rc;     // (R, RC_STRIDE)
+    const float* s0;     // (R, nc_pad) smoother start states
+    float* gs;           // (R, stride) out: smoothed gain reduction in dB (saved for backward), may be null
+    float* bus;          // (bs, 2, bus_stride) out
+    int64_t bus_stride;
+    float* mixed;        // (bs, 2, T, n) out or null
+    int T, nc_pad, lookahead, comp_on;
+    int64_t n;
+};
+struct MasterApplyArgs {
+    const float* v;      // (bs*2, stride) master EQ output (or the raw bus when the master bus is off)
+    int64_t stride;
+    const float* rc;     // (bs, RC_STRIDE)
+    const float* s0;     // (bs, nc_pad)
+    float* gs;           // (bs, stride) or null
+    float* out;          // (bs, 2, out_stride)
+    int64_t out_stride;
+    int nc_pad, lookahead, comp_on;
+    int64_t n;
+};
+// One argument block for tracks (NCH = 1) and master (NCH = 2).
+struct CompBwdArgs {
+    const float* u;       // (rows*NCH, stride)  compressor input (EQ output)
+    int64_t stride;
+    const float* gs;      // (rows, stride) saved smoothed gain (dB)
+    const float* rc;      // (rows, RC_STRIDE)
+    const float* s0;      // run pass: adjoint smoother state entering each chunk from the right
+    float* zq;            // (rows, nc_pad) out of the zs pass
+    float* du;            // (rows*NCH, stride) out of the run pass: cotangent of the compressor input
+    float* part;          // (rows, nblk, CP_COUNT) out of the run pass
+    const float* gup;     // tracks: grad wrt stereo bus ; master: grad wrt mix ; (bs,2,gup_stride)
+    int64_t gup_stride;
+    const float* gmixed;  // tracks only: grad wrt mixed_tracks (bs,2,T,n) or null
+    int T, nc_pad, lookahead, comp_on;
+    int64_t n;
+};
+void launch_comp_zs(int nch, const float* u, int64_t stride, const float* rc, float* zs, int nc_pad, int64_t n, int rows,
+                    hipStream_t stream);
+void launch_apply_tracks(const TrackApplyArgs& a, int bs, hipStream_t stream);
+void launch_apply_master(const MasterApplyArgs& a, int bs, hipStream_t stream);
+void launch_comp_bwd(bool master, bool run, const CompBwdArgs& a, int rows, hipStream_t stream);
+
+}  // namespace mst

@@ -1,0 +1,430 @@
+// mst_params.hip - parameter kernels of the console:
+//   k_prep      normalised params -> range check, denormalise, RBJ biquad design, compressor /
+//               pan constants, and the S-step transition-matrix power tables the carry scans use
+//   k_prep_bwd  reduce the per-workgroup partial sums and chain them back to the NORMALISED params
+//
+// Reference semantics restated: denormalize / range check mst/modules.py:71-97; index maps
+// :353-460; biquad design + compressor constants + pan law = dasp-pytorch 0.0.1.
+#include "mst_kernels.h"
+
+namespace mst {
+
+// ---------------------------------------------------------------------------------------------
+// fp32-faithful design: the same sequence of fp32 roundings the reference's torch-CPU ops make
+// (no FMA contraction); transcendental values come from fp64 libm rounded once to fp32.
+// kind: 0 low shelf, 1 peaking, 2 high shelf.  out = {b0,b1,b2,a1,a2}/a0.
+// ---------------------------------------------------------------------------------------------
+__device__ void design_section_f32(int kind, float gain_db, float freq, float q, float sr, float* out) {
+#pragma clang fp contract(off)
+    const float A = (float)pow(10.0, (double)(gain_db / 40.0f));
+    const float w0 = 6.283185307179586f * (freq / sr);
+    const float sn = (float)sin((double)w0);
+    const float cw = (float)cos((double)w0);
+    const float alpha = sn / (2.0f * q);
+    const float sA = sqrtf(A);
+    float b0, b1, b2, a0, a1, a2;
+    if (kind == 1) {
+        const float aA = alpha * A;
+        const float aoA = alpha / A;
+        b0 = 1.0f + aA;
+        b1 = -2.0f * cw;
+        b2 = 1.0f - aA;
+        a0 = 1.0f + aoA;
+        a1 = -2.0f * cw;
+        a2 = 1.0f - aoA;
+    } else {
+        const float Ap1 = A + 1.0f, Am1 = A - 1.0f;
+        const float t = (2.0f * sA) * alpha;
+        const float m1 = Am1 * cw, p1 = Ap1 * cw;
+        if (kind == 0) {
+            b0 = A * ((Ap1 - m1) + t);
+            b1 = (2.0f * A) * (Am1 - p1);
+            b2 = A * ((Ap1 - m1) - t);
+            a0 = (Ap1 + m1) + t;
+            a1 = -2.0f * (Am1 + p1);
+            a2 = (Ap1 + m1) - t;
+        } else {
+            b0 = A * ((Ap1 + m1) + t);
+            b1 = (-2.0f * A) * (Am1 + p1);
+            b2 = A * ((Ap1 + m1) - t);
+            a0 = (Ap1 - m1) + t;
+            a1 = 2.0f * (Am1 - p1);
+            a2 = (Ap1 - m1) - t;
+        }
+    }
+    out[0] = b0 / a0;
+    out[1] = b1 / a0;
+    out[2] = b2 / a0;
+    out[3] = a1 / a0;
+    out[4] = a2 / a0;
+}
+
+// forward-mode dual numbers (value + d/d{gain_db, freq, q}) for the design Jacobian
+struct D3 {
+    double v, d[3];
+};
+__device__ inline D3 dconst(double c) { return D3{c, {0, 0, 0}}; }
+__device__ inline D3 operator+(D3 a, D3 b) { return D3{a.v + b.v, {a.d[0] + b.d[0], a.d[1] + b.d[1], a.d[2] + b.d[2]}}; }
+__device__ inline D3 operator-(D3 a, D3 b) { return D3{a.v - b.v, {a.d[0] - b.d[0], a.d[1] - b.d[1], a.d[2] - b.d[2]}}; }
+__device__ inline D3 operator*(D3 a, D3 b) {
+    return D3{a.v * b.v, {a.d[0] * b.v + a.v * b.d[0], a.d[1] * b.v + a.v * b.d[1], a.d[2] * b.v + a.v * b.d[2]}};
+}
+__device__ inline D3 operator/(D3 a, D3 b) {
+    const double r = 1.0 / b.v, q = a.v * r;
+    return D3{q, {(a.d[0] - q * b.d[0]) * r, (a.d[1] - q * b.d[1]) * r, (a.d[2] - q * b.d[2]) * r}};
+}
+__device__ inline D3 dscale(D3 a, double s) { return D3{a.v * s, {a.d[0] * s, a.d[1] * s, a.d[2] * s}}; }
+__device__ inline D3 dfun(D3 a, double f, double fp) { return D3{f, {a.d[0] * fp, a.d[1] * fp, a.d[2] * fp}}; }
+
+__device__ void design_section_dual(int kind, double gain_db, double freq, double q, double sr, D3* out) {
+    D3 g{gain_db, {1, 0, 0}}, f{freq, {0, 1, 0}}, qq{q, {0, 0, 1}};
+    const double Av = pow(10.0, gain_db / 40.0);
+    D3 A = dfun(g, Av, Av * 2.302585092994046 / 40.0);
+    D3 w0 = dscale(f, 6.283185307179586 / sr);
+    D3 sn = dfun(w0, sin(w0.v), cos(w0.v));
+    D3 cw = dfun(w0, cos(w0.v), -sin(w0.v));
+    D3 alpha = sn / dscale(qq, 2.0);
+    const double sAv = sqrt(Av);
+    D3 sA = dfun(A, sAv, 0.5 / sAv);
+    D3 one = dconst(1.0);
+    D3 b0, b1, b2, a0, a1, a2;
+    if (kind == 1) {
+        b0 = one + alpha * A;
+        b1 = dscale(cw, -2.0);
+        b2 = one - alpha * A;
+        a0 = one + alpha / A;
+        a1 = dscale(cw, -2.0);
+        a2 = one - alpha / A;
+    } else {
+        D3 Ap1 = A + one, Am1 = A - one, t = dscale(sA * alpha, 2.0);
+        if (kind == 0) {
+            b0 = A * (Ap1 - Am1 * cw + t);
+            b1 = dscale(A * (Am1 - Ap1 * cw), 2.0);
+            b2 = A * (Ap1 - Am1 * cw - t);
+            a0 = Ap1 + Am1 * cw + t;
+            a1 = dscale(Am1 + Ap1 * cw, -2.0);
+            a2 = Ap1 + Am1 * cw - t;
+        } else {
+            b0 = A * (Ap1 + Am1 * cw + t);
+            b1 = dscale(A * (Am1 + Ap1 * cw), -2.0);
+            b2 = A * (Ap1 + Am1 * cw - t);
+            a0 = Ap1 - Am1 * cw + t;
+            a1 = dscale(Am1 - Ap1 * cw, 2.0);
+            a2 = Ap1 - Am1 * cw - t;
+        }
+    }
+    out[0] = b0 / a0;
+    out[1] = b1 / a0;
+    out[2] = b2 / a0;
+    out[3] = a1 / a0;
+    out[4] = a2 / a0;
+}
+
+__device__ __forceinline__ float denorm(float v, float lo, float hi) {
+#pragma clang fp contract(off)
+    return v * (hi - lo) + lo;
+}
+__device__ __forceinline__ int section_kind(int k) { return k == 0 ? 0 : (k == 5 ? 2 : 1); }
+
+// LDS matrix product C = A*B for 12x12 doubles, one element per lane (lanes 0..143 of the group)
+__device__ __forceinline__ void mat12_mul(const double* A, const double* B, double* C, int e) {
+    const int i = e / 12, j = e % 12;
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) acc += A[i * 12 + k] * B[k * 12 + j];
+    C[e] = acc;
+}
+
+// One workgroup (320 lanes) per filter row: rows [0,R) are tracks, [R,R+bs) master buses.
+__global__ __launch_bounds__(320) void k_prep(PrepArgs a) {
+    __shared__ double mats[2][3][144];  // [fwd|adj][cur, tmp, acc]
+    __shared__ float coef[32];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const bool is_master = row >= a.R;
+    const int mrow = row - a.R;
+    const mst_console_desc& d = a.d;
+    const float sr = d.sample_rate;
+    const float* p = is_master ? a.master_params + (int64_t)mrow * MST_NUM_MASTER_PARAMS
+                               : a.track_params + (int64_t)row * MST_NUM_TRACK_PARAMS;
+    const float* lo = is_master ? d.master_lo : d.track_lo;
+    const float* hi = is_master ? d.master_hi : d.track_hi;
+    float* rc = is_master ? a.rc_m + (int64_t)mrow * RC_STRIDE : a.rc_t + (int64_t)row * RC_STRIDE;
+    const int eq0 = is_master ? 0 : 1;     // index of low_shelf_gain_db
+    const int cmp0 = is_master ? 18 : 19;  // index of threshold_db
+    const int np = is_master ? MST_NUM_MASTER_PARAMS : MST_NUM_TRACK_PARAMS;
+
+    // ---- range check (reference mst/modules.py:86-89), first offender in dictionary order wins
+    if (tid < np) {
+        const float v = p[tid];
+        if (v < 0.0f || v > 1.0f) atomicMax(a.status, 1000 - (1 + (is_master ? 52 : 0) + tid));
+    }
+    if (is_master && tid >= 32 && tid < 32 + 24) {  // fx-bus band gains/decays; "mix" is forced to 1
+        const float v = a.fx_params[(int64_t)mrow * MST_NUM_FX_PARAMS + (tid - 32)];
+        if (v < 0.0f || v > 1.0f) atomicMax(a.status, 1000 - (1 + 27 + (tid - 32)));
+    }
+
+    const bool eq_on = is_master ? (d.flags & MST_USE_MASTER_BUS) : (d.flags & MST_USE_TRACK_EQ);
+    const bool comp_on = is_master ? (d.flags & MST_USE_MASTER_BUS) : (d.flags & MST_USE_TRACK_COMPRESSOR);
+    const bool gin_on = is_master ? (d.flags & MST_USE_MASTER_BUS) : (d.flags & MST_USE_TRACK_INPUT_FADER);
+
+    if (tid < kSections) {
+        float c[5] = {1.f, 0.f, 0.f, 0.f, 0.f};
+        if (eq_on) {
+            const int i = eq0 + 3 * tid;
+            design_section_f32(section_kind(tid), denorm(p[i], lo[i], hi[i]), denorm(p[i + 1], lo[i + 1], hi[i + 1]),
+                               denorm(p[i + 2], lo[i + 2], hi[i + 2]), sr, c);
+        }
+        for (int j = 0; j < 5; ++j) coef[5 * tid + j] = c[j];
+    } else if (tid == 6) {
+#pragma clang fp contract(off)
+        float thr = 0.f, kappa = 0.f, knee = 1.f, alpha = 0.f, mk = 0.f;
+        if (comp_on) {
+            thr = denorm(p[cmp0], lo[cmp0], hi[cmp0]);
+            const float ratio = denorm(p[cmp0 + 1], lo[cmp0 + 1], hi[cmp0 + 1]);
+            const float att = denorm(p[cmp0 + 2], lo[cmp0 + 2], hi[cmp0 + 2]);
+            knee = denorm(p[cmp0 + 4], lo[cmp0 + 4], hi[cmp0 + 4]);
+            mk = denorm(p[cmp0 + 5], lo[cmp0 + 5], hi[cmp0 + 5]);
+            kappa = (1.0f / ratio) - 1.0f;
+            const float nat = sr * (att / 1000.0f);
+            alpha = (float)exp((double)(-2.1972245773362196f / nat));
+        }
+        rc[RC_THR] = thr;
+        rc[RC_KAPPA] = kappa;
+        rc[RC_KNEE] = knee;
+        rc[RC_ALPHA] = alpha;
+        rc[RC_MAKEUP] = mk;
+        rc[RC_ALPHA_C] = (float)pow((double)alpha, (double)kCompChunk);
+    } else if (tid == 7) {
+#pragma clang fp contract(off)
+        float gin = 1.0f;
+        const int gi = is_master ? 25 : 0;
+        if (gin_on) gin = (float)pow(10.0, (double)(denorm(p[gi], lo[gi], hi[gi]) / 20.0f));
+        rc[RC_GIN] = gin;
+        if (is_master) {
+            float gout = 1.0f;
+            if (d.flags & MST_USE_OUTPUT_FADER) gout = (float)pow(10.0, (double)(denorm(p[24], lo[24], hi[24]) / 20.0f));
+            rc[RC_PANL] = gout;
+            rc[RC_PANR] = gout;
+        } else {
+            const float half_pi = 1.5707963267948966f, two_over_pi = 0.6366197723675814f;
+            const float theta = denorm(p[25], lo[25], hi[25]) * half_pi;
+            rc[RC_PANL] = sqrtf(((half_pi - theta) * two_over_pi) * (float)cos((double)theta));
+            rc[RC_PANR] = sqrtf((theta * two_over_pi) * (float)sin((double)theta));
+        }
+    }
+    __syncthreads();
+    if (tid < 30) {
+        float v = coef[tid];
+        if (tid < 3) v *= rc[RC_GIN];  // fold the input fader into section 0's numerator
+        rc[RC_SOS + tid] = v;
+    }
+    __syncthreads();
+
+    // ---- one-sample transition matrices of the forward and the adjoint cascade (zero input)
+    double c64[30];
+    for (int i = 0; i < 30; ++i) c64[i] = (double)rc[RC_SOS + i];
+    if (tid < 24) {
+        const int which = tid / 12, col = tid % 12;
+        double st[12];
+        for (int i = 0; i < 12; ++i) st[i] = (i == col) ? 1.0 : 0.0;
+        if (which == 0) cascade_step<double>(0.0, c64, st);
+        else cascade_adj_step<double>(0.0, c64, st);
+        for (int i = 0; i < 12; ++i) mats[which][0][i * 12 + col] = st[i];
+    }
+    __syncthreads();
+
+    const int grp = tid / 144, e = tid % 144;  // lanes 0..287 own one matrix element each
+    const bool mat_lane = tid < 288;
+    float* powF = (is_master ? a.powF_m + (int64_t)mrow * kPow * 144 : a.powF_t + (int64_t)row * kPow * 144);
+    float* powA = (is_master ? a.powA_m + (int64_t)mrow * kPow * 144 : a.powA_t + (int64_t)row * kPow * 144);
+    float* pw = grp == 0 ? powF : powA;
+    // cur = A^(kEqChunk) by log2(kEqChunk) squarings
+    int cur = 0;
+    for (int s = 1; s < kEqChunk; s <<= 1) {
+        if (mat_lane) mat12_mul(mats[grp][cur], mats[grp][cur], mats[grp][cur ^ 1], e);
+        __syncthreads();
+        cur ^= 1;
+    }
+    if (mat_lane) pw[0 * 144 + e] = (float)mats[grp][cur][e];
+    // acc (slot 2) = cur^KE by binary exponentiation; `cur`/`cur^1` ping-pong the running square
+    if (mat_lane) mats[grp][2][e] = (e / 12 == e % 12) ? 1.0 : 0.0;
+    __syncthreads();
+    for (int k = a.KE; k > 0; k >>= 1) {
+        if (k & 1) {
+            double tmpv = 0.0;
+            if (mat_lane) {
+                const int i = e / 12, j = e % 12;
+                for (int q = 0; q < 12; ++q) tmpv += mats[grp][2][i * 12 + q] * mats[grp][cur][q * 12 + j];
+            }
+            __syncthreads();
+            if (mat_lane) mats[grp][2][e] = tmpv;
+            __syncthreads();
+        }
+        if (k > 1) {
+            if (mat_lane) mat12_mul(mats[grp][cur], mats[grp][cur], mats[grp][cur ^ 1], e);
+            __syncthreads();
+            cur ^= 1;
+        }
+    }
+    // tables 1..kScanLevels: (M^KE)^(2^j)
+    int src = 2;  // accumulator slot holds M^KE
+    for (int j = 0; j < kScanLevels; ++j) {
+        if (mat_lane) pw[(1 + j) * 144 + e] = (float)mats[grp][src][e];
+        if (j + 1 < kScanLevels) {
+            const int dst = (src == 2) ? 0 : (src == 0 ? 1 : 0);
+            if (mat_lane) mat12_mul(mats[grp][src], mats[grp][src], mats[grp][dst], e);
+            __syncthreads();
+            src = dst;
+        }
+    }
+
+    // ---- all-pole filters used by the coefficient-gradient pass: f = 2k (1/A_k), 2k+1 (1/B_k)
+    if (tid >= 288 && tid < 300) {
+        const int f = tid - 288, k = f >> 1;
+        double c1, c2;
+        if (f & 1) {
+            c1 = c64[5 * k + 1] / c64[5 * k + 0];
+            c2 = c64[5 * k + 2] / c64[5 * k + 0];
+        } else {
+            c1 = c64[5 * k + 3];
+            c2 = c64[5 * k + 4];
+        }
+        double m[4] = {-c1, -c2, 1.0, 0.0}, t[4];
+        auto mul = [](const double* x, const double* y, double* o) {
+            o[0] = x[0] * y[0] + x[1] * y[2];
+            o[1] = x[0] * y[1] + x[1] * y[3];
+            o[2] = x[2] * y[0] + x[3] * y[2];
+            o[3] = x[2] * y[1] + x[3] * y[3];
+        };
+        for (int s = 1; s < kEqChunk; s <<= 1) {
+            mul(m, m, t);
+            for (int i = 0; i < 4; ++i) m[i] = t[i];
+        }
+        float* pp = (is_master ? a.powP_m + ((int64_t)mrow * 12 + f) * kPow * 4 : a.powP_t + ((int64_t)row * 12 + f) * kPow * 4);
+        for (int i = 0; i < 4; ++i) pp[i] = (float)m[i];
+        double acc[4] = {1, 0, 0, 1}, base[4] = {m[0], m[1], m[2], m[3]};
+        for (int k2 = a.KE; k2 > 0; k2 >>= 1) {
+            if (k2 & 1) {
+                mul(acc, base, t);
+                for (int i = 0; i < 4; ++i) acc[i] = t[i];
+            }
+            mul(base, base, t);
+            for (int i = 0; i < 4; ++i) base[i] = t[i];
+        }
+        for (int j = 0; j < kScanLevels; ++j) {
+            for (int i = 0; i < 4; ++i) pp[(1 + j) * 4 + i] = (float)acc[i];
+            mul(acc, acc, t);
+            for (int i = 0; i < 4; ++i) acc[i] = t[i];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward of the parameter maps.  One workgroup (64 lanes) per filter row.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_prep_bwd(PrepBwdArgs a) {
+    __shared__ double dsos[EP_COUNT];
+    __shared__ double dcp[CP_COUNT];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const bool is_master = row >= a.R;
+    const int mrow = row - a.R;
+    const mst_console_desc& d = a.d;
+    const double sr = d.sample_rate;
+    const float* p = is_master ? a.master_params + (int64_t)mrow * MST_NUM_MASTER_PARAMS
+                               : a.track_params + (int64_t)row * MST_NUM_TRACK_PARAMS;
+    const float* lo = is_master ? d.master_lo : d.track_lo;
+    const float* hi = is_master ? d.master_hi : d.track_hi;
+    const float* rc = is_master ? a.rc_m + (int64_t)mrow * RC_STRIDE : a.rc_t + (int64_t)row * RC_STRIDE;
+    float* g = is_master ? a.grad_master_params + (int64_t)mrow * MST_NUM_MASTER_PARAMS
+                         : a.grad_track_params + (int64_t)row * MST_NUM_TRACK_PARAMS;
+    const int np = is_master ? MST_NUM_MASTER_PARAMS : MST_NUM_TRACK_PARAMS;
+    const int eq0 = is_master ? 0 : 1, cmp0 = is_master ? 18 : 19;
+    const bool eq_on = is_master ? (d.flags & MST_USE_MASTER_BUS) : (d.flags & MST_USE_TRACK_EQ);
+    const bool comp_on = is_master ? (d.flags & MST_USE_MASTER_BUS) : (d.flags & MST_USE_TRACK_COMPRESSOR);
+    const bool gin_on = is_master ? (d.flags & MST_USE_MASTER_BUS) : (d.flags & MST_USE_TRACK_INPUT_FADER);
+    const bool chain_on = is_master ? (d.flags & MST_USE_MASTER_BUS) : true;  // does the EQ/gain stage exist
+
+    // deterministic reduction of the partial sums (fixed order, fp64)
+    if (tid < EP_COUNT) {
+        double s = 0.0;
+        if (chain_on) {
+            const int nsig = is_master ? 2 : 1;
+            for (int ch = 0; ch < nsig; ++ch) {
+                const float* ep = is_master ? a.ep_m + ((int64_t)(mrow * 2 + ch) * a.nblkE) * EP_COUNT
+                                            : a.ep_t + ((int64_t)row * a.nblkE) * EP_COUNT;
+                for (int b = 0; b < a.nblkE; ++b) s += (double)ep[(int64_t)b * EP_COUNT + tid];
+            }
+        }
+        dsos[tid] = s;
+    } else if (tid >= 32 && tid < 32 + CP_COUNT) {
+        const int i = tid - 32;
+        const float* cp = is_master ? a.cp_m + ((int64_t)mrow * a.nblkC) * CP_COUNT : a.cp_t + ((int64_t)row * a.nblkC) * CP_COUNT;
+        double s = 0.0;
+        for (int b = 0; b < a.nblkC; ++b) s += (double)cp[(int64_t)b * CP_COUNT + i];
+        dcp[i] = s;
+    }
+    if (tid < np) g[tid] = 0.0f;
+    __syncthreads();
+
+    const double gin = rc[RC_GIN];
+    if (tid < kSections) {
+        if (eq_on) {
+            const int k = tid, i = eq0 + 3 * k;
+            D3 J[5];
+            design_section_dual(section_kind(k), (double)denorm(p[i], lo[i], hi[i]), (double)denorm(p[i + 1], lo[i + 1], hi[i + 1]),
+                                (double)denorm(p[i + 2], lo[i + 2], hi[i + 2]), sr, J);
+            const double bs0 = (k == 0) ? gin : 1.0;  // section 0's numerator was scaled by the fader
+            for (int v = 0; v < 3; ++v) {
+                double acc = 0.0;
+                for (int j = 0; j < 5; ++j) acc += dsos[5 * k + j] * J[j].d[v] * (j < 3 ? bs0 : 1.0);
+                g[i + v] = (float)(acc * (double)(hi[i + v] - lo[i + v]));
+            }
+        }
+    } else if (tid == 6) {
+        if (gin_on) {
+            // d/d gin: section-0 numerator b' = gin*b  =>  sum_j dL/db'_j * b_j ;  b_j = b'_j / gin
+            double acc = 0.0;
+            for (int j = 0; j < 3; ++j) acc += dsos[j] * (double)rc[RC_SOS + j];
+            const int gi = is_master ? 25 : 0;
+            // acc = gin * dL/dgin ; d gin / d gain_db = gin*ln10/20
+            g[gi] = (float)(acc * (double)kLn10Over20 * (double)(hi[gi] - lo[gi]));
+        }
+    } else if (tid == 7) {
+        if (comp_on) {
+            const double ratio = (double)denorm(p[cmp0 + 1], lo[cmp0 + 1], hi[cmp0 + 1]);
+            const double att = (double)denorm(p[cmp0 + 2], lo[cmp0 + 2], hi[cmp0 + 2]);
+            const double alpha = rc[RC_ALPHA];
+            g[cmp0 + 0] = (float)(dcp[CP_THR] * (double)(hi[cmp0] - lo[cmp0]));
+            g[cmp0 + 1] = (float)(dcp[CP_KAPPA] * (-1.0 / (ratio * ratio)) * (double)(hi[cmp0 + 1] - lo[cmp0 + 1]));
+            g[cmp0 + 2] = (float)(dcp[CP_ALPHA] * alpha * 2.1972245773362196 * 1000.0 / (sr * att * att) *
+                                  (double)(hi[cmp0 + 2] - lo[cmp0 + 2]));
+            g[cmp0 + 3] = 0.0f;  // release_ms is accepted but unused by the reference op
+            g[cmp0 + 4] = (float)(dcp[CP_KNEE] * (double)(hi[cmp0 + 4] - lo[cmp0 + 4]));
+            g[cmp0 + 5] = (float)(dcp[CP_MAKEUP] * (double)(hi[cmp0 + 5] - lo[cmp0 + 5]));
+        }
+    } else if (tid == 8) {
+        if (is_master) {
+            if (d.flags & MST_USE_OUTPUT_FADER) {
+                // CP_PANL holds sum(grad_out * out_before_fader); d gout/d db = gout*ln10/20
+                g[24] = (float)(dcp[CP_PANL] * (double)rc[RC_PANL] * (double)kLn10Over20 * (double)(hi[24] - lo[24]));
+            }
+        } else {
+            const double half_pi = 1.5707963267948966, two_over_pi = 0.6366197723675814;
+            const double theta = (double)denorm(p[25], lo[25], hi[25]) * half_pi;
+            const double L = rc[RC_PANL], Rr = rc[RC_PANR];
+            double dLdth = 0.0, dRdth = 0.0;
+            if (L > 0.0) dLdth = (-two_over_pi * cos(theta) - (half_pi - theta) * two_over_pi * sin(theta)) / (2.0 * L);
+            if (Rr > 0.0) dRdth = (two_over_pi * sin(theta) + theta * two_over_pi * cos(theta)) / (2.0 * Rr);
+            g[25] = (float)((dcp[CP_PANL] * dLdth + dcp[CP_PANR] * dRdth) * half_pi * (double)(hi[25] - lo[25]));
+        }
+    }
+}
+
+void launch_prep(const PrepArgs& a, hipStream_t stream) {
+    hipLaunchKernelGGL(k_prep, dim3(a.R + a.bs), dim3(320), 0, stream, a);
+}
+void launch_prep_bwd(const PrepBwdArgs& a, hipStream_t stream) {
+    hipLaunchKernelGGL(k_prep_bwd, dim3(a.R + a.bs), dim3(64), 0, stream, a);
+}
+
+}  // namespace mst

@@ -1,0 +1,148 @@
+// mst_scan.hip - carry scans that turn per-chunk zero-state end states into true start states:
+//      s0[c+1] = M s0[c] + z[c]      (forward)       s0[c-1] = M s0[c] + z[c]   (reverse)
+// with a constant D x D matrix per row (D = 12 cascade, D = 2 all-pole, D = 1 envelope smoother).
+// One 1024-lane workgroup per row: each lane folds K consecutive chunks sequentially, a
+// Hillis-Steele scan over the 1024 lane aggregates uses the precomputed powers M^(K 2^j)
+// (uniform per row => scalar loads), then each lane replays its K chunks from its true start.
+#include "mst_kernels.h"
+
+namespace mst {
+
+template <int D>
+__device__ __forceinline__ void matvec_acc(const float* __restrict__ M, const float* v, float* acc) {
+    // acc += M v ; M row-major D x D, uniform address
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        float s = acc[i];
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            if (D == 12 && (j / 2) > (i / 2)) continue;  // cascade matrices are block lower-triangular
+            s = fmaf(M[i * D + j], v[j], s);
+        }
+        acc[i] = s;
+    }
+}
+
+// z, s0: [row][D][nc_pad].  tab: [table_row][kPow][D*D], table_row = (row / tab_div) * tab_mod + row % tab_mod
+template <int D, bool REVERSE>
+__global__ __launch_bounds__(kScanThreads) void k_scan(const float* __restrict__ z, float* __restrict__ s0,
+                                                       const float* __restrict__ tab, int tab_div, int tab_mod,
+                                                       int nc, int nc_pad, int K) {
+    __shared__ float buf[2][D][kScanThreads];
+    const int tid = threadIdx.x, row = blockIdx.x;
+    const float* T = tab + ((int64_t)(row / tab_div) * tab_mod + (row % tab_mod)) * kPow * D * D;
+    const float* zr = z + (int64_t)row * D * nc_pad;
+    float* sr = s0 + (int64_t)row * D * nc_pad;
+    auto cidx = [&](int i) { return REVERSE ? nc - 1 - i : i; };
+
+    // 1. fold my K chunks from zero
+    float agg[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) agg[d] = 0.0f;
+    for (int k = 0; k < K; ++k) {
+        const int i = tid * K + k;
+        float nv[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) nv[d] = (i < nc) ? zr[(int64_t)d * nc_pad + cidx(i)] : 0.0f;
+        matvec_acc<D>(T, agg, nv);
+#pragma unroll
+        for (int d = 0; d < D; ++d) agg[d] = nv[d];
+    }
+    // 2. inclusive Hillis-Steele over lanes
+    int cur = 0;
+#pragma unroll
+    for (int d = 0; d < D; ++d) buf[0][d][tid] = agg[d];
+    __syncthreads();
+    for (int j = 0; j < kScanLevels; ++j) {
+        const int off = 1 << j;
+        if (tid >= off) {
+            float o[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d) o[d] = buf[cur][d][tid - off];
+            matvec_acc<D>(T + (int64_t)(1 + j) * D * D, o, agg);
+        }
+#pragma unroll
+        for (int d = 0; d < D; ++d) buf[cur ^ 1][d][tid] = agg[d];
+        __syncthreads();
+        cur ^= 1;
+    }
+    // 3. exclusive start of my span = inclusive value of the previous lane
+    float st[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) st[d] = (tid > 0) ? buf[cur][d][tid - 1] : 0.0f;
+    for (int k = 0; k < K; ++k) {
+        const int i = tid * K + k;
+        if (i >= nc) break;
+        const int c = cidx(i);
+        float nv[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            sr[(int64_t)d * nc_pad + c] = st[d];
+            nv[d] = zr[(int64_t)d * nc_pad + c];
+        }
+        matvec_acc<D>(T, st, nv);
+#pragma unroll
+        for (int d = 0; d < D; ++d) st[d] = nv[d];
+    }
+}
+
+// D = 1 (envelope smoother): the "matrix" is alpha^kCompChunk taken from the row constants.
+template <bool REVERSE>
+__global__ __launch_bounds__(kScanThreads) void k_scan1(const float* __restrict__ z, float* __restrict__ s0,
+                                                        const float* __restrict__ rc, int nc, int nc_pad, int K) {
+    __shared__ float buf[2][kScanThreads];
+    const int tid = threadIdx.x, row = blockIdx.x;
+    const float a = rc[(int64_t)row * RC_STRIDE + RC_ALPHA_C];
+    const float* zr = z + (int64_t)row * nc_pad;
+    float* sr = s0 + (int64_t)row * nc_pad;
+    auto cidx = [&](int i) { return REVERSE ? nc - 1 - i : i; };
+    float agg = 0.0f;
+    for (int k = 0; k < K; ++k) {
+        const int i = tid * K + k;
+        agg = fmaf(a, agg, (i < nc) ? zr[cidx(i)] : 0.0f);
+    }
+    // a^K by repeated multiplication in double (K is small), then squared per level
+    double pk = 1.0;
+    for (int k = 0; k < K; ++k) pk *= (double)a;
+    float p = (float)pk;
+    int cur = 0;
+    buf[0][tid] = agg;
+    __syncthreads();
+    for (int j = 0; j < kScanLevels; ++j) {
+        const int off = 1 << j;
+        if (tid >= off) agg = fmaf(p, buf[cur][tid - off], agg);
+        buf[cur ^ 1][tid] = agg;
+        __syncthreads();
+        cur ^= 1;
+        p = p * p;
+    }
+    float st = (tid > 0) ? buf[cur][tid - 1] : 0.0f;
+    for (int k = 0; k < K; ++k) {
+        const int i = tid * K + k;
+        if (i >= nc) break;
+        const int c = cidx(i);
+        sr[c] = st;
+        st = fmaf(a, st, zr[c]);
+    }
+}
+
+void launch_scan12(bool reverse, const float* z, float* s0, const float* tab, int nch, int nc, int nc_pad, int K,
+                   int nsig, hipStream_t stream) {
+    if (reverse)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan<12, true>), dim3(nsig), dim3(kScanThreads), 0, stream, z, s0, tab, nch, 1, nc, nc_pad, K);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan<12, false>), dim3(nsig), dim3(kScanThreads), 0, stream, z, s0, tab, nch, 1, nc, nc_pad, K);
+}
+void launch_scan2(const float* z, float* s0, const float* tab, int nch, int nc, int nc_pad, int K, int nsig,
+                  hipStream_t stream) {
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan<2, false>), dim3(nsig * 12), dim3(kScanThreads), 0, stream, z, s0, tab, nch * 12, 12, nc, nc_pad, K);
+}
+void launch_scan1(bool reverse, const float* z, float* s0, const float* rc, int nc, int nc_pad, int K, int nrows,
+                  hipStream_t stream) {
+    if (reverse)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan1<true>), dim3(nrows), dim3(kScanThreads), 0, stream, z, s0, rc, nc, nc_pad, K);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan1<false>), dim3(nrows), dim3(kScanThreads), 0, stream, z, s0, rc, nc, nc_pad, K);
+}
+
+}  // namespace mst

@@ -1,0 +1,66 @@
+"""ctypes binding of the C ABI declared in ``include/diffmst_hip.h``.
+
+``bind(lib)`` only attaches argument / return types to an already opened shared
+library; which library gets opened is decided elsewhere (``mst._hip`` opens the
+gfx950 build and nothing else).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+NUM_TRACK_PARAMS = 27
+NUM_FX_PARAMS = 25
+NUM_MASTER_PARAMS = 26
+
+USE_TRACK_INPUT_FADER = 0x01
+USE_TRACK_EQ = 0x02
+USE_TRACK_COMPRESSOR = 0x04
+USE_TRACK_PANNER = 0x08
+USE_FX_BUS = 0x10
+USE_MASTER_BUS = 0x20
+USE_OUTPUT_FADER = 0x40
+SAVE_FOR_BACKWARD = 0x100
+
+ABI_VERSION = 1
+
+
+class ConsoleDesc(C.Structure):
+    _fields_ = [
+        ("bs", C.c_int32),
+        ("n_tracks", C.c_int32),
+        ("n_samples", C.c_int64),
+        ("track_row_stride", C.c_int64),
+        ("sample_rate", C.c_float),
+        ("flags", C.c_uint32),
+        ("track_lookahead", C.c_int32),
+        ("master_lookahead", C.c_int32),
+        ("track_lo", C.c_float * NUM_TRACK_PARAMS),
+        ("track_hi", C.c_float * NUM_TRACK_PARAMS),
+        ("master_lo", C.c_float * NUM_MASTER_PARAMS),
+        ("master_hi", C.c_float * NUM_MASTER_PARAMS),
+    ]
+
+
+_P = C.c_void_p
+
+SIGNATURES = {
+    "mst_abi_version": (C.c_int, []),
+    "mst_console_workspace_bytes": (C.c_size_t, [C.POINTER(ConsoleDesc)]),
+    "mst_console_forward": (C.c_int, [C.POINTER(ConsoleDesc), _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
+    "mst_console_backward": (C.c_int, [C.POINTER(ConsoleDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
+}
+
+
+def bind(lib: C.CDLL) -> C.CDLL:
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    if lib.mst_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"diffmst ABI mismatch: library {lib.mst_abi_version()} != binding {ABI_VERSION}")
+    return lib
+
+
+def ptr(t):
+    """Device (or host, in the simulator tests) address of a tensor, or NULL for None."""
+    return None if t is None else C.c_void_p(t.data_ptr())

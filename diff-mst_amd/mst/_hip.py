@@ -1,0 +1,48 @@
+"""Loader of the gfx950 kernel library.  Fails loudly: there is NO fallback path."""
+from __future__ import annotations
+
+import ctypes
+import os
+
+from . import _cabi
+
+_PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG_ROOT, "lib", "libdiffmst_hip.so")
+_lib = None
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipLibraryMissing(
+                f"{LIB_PATH} not found - build it with `make -C diff-mst_amd/csrc` "
+                "(hipcc --offload-arch=gfx950) or `python -c 'import __graft_entry__ as g; g.build()'`. "
+                "The mst package has no CPU fallback."
+            )
+        _lib = _cabi.bind(ctypes.CDLL(LIB_PATH))
+    return _lib
+
+
+def current_stream_ptr(device) -> ctypes.c_void_p:
+    import torch
+
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "mst (MI355X build): tensors must live on a ROCm device (got a CPU tensor); "
+                "there is no CPU path in this package"
+            )
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed with hipError {rc}")

@@ -1,0 +1,106 @@
+/* diffmst_hip.h - C ABI of the MI355X-native Diff-MST mix-console hot path.
+ *
+ * The reference (sai-soum/Diff-MST) is pure Python and has no FFI; its seam for this
+ * path is the operator ring of six functions imported from dasp_pytorch.functional
+ * (reference mst/modules.py:7-14, called at :231-312) plus the loss objects called as
+ * loss(pred, target) (reference mst/system.py:331-338).  This header is the C-ABI
+ * ring a maintainer binds instead (ctypes stub: INTEGRATION.md): stateless launchers
+ * over caller-owned device buffers.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless stated; the caller (PyTorch's caching
+ *    allocator) owns all memory; nothing is allocated, freed or retained here;
+ *  - all signals are fp32; tracks are (bs, n_tracks, n_samples) with unit sample stride
+ *    and `track_row_stride` elements between consecutive (b,t) rows (reference
+ *    mst/system.py:258 passes a last-dim slice - SURVEY App. C.7); stereo signals are
+ *    dense (bs, 2, n_samples);
+ *  - every launcher enqueues on `stream` and returns immediately; return value is a
+ *    hipError_t-compatible int (0 = ok), never an exception / abort;
+ *  - semantic errors keep the reference's Python exceptions: the launcher only writes
+ *    a code to `status` (see mst_console_forward) and the host wrapper raises;
+ *  - re-entrant, no global mutable state; one process per GPU.
+ */
+#ifndef DIFFMST_HIP_H
+#define DIFFMST_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MST_NUM_TRACK_PARAMS 27  /* reference mst/modules.py:182 */
+#define MST_NUM_FX_PARAMS 25     /* :183 */
+#define MST_NUM_MASTER_PARAMS 26 /* :184 */
+
+/* flag bits = keyword flags of AdvancedMixConsole.forward (reference mst/modules.py:316-329) */
+#define MST_USE_TRACK_INPUT_FADER 0x01u
+#define MST_USE_TRACK_EQ 0x02u
+#define MST_USE_TRACK_COMPRESSOR 0x04u
+#define MST_USE_TRACK_PANNER 0x08u
+#define MST_USE_FX_BUS 0x10u /* not implemented: launcher returns error */
+#define MST_USE_MASTER_BUS 0x20u
+#define MST_USE_OUTPUT_FADER 0x40u
+#define MST_SAVE_FOR_BACKWARD 0x100u /* keep intermediates in the workspace for mst_console_backward */
+
+/* *status after mst_console_forward: 0 = all parameters in [0,1]; otherwise 1000 - code with
+ * code = 1 + k           track parameter index k out of range   (reference mst/modules.py:353-392)
+ *        1 + 27 + k      fx-bus parameter index k out of range  (:394-422)
+ *        1 + 52 + k      master-bus parameter index k           (:424-460)
+ * the smallest code wins (atomic max of 1000-code), which is the reference's dictionary
+ * iteration order (:79-97).  The launcher zeroes *status itself. */
+
+typedef struct mst_console_desc {
+    int32_t bs;
+    int32_t n_tracks;
+    int64_t n_samples;
+    int64_t track_row_stride; /* elements between (b,t) rows of `tracks` */
+    float sample_rate;
+    uint32_t flags;
+    int32_t track_lookahead;  /* 2048, reference mst/modules.py:250 */
+    int32_t master_lookahead; /* 1024, reference mst/modules.py:304 */
+    /* denormalisation ranges v*(hi-lo)+lo, reference mst/modules.py:71-72,121-181 */
+    float track_lo[MST_NUM_TRACK_PARAMS], track_hi[MST_NUM_TRACK_PARAMS];
+    float master_lo[MST_NUM_MASTER_PARAMS], master_hi[MST_NUM_MASTER_PARAMS];
+} mst_console_desc;
+
+/* Library / ABI version (bumped when a signature changes). */
+int mst_abi_version(void);
+
+/* Bytes of scratch the console needs for `d` (includes everything forward saves for backward). */
+size_t mst_console_workspace_bytes(const mst_console_desc* d);
+
+/* AdvancedMixConsole.forward_mix_console (reference mst/modules.py:186-314) incl. the
+ * denormalise + range check of :79-97: per-track gain -> 6-biquad EQ -> compressor -> pan ->
+ * bus sum -> master gain/EQ/stereo-linked compressor -> output fader.
+ *   tracks            (bs, n_tracks, n_samples) fp32, see strides above
+ *   track_params      (bs, n_tracks, 27) normalised [0,1], dense
+ *   fx_bus_params     (bs, 25) - range-checked only
+ *   master_bus_params (bs, 26)
+ *   mix               (bs, 2, n_samples) out
+ *   mixed_tracks      (bs, 2, n_tracks, n_samples) out, or NULL to skip the API-only copy
+ *   status            one int32 on the device, see codes above
+ *   workspace         >= mst_console_workspace_bytes(d), 256-byte aligned */
+int mst_console_forward(const mst_console_desc* d, const float* tracks, const float* track_params,
+                        const float* fx_bus_params, const float* master_bus_params, float* mix,
+                        float* mixed_tracks, int32_t* status, void* workspace, size_t workspace_bytes,
+                        void* stream);
+
+/* Reverse-mode of the above (what autograd does through the reference's op graph).
+ * `workspace` must be the buffer a forward call with MST_SAVE_FOR_BACKWARD filled, untouched.
+ *   grad_mix           (bs, 2, n_samples)
+ *   grad_mixed_tracks  (bs, 2, n_tracks, n_samples) or NULL
+ *   grad_track_params  (bs, n_tracks, 27) out (w.r.t. the NORMALISED parameters)
+ *   grad_master_params (bs, 26) out
+ *   grad_tracks        (bs, n_tracks, n_samples) dense out, or NULL when tracks need no grad */
+int mst_console_backward(const mst_console_desc* d, const float* tracks, const float* track_params,
+                         const float* master_bus_params, const float* grad_mix,
+                         const float* grad_mixed_tracks, float* grad_track_params,
+                         float* grad_master_params, float* grad_tracks, void* workspace,
+                         size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIFFMST_HIP_H */

@@ -1,0 +1,66 @@
+"""Test harness: runs the C ABI of the kernel sources built against the host-side HIP simulator.
+
+TEST INFRASTRUCTURE ONLY - the product package never loads this library.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "build", "libdiffmst_hostsim.so")
+
+
+def build():
+    subprocess.run(["make", "-s", "-j8", "-C", HERE], check=True)
+    return LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        from mst import _cabi
+
+        build()
+        _lib = _cabi.bind(C.CDLL(LIB))
+    return _lib
+
+
+def console(param_ranges, tracks, tp, fp, mp, flags, grad_mix=None, want_mixed=True, grad_mixed=None,
+            want_grad_tracks=False, sample_rate=44100):
+    """CPU tensors in; returns dict(mix, mixed, status, grad_tp, grad_mp, grad_tracks)."""
+    from mst import _cabi, _desc
+
+    L = lib()
+    bs, T, n = tracks.shape
+    tracks = tracks.contiguous().float()
+    word = _desc.flag_word(save_for_backward=grad_mix is not None, **flags)
+    d = _desc.make_desc(param_ranges, sample_rate, bs, T, n, tracks.stride(1), word)
+    nbytes = L.mst_console_workspace_bytes(C.byref(d))
+    assert nbytes > 0
+    ws = torch.zeros(nbytes // 4 + 64, dtype=torch.float32)
+    off = (-ws.data_ptr() % 256) // 4
+    ws = ws[off:]
+    mix = torch.zeros(bs, 2, n)
+    mixed = torch.zeros(bs, 2, T, n) if want_mixed else None
+    status = torch.zeros(1, dtype=torch.int32)
+    tp, fp, mp = tp.contiguous().float(), fp.contiguous().float(), mp.contiguous().float()
+    rc = L.mst_console_forward(C.byref(d), _cabi.ptr(tracks), _cabi.ptr(tp), _cabi.ptr(fp), _cabi.ptr(mp), _cabi.ptr(mix),
+                               _cabi.ptr(mixed), _cabi.ptr(status), _cabi.ptr(ws), nbytes, None)
+    assert rc == 0, rc
+    out = dict(mix=mix, mixed=mixed, status=int(status.item()))
+    if grad_mix is not None:
+        gtp = torch.full((bs, T, 27), float("nan"))
+        gmp = torch.full((bs, 26), float("nan"))
+        gtr = torch.zeros(bs, T, n) if want_grad_tracks else None
+        gm = grad_mix.contiguous().float()
+        gmx = None if grad_mixed is None else grad_mixed.contiguous().float()
+        rc = L.mst_console_backward(C.byref(d), _cabi.ptr(tracks), _cabi.ptr(tp), _cabi.ptr(mp), _cabi.ptr(gm), _cabi.ptr(gmx),
+                                    _cabi.ptr(gtp), _cabi.ptr(gmp), _cabi.ptr(gtr), _cabi.ptr(ws), nbytes, None)
+        assert rc == 0, rc
+        out.update(grad_tp=gtp, grad_mp=gmp, grad_tracks=gtr)
+    return out

@@ -1,0 +1,156 @@
+// tests/hostsim - a tiny host-side SIMULATOR of the HIP execution model.
+//
+// TEST INFRASTRUCTURE ONLY.  It lets `pytest -m "not gpu"` run the *unchanged*
+// kernel sources of diff-mst_amd/csrc on the CPU (g++ sees this header instead
+// of ROCm's <hip/hip_runtime.h>) so that indexing / scan / carry logic is checked
+// against the oracle in the build container, which has no GPU.  It is never
+// linked into the product library (libdiffmst_hip.so is built by hipcc for
+// gfx950 only) and the mst package refuses to load it.
+//
+// Model: one OS thread per HIP thread of a block, blocks executed one after the
+// other; __syncthreads() = std::barrier over the block; wave64 shuffles through
+// a per-wave exchange buffer + per-wave barrier.  `__shared__` maps to `static`
+// (safe because blocks run sequentially).
+#pragma once
+#include <atomic>
+#include <barrier>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <thread>
+#include <tuple>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __shared__ static
+#define __launch_bounds__(...)
+#define __restrict__ __restrict
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct float2 { float x, y; };
+struct alignas(16) float4 { float x, y, z, w; };
+struct double2 { double x, y; };
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+static inline float2 make_float2(float x, float y) { return float2{x, y}; }
+
+typedef int hipError_t;
+typedef void* hipStream_t;
+#define hipSuccess 0
+#define hipErrorInvalidValue 1
+static inline hipError_t hipGetLastError() { return 0; }
+static inline hipError_t hipPeekAtLastError() { return 0; }
+static inline const char* hipGetErrorString(hipError_t) { return "hostsim"; }
+static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return 0; }
+static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { memcpy(d, s, n); return 0; }
+#define hipMemcpyDeviceToDevice 3
+
+namespace hostsim {
+struct BlockCtx {
+    unsigned nthreads = 0;
+    std::unique_ptr<std::barrier<>> block_bar;
+    std::vector<std::unique_ptr<std::barrier<>>> wave_bar;
+    std::vector<uint64_t> xchg;  // one 64-bit slot per thread
+};
+extern thread_local dim3 t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
+extern thread_local BlockCtx* t_ctx;
+extern thread_local unsigned t_tid;
+
+template <typename T>
+inline T shfl_idx(T v, unsigned src_lane) {
+    static_assert(sizeof(T) <= 8, "shuffle payload");
+    BlockCtx* c = t_ctx;
+    unsigned wave = t_tid >> 6;
+    uint64_t bits = 0;
+    memcpy(&bits, &v, sizeof(T));
+    c->xchg[t_tid] = bits;
+    c->wave_bar[wave]->arrive_and_wait();
+    unsigned src = (wave << 6) + (src_lane & 63u);
+    uint64_t got = (src < c->nthreads) ? c->xchg[src] : bits;
+    c->wave_bar[wave]->arrive_and_wait();
+    T out;
+    memcpy(&out, &got, sizeof(T));
+    return out;
+}
+
+template <typename K, typename... Args>
+void launch(K kernel, dim3 grid, dim3 block, Args... args) {
+    unsigned nt = block.x * block.y * block.z;
+    BlockCtx ctx;
+    ctx.nthreads = nt;
+    ctx.block_bar = std::make_unique<std::barrier<>>(nt);
+    unsigned nw = (nt + 63) / 64;
+    for (unsigned w = 0; w < nw; ++w) {
+        unsigned cnt = (w == nw - 1) ? nt - 64 * w : 64;
+        ctx.wave_bar.emplace_back(std::make_unique<std::barrier<>>(cnt));
+    }
+    ctx.xchg.assign(nt, 0);
+    auto worker = [&](unsigned tid) {
+        t_ctx = &ctx;
+        t_tid = tid;
+        t_blockDim = block;
+        t_gridDim = grid;
+        t_threadIdx = dim3(tid % block.x, (tid / block.x) % block.y, tid / (block.x * block.y));
+        for (unsigned bz = 0; bz < grid.z; ++bz)
+            for (unsigned by = 0; by < grid.y; ++by)
+                for (unsigned bx = 0; bx < grid.x; ++bx) {
+                    t_blockIdx = dim3(bx, by, bz);
+                    kernel(args...);
+                    ctx.block_bar->arrive_and_wait();
+                }
+    };
+    std::vector<std::thread> th;
+    th.reserve(nt);
+    for (unsigned t = 0; t < nt; ++t) th.emplace_back(worker, t);
+    for (auto& t : th) t.join();
+}
+}  // namespace hostsim
+
+#define threadIdx (hostsim::t_threadIdx)
+#define blockIdx (hostsim::t_blockIdx)
+#define blockDim (hostsim::t_blockDim)
+#define gridDim (hostsim::t_gridDim)
+
+#define HIP_KERNEL_NAME(...) __VA_ARGS__
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+    hostsim::launch(kernel, dim3(grid), dim3(block), ##__VA_ARGS__)
+
+static inline void __syncthreads() { hostsim::t_ctx->block_bar->arrive_and_wait(); }
+template <typename T> inline T __shfl(T v, int src, int = 64) { return hostsim::shfl_idx(v, (unsigned)src); }
+template <typename T> inline T __shfl_xor(T v, int m, int = 64) { return hostsim::shfl_idx(v, (hostsim::t_tid & 63u) ^ (unsigned)m); }
+template <typename T> inline T __shfl_up(T v, unsigned d, int = 64) {
+    unsigned lane = hostsim::t_tid & 63u;
+    return hostsim::shfl_idx(v, lane >= d ? lane - d : lane);
+}
+template <typename T> inline T __shfl_down(T v, unsigned d, int = 64) {
+    unsigned lane = hostsim::t_tid & 63u;
+    return hostsim::shfl_idx(v, lane + d < 64 ? lane + d : lane);
+}
+
+static inline int atomicMin(int* p, int v) {
+    int old = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (old > v && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+    return old;
+}
+static inline int atomicMax(int* p, int v) {
+    int old = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (old < v && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+    return old;
+}
+static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+static inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+
+// raw gfx950 transcendental builtins used by the kernels
+static inline float __builtin_amdgcn_logf(float x) { return log2f(x); }
+static inline float __builtin_amdgcn_exp2f(float x) { return exp2f(x); }
+static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
+static inline float __builtin_amdgcn_sqrtf(float x) { return sqrtf(x); }
+static inline float __fdividef(float a, float b) { return a / b; }

@@ -1,0 +1,312 @@
+"""GPU parity tests of the HIP mix console against the oracle and the golden fixtures.
+
+Tolerances (BASELINE north_star: <= 1e-4 relative fp32 vs the CPU reference path):
+  * signals (mix, mixed_tracks, grad_tracks): rel-L2 <= 1e-4 vs the fp32 reference algorithm
+    on the uniform-random parameter set;
+  * parameter gradients: the fp32 reference's own autograd differs from float64 by ~1e-3 overall
+    (ill-conditioned biquad design in fp32), so they are checked three-way:
+    err(HIP, f64) <= 2 * err(ref32, f64) + 1e-4 and overall rel-L2(HIP, ref32) <= 1e-2.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+FULL = dict(use_track_input_fader=True, use_track_eq=True, use_track_compressor=True, use_track_panner=True,
+            use_fx_bus=False, use_master_bus=True, use_output_fader=True)
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-300)).item()
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need the MI355X"
+    from mst import _hip
+
+    _hip.lib()  # the HIP library must be the thing that runs
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def console():
+    from mst.modules import AdvancedMixConsole
+
+    return AdvancedMixConsole(44100)
+
+
+def run_hip(console, dev, tracks, tp, fp, mp, flags, gmix=None, gmixed=None, grad_tracks=False):
+    tr = tracks.to(dev).requires_grad_(grad_tracks)
+    tp_d = tp.to(dev).requires_grad_(gmix is not None)
+    mp_d = mp.to(dev).requires_grad_(gmix is not None)
+    mixed, mix, tpd, fpd, mpd = console(tr, tp_d, fp.to(dev), mp_d, **flags)
+    out = dict(mix=mix, mixed=mixed, tpd=tpd, mpd=mpd)
+    if gmix is not None:
+        loss = (mix * gmix.to(dev)).sum()
+        if gmixed is not None:
+            loss = loss + (mixed * gmixed.to(dev)).sum()
+        loss.backward()
+        out.update(g_tp=tp_d.grad, g_mp=mp_d.grad, g_tracks=tr.grad)
+    torch.cuda.synchronize()
+    return out
+
+
+def run_oracle(tracks, tp, fp, mp, flags, gmix=None, gmixed=None, dtype=torch.float32, grad_tracks=False):
+    from oracle import console_restated as oc
+
+    tr = tracks.to(dtype).requires_grad_(grad_tracks)
+    tp_o = tp.to(dtype).requires_grad_(gmix is not None)
+    mp_o = mp.to(dtype).requires_grad_(gmix is not None)
+    mixed, mix, *_ = oc.console_forward(tr, tp_o, fp.to(dtype), mp_o, **flags)
+    out = dict(mix=mix, mixed=mixed)
+    if gmix is not None:
+        loss = (mix * gmix.to(dtype)).sum()
+        if gmixed is not None:
+            loss = loss + (mixed * gmixed.to(dtype)).sum()
+        loss.backward()
+        zero = lambda t: torch.zeros_like(t) if t.grad is None else t.grad
+        out.update(g_tp=zero(tp_o), g_mp=zero(mp_o), g_tracks=tr.grad)
+    return out
+
+
+def parse_flags(arr):
+    return {k: v == "True" for k, v in arr}
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "console_*.npz"))))
+def test_console_golden(path, console, dev):
+    """Fixtures produced by the REAL reference orchestration (tests/golden/make_golden.py)."""
+    g = np.load(path, allow_pickle=True)
+    flags = parse_flags(g["flags"])
+    t = lambda k: torch.from_numpy(g[k])
+    out = run_hip(console, dev, t("tracks"), t("track_params"), t("fx_bus_params"), t("master_bus_params"), flags,
+                  gmix=t("grad_mix"))
+    assert rel(out["mix"], t("mix")) < 1e-4
+    assert rel(out["mixed"][..., ::64], t("mixed_tracks_sub")) < 1e-4
+    if np.abs(g["grad_track_params"]).max() > 0:
+        assert rel(out["g_tp"], t("grad_track_params")) < 1e-2
+    if np.abs(g["grad_master_bus_params"]).max() > 0:
+        assert rel(out["g_mp"], t("grad_master_bus_params")) < 1e-2
+    else:
+        assert float(out["g_mp"].abs().max()) == 0.0
+    # denormalised parameter dictionaries (reference mst/modules.py:462-466) - exact affine map
+    for k in g.files:
+        if k.startswith("tp."):
+            _, eff, name = k.split(".")
+            assert torch.allclose(out["tpd"][eff][name].cpu(), t(k), rtol=1e-6, atol=1e-6), k
+        if k.startswith("mp."):
+            _, eff, name = k.split(".")
+            assert torch.allclose(out["mpd"][eff][name].cpu(), t(k), rtol=1e-6, atol=1e-6), k
+
+
+@pytest.mark.parametrize("bs,T,n,seed", [(2, 8, 262144, 0), (1, 4, 65536, 1), (2, 3, 131072, 2)])
+def test_console_three_way(bs, T, n, seed, console, dev):
+    """HIP vs fp32 reference algorithm vs float64, forward and backward, BASELINE cfg #2 row shape."""
+    torch.manual_seed(seed)
+    tracks = 0.1 * torch.randn(bs, T, n)
+    tp, fp, mp = torch.rand(bs, T, 27), torch.rand(bs, 25), torch.rand(bs, 26)
+    gmix = torch.randn(bs, 2, n)
+    hip = run_hip(console, dev, tracks, tp, fp, mp, FULL, gmix=gmix, grad_tracks=True)
+    r32 = run_oracle(tracks, tp, fp, mp, FULL, gmix=gmix, grad_tracks=True)
+    r64 = run_oracle(tracks, tp, fp, mp, FULL, gmix=gmix, dtype=torch.float64, grad_tracks=True)
+    report = {}
+    for k in ("mix", "mixed", "g_tracks", "g_tp", "g_mp"):
+        report[k] = (rel(hip[k], r32[k]), rel(hip[k], r64[k]), rel(r32[k], r64[k]))
+    print("\n[three-way] key: (hip vs ref32, hip vs f64, ref32 vs f64)\n", report)
+    for k in ("mix", "mixed"):
+        assert report[k][0] < 1e-4, (k, report[k])
+    for k in ("g_tracks", "g_tp", "g_mp"):
+        h32, h64, r = report[k]
+        assert h64 <= 2 * r + 1e-4, (k, report[k])
+        assert h32 < 1e-2, (k, report[k])
+
+
+def test_interior_parameter_set(console, dev):
+    """0.05 + 0.9*rand parameters: away from the ill-conditioned corners all errors are small."""
+    torch.manual_seed(5)
+    bs, T, n = 2, 4, 65536
+    tracks = 0.1 * torch.randn(bs, T, n)
+    tp, fp, mp = 0.05 + 0.9 * torch.rand(bs, T, 27), torch.rand(bs, 25), 0.05 + 0.9 * torch.rand(bs, 26)
+    tp[..., 2] = 0.3 + 0.6 * torch.rand(bs, T)  # keep the low shelf away from 20 Hz
+    tp[..., 5] = 0.3 + 0.6 * torch.rand(bs, T)
+    mp[..., 1] = 0.3 + 0.6 * torch.rand(bs)
+    mp[..., 4] = 0.3 + 0.6 * torch.rand(bs)
+    gmix = torch.randn(bs, 2, n)
+    hip = run_hip(console, dev, tracks, tp, fp, mp, FULL, gmix=gmix)
+    r64 = run_oracle(tracks, tp, fp, mp, FULL, gmix=gmix, dtype=torch.float64)
+    assert rel(hip["mix"], r64["mix"]) < 1e-4
+    assert rel(hip["g_tp"], r64["g_tp"]) < 2e-3
+    assert rel(hip["g_mp"], r64["g_mp"]) < 2e-3
+
+
+@pytest.mark.parametrize("n", [1, 7, 1000, 2049, 12345, 16384 + 3])
+def test_ragged_lengths(n, console, dev):
+    """Lengths that are not multiples of the chunk / vector width, shorter than the look-ahead, etc."""
+    torch.manual_seed(n)
+    bs, T = 2, 3
+    tracks = 0.1 * torch.randn(bs, T, n)
+    tp, fp, mp = torch.rand(bs, T, 27), torch.rand(bs, 25), torch.rand(bs, 26)
+    gmix = torch.randn(bs, 2, n)
+    hip = run_hip(console, dev, tracks, tp, fp, mp, FULL, gmix=gmix, grad_tracks=True)
+    r64 = run_oracle(tracks, tp, fp, mp, FULL, gmix=gmix, dtype=torch.float64, grad_tracks=True)
+    scale = r64["mix"].abs().max().item() + 1e-30
+    assert (hip["mix"].cpu().double() - r64["mix"]).abs().max().item() / scale < 2e-4
+    assert torch.isfinite(hip["g_tp"]).all() and torch.isfinite(hip["g_mp"]).all()
+    if n >= 1000:
+        assert rel(hip["g_tp"], r64["g_tp"]) < 2e-2
+        assert rel(hip["g_tracks"], r64["g_tracks"]) < 5e-3
+
+
+@pytest.mark.parametrize("off", ["use_track_input_fader", "use_track_eq", "use_track_compressor", "use_master_bus",
+                                 "use_output_fader", "all"])
+def test_flag_combinations(off, console, dev):
+    torch.manual_seed(3)
+    bs, T, n = 2, 3, 20000
+    flags = dict(FULL)
+    if off == "all":
+        flags.update(use_track_eq=False, use_track_compressor=False, use_master_bus=False, use_output_fader=False)
+    else:
+        flags[off] = False
+    tracks = 0.1 * torch.randn(bs, T, n)
+    tp, fp, mp = torch.rand(bs, T, 27), torch.rand(bs, 25), torch.rand(bs, 26)
+    gmix, gmixed = torch.randn(bs, 2, n), torch.randn(bs, 2, T, n)
+    hip = run_hip(console, dev, tracks, tp, fp, mp, flags, gmix=gmix, gmixed=gmixed, grad_tracks=True)
+    r64 = run_oracle(tracks, tp, fp, mp, flags, gmix=gmix, gmixed=gmixed, dtype=torch.float64, grad_tracks=True)
+    assert rel(hip["mix"], r64["mix"]) < 2e-4
+    assert rel(hip["mixed"], r64["mixed"]) < 2e-4
+    assert rel(hip["g_tracks"], r64["g_tracks"]) < 5e-3
+    assert rel(hip["g_tp"], r64["g_tp"]) < 2e-2
+    if r64["g_mp"].abs().max() > 0:
+        assert rel(hip["g_mp"], r64["g_mp"]) < 2e-2
+    else:
+        assert float(hip["g_mp"].abs().max()) == 0.0
+    # parameters of switched-off stages get exactly zero gradient, like autograd's unused leaves
+    g = hip["g_tp"].cpu()
+    if not flags["use_track_eq"]:
+        assert float(g[..., 1:19].abs().max()) == 0.0
+    if not flags["use_track_compressor"]:
+        assert float(g[..., 19:25].abs().max()) == 0.0
+    if not flags["use_track_input_fader"]:
+        assert float(g[..., 0].abs().max()) == 0.0
+    assert float(g[..., 26].abs().max()) == 0.0  # fx send (fx bus off)
+    assert float(g[..., 22].abs().max()) == 0.0  # release_ms is unused by the op
+
+
+def test_basic_console_bitlevel(dev):
+    """BASELINE cfg #1: gain + pan + bus sum, 4 tracks x 65536, batch 2 - the plumbing gate."""
+    from mst.modules import BasicMixConsole
+
+    torch.manual_seed(0)
+    bs, T, n = 2, 4, 65536
+    c = BasicMixConsole(44100)
+    tracks = 0.1 * torch.randn(bs, T, n)
+    tp = torch.rand(bs, T, 27)
+    mixed, mix, *_ = c(tracks.to(dev), tp.to(dev))
+    flags = dict(use_track_input_fader=True, use_track_eq=False, use_track_compressor=False, use_track_panner=True,
+                 use_fx_bus=False, use_master_bus=False, use_output_fader=False)
+    ref = run_oracle(tracks, tp, torch.rand(bs, 25), torch.rand(bs, 26), flags)
+    # element-wise: a few ulp (the reference multiplies then sums; the kernel uses fused multiply-adds)
+    err = (mix.cpu() - ref["mix"]).abs().max().item() / ref["mix"].abs().max().item()
+    assert err < 5e-7, err
+    assert rel(mixed, ref["mixed"]) < 2e-7
+
+
+def test_linearity_and_determinism_full_size(console, dev):
+    """Size-independent properties at BASELINE cfg #2 size: with the compressors off the console is
+    linear in the tracks; every kernel is run-to-run bitwise deterministic (no float atomics)."""
+    torch.manual_seed(9)
+    bs, T, n = 8, 8, 262144
+    flags = dict(FULL, use_track_compressor=False, use_master_bus=True)
+    tp, fp, mp = torch.rand(bs, T, 27).to(dev), torch.rand(bs, 25).to(dev), torch.rand(bs, 26).to(dev)
+    a = (0.1 * torch.randn(bs, T, n)).to(dev)
+    with torch.no_grad():
+        _, m1, *_ = console(a, tp, fp, mp, **FULL)
+        _, m2, *_ = console(a, tp, fp, mp, **FULL)
+    assert torch.equal(m1, m2)
+    # linear sub-chain: tracks -> gain -> EQ -> pan -> bus (master off, so no second compressor)
+    lin = dict(FULL, use_track_compressor=False, use_master_bus=False)
+    b = (0.1 * torch.randn(bs, T, n)).to(dev)
+    with torch.no_grad():
+        _, ma, *_ = console(a, tp, fp, mp, **lin)
+        _, mb, *_ = console(b, tp, fp, mp, **lin)
+        _, mab, *_ = console(2.0 * a - 0.5 * b, tp, fp, mp, **lin)
+    assert rel(mab, 2.0 * ma - 0.5 * mb) < 2e-5
+    del flags
+
+
+def test_strided_tracks_like_system(console, dev):
+    """System passes tracks[..., middle:] (reference mst/system.py:258): row stride != length."""
+    torch.manual_seed(4)
+    bs, T, n = 2, 4, 32768
+    full = (0.1 * torch.randn(bs, T, 2 * n)).to(dev)
+    tp, fp, mp = torch.rand(bs, T, 27).to(dev), torch.rand(bs, 25).to(dev), torch.rand(bs, 26).to(dev)
+    view = full[..., n:]
+    assert not view.is_contiguous()
+    with torch.no_grad():
+        _, m_view, *_ = console(view, tp, fp, mp, **FULL)
+        _, m_copy, *_ = console(view.contiguous(), tp, fp, mp, **FULL)
+    assert torch.equal(m_view, m_copy)
+    with pytest.raises(RuntimeError):  # genuinely non-collapsible input: same failure mode as reference .view
+        console(full.transpose(0, 1), tp, fp, mp, **FULL)
+
+
+def test_out_of_range_value_error(console, dev):
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "bark_fb.npz"))
+    tp, fp, mp = torch.rand(1, 2, 27), torch.rand(1, 25), torch.rand(1, 26)
+    tp[0, 1, 25] = 1.5
+    with pytest.raises(ValueError) as e:
+        console(torch.zeros(1, 2, 4096).to(dev), tp.to(dev), fp.to(dev), mp.to(dev), use_fx_bus=False)
+    assert str(e.value) == str(g["err_text"])  # text produced by the real reference
+    tp[0, 1, 25] = 0.5
+    mp[0, 3] = -0.1
+    tp[0, 0, 7] = 2.0  # two offenders: the reference reports the first in dictionary order (track dict first)
+    with pytest.raises(ValueError, match="Parameter band1_gain_db of effect parametric_eq"):
+        console(torch.zeros(1, 2, 4096).to(dev), tp.to(dev), fp.to(dev), mp.to(dev), use_fx_bus=False)
+    tp[0, 0, 7] = 0.5
+    with pytest.raises(ValueError, match="Parameter band0_gain_db of effect parametric_eq"):
+        console(torch.zeros(1, 2, 4096).to(dev), tp.to(dev), fp.to(dev), mp.to(dev), use_fx_bus=False)
+
+
+def test_deferred_validation(dev):
+    from mst.modules import AdvancedMixConsole
+
+    c = AdvancedMixConsole(44100, validate="deferred", materialize_mixed_tracks=False)
+    tp, fp, mp = torch.rand(1, 2, 27), torch.rand(1, 25), torch.rand(1, 26)
+    fp[0, 3] = 7.0
+    mixed, mix, *_ = c(torch.zeros(1, 2, 4096).to(dev), tp.to(dev), fp.to(dev), mp.to(dev), use_fx_bus=False)
+    assert mixed is None and mix.shape == (1, 2, 4096)
+    with pytest.raises(ValueError, match="Parameter band3_gain of effect reverberation"):
+        c.check_parameters()
+    c.check_parameters()  # cleared
+
+
+def test_naive_random_mix_golden(console, dev):
+    from mst.mixing import naive_random_mix
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "naive_random_mix.npz"))
+    tracks = torch.from_numpy(g["tracks"]).to(dev)
+    torch.manual_seed(int(g["seed"]))
+    r = naive_random_mix(tracks, console, use_fx_bus=False)
+    assert len(r) == 8
+    assert torch.equal(r[5].cpu(), torch.from_numpy(g["mix_params"]))
+    assert torch.equal(r[6].cpu(), torch.from_numpy(g["fx_bus_params"]))
+    assert torch.equal(r[7].cpu(), torch.from_numpy(g["master_bus_params"]))
+    assert rel(r[1], torch.from_numpy(g["mix"])) < 1e-4
+    assert not r[1].requires_grad
+
+
+def test_zero_input_and_silence(console, dev):
+    """All-zero tracks (the reference prints a warning and carries on): output exactly zero, finite grads."""
+    bs, T, n = 1, 2, 8192
+    tp = torch.rand(bs, T, 27).to(dev).requires_grad_(True)
+    mp = torch.rand(bs, 26).to(dev).requires_grad_(True)
+    _, mix, *_ = console(torch.zeros(bs, T, n).to(dev), tp, torch.rand(bs, 25).to(dev), mp, **FULL)
+    mix.sum().backward()
+    assert float(mix.abs().max()) == 0.0
+    assert torch.isfinite(tp.grad).all() and torch.isfinite(mp.grad).all()
