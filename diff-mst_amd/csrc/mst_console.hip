@@ -8,7 +8,7 @@ static int check_desc(const mst_console_desc* d) {
     if (!d || d->bs <= 0 || d->n_tracks <= 0 || d->n_samples <= 0) return hipErrorInvalidValue;
     if (d->flags & MST_USE_FX_BUS) return hipErrorInvalidValue;          // SURVEY 8f rank 4, not built yet
     if (!(d->flags & MST_USE_TRACK_PANNER)) return hipErrorInvalidValue;  // reference branch is broken (mst/modules.py:269)
-    if (d->track_row_stride < d->n_samples || (d->track_row_stride & 3)) return hipErrorInvalidValue;
+    if (d->track_row_stride < d->n_samples) return hipErrorInvalidValue;
     if ((d->track_lookahead & 3) || (d->master_lookahead & 3) || d->track_lookahead < 0 || d->master_lookahead < 0)
         return hipErrorInvalidValue;
     return hipSuccess;
@@ -32,7 +32,6 @@ extern "C" int mst_console_forward(const mst_console_desc* d, const float* track
     const Layout L = make_layout(d);
     if (!workspace || workspace_bytes < (size_t)L.total * sizeof(float) || ((uintptr_t)workspace & 255)) return hipErrorInvalidValue;
     if (!tracks || !track_params || !fx_bus_params || !master_bus_params || !mix || !status) return hipErrorInvalidValue;
-    if (((uintptr_t)tracks & 15) || ((uintptr_t)mix & 15)) return hipErrorInvalidValue;
     hipStream_t stream = (hipStream_t)stream_;
     float* ws = (float*)workspace;
     const int64_t n = L.N, Ns = round_up(L.N, 4);

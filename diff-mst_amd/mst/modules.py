@@ -62,7 +62,7 @@ class _ConsoleFunction(torch.autograd.Function):
         tracks = tracks.float()
         rows = tracks.view(-1, 1, n)  # same contiguity requirement (and RuntimeError) as reference :223
         row_stride = rows.stride(0) if rows.size(0) > 1 else n
-        if rows.stride(2) != 1 or (row_stride % 4) or (rows.data_ptr() % 16) or row_stride < n:
+        if rows.stride(2) != 1 or row_stride < n:
             tracks = tracks.contiguous()
             rows, row_stride = tracks.view(-1, 1, n), n
         tp = track_params.float().contiguous()

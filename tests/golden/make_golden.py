@@ -62,14 +62,42 @@ def flat(d):
     return {f"{e}.{p}": v for e, pd in d.items() for p, v in pd.items()}
 
 
-def console_case(name, bs, T, n, seed, flags, ref_console):
+def short_ir(tp, mp):
+    """Keep every impulse response far shorter than the clip.
+
+    The reference filters by frequency sampling with n_fft = 2^ceil(log2(2n-1)): a CIRCULAR
+    convolution.  At production lengths (n >= 131072) the wrapped tail is < 1e-11, but in a
+    16384-sample fixture a 250 ms attack (tau ~ 5000 samples) or a 20 Hz / Q 5 shelf would alias
+    by percents - an artefact of the short clip, not of the console.  Small fixtures therefore
+    draw attack <= 29.5 ms and low-shelf / band0 corner >= ~300 Hz; the full parameter box is
+    exercised by the n = 131072 fixture.
+    """
+    tp = tp.clone()
+    mp = mp.clone()
+    tp[..., 21] *= 0.1
+    mp[..., 20] *= 0.1
+    tp[..., 2] = 0.15 + 0.85 * tp[..., 2]
+    tp[..., 5] = 0.15 + 0.85 * tp[..., 5]
+    mp[..., 1] = 0.15 + 0.85 * mp[..., 1]
+    mp[..., 4] = 0.15 + 0.85 * mp[..., 4]
+    return tp, mp
+
+
+def console_case(name, bs, T, n, seed, flags, ref_console, full_box=False):
     torch.manual_seed(seed)
     tracks = 0.1 * torch.randn(bs, T, n)
-    tp = torch.rand(bs, T, 27, requires_grad=True)
+    tp = torch.rand(bs, T, 27)
     fp = torch.rand(bs, 25)
-    mp = torch.rand(bs, 26, requires_grad=True)
+    mp = torch.rand(bs, 26)
+    if not full_box:
+        tp, mp = short_ir(tp, mp)
+    tp.requires_grad_(True)
+    mp.requires_grad_(True)
     gmix = torch.randn(bs, 2, n)
 
+    if full_box:  # stored as float16 to keep the fixture small: make the input exactly representable
+        tracks = tracks.half().float()
+        gmix = torch.sign(gmix)
     mixed, mix, tpd, fpd, mpd = ref_console(tracks, tp, fp, mp, **flags)
     (mix * gmix).sum().backward()
     zg = lambda t: torch.zeros_like(t) if t.grad is None else t.grad.clone()
@@ -89,12 +117,13 @@ def console_case(name, bs, T, n, seed, flags, ref_console):
         assert torch.equal(v, flat(o_mpd)[k]), k
 
     out = dict(
-        tracks=tracks.numpy(),
+        tracks=tracks.numpy().astype(np.float16) if full_box else tracks.numpy(),
         track_params=tp.detach().numpy(),
         fx_bus_params=fp.numpy(),
         master_bus_params=mp.detach().numpy(),
-        grad_mix=gmix.numpy(),
-        mix=mix.detach().numpy(),
+        grad_mix=gmix.numpy().astype(np.int8) if full_box else gmix.numpy(),
+        mix=mix.detach().numpy()[..., ::4] if full_box else mix.detach().numpy(),
+        mix_stride=np.array(4 if full_box else 1),
         mixed_tracks_sub=mixed.detach().numpy()[..., ::64],
         grad_track_params=g_tp.numpy(),
         grad_master_bus_params=g_mp.numpy(),
@@ -134,16 +163,19 @@ def main():
     console_case("full_2x4x16384", 2, 4, 16384, 2, full, ref_console)
     console_case("full_1x8x32768", 1, 8, 32768, 3, full, ref_console)
     console_case("refmix_2x3x8192", 2, 3, 8192, 4, refmix, ref_console)
+    # System's training length (mst/system.py:255-258), full parameter box
+    console_case("fullbox_1x2x131072", 1, 2, 131072, 5, full, ref_console, full_box=True)
 
     # naive_random_mix (mixing.py:35-94): RNG draw order and the 8-tuple
     torch.manual_seed(11)
     tracks = 0.1 * torch.randn(2, 4, 8192)
+    tracks = torch.cat([tracks] * 8, dim=-1)  # 65536 samples: long enough for the full parameter box
     torch.manual_seed(12)
     r = rmixing.naive_random_mix(tracks, ref_console, use_fx_bus=False)
     assert len(r) == 8
     np.savez_compressed(
         os.path.join(HERE, "naive_random_mix.npz"),
-        tracks=tracks.numpy(), seed=12, mix=r[1].numpy(), mix_params=r[5].numpy(),
+        tracks=tracks.numpy()[..., :8192], seed=12, mix=r[1].numpy()[..., ::8], mix_params=r[5].numpy(),
         fx_bus_params=r[6].numpy(), master_bus_params=r[7].numpy(),
     )
 
