@@ -1,0 +1,465 @@
+// mst_stft.hip - multi-resolution STFT loss (auraloss 0.4.0 semantics; reference
+// configuration configs/models/naive.yaml:54-68, call site mst/system.py:331).
+//
+//   per resolution: frames of torch.stft(center=True, reflect pad, periodic Hann), hop = n_fft/2..n_fft/4
+//   mag = sqrt(max(re^2+im^2, 1e-8));  SC = ||ym - xm||_F / ||ym||_F (per row or global);
+//   logmag = mean |log xm - log ym|;  loss = mean over resolutions of w_sc SC + w_log logmag + w_lin L1.
+//
+// Kernel shape: one workgroup owns a strip of consecutive frames of one (batch, channel) row.  A
+// frame of the prediction and the same frame of the target are transformed by ONE complex FFT
+// (z = w*(x + i y)) living in LDS (mixed radix-2/4 decimation-in-time, digit-reversed on load),
+// the two spectra are separated by Hermitian symmetry and the magnitude / log / partial-sum
+// epilogue is fused - no spectrogram ever reaches HBM.  Backward recomputes the forward tile,
+// forms dL/dX, and returns two frames' time-domain cotangents per complex FFT; the overlap-add
+// (incl. the reflect-padding fold-back) uses hardware float atomics into grad_pred.
+#include "mst_common.h"
+
+namespace mst {
+
+constexpr int kMaxRes = 8;
+constexpr int kFramesPerWG = 8;  // strip length (forward); backward handles pairs
+
+struct ResInfo {
+    int n_fft, hop, n_frames, n_bins;
+    int64_t tw_off, win_off;  // float offsets into the tables buffer (tw: n_fft float2, win: n_fft floats)
+};
+
+// position of natural index n in the digit-reversed DIT input order.
+// radices (first -> last stage): one radix-2 stage if log2(n_fft) is odd, then radix-4 stages.
+__device__ __forceinline__ int dit_pos(int n, int n_fft, int log2n) {
+    int M = n_fft, p = 0;
+    const int n4 = log2n >> 1;
+    for (int s = 0; s < n4; ++s) {  // last stages first
+        M >>= 2;
+        p += (n & 3) * M;
+        n >>= 2;
+    }
+    if (log2n & 1) p += (n & 1) * (M >> 1);
+    return p;
+}
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+
+// In-place forward DFT (e^{-i...}) of `buf` (n_fft float2 in LDS, input already digit-reversed).
+// tw[t] = (cos, -sin)(2 pi t / n_fft), t < n_fft.  All lanes of the workgroup participate.
+__device__ void lds_fft(float2* buf, const float2* __restrict__ tw, int n_fft, int log2n, int tid, int nthreads) {
+    int L = 1;
+    if (log2n & 1) {
+        for (int b = tid; b < n_fft / 2; b += nthreads) {
+            const float2 a0 = buf[2 * b], a1 = buf[2 * b + 1];
+            buf[2 * b] = make_float2(a0.x + a1.x, a0.y + a1.y);
+            buf[2 * b + 1] = make_float2(a0.x - a1.x, a0.y - a1.y);
+        }
+        L = 2;
+        __syncthreads();
+    }
+    for (; L < n_fft; L <<= 2) {
+        const int tstep = n_fft / (4 * L);
+        for (int b = tid; b < n_fft / 4; b += nthreads) {
+            const int j = b & (L - 1);
+            const int base = ((b - j) << 2) + j;
+            float2 a0 = buf[base], a1 = buf[base + L], a2 = buf[base + 2 * L], a3 = buf[base + 3 * L];
+            if (j) {
+                a1 = cmul(a1, tw[j * tstep]);
+                a2 = cmul(a2, tw[2 * j * tstep]);
+                a3 = cmul(a3, tw[3 * j * tstep]);
+            }
+            const float2 s02 = make_float2(a0.x + a2.x, a0.y + a2.y), d02 = make_float2(a0.x - a2.x, a0.y - a2.y);
+            const float2 s13 = make_float2(a1.x + a3.x, a1.y + a3.y), d13 = make_float2(a1.x - a3.x, a1.y - a3.y);
+            buf[base] = make_float2(s02.x + s13.x, s02.y + s13.y);
+            buf[base + L] = make_float2(d02.x + d13.y, d02.y - d13.x);  // d02 - i d13
+            buf[base + 2 * L] = make_float2(s02.x - s13.x, s02.y - s13.y);
+            buf[base + 3 * L] = make_float2(d02.x - d13.y, d02.y + d13.x);  // d02 + i d13
+        }
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ int64_t reflect_index(int64_t i, int64_t n) {
+    if (i < 0) i = -i;
+    if (i >= n) i = 2 * (n - 1) - i;
+    return i;
+}
+
+// load frame f of (x, y) as z = w (x + i y) into digit-reversed positions
+__device__ __forceinline__ void load_frame(float2* buf, const float* __restrict__ x, const float* __restrict__ y,
+                                           const float* __restrict__ win, int f, const ResInfo& r, int log2n, int64_t n,
+                                           int tid, int nthreads) {
+    const int64_t start = (int64_t)f * r.hop - r.n_fft / 2;
+    for (int k = tid; k < r.n_fft; k += nthreads) {
+        const int64_t i = reflect_index(start + k, n);
+        const float w = win[k];
+        buf[dit_pos(k, r.n_fft, log2n)] = make_float2(w * x[i], y ? w * y[i] : 0.0f);
+    }
+}
+
+struct StftArgs {
+    const float* pred;     // (rows, n)
+    const float* target;   // (rows, n)
+    const float* tables;
+    float* part;           // forward: (rows, n_groups, 4) partial sums {S1, S2, S3, S4}
+    const float* sums;     // backward: (rows, 4) reduced sums of this resolution
+    const float* coef;     // backward: (rows, 4) per-row gradient coefficients {c_sc, c_log, c_lin, -}
+    float* grad_pred;      // backward: (rows, n), accumulated with float atomics
+    ResInfo r;
+    int log2n;
+    int64_t n;
+    float eps;
+};
+
+// separate the two real spectra packed in one complex FFT
+__device__ __forceinline__ void split_xy(const float2* buf, int k, int n_fft, float2& X, float2& Y) {
+    const float2 zk = buf[k], zn = buf[(n_fft - k) & (n_fft - 1)];
+    X = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
+    Y = make_float2(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
+}
+
+constexpr int stft_threads(int n_fft) { return n_fft <= 512 ? 128 : (n_fft <= 2048 ? 512 : 1024); }
+
+template <int NFFT>
+__global__ __launch_bounds__(stft_threads(NFFT)) void k_stft_fwd(StftArgs a) {
+    constexpr int THREADS = stft_threads(NFFT);
+    __shared__ __attribute__((aligned(16))) float2 buf[NFFT];
+    __shared__ float red[16][4];
+    const int tid = threadIdx.x, row = blockIdx.y;
+    const ResInfo r = a.r;
+    const float2* tw = reinterpret_cast<const float2*>(a.tables + r.tw_off);
+    const float* win = a.tables + r.win_off;
+    const float* x = a.pred + (int64_t)row * a.n;
+    const float* y = a.target + (int64_t)row * a.n;
+    float s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f;
+    const int f0 = blockIdx.x * kFramesPerWG;
+    for (int f = f0; f < f0 + kFramesPerWG && f < r.n_frames; ++f) {
+        load_frame(buf, x, y, win, f, r, a.log2n, a.n, tid, THREADS);
+        __syncthreads();
+        lds_fft(buf, tw, r.n_fft, a.log2n, tid, THREADS);
+        for (int k = tid; k < r.n_bins; k += THREADS) {
+            float2 X, Y;
+            split_xy(buf, k, r.n_fft, X, Y);
+            const float xm = sqrtf(fmaxf(X.x * X.x + X.y * X.y, a.eps));
+            const float ym = sqrtf(fmaxf(Y.x * Y.x + Y.y * Y.y, a.eps));
+            const float d = ym - xm;
+            s1 = fmaf(d, d, s1);
+            s2 = fmaf(ym, ym, s2);
+            s3 += fabsf(logf(xm) - logf(ym));
+            s4 += fabsf(d);
+        }
+        __syncthreads();
+    }
+    const int wave = tid >> 6, lane = tid & 63;
+    s1 = wave_sum(s1); s2 = wave_sum(s2); s3 = wave_sum(s3); s4 = wave_sum(s4);
+    if (lane == 0) { red[wave][0] = s1; red[wave][1] = s2; red[wave][2] = s3; red[wave][3] = s4; }
+    __syncthreads();
+    if (tid < 4) {
+        float v = 0.f;
+        for (int w = 0; w < THREADS / 64; ++w) v += red[w][tid];
+        a.part[((int64_t)row * gridDim.x + blockIdx.x) * 4 + tid] = v;
+    }
+}
+
+// cotangent of the packed spectrum for frame f -> accumulated into hbuf as He (first frame) or i*He (second)
+__device__ __forceinline__ void accumulate_dx(const float2* buf, float2* hbuf, const StftArgs& a, const float* coef,
+                                              bool second, int tid, int nthreads) {
+    const ResInfo& r = a.r;
+    const float c_sc = coef[0], c_log = coef[1], c_lin = coef[2];
+    for (int k = tid; k < r.n_bins; k += nthreads) {
+        float2 X, Y;
+        split_xy(buf, k, r.n_fft, X, Y);
+        const float p2 = X.x * X.x + X.y * X.y;
+        const float xm = sqrtf(fmaxf(p2, a.eps));
+        const float ym = sqrtf(fmaxf(Y.x * Y.x + Y.y * Y.y, a.eps));
+        float g = c_sc * (xm - ym);
+        const float dl = logf(xm) - logf(ym);
+        g += c_log * ((dl > 0.f) - (dl < 0.f)) / xm;
+        g += c_lin * ((xm > ym) - (xm < ym));
+        // through sqrt(clamp(|X|^2, eps)): zero below the clamp
+        const float s = (p2 >= a.eps) ? g / xm : 0.0f;
+        float2 G = make_float2(s * X.x, s * X.y);
+        // Hermitian extension whose inverse DFT is the real cotangent frame
+        const bool edge = (k == 0) || (k == r.n_fft / 2);
+        float2 hk = edge ? make_float2(G.x, 0.f) : make_float2(0.5f * G.x, 0.5f * G.y);
+        float2 hn = make_float2(hk.x, -hk.y);
+        if (second) {  // multiply by i
+            hk = make_float2(-hk.y, hk.x);
+            hn = make_float2(-hn.y, hn.x);
+        }
+        const int kn = (r.n_fft - k) & (r.n_fft - 1);
+        if (second) {
+            hbuf[k].x += hk.x; hbuf[k].y += hk.y;
+            if (!edge) { hbuf[kn].x += hn.x; hbuf[kn].y += hn.y; }
+        } else {
+            hbuf[k] = hk;
+            if (!edge) hbuf[kn] = hn;
+        }
+    }
+}
+
+template <int NFFT>
+__global__ __launch_bounds__(stft_threads(NFFT)) void k_stft_bwd(StftArgs a) {
+    constexpr int THREADS = stft_threads(NFFT);
+    __shared__ __attribute__((aligned(16))) float2 buf[NFFT];
+    __shared__ __attribute__((aligned(16))) float2 hbuf[NFFT];
+    const ResInfo r = a.r;
+    const int tid = threadIdx.x, row = blockIdx.y;
+    const float2* tw = reinterpret_cast<const float2*>(a.tables + r.tw_off);
+    const float* win = a.tables + r.win_off;
+    const float* x = a.pred + (int64_t)row * a.n;
+    const float* y = a.target + (int64_t)row * a.n;
+    const float* coef = a.coef + (int64_t)row * 4;
+    float* gx = a.grad_pred + (int64_t)row * a.n;
+    const int fa = 2 * blockIdx.x, fb = fa + 1;
+    const bool have_b = fb < r.n_frames;
+
+    load_frame(buf, x, y, win, fa, r, a.log2n, a.n, tid, THREADS);
+    __syncthreads();
+    lds_fft(buf, tw, r.n_fft, a.log2n, tid, THREADS);
+    accumulate_dx(buf, hbuf, a, coef, false, tid, THREADS);
+    __syncthreads();
+    if (have_b) {
+        load_frame(buf, x, y, win, fb, r, a.log2n, a.n, tid, THREADS);
+        __syncthreads();
+        lds_fft(buf, tw, r.n_fft, a.log2n, tid, THREADS);
+        accumulate_dx(buf, hbuf, a, coef, true, tid, THREADS);
+        __syncthreads();
+    }
+    // inverse DFT via conj(FFT(conj(.))): r1 + i r2
+    for (int k = tid; k < r.n_fft; k += THREADS) {
+        const float2 h = hbuf[k];
+        buf[dit_pos(k, r.n_fft, a.log2n)] = make_float2(h.x, -h.y);
+    }
+    __syncthreads();
+    lds_fft(buf, tw, r.n_fft, a.log2n, tid, THREADS);
+    const int64_t sa = (int64_t)fa * r.hop - r.n_fft / 2, sb = (int64_t)fb * r.hop - r.n_fft / 2;
+    for (int k = tid; k < r.n_fft; k += THREADS) {
+        const float2 v = buf[k];
+        const float w = win[k];
+        unsafeAtomicAdd(&gx[reflect_index(sa + k, a.n)], w * v.x);
+        if (have_b) unsafeAtomicAdd(&gx[reflect_index(sb + k, a.n)], -w * v.y);
+    }
+}
+
+// ---- tables: twiddles (cos, -sin) and the (centre-padded) periodic Hann window -------------------
+__global__ void k_stft_tables(float* tables, ResInfo r, int win_length) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= r.n_fft) return;
+    const double ang = 6.283185307179586476925 * (double)t / (double)r.n_fft;
+    tables[r.tw_off + 2 * t] = (float)cos(ang);
+    tables[r.tw_off + 2 * t + 1] = (float)(-sin(ang));
+    const int off = (r.n_fft - win_length) / 2;
+    float w = 0.0f;
+    if (t >= off && t < off + win_length) {
+        // torch.hann_window(win_length) (periodic), evaluated in fp32 like torch does
+        const float ph = 6.283185307179586f * (float)(t - off) / (float)win_length;
+        w = 0.5f - 0.5f * (float)cos((double)ph);
+    }
+    tables[r.win_off + t] = w;
+}
+
+// ---- reduction of the partial sums + loss + backward coefficients ---------------------------------
+struct LossArgs {
+    const float* part;   // concatenated per resolution: (rows, n_groups[res], 4)
+    float* sums;         // (n_res, rows, 4)
+    float* coef;         // (n_res, rows, 4)
+    float* loss;         // scalar out
+    int n_res, rows;
+    int n_groups[kMaxRes];
+    int64_t part_off[kMaxRes];
+    float count[kMaxRes];  // rows * n_bins * n_frames
+    float w_sc, w_log, w_lin;
+    int sc_per_example;
+};
+// one workgroup of 64 lanes; deterministic
+__global__ __launch_bounds__(64) void k_mrstft_reduce(LossArgs a) {
+    __shared__ double rs[kMaxRes][4];
+    const int tid = threadIdx.x;
+    double total = 0.0;
+    for (int res = 0; res < a.n_res; ++res) {
+        double tot[4] = {0, 0, 0, 0};
+        double sc_acc = 0.0;
+        for (int row = 0; row < a.rows; ++row) {
+            double s[4] = {0, 0, 0, 0};
+            const float* p = a.part + a.part_off[res] + (int64_t)row * a.n_groups[res] * 4;
+            for (int g = tid; g < a.n_groups[res]; g += 64)
+                for (int q = 0; q < 4; ++q) s[q] += (double)p[(int64_t)g * 4 + q];
+            for (int q = 0; q < 4; ++q) {
+                for (int m = 32; m >= 1; m >>= 1) s[q] += __shfl_xor(s[q], m);
+                tot[q] += s[q];
+            }
+            if (tid < 4) a.sums[((int64_t)res * a.rows + row) * 4 + tid] = (float)s[tid];
+            sc_acc += sqrt(s[0]) / sqrt(s[1]);
+        }
+        const double sc = a.sc_per_example ? sc_acc / a.rows : sqrt(tot[0]) / sqrt(tot[1]);
+        total += a.w_sc * sc + a.w_log * tot[2] / a.count[res] + a.w_lin * tot[3] / a.count[res];
+        if (tid < 4) rs[res][tid] = tot[tid];
+    }
+    __syncthreads();
+    if (tid == 0) a.loss[0] = (float)(total / a.n_res);
+    // backward coefficients (without the upstream dL/dloss, applied by k_mrstft_coef)
+    for (int res = 0; res < a.n_res; ++res)
+        for (int row = tid; row < a.rows; row += 64) {
+            const float* s = a.sums + ((int64_t)res * a.rows + row) * 4;
+            double c_sc;
+            if (a.sc_per_example) c_sc = a.w_sc / ((double)a.rows * sqrt((double)s[0]) * sqrt((double)s[1]));
+            else c_sc = a.w_sc / (sqrt(rs[res][0]) * sqrt(rs[res][1]));
+            if (!(c_sc == c_sc) || c_sc > 1e30) c_sc = 0.0;  // identical signals: 0/0 -> no SC gradient
+            float* c = a.coef + ((int64_t)res * a.rows + row) * 4;
+            c[0] = (float)(c_sc / a.n_res);
+            c[1] = (float)(a.w_log / a.count[res] / a.n_res);
+            c[2] = (float)(a.w_lin / a.count[res] / a.n_res);
+            c[3] = 0.f;
+        }
+}
+__global__ void k_scale_coef(const float* coef, const float* grad_loss, float* out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = coef[i] * grad_loss[0];
+}
+
+}  // namespace mst
+
+// ======================================================================================= C ABI
+using namespace mst;
+
+namespace {
+struct Plan {
+    ResInfo res[kMaxRes];
+    int log2n[kMaxRes], n_groups[kMaxRes], win[kMaxRes];
+    int64_t part_off[kMaxRes];
+    int64_t tables_floats;
+    // workspace (floats): part | sums | coef | coef_scaled
+    int64_t part_total, sums_off, coef_off, coefs_off, ws_floats;
+    bool ok;
+};
+Plan make_plan(const mst_mrstft_desc* d) {
+    Plan p{};
+    p.ok = false;
+    if (!d || d->rows <= 0 || d->n_res <= 0 || d->n_res > kMaxRes) return p;
+    int64_t t = 0, po = 0;
+    for (int i = 0; i < d->n_res; ++i) {
+        const int nf = d->fft_size[i];
+        int lg = 0;
+        while ((1 << lg) < nf) ++lg;
+        if ((1 << lg) != nf || nf < 128 || nf > 8192) return p;
+        if (d->hop_size[i] <= 0 || d->win_length[i] <= 0 || d->win_length[i] > nf) return p;
+        if (d->n_samples <= nf / 2) return p;  // reflect padding needs n > n_fft/2 (torch.stft raises)
+        ResInfo& r = p.res[i];
+        r.n_fft = nf;
+        r.hop = d->hop_size[i];
+        r.n_frames = 1 + (int)(d->n_samples / r.hop);
+        r.n_bins = nf / 2 + 1;
+        r.tw_off = t;
+        t += 2 * (int64_t)nf;
+        r.win_off = t;
+        t += nf;
+        p.log2n[i] = lg;
+        p.win[i] = d->win_length[i];
+        p.n_groups[i] = (r.n_frames + kFramesPerWG - 1) / kFramesPerWG;
+        p.part_off[i] = po;
+        po += (int64_t)d->rows * p.n_groups[i] * 4;
+    }
+    p.tables_floats = t;
+    p.part_total = round_up(po, 64);
+    p.sums_off = p.part_total;
+    p.coef_off = p.sums_off + round_up((int64_t)d->n_res * d->rows * 4, 64);
+    p.coefs_off = p.coef_off + round_up((int64_t)d->n_res * d->rows * 4, 64);
+    p.ws_floats = p.coefs_off + round_up((int64_t)d->n_res * d->rows * 4, 64);
+    p.ok = true;
+    return p;
+}
+#define MST_FOR_NFFT(nf, CALL) \
+    switch (nf) {               \
+        case 128: CALL(128); break;   \
+        case 256: CALL(256); break;   \
+        case 512: CALL(512); break;   \
+        case 1024: CALL(1024); break; \
+        case 2048: CALL(2048); break; \
+        case 4096: CALL(4096); break; \
+        case 8192: CALL(8192); break; \
+        default: break;               \
+    }
+}  // namespace
+
+extern "C" size_t mst_mrstft_tables_bytes(const mst_mrstft_desc* d) {
+    const Plan p = make_plan(d);
+    return p.ok ? (size_t)p.tables_floats * sizeof(float) : 0;
+}
+extern "C" size_t mst_mrstft_workspace_bytes(const mst_mrstft_desc* d) {
+    const Plan p = make_plan(d);
+    return p.ok ? (size_t)p.ws_floats * sizeof(float) : 0;
+}
+extern "C" int mst_mrstft_init_tables(const mst_mrstft_desc* d, void* tables, void* stream_) {
+    const Plan p = make_plan(d);
+    if (!p.ok || !tables) return hipErrorInvalidValue;
+    hipStream_t stream = (hipStream_t)stream_;
+    for (int i = 0; i < d->n_res; ++i)
+        hipLaunchKernelGGL(k_stft_tables, dim3((p.res[i].n_fft + 255) / 256), dim3(256), 0, stream, (float*)tables, p.res[i], p.win[i]);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mst_mrstft_forward(const mst_mrstft_desc* d, const float* pred, const float* target, const void* tables,
+                                  float* loss, void* workspace, size_t workspace_bytes, void* stream_) {
+    const Plan p = make_plan(d);
+    if (!p.ok || !pred || !target || !tables || !loss || !workspace) return hipErrorInvalidValue;
+    if (workspace_bytes < (size_t)p.ws_floats * sizeof(float)) return hipErrorInvalidValue;
+    hipStream_t stream = (hipStream_t)stream_;
+    float* ws = (float*)workspace;
+    LossArgs la{};
+    la.part = ws;
+    la.sums = ws + p.sums_off;
+    la.coef = ws + p.coef_off;
+    la.loss = loss;
+    la.n_res = d->n_res;
+    la.rows = d->rows;
+    la.w_sc = d->w_sc;
+    la.w_log = d->w_log_mag;
+    la.w_lin = d->w_lin_mag;
+    la.sc_per_example = d->sc_per_example;
+    for (int i = 0; i < d->n_res; ++i) {
+        StftArgs a{};
+        a.pred = pred;
+        a.target = target;
+        a.tables = (const float*)tables;
+        a.part = ws + p.part_off[i];
+        a.r = p.res[i];
+        a.log2n = p.log2n[i];
+        a.n = d->n_samples;
+        a.eps = d->eps;
+        const dim3 grid(p.n_groups[i], d->rows);
+#define MST_LAUNCH_FWD(NF) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stft_fwd<NF>), grid, dim3(stft_threads(NF)), 0, stream, a)
+        MST_FOR_NFFT(a.r.n_fft, MST_LAUNCH_FWD)
+        la.n_groups[i] = p.n_groups[i];
+        la.part_off[i] = p.part_off[i];
+        la.count[i] = (float)((double)d->rows * p.res[i].n_bins * p.res[i].n_frames);
+    }
+    hipLaunchKernelGGL(k_mrstft_reduce, dim3(1), dim3(64), 0, stream, la);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mst_mrstft_backward(const mst_mrstft_desc* d, const float* pred, const float* target, const void* tables,
+                                   const float* grad_loss, float* grad_pred, void* workspace, size_t workspace_bytes,
+                                   void* stream_) {
+    const Plan p = make_plan(d);
+    if (!p.ok || !pred || !target || !tables || !grad_loss || !grad_pred || !workspace) return hipErrorInvalidValue;
+    if (workspace_bytes < (size_t)p.ws_floats * sizeof(float)) return hipErrorInvalidValue;
+    hipStream_t stream = (hipStream_t)stream_;
+    float* ws = (float*)workspace;
+    const int nc = d->n_res * d->rows * 4;
+    hipLaunchKernelGGL(k_scale_coef, dim3((nc + 255) / 256), dim3(256), 0, stream, ws + p.coef_off, grad_loss, ws + p.coefs_off, nc);
+    hipMemsetAsync(grad_pred, 0, (size_t)d->rows * d->n_samples * sizeof(float), stream);
+    for (int i = 0; i < d->n_res; ++i) {
+        StftArgs a{};
+        a.pred = pred;
+        a.target = target;
+        a.tables = (const float*)tables;
+        a.sums = ws + p.sums_off + (int64_t)i * d->rows * 4;
+        a.coef = ws + p.coefs_off + (int64_t)i * d->rows * 4;
+        a.grad_pred = grad_pred;
+        a.r = p.res[i];
+        a.log2n = p.log2n[i];
+        a.n = d->n_samples;
+        a.eps = d->eps;
+        const dim3 grid((a.r.n_frames + 1) / 2, d->rows);
+#define MST_LAUNCH_BWD(NF) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stft_bwd<NF>), grid, dim3(stft_threads(NF)), 0, stream, a)
+        MST_FOR_NFFT(a.r.n_fft, MST_LAUNCH_BWD)
+    }
+    return (int)hipGetLastError();
+}

@@ -41,6 +41,25 @@ class ConsoleDesc(C.Structure):
     ]
 
 
+MAX_RESOLUTIONS = 8
+
+
+class MrstftDesc(C.Structure):
+    _fields_ = [
+        ("rows", C.c_int32),
+        ("n_samples", C.c_int64),
+        ("n_res", C.c_int32),
+        ("fft_size", C.c_int32 * MAX_RESOLUTIONS),
+        ("hop_size", C.c_int32 * MAX_RESOLUTIONS),
+        ("win_length", C.c_int32 * MAX_RESOLUTIONS),
+        ("w_sc", C.c_float),
+        ("w_log_mag", C.c_float),
+        ("w_lin_mag", C.c_float),
+        ("sc_per_example", C.c_int32),
+        ("eps", C.c_float),
+    ]
+
+
 _P = C.c_void_p
 
 SIGNATURES = {
@@ -48,6 +67,14 @@ SIGNATURES = {
     "mst_console_workspace_bytes": (C.c_size_t, [C.POINTER(ConsoleDesc)]),
     "mst_console_forward": (C.c_int, [C.POINTER(ConsoleDesc), _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "mst_console_backward": (C.c_int, [C.POINTER(ConsoleDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
+    "mst_mrstft_tables_bytes": (C.c_size_t, [C.POINTER(MrstftDesc)]),
+    "mst_mrstft_init_tables": (C.c_int, [C.POINTER(MrstftDesc), _P, _P]),
+    "mst_mrstft_workspace_bytes": (C.c_size_t, [C.POINTER(MrstftDesc)]),
+    "mst_mrstft_forward": (C.c_int, [C.POINTER(MrstftDesc), _P, _P, _P, _P, _P, C.c_size_t, _P]),
+    "mst_mrstft_backward": (C.c_int, [C.POINTER(MrstftDesc), _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
+    "mst_peak_normalize_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int64]),
+    "mst_peak_normalize_forward": (C.c_int, [_P, _P, C.c_int32, C.c_int64, _P, C.c_size_t, _P]),
+    "mst_peak_normalize_backward": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int64, _P, C.c_size_t, _P]),
 }
 
 

@@ -100,6 +100,46 @@ int mst_console_backward(const mst_console_desc* d, const float* tracks, const f
                          float* grad_master_params, float* grad_tracks, void* workspace,
                          size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Multi-resolution STFT loss: auraloss.freq.MultiResolutionSTFTLoss as configured by the
+ * reference (configs/models/naive.yaml:54-68; called as loss(pred, target), mst/system.py:331).
+ * pred / target are (rows, n_samples) dense fp32 with rows = bs * channels. */
+#define MST_MAX_RESOLUTIONS 8
+typedef struct mst_mrstft_desc {
+    int32_t rows;
+    int64_t n_samples;
+    int32_t n_res;
+    int32_t fft_size[MST_MAX_RESOLUTIONS];   /* powers of two, 128..8192 */
+    int32_t hop_size[MST_MAX_RESOLUTIONS];
+    int32_t win_length[MST_MAX_RESOLUTIONS]; /* periodic Hann, centre-padded to fft_size */
+    float w_sc, w_log_mag, w_lin_mag;        /* auraloss defaults 1, 1, 0 */
+    int32_t sc_per_example;                  /* 1: mean over rows of per-row norm ratios (0.4.0); 0: global ratio */
+    float eps;                               /* clamp of |X|^2, 1e-8 */
+} mst_mrstft_desc;
+
+/* Twiddle + window tables: built once per descriptor into caller memory, read-only afterwards. */
+size_t mst_mrstft_tables_bytes(const mst_mrstft_desc* d);
+int mst_mrstft_init_tables(const mst_mrstft_desc* d, void* tables, void* stream);
+/* Per-call scratch; forward leaves what backward needs in it. */
+size_t mst_mrstft_workspace_bytes(const mst_mrstft_desc* d);
+/* loss: one fp32 on the device. */
+int mst_mrstft_forward(const mst_mrstft_desc* d, const float* pred, const float* target, const void* tables,
+                       float* loss, void* workspace, size_t workspace_bytes, void* stream);
+/* grad_loss: one fp32 on the device (dL/dloss); grad_pred (rows, n_samples) is overwritten. */
+int mst_mrstft_backward(const mst_mrstft_desc* d, const float* pred, const float* target, const void* tables,
+                        const float* grad_loss, float* grad_pred, void* workspace, size_t workspace_bytes,
+                        void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * batch_stereo_peak_normalize (reference mst/utils.py:14-29): y = x / clamp(max_{ch,t}|x|, 1e-8)
+ * per batch item; x, y, grads are dense (bs, 2, n_samples).  The workspace written by forward is
+ * what backward reads (peak and arg-max per batch item). */
+size_t mst_peak_normalize_workspace_bytes(int32_t bs, int64_t n_samples);
+int mst_peak_normalize_forward(const float* x, float* y, int32_t bs, int64_t n_samples, void* workspace,
+                               size_t workspace_bytes, void* stream);
+int mst_peak_normalize_backward(const float* x, const float* grad_y, float* grad_x, int32_t bs, int64_t n_samples,
+                                void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

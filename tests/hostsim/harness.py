@@ -64,3 +64,33 @@ def console(param_ranges, tracks, tp, fp, mp, flags, grad_mix=None, want_mixed=T
         assert rc == 0, rc
         out.update(grad_tp=gtp, grad_mp=gmp, grad_tracks=gtr)
     return out
+
+
+def mrstft(pred, target, resolutions, w_sc=1.0, w_log_mag=1.0, w_lin_mag=0.0, sc_per_example=True, grad=True):
+    """(bs, chs, n) CPU tensors -> dict(loss, grad_pred)."""
+    from mst import _cabi
+
+    L = lib()
+    x = pred.reshape(-1, pred.shape[-1]).contiguous().float()
+    y = target.reshape(-1, target.shape[-1]).contiguous().float()
+    d = _cabi.MrstftDesc()
+    d.rows, d.n_samples, d.n_res = x.shape[0], x.shape[1], len(resolutions)
+    for i, (nf, hop, win) in enumerate(resolutions):
+        d.fft_size[i], d.hop_size[i], d.win_length[i] = nf, hop, win
+    d.w_sc, d.w_log_mag, d.w_lin_mag = w_sc, w_log_mag, w_lin_mag
+    d.sc_per_example, d.eps = int(sc_per_example), 1e-8
+    tb, wb = L.mst_mrstft_tables_bytes(C.byref(d)), L.mst_mrstft_workspace_bytes(C.byref(d))
+    assert tb > 0 and wb > 0
+    tables = torch.zeros(tb // 4)
+    ws = torch.zeros(wb // 4)
+    assert L.mst_mrstft_init_tables(C.byref(d), _cabi.ptr(tables), None) == 0
+    loss = torch.zeros(1)
+    assert L.mst_mrstft_forward(C.byref(d), _cabi.ptr(x), _cabi.ptr(y), _cabi.ptr(tables), _cabi.ptr(loss), _cabi.ptr(ws), wb, None) == 0
+    out = dict(loss=loss.clone())
+    if grad:
+        gl = torch.ones(1)
+        gx = torch.full_like(x, float("nan"))
+        assert L.mst_mrstft_backward(C.byref(d), _cabi.ptr(x), _cabi.ptr(y), _cabi.ptr(tables), _cabi.ptr(gl), _cabi.ptr(gx),
+                                     _cabi.ptr(ws), wb, None) == 0
+        out["grad_pred"] = gx.view_as(pred)
+    return out

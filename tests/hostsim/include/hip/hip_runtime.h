@@ -145,6 +145,17 @@ static inline int atomicMax(int* p, int v) {
     while (old < v && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
     return old;
 }
+static inline float unsafeAtomicAdd(float* p, float v) {
+    uint32_t o = __atomic_load_n((uint32_t*)p, __ATOMIC_RELAXED);  // CAS loop on the bit pattern
+    for (;;) {
+        float old;
+        memcpy(&old, &o, 4);
+        const float want = old + v;
+        uint32_t w;
+        memcpy(&w, &want, 4);
+        if (__atomic_compare_exchange_n((uint32_t*)p, &o, w, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) return old;
+    }
+}
 static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 
@@ -154,3 +165,5 @@ static inline float __builtin_amdgcn_exp2f(float x) { return exp2f(x); }
 static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
 static inline float __builtin_amdgcn_sqrtf(float x) { return sqrtf(x); }
 static inline float __fdividef(float a, float b) { return a / b; }
+static inline float __int_as_float(int v) { float f; memcpy(&f, &v, 4); return f; }
+static inline int __float_as_int(float f) { int v; memcpy(&v, &f, 4); return v; }
