@@ -29,6 +29,7 @@ constexpr int RC_ALPHA_C = 35; // alpha^kCompChunk
 constexpr int RC_PANL = 36;    // tracks: left pan gain   | master: output-fader linear gain
 constexpr int RC_PANR = 37;    // tracks: right pan gain  | master: output-fader linear gain
 constexpr int RC_GIN = 38;     // input-fader linear gain (already folded into section 0)
+constexpr int RC_LOG2A_C = 39; // log2(alpha^kCompChunk), from fp64
 constexpr int RC_STRIDE = 40;
 
 // partial-sum slots of the compressor backward kernel

@@ -58,7 +58,50 @@ __device__ __forceinline__ void st8(float* row, int64_t i, int64_t n, const floa
     store4(row, i + 4, n, make_float4(v[4], v[5], v[6], v[7]));
 }
 
-// ---- forward: zero-state end value of the smoother per lane chunk ------------------------------
+// ---- first-order carry machinery -------------------------------------------------------------------
+// Per lane chunk the smoother is  s_out = a s_in + z  (a = alpha^8, z = zero-state end value).
+// block_enter<REV>() returns the state ENTERING this lane's chunk given the state S entering the
+// workgroup's 2048-sample block: wave-level Hillis-Steele with shuffles, wave aggregates through LDS.
+// Scan order is lane-ascending (forward recursion) or lane-descending (REV, the adjoint recursion).
+template <bool REV>
+__device__ __forceinline__ float block_enter(float z, float a, float log2a, float S, float* lds, int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const int rl = REV ? 63 - lane : lane, rw = REV ? 3 - wave : wave;
+    float v = z, p = a;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const float o = REV ? __shfl_down(v, d) : __shfl_up(v, d);
+        if (rl >= d) v = fmaf(p, o, v);
+        p *= p;
+    }
+    if (rl == 63) lds[rw] = v;  // zero-entry aggregate of this wave
+    __syncthreads();
+    float sw = S;  // state entering this wave
+    for (int w = 0; w < rw; ++w) sw = fmaf(p, sw, lds[w]);  // p == a^64
+    float ex = REV ? __shfl_down(v, 1) : __shfl_up(v, 1);
+    if (rl == 0) ex = 0.0f;
+    __syncthreads();  // lds may be reused by the caller's next call
+    return fmaf(__builtin_amdgcn_exp2f((float)rl * log2a), sw, ex);
+}
+// state entering block `blk` from the aggregates of the blocks before it (after it when REV):
+//   S = sum_j A^(dist-1) agg[j],  A = a^256, computed in a fixed order by the whole workgroup
+template <bool REV>
+__device__ __forceinline__ float block_carry(const float* __restrict__ agg, int blk, int nblk, float log2a, float* lds, int tid) {
+    float acc = 0.0f;
+    if (REV) {
+        for (int j = blk + 1 + tid; j < nblk; j += kWG) acc += __builtin_amdgcn_exp2f((float)(j - blk - 1) * 256.0f * log2a) * agg[j];
+    } else {
+        for (int j = blk - 1 - tid; j >= 0; j -= kWG) acc += __builtin_amdgcn_exp2f((float)(blk - 1 - j) * 256.0f * log2a) * agg[j];
+    }
+    acc = wave_sum(acc);
+    if ((tid & 63) == 0) lds[4 + (tid >> 6)] = acc;
+    __syncthreads();
+    const float S = (lds[4] + lds[5]) + (lds[6] + lds[7]);
+    __syncthreads();
+    return S;
+}
+
+// ---- forward: zero-state end value of the smoother per 2048-sample block ---------------------------
 // u: [(row*NCH+ch)][stride]; zs: [row][nc_pad]
 template <int NCH>
 __global__ __launch_bounds__(kWG) void k_comp_zs(const float* __restrict__ u, int64_t stride, const float* __restrict__ rc,
@@ -74,6 +117,7 @@ __global__ __launch_bounds__(kWG) void k_comp_zs(const float* __restrict__ u, in
 #pragma unroll
         for (int i = 0; i < CC; ++i) side[i] += o[i];
     }
+    __shared__ float lds[8];
     float acc = 0.0f;
 #pragma unroll
     for (int i = 0; i < CC; ++i) {
@@ -82,11 +126,15 @@ __global__ __launch_bounds__(kWG) void k_comp_zs(const float* __restrict__ u, in
         // samples past the end contribute nothing (their state is never consumed)
         acc = fmaf(k.alpha, acc, k.oma * gc);
     }
-    zs[(int64_t)row * nc_pad + chunk] = acc;
+    const float* rcr = rc + (int64_t)row * RC_STRIDE;
+    const float a = rcr[RC_ALPHA_C], log2a = rcr[RC_LOG2A_C];
+    const float enter = block_enter<false>(acc, a, log2a, 0.0f, lds, threadIdx.x);
+    if (threadIdx.x == kWG - 1) zs[(int64_t)row * gridDim.x + blockIdx.x] = fmaf(a, enter, acc);
 }
 
 // ---- forward: tracks.  grid (nblk, bs).  Accumulates the stereo bus over the T tracks of mix b.
 __global__ __launch_bounds__(kWG) void k_apply_tracks(TrackApplyArgs a) {
+    __shared__ float lds[8];
     const int b = blockIdx.y, chunk = blockIdx.x * kWG + threadIdx.x;
     const int64_t i0 = (int64_t)chunk * CC;
     float accL[CC], accR[CC];
@@ -103,12 +151,19 @@ __global__ __launch_bounds__(kWG) void k_apply_tracks(TrackApplyArgs a) {
             float x[CC], xd[CC], g[CC];
             ld8(urow, i0, a.n, x);
             ld8s(urow, i0 - a.lookahead, a.n, xd);
-            float s = a.s0[(int64_t)row * a.nc_pad + chunk];
+            float z = 0.0f;
 #pragma unroll
             for (int i = 0; i < CC; ++i) {
                 float d;
-                const float gc = gain_computer(x[i], k, d);
-                s = fmaf(k.alpha, s, k.oma * gc);
+                g[i] = k.oma * gain_computer(x[i], k, d);
+                z = fmaf(k.alpha, z, g[i]);
+            }
+            const float ac = rc[RC_ALPHA_C], l2a = rc[RC_LOG2A_C];
+            const float S = block_carry<false>(a.s0 + (int64_t)row * gridDim.x, blockIdx.x, gridDim.x, l2a, lds, threadIdx.x);
+            float s = block_enter<false>(z, ac, l2a, S, lds, threadIdx.x);
+#pragma unroll
+            for (int i = 0; i < CC; ++i) {
+                s = fmaf(k.alpha, s, g[i]);
                 g[i] = s;
                 y[i] = xd[i] * lin_gain(s, k);
             }
@@ -138,6 +193,7 @@ __global__ __launch_bounds__(kWG) void k_apply_tracks(TrackApplyArgs a) {
 
 // ---- forward: master bus.  grid (nblk, bs).  out = delay(v) * G * gout  (stereo-linked)
 __global__ __launch_bounds__(kWG) void k_apply_master(MasterApplyArgs a) {
+    __shared__ float lds[8];
     const int b = blockIdx.y, chunk = blockIdx.x * kWG + threadIdx.x;
     const int64_t i0 = (int64_t)chunk * CC;
     const float* rc = a.rc + (int64_t)b * RC_STRIDE;
@@ -152,12 +208,19 @@ __global__ __launch_bounds__(kWG) void k_apply_master(MasterApplyArgs a) {
         ld8(v1, i0, a.n, r);
         ld8s(v0, i0 - a.lookahead, a.n, yl);
         ld8s(v1, i0 - a.lookahead, a.n, yr);
-        float s = a.s0[(int64_t)b * a.nc_pad + chunk];
+        float z = 0.0f;
 #pragma unroll
         for (int i = 0; i < CC; ++i) {
             float d;
-            const float gc = gain_computer(l[i] + r[i], k, d);
-            s = fmaf(k.alpha, s, k.oma * gc);
+            g[i] = k.oma * gain_computer(l[i] + r[i], k, d);
+            z = fmaf(k.alpha, z, g[i]);
+        }
+        const float ac = rc[RC_ALPHA_C], l2a = rc[RC_LOG2A_C];
+        const float S = block_carry<false>(a.s0 + (int64_t)b * gridDim.x, blockIdx.x, gridDim.x, l2a, lds, threadIdx.x);
+        float s = block_enter<false>(z, ac, l2a, S, lds, threadIdx.x);
+#pragma unroll
+        for (int i = 0; i < CC; ++i) {
+            s = fmaf(k.alpha, s, g[i]);
             g[i] = s;
             const float G = lin_gain(s, k) * gout;
             yl[i] *= G;
@@ -208,6 +271,7 @@ __device__ __forceinline__ void load_gy(const CompBwdArgs& a, int row, const flo
 template <bool MASTER>
 __global__ __launch_bounds__(kWG) void k_comp_bwd_zs(CompBwdArgs a) {
     constexpr int NCH = MASTER ? 2 : 1;
+    __shared__ float lds[8];
     const int row = blockIdx.y, chunk = blockIdx.x * kWG + threadIdx.x;
     const int64_t i0 = (int64_t)chunk * CC;
     const float* rc = a.rc + (int64_t)row * RC_STRIDE;
@@ -226,13 +290,15 @@ __global__ __launch_bounds__(kWG) void k_comp_bwd_zs(CompBwdArgs a) {
         const float dgs = (i0 + i < a.n) ? dot * G * kLn10Over20 : 0.0f;
         acc = fmaf(k.alpha, acc, dgs);
     }
-    a.zq[(int64_t)row * a.nc_pad + chunk] = acc;
+    const float ac = rc[RC_ALPHA_C], l2a = rc[RC_LOG2A_C];
+    const float enter = block_enter<true>(acc, ac, l2a, 0.0f, lds, threadIdx.x);
+    if (threadIdx.x == 0) a.zq[(int64_t)row * gridDim.x + blockIdx.x] = fmaf(ac, enter, acc);
 }
 
 template <bool MASTER>
 __global__ __launch_bounds__(kWG) void k_comp_bwd_run(CompBwdArgs a) {
     constexpr int NCH = MASTER ? 2 : 1;
-    __shared__ float red[4][CP_COUNT];
+    __shared__ float red[4][CP_COUNT];  // red[0] doubles as the 8-float scan scratch
     const int tid = threadIdx.x, row = blockIdx.y, chunk = blockIdx.x * kWG + tid;
     const int64_t i0 = (int64_t)chunk * CC;
     const float* rc = a.rc + (int64_t)row * RC_STRIDE;
@@ -259,13 +325,23 @@ __global__ __launch_bounds__(kWG) void k_comp_bwd_run(CompBwdArgs a) {
         ld8s(a.gs + (int64_t)row * a.stride, i0 + a.lookahead, a.n, gF);
         load_gy<MASTER>(a, row, rc, i0 + a.lookahead, glF, grF);
         const float g_prev0 = (i0 > 0 && i0 - 1 < a.n) ? a.gs[(int64_t)row * a.stride + i0 - 1] : 0.0f;
-        float q = a.s0[(int64_t)row * a.nc_pad + chunk];
+        float dgsv[CC], Gv[CC];
+        float zq = 0.0f;
+#pragma unroll
+        for (int i = CC - 1; i >= 0; --i) {
+            Gv[i] = lin_gain(g[i], k);
+            const float dot = MASTER ? pl * (gl[i] * xd0[i] + gr[i] * xd1[i]) : (pl * gl[i] + pr * gr[i]) * xd0[i];
+            dgsv[i] = (i0 + i < a.n) ? dot * Gv[i] * kLn10Over20 : 0.0f;
+            zq = fmaf(k.alpha, zq, dgsv[i]);
+        }
+        const float ac = rc[RC_ALPHA_C], l2a = rc[RC_LOG2A_C];
+        const float S = block_carry<true>(a.s0 + (int64_t)row * gridDim.x, blockIdx.x, gridDim.x, l2a, red[0], tid);
+        float q = block_enter<true>(zq, ac, l2a, S, red[0], tid);
 #pragma unroll
         for (int i = CC - 1; i >= 0; --i) {
             const bool live = i0 + i < a.n;
-            const float G = lin_gain(g[i], k);
-            const float dot = MASTER ? pl * (gl[i] * xd0[i] + gr[i] * xd1[i]) : (pl * gl[i] + pr * gr[i]) * xd0[i];
-            const float dgs = live ? dot * G * kLn10Over20 : 0.0f;
+            const float G = Gv[i];
+            const float dgs = dgsv[i];
             q = fmaf(k.alpha, q, dgs);
             const float dgc = k.oma * q;
             const float side = MASTER ? x0[i] + x1[i] : x0[i];

@@ -52,10 +52,9 @@ extern "C" int mst_console_forward(const mst_console_desc* d, const float* track
     launch_cascade(EQ_FWD, true, tracks, d->track_row_stride, ws + L.u_t, Ns, ws + L.rc_t, 1, ws + L.sE_t, nullptr, L.ncE_pad, n, L.R, stream);
     if (t_comp) {
         launch_comp_zs(1, ws + L.u_t, Ns, ws + L.rc_t, ws + L.zS_t, L.ncC_pad, n, L.R, stream);
-        launch_scan1(false, ws + L.zS_t, ws + L.sS_t, ws + L.rc_t, L.ncC, L.ncC_pad, L.KC, L.R, stream);
     }
     const bool bus_is_mix = !m_on && !o_on;
-    TrackApplyArgs ta{ws + L.u_t, Ns, ws + L.rc_t, ws + L.sS_t, (save && t_comp) ? ws + L.gs_t : nullptr,
+    TrackApplyArgs ta{ws + L.u_t, Ns, ws + L.rc_t, ws + L.zS_t, (save && t_comp) ? ws + L.gs_t : nullptr,
                       bus_is_mix ? mix : ws + L.bus, bus_is_mix ? n : Ns, mixed_tracks,
                       L.T, L.ncC_pad, d->track_lookahead, t_comp ? 1 : 0, n};
     launch_apply_tracks(ta, L.bs, stream);
@@ -66,8 +65,7 @@ extern "C" int mst_console_forward(const mst_console_desc* d, const float* track
         launch_scan12(false, ws + L.zE_m, ws + L.sE_m, ws + L.powF_m, 2, L.ncE, L.ncE_pad, L.KE, 2 * L.bs, stream);
         launch_cascade(EQ_FWD, true, ws + L.bus, Ns, ws + L.v_m, Ns, ws + L.rc_m, 2, ws + L.sE_m, nullptr, L.ncE_pad, n, 2 * L.bs, stream);
         launch_comp_zs(2, ws + L.v_m, Ns, ws + L.rc_m, ws + L.zS_m, L.ncC_pad, n, L.bs, stream);
-        launch_scan1(false, ws + L.zS_m, ws + L.sS_m, ws + L.rc_m, L.ncC, L.ncC_pad, L.KC, L.bs, stream);
-        MasterApplyArgs ma{ws + L.v_m, Ns, ws + L.rc_m, ws + L.sS_m, save ? ws + L.gs_m : nullptr, mix, n,
+        MasterApplyArgs ma{ws + L.v_m, Ns, ws + L.rc_m, ws + L.zS_m, save ? ws + L.gs_m : nullptr, mix, n,
                            L.ncC_pad, d->master_lookahead, 1, n};
         launch_apply_master(ma, L.bs, stream);
     } else if (o_on) {
@@ -101,8 +99,7 @@ extern "C" int mst_console_backward(const mst_console_desc* d, const float* trac
         CompBwdArgs ca{ws + L.v_m, Ns, ws + L.gs_m, ws + L.rc_m, nullptr, ws + L.zQ_m, ws + L.du_m, ws + L.cp_m,
                        grad_mix, n, nullptr, 1, L.ncC_pad, d->master_lookahead, 1, n};
         launch_comp_bwd(true, false, ca, L.bs, stream);
-        launch_scan1(true, ws + L.zQ_m, ws + L.sQ_m, ws + L.rc_m, L.ncC, L.ncC_pad, L.KC, L.bs, stream);
-        ca.s0 = ws + L.sQ_m;
+        ca.s0 = ws + L.zQ_m;
         launch_comp_bwd(true, true, ca, L.bs, stream);
         launch_cascade(EQ_ADJ, false, ws + L.du_m, Ns, nullptr, 0, ws + L.rc_m, 2, nullptr, ws + L.zA_m, L.ncE_pad, n, 2 * L.bs, stream);
         launch_scan12(true, ws + L.zA_m, ws + L.sA_m, ws + L.powA_m, 2, L.ncE, L.ncE_pad, L.KE, 2 * L.bs, stream);
@@ -128,8 +125,7 @@ extern "C" int mst_console_backward(const mst_console_desc* d, const float* trac
                        gbus, gbus_stride, grad_mixed_tracks, L.T, L.ncC_pad, d->track_lookahead, t_comp ? 1 : 0, n};
         if (t_comp) {
             launch_comp_bwd(false, false, ca, L.R, stream);
-            launch_scan1(true, ws + L.zQ_t, ws + L.sQ_t, ws + L.rc_t, L.ncC, L.ncC_pad, L.KC, L.R, stream);
-            ca.s0 = ws + L.sQ_t;
+            ca.s0 = ws + L.zQ_t;
         }
         launch_comp_bwd(false, true, ca, L.R, stream);
         launch_allpole_zs(ws + L.u_t, Ns, ws + L.rc_t, 1, ws + L.zP_t, L.ncE_pad, n, L.R, stream);

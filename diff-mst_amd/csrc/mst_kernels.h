@@ -49,8 +49,6 @@ void launch_coefgrad(const float* u, int64_t u_stride, const float* g, int64_t g
 void launch_scan12(bool reverse, const float* z, float* s0, const float* tab, int nch, int nc, int nc_pad, int K, int nsig,
                    hipStream_t stream);
 void launch_scan2(const float* z, float* s0, const float* tab, int nch, int nc, int nc_pad, int K, int nsig, hipStream_t stream);
-void launch_scan1(bool reverse, const float* z, float* s0, const float* rc, int nc, int nc_pad, int K, int nrows,
-                  hipStream_t stream);
 
 // ---- mst_comp.hip
 struct TrackApplyArgs {

@@ -194,6 +194,7 @@ __global__ __launch_bounds__(320) void k_prep(PrepArgs a) {
         rc[RC_ALPHA] = alpha;
         rc[RC_MAKEUP] = mk;
         rc[RC_ALPHA_C] = (float)pow((double)alpha, (double)kCompChunk);
+        rc[RC_LOG2A_C] = alpha > 0.0f ? (float)((double)kCompChunk * log2((double)alpha)) : -1.0e30f;
     } else if (tid == 7) {
 #pragma clang fp contract(off)
         float gin = 1.0f;
@@ -344,24 +345,25 @@ __global__ __launch_bounds__(64) void k_prep_bwd(PrepBwdArgs a) {
     const bool gin_on = is_master ? (d.flags & MST_USE_MASTER_BUS) : (d.flags & MST_USE_TRACK_INPUT_FADER);
     const bool chain_on = is_master ? (d.flags & MST_USE_MASTER_BUS) : true;  // does the EQ/gain stage exist
 
-    // deterministic reduction of the partial sums (fixed order, fp64)
-    if (tid < EP_COUNT) {
-        double s = 0.0;
-        if (chain_on) {
-            const int nsig = is_master ? 2 : 1;
-            for (int ch = 0; ch < nsig; ++ch) {
-                const float* ep = is_master ? a.ep_m + ((int64_t)(mrow * 2 + ch) * a.nblkE) * EP_COUNT
-                                            : a.ep_t + ((int64_t)row * a.nblkE) * EP_COUNT;
-                for (int b = 0; b < a.nblkE; ++b) s += (double)ep[(int64_t)b * EP_COUNT + tid];
-            }
+    // deterministic reduction of the partial sums: lane-strided fp64 partials + a fixed shuffle tree
+    {
+        const int nsig = is_master ? 2 : 1;
+        const float* ep = is_master ? a.ep_m + ((int64_t)(mrow * 2) * a.nblkE) * EP_COUNT
+                                    : a.ep_t + ((int64_t)row * a.nblkE) * EP_COUNT;
+        const int nE = chain_on ? nsig * a.nblkE : 0;  // the two channels of a master row are adjacent
+        for (int q = 0; q < EP_COUNT; ++q) {
+            double s = 0.0;
+            for (int b = tid; b < nE; b += 64) s += (double)ep[(int64_t)b * EP_COUNT + q];
+            for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+            if (tid == 0) dsos[q] = s;
         }
-        dsos[tid] = s;
-    } else if (tid >= 32 && tid < 32 + CP_COUNT) {
-        const int i = tid - 32;
         const float* cp = is_master ? a.cp_m + ((int64_t)mrow * a.nblkC) * CP_COUNT : a.cp_t + ((int64_t)row * a.nblkC) * CP_COUNT;
-        double s = 0.0;
-        for (int b = 0; b < a.nblkC; ++b) s += (double)cp[(int64_t)b * CP_COUNT + i];
-        dcp[i] = s;
+        for (int q = 0; q < CP_COUNT; ++q) {
+            double s = 0.0;
+            for (int b = tid; b < a.nblkC; b += 64) s += (double)cp[(int64_t)b * CP_COUNT + q];
+            for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+            if (tid == 0) dcp[q] = s;
+        }
     }
     if (tid < np) g[tid] = 0.0f;
     __syncthreads();

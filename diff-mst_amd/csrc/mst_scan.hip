@@ -24,36 +24,62 @@ __device__ __forceinline__ void matvec_acc(const float* __restrict__ M, const fl
 }
 
 // z, s0: [row][D][nc_pad].  tab: [table_row][kPow][D*D], table_row = (row / tab_div) * tab_mod + row % tab_mod
-template <int D, bool REVERSE>
+// KT > 0: K == KT known at compile time - all of a lane's chunk states are fetched up front (one
+// memory round trip instead of K dependent ones) and the fold / replay loops are unrolled.
+template <int D, bool REVERSE, int KT>
 __global__ __launch_bounds__(kScanThreads) void k_scan(const float* __restrict__ z, float* __restrict__ s0,
                                                        const float* __restrict__ tab, int tab_div, int tab_mod,
-                                                       int nc, int nc_pad, int K) {
+                                                       int nc, int nc_pad, int Krt) {
     __shared__ float buf[2][D][kScanThreads];
     const int tid = threadIdx.x, row = blockIdx.x;
+    const int K = KT > 0 ? KT : Krt;
     const float* T = tab + ((int64_t)(row / tab_div) * tab_mod + (row % tab_mod)) * kPow * D * D;
     const float* zr = z + (int64_t)row * D * nc_pad;
     float* sr = s0 + (int64_t)row * D * nc_pad;
     auto cidx = [&](int i) { return REVERSE ? nc - 1 - i : i; };
 
     // 1. fold my K chunks from zero
+    constexpr int KL = KT > 0 ? KT : 1;
+    float zl[KL][D];
+    if (KT > 0) {
+#pragma unroll
+        for (int k = 0; k < KL; ++k) {
+            const int i = tid * KT + k;
+#pragma unroll
+            for (int d = 0; d < D; ++d) zl[k][d] = (i < nc) ? zr[(int64_t)d * nc_pad + cidx(i)] : 0.0f;
+        }
+    }
     float agg[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) agg[d] = 0.0f;
-    for (int k = 0; k < K; ++k) {
-        const int i = tid * K + k;
-        float nv[D];
+    if (KT > 0) {
 #pragma unroll
-        for (int d = 0; d < D; ++d) nv[d] = (i < nc) ? zr[(int64_t)d * nc_pad + cidx(i)] : 0.0f;
-        matvec_acc<D>(T, agg, nv);
+        for (int k = 0; k < KL; ++k) {
+            float nv[D];
 #pragma unroll
-        for (int d = 0; d < D; ++d) agg[d] = nv[d];
+            for (int d = 0; d < D; ++d) nv[d] = zl[k][d];
+            matvec_acc<D>(T, agg, nv);
+#pragma unroll
+            for (int d = 0; d < D; ++d) agg[d] = nv[d];
+        }
+    } else {
+        for (int k = 0; k < K; ++k) {
+            const int i = tid * K + k;
+            float nv[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d) nv[d] = (i < nc) ? zr[(int64_t)d * nc_pad + cidx(i)] : 0.0f;
+            matvec_acc<D>(T, agg, nv);
+#pragma unroll
+            for (int d = 0; d < D; ++d) agg[d] = nv[d];
+        }
     }
-    // 2. inclusive Hillis-Steele over lanes
+    // 2. inclusive Hillis-Steele over lanes (levels beyond the populated lanes are skipped)
+    const int active = (nc + K - 1) / K;
     int cur = 0;
 #pragma unroll
     for (int d = 0; d < D; ++d) buf[0][d][tid] = agg[d];
     __syncthreads();
-    for (int j = 0; j < kScanLevels; ++j) {
+    for (int j = 0; j < kScanLevels && (1 << j) < active; ++j) {
         const int off = 1 << j;
         if (tid >= off) {
             float o[D];
@@ -70,79 +96,56 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const float* __restrict__
     float st[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) st[d] = (tid > 0) ? buf[cur][d][tid - 1] : 0.0f;
-    for (int k = 0; k < K; ++k) {
-        const int i = tid * K + k;
-        if (i >= nc) break;
-        const int c = cidx(i);
-        float nv[D];
+    if (KT > 0) {
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            sr[(int64_t)d * nc_pad + c] = st[d];
-            nv[d] = zr[(int64_t)d * nc_pad + c];
+        for (int k = 0; k < KL; ++k) {
+            const int i = tid * KT + k;
+            if (i < nc) {
+                const int c = cidx(i);
+#pragma unroll
+                for (int d = 0; d < D; ++d) sr[(int64_t)d * nc_pad + c] = st[d];
+            }
+            float nv[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d) nv[d] = zl[k][d];
+            matvec_acc<D>(T, st, nv);
+#pragma unroll
+            for (int d = 0; d < D; ++d) st[d] = nv[d];
         }
-        matvec_acc<D>(T, st, nv);
+    } else {
+        for (int k = 0; k < K; ++k) {
+            const int i = tid * K + k;
+            if (i >= nc) break;
+            const int c = cidx(i);
+            float nv[D];
 #pragma unroll
-        for (int d = 0; d < D; ++d) st[d] = nv[d];
+            for (int d = 0; d < D; ++d) {
+                sr[(int64_t)d * nc_pad + c] = st[d];
+                nv[d] = zr[(int64_t)d * nc_pad + c];
+            }
+            matvec_acc<D>(T, st, nv);
+#pragma unroll
+            for (int d = 0; d < D; ++d) st[d] = nv[d];
+        }
     }
 }
 
-// D = 1 (envelope smoother): the "matrix" is alpha^kCompChunk taken from the row constants.
-template <bool REVERSE>
-__global__ __launch_bounds__(kScanThreads) void k_scan1(const float* __restrict__ z, float* __restrict__ s0,
-                                                        const float* __restrict__ rc, int nc, int nc_pad, int K) {
-    __shared__ float buf[2][kScanThreads];
-    const int tid = threadIdx.x, row = blockIdx.x;
-    const float a = rc[(int64_t)row * RC_STRIDE + RC_ALPHA_C];
-    const float* zr = z + (int64_t)row * nc_pad;
-    float* sr = s0 + (int64_t)row * nc_pad;
-    auto cidx = [&](int i) { return REVERSE ? nc - 1 - i : i; };
-    float agg = 0.0f;
-    for (int k = 0; k < K; ++k) {
-        const int i = tid * K + k;
-        agg = fmaf(a, agg, (i < nc) ? zr[cidx(i)] : 0.0f);
-    }
-    // a^K by repeated multiplication in double (K is small), then squared per level
-    double pk = 1.0;
-    for (int k = 0; k < K; ++k) pk *= (double)a;
-    float p = (float)pk;
-    int cur = 0;
-    buf[0][tid] = agg;
-    __syncthreads();
-    for (int j = 0; j < kScanLevels; ++j) {
-        const int off = 1 << j;
-        if (tid >= off) agg = fmaf(p, buf[cur][tid - off], agg);
-        buf[cur ^ 1][tid] = agg;
-        __syncthreads();
-        cur ^= 1;
-        p = p * p;
-    }
-    float st = (tid > 0) ? buf[cur][tid - 1] : 0.0f;
-    for (int k = 0; k < K; ++k) {
-        const int i = tid * K + k;
-        if (i >= nc) break;
-        const int c = cidx(i);
-        sr[c] = st;
-        st = fmaf(a, st, zr[c]);
-    }
+template <int D, bool REV>
+static void launch_scan_k(dim3 grid, hipStream_t stream, const float* z, float* s0, const float* tab, int tab_div, int tab_mod,
+                          int nc, int nc_pad, int K) {
+    const dim3 block(kScanThreads);
+    if (K == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan<D, REV, 1>), grid, block, 0, stream, z, s0, tab, tab_div, tab_mod, nc, nc_pad, K);
+    else if (K == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan<D, REV, 2>), grid, block, 0, stream, z, s0, tab, tab_div, tab_mod, nc, nc_pad, K);
+    else if (K == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan<D, REV, 4>), grid, block, 0, stream, z, s0, tab, tab_div, tab_mod, nc, nc_pad, K);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan<D, REV, 0>), grid, block, 0, stream, z, s0, tab, tab_div, tab_mod, nc, nc_pad, K);
 }
-
-void launch_scan12(bool reverse, const float* z, float* s0, const float* tab, int nch, int nc, int nc_pad, int K,
-                   int nsig, hipStream_t stream) {
-    if (reverse)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan<12, true>), dim3(nsig), dim3(kScanThreads), 0, stream, z, s0, tab, nch, 1, nc, nc_pad, K);
-    else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan<12, false>), dim3(nsig), dim3(kScanThreads), 0, stream, z, s0, tab, nch, 1, nc, nc_pad, K);
+void launch_scan12(bool reverse, const float* z, float* s0, const float* tab, int nch, int nc, int nc_pad, int K, int nsig,
+                   hipStream_t stream) {
+    if (reverse) launch_scan_k<12, true>(dim3(nsig), stream, z, s0, tab, nch, 1, nc, nc_pad, K);
+    else launch_scan_k<12, false>(dim3(nsig), stream, z, s0, tab, nch, 1, nc, nc_pad, K);
 }
-void launch_scan2(const float* z, float* s0, const float* tab, int nch, int nc, int nc_pad, int K, int nsig,
-                  hipStream_t stream) {
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan<2, false>), dim3(nsig * 12), dim3(kScanThreads), 0, stream, z, s0, tab, nch * 12, 12, nc, nc_pad, K);
-}
-void launch_scan1(bool reverse, const float* z, float* s0, const float* rc, int nc, int nc_pad, int K, int nrows,
-                  hipStream_t stream) {
-    if (reverse)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan1<true>), dim3(nrows), dim3(kScanThreads), 0, stream, z, s0, rc, nc, nc_pad, K);
-    else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan1<false>), dim3(nrows), dim3(kScanThreads), 0, stream, z, s0, rc, nc, nc_pad, K);
+void launch_scan2(const float* z, float* s0, const float* tab, int nch, int nc, int nc_pad, int K, int nsig, hipStream_t stream) {
+    launch_scan_k<2, false>(dim3(nsig * 12), stream, z, s0, tab, nch * 12, 12, nc, nc_pad, K);
 }
 
 }  // namespace mst

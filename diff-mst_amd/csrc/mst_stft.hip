@@ -17,11 +17,11 @@
 namespace mst {
 
 constexpr int kMaxRes = 8;
-constexpr int kFramesPerWG = 8;  // strip length (forward); backward handles pairs
 
 struct ResInfo {
     int n_fft, hop, n_frames, n_bins;
-    int64_t tw_off, win_off;  // float offsets into the tables buffer (tw: n_fft float2, win: n_fft floats)
+    int64_t tw_off, win_off, perm_off;  // float offsets into the tables buffer (tw: n_fft float2, win: n_fft floats, perm: n_fft ints)
+    int frames_per_wg;                  // forward strip length
 };
 
 // position of natural index n in the digit-reversed DIT input order.
@@ -83,13 +83,13 @@ __device__ __forceinline__ int64_t reflect_index(int64_t i, int64_t n) {
 
 // load frame f of (x, y) as z = w (x + i y) into digit-reversed positions
 __device__ __forceinline__ void load_frame(float2* buf, const float* __restrict__ x, const float* __restrict__ y,
-                                           const float* __restrict__ win, int f, const ResInfo& r, int log2n, int64_t n,
-                                           int tid, int nthreads) {
+                                           const float* __restrict__ win, const int* __restrict__ perm, int f,
+                                           const ResInfo& r, int64_t n, int tid, int nthreads) {
     const int64_t start = (int64_t)f * r.hop - r.n_fft / 2;
     for (int k = tid; k < r.n_fft; k += nthreads) {
         const int64_t i = reflect_index(start + k, n);
         const float w = win[k];
-        buf[dit_pos(k, r.n_fft, log2n)] = make_float2(w * x[i], y ? w * y[i] : 0.0f);
+        buf[perm[k]] = make_float2(w * x[i], w * y[i]);
     }
 }
 
@@ -125,12 +125,13 @@ __global__ __launch_bounds__(stft_threads(NFFT)) void k_stft_fwd(StftArgs a) {
     const ResInfo r = a.r;
     const float2* tw = reinterpret_cast<const float2*>(a.tables + r.tw_off);
     const float* win = a.tables + r.win_off;
+    const int* perm = reinterpret_cast<const int*>(a.tables + r.perm_off);
     const float* x = a.pred + (int64_t)row * a.n;
     const float* y = a.target + (int64_t)row * a.n;
     float s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f;
-    const int f0 = blockIdx.x * kFramesPerWG;
-    for (int f = f0; f < f0 + kFramesPerWG && f < r.n_frames; ++f) {
-        load_frame(buf, x, y, win, f, r, a.log2n, a.n, tid, THREADS);
+    const int f0 = blockIdx.x * r.frames_per_wg;
+    for (int f = f0; f < f0 + r.frames_per_wg && f < r.n_frames; ++f) {
+        load_frame(buf, x, y, win, perm, f, r, a.n, tid, THREADS);
         __syncthreads();
         lds_fft(buf, tw, r.n_fft, a.log2n, tid, THREADS);
         for (int k = tid; k < r.n_bins; k += THREADS) {
@@ -203,6 +204,7 @@ __global__ __launch_bounds__(stft_threads(NFFT)) void k_stft_bwd(StftArgs a) {
     const int tid = threadIdx.x, row = blockIdx.y;
     const float2* tw = reinterpret_cast<const float2*>(a.tables + r.tw_off);
     const float* win = a.tables + r.win_off;
+    const int* perm = reinterpret_cast<const int*>(a.tables + r.perm_off);
     const float* x = a.pred + (int64_t)row * a.n;
     const float* y = a.target + (int64_t)row * a.n;
     const float* coef = a.coef + (int64_t)row * 4;
@@ -210,13 +212,13 @@ __global__ __launch_bounds__(stft_threads(NFFT)) void k_stft_bwd(StftArgs a) {
     const int fa = 2 * blockIdx.x, fb = fa + 1;
     const bool have_b = fb < r.n_frames;
 
-    load_frame(buf, x, y, win, fa, r, a.log2n, a.n, tid, THREADS);
+    load_frame(buf, x, y, win, perm, fa, r, a.n, tid, THREADS);
     __syncthreads();
     lds_fft(buf, tw, r.n_fft, a.log2n, tid, THREADS);
     accumulate_dx(buf, hbuf, a, coef, false, tid, THREADS);
     __syncthreads();
     if (have_b) {
-        load_frame(buf, x, y, win, fb, r, a.log2n, a.n, tid, THREADS);
+        load_frame(buf, x, y, win, perm, fb, r, a.n, tid, THREADS);
         __syncthreads();
         lds_fft(buf, tw, r.n_fft, a.log2n, tid, THREADS);
         accumulate_dx(buf, hbuf, a, coef, true, tid, THREADS);
@@ -225,7 +227,7 @@ __global__ __launch_bounds__(stft_threads(NFFT)) void k_stft_bwd(StftArgs a) {
     // inverse DFT via conj(FFT(conj(.))): r1 + i r2
     for (int k = tid; k < r.n_fft; k += THREADS) {
         const float2 h = hbuf[k];
-        buf[dit_pos(k, r.n_fft, a.log2n)] = make_float2(h.x, -h.y);
+        buf[perm[k]] = make_float2(h.x, -h.y);
     }
     __syncthreads();
     lds_fft(buf, tw, r.n_fft, a.log2n, tid, THREADS);
@@ -239,9 +241,10 @@ __global__ __launch_bounds__(stft_threads(NFFT)) void k_stft_bwd(StftArgs a) {
 }
 
 // ---- tables: twiddles (cos, -sin) and the (centre-padded) periodic Hann window -------------------
-__global__ void k_stft_tables(float* tables, ResInfo r, int win_length) {
+__global__ void k_stft_tables(float* tables, ResInfo r, int win_length, int log2n) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= r.n_fft) return;
+    reinterpret_cast<int*>(tables + r.perm_off)[t] = dit_pos(t, r.n_fft, log2n);
     const double ang = 6.283185307179586476925 * (double)t / (double)r.n_fft;
     tables[r.tw_off + 2 * t] = (float)cos(ang);
     tables[r.tw_off + 2 * t + 1] = (float)(-sin(ang));
@@ -350,9 +353,14 @@ Plan make_plan(const mst_mrstft_desc* d) {
         t += 2 * (int64_t)nf;
         r.win_off = t;
         t += nf;
+        r.perm_off = t;
+        t += nf;
         p.log2n[i] = lg;
         p.win[i] = d->win_length[i];
-        p.n_groups[i] = (r.n_frames + kFramesPerWG - 1) / kFramesPerWG;
+        // aim for >= ~2000 workgroups per launch (256 CUs x several resident) but cap the strip at 8 frames
+        int fpw = (int)(((int64_t)r.n_frames * d->rows) / 2048);
+        r.frames_per_wg = fpw < 1 ? 1 : (fpw > 8 ? 8 : fpw);
+        p.n_groups[i] = (r.n_frames + r.frames_per_wg - 1) / r.frames_per_wg;
         p.part_off[i] = po;
         po += (int64_t)d->rows * p.n_groups[i] * 4;
     }
@@ -391,7 +399,7 @@ extern "C" int mst_mrstft_init_tables(const mst_mrstft_desc* d, void* tables, vo
     if (!p.ok || !tables) return hipErrorInvalidValue;
     hipStream_t stream = (hipStream_t)stream_;
     for (int i = 0; i < d->n_res; ++i)
-        hipLaunchKernelGGL(k_stft_tables, dim3((p.res[i].n_fft + 255) / 256), dim3(256), 0, stream, (float*)tables, p.res[i], p.win[i]);
+        hipLaunchKernelGGL(k_stft_tables, dim3((p.res[i].n_fft + 255) / 256), dim3(256), 0, stream, (float*)tables, p.res[i], p.win[i], p.log2n[i]);
     return (int)hipGetLastError();
 }
 

@@ -51,6 +51,61 @@ def _nested(index, tensor):
     return d
 
 
+class _LazyParamDict(dict):
+    """Nested ``{effect: {param: tensor}}`` dictionary that is only computed when somebody looks.
+
+    The reference rebuilds three dictionaries of denormalised parameter views on every console call
+    (mst/modules.py:353-466); in-repo consumers only read them in logging callbacks.  Deferring the
+    (autograd-connected) affine map keeps a handful of tiny launches off the per-step critical path
+    without changing what a reader sees.
+    """
+
+    def __init__(self, build):
+        super().__init__()
+        self._build = build
+
+    def _fill(self):
+        if self._build is not None:
+            build, self._build = self._build, None
+            super().update(build())
+
+    def __getitem__(self, k):
+        self._fill()
+        return super().__getitem__(k)
+
+    def __iter__(self):
+        self._fill()
+        return super().__iter__()
+
+    def __len__(self):
+        self._fill()
+        return super().__len__()
+
+    def __contains__(self, k):
+        self._fill()
+        return super().__contains__(k)
+
+    def keys(self):
+        self._fill()
+        return super().keys()
+
+    def values(self):
+        self._fill()
+        return super().values()
+
+    def items(self):
+        self._fill()
+        return super().items()
+
+    def get(self, k, default=None):
+        self._fill()
+        return super().get(k, default)
+
+    def __repr__(self):
+        self._fill()
+        return super().__repr__()
+
+
 class _ConsoleFunction(torch.autograd.Function):
     """One fused forward / backward pair over the C ABI (mst_console_forward / _backward)."""
 
@@ -222,15 +277,22 @@ class AdvancedMixConsole(torch.nn.Module):
 
     def _denormalized_dicts(self, track_params, fx_bus_params, master_bus_params):
         """Same nested dicts as reference :353-466; one fused affine map per tensor, entries are views."""
-        scale, lo = self._affine(_desc.TRACK_INDEX, track_params.device)
-        tpd = _nested(_desc.TRACK_INDEX, track_params * scale + lo)
-        fx = fx_bus_params.clone()
-        fx[..., 24] = 1.0  # reference :420 forces the reverb mix to ones
-        scale, lo = self._affine(_desc.FX_INDEX, fx.device)
-        fpd = _nested(_desc.FX_INDEX, fx * scale + lo)
-        scale, lo = self._affine(_desc.MASTER_INDEX, master_bus_params.device)
-        m = _nested(_desc.MASTER_INDEX, master_bus_params * scale + lo)
-        return tpd, fpd, m
+
+        def tracks():
+            scale, lo = self._affine(_desc.TRACK_INDEX, track_params.device)
+            return _nested(_desc.TRACK_INDEX, torch.addcmul(lo, track_params, scale))
+
+        def fx():
+            scale, lo = self._affine(_desc.FX_INDEX, fx_bus_params.device)
+            scale, lo = scale.clone(), lo.clone()
+            scale[24], lo[24] = 0.0, 1.0  # reference :420 forces the reverb mix to ones
+            return _nested(_desc.FX_INDEX, torch.addcmul(lo, fx_bus_params, scale))
+
+        def master():
+            scale, lo = self._affine(_desc.MASTER_INDEX, master_bus_params.device)
+            return _nested(_desc.MASTER_INDEX, torch.addcmul(lo, master_bus_params, scale))
+
+        return _LazyParamDict(tracks), _LazyParamDict(fx), _LazyParamDict(master)
 
     def _normalize_dict(self, d, index):
         cols = []

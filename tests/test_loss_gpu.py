@@ -58,10 +58,29 @@ def test_mrstft_three_way(bs, n, kw, dev):
     assert abs(loss.item() - l64) / l64 < 1e-5, (loss.item(), l32, l64)
     h32, h64, r = rel(xd.grad, g32), rel(xd.grad, g64), rel(g32, g64)
     print(f"\n[mrstft {bs}x2x{n} {kw}] loss hip {loss.item():.7f} ref32 {l32:.7f} f64 {l64:.7f}; grad hip-ref32 {h32:.2e} hip-f64 {h64:.2e} ref32-f64 {r:.2e}")
-    assert h32 < 1e-3 and h64 <= 2 * r + 1e-4
-    # away from the two edge frames the gradient is well conditioned
-    mid = slice(8192, n - 8192)
-    assert rel(xd.grad[..., mid], g64[..., mid]) < 2e-5
+    # d log|X| / dX ~ 1/|X| : among 1e6..1e7 bins a few are nearly zero and dominate the fp32 error of
+    # BOTH fp32 implementations (ref32 sits 5e-4..1e-2 from float64); HIP must not be worse than that
+    assert h64 <= 2 * r + 2e-4 and h32 <= 2 * (h64 + r)
+
+
+@pytest.mark.parametrize("kw", [dict(w_sc=1.0, w_log_mag=0.0), dict(w_sc=0.0, w_log_mag=0.0, w_lin_mag=1.0)])
+def test_mrstft_well_conditioned_terms(kw, dev):
+    """Spectral-convergence and linear-magnitude terms have no 1/|X| factor: their gradient pins the
+    FFT / Hermitian split / adjoint / overlap-add machinery to fp32 round-off."""
+    from oracle import loss_restated as ol
+
+    torch.manual_seed(11)
+    bs, n = 2, 65536
+    x = 0.3 * torch.randn(bs, 2, n)
+    y = 0.5 * x + 0.2 * torch.randn(bs, 2, n)
+    xd = x.to(dev).requires_grad_(True)
+    loss = make_loss(**kw)(xd, y.to(dev))
+    loss.backward()
+    xo = x.double().requires_grad_(True)
+    lo = ol.mrstft_loss(xo, y.double(), RES, **kw)
+    lo.backward()
+    assert abs(loss.item() - lo.item()) / lo.item() < 1e-5
+    assert rel(xd.grad, xo.grad) < 5e-6
 
 
 def test_mrstft_known_answers(dev):
