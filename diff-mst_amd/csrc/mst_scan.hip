@@ -31,9 +31,13 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const float* __restrict__
                                                        const float* __restrict__ tab, int tab_div, int tab_mod,
                                                        int nc, int nc_pad, int Krt) {
     __shared__ float buf[2][D][kScanThreads];
+    __shared__ __attribute__((aligned(16))) float T[kPow * D * D];  // this row's power table, staged once
     const int tid = threadIdx.x, row = blockIdx.x;
     const int K = KT > 0 ? KT : Krt;
-    const float* T = tab + ((int64_t)(row / tab_div) * tab_mod + (row % tab_mod)) * kPow * D * D;
+    {
+        const float* Tg = tab + ((int64_t)(row / tab_div) * tab_mod + (row % tab_mod)) * kPow * D * D;
+        for (int i = tid; i < kPow * D * D; i += kScanThreads) T[i] = Tg[i];
+    }
     const float* zr = z + (int64_t)row * D * nc_pad;
     float* sr = s0 + (int64_t)row * D * nc_pad;
     auto cidx = [&](int i) { return REVERSE ? nc - 1 - i : i; };
@@ -49,6 +53,7 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const float* __restrict__
             for (int d = 0; d < D; ++d) zl[k][d] = (i < nc) ? zr[(int64_t)d * nc_pad + cidx(i)] : 0.0f;
         }
     }
+    __syncthreads();  // table staged
     float agg[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) agg[d] = 0.0f;
@@ -75,17 +80,27 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const float* __restrict__
     }
     // 2. inclusive Hillis-Steele over lanes (levels beyond the populated lanes are skipped)
     const int active = (nc + K - 1) / K;
+    const int lane = tid & 63;
+    // levels 0..5 stay inside the wave: shuffles, no LDS round trip, no barrier
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int off = 1 << j;
+        float o[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) o[d] = __shfl_up(agg[d], off);
+        if (lane >= off) matvec_acc<D>(T + (1 + j) * D * D, o, agg);
+    }
     int cur = 0;
 #pragma unroll
     for (int d = 0; d < D; ++d) buf[0][d][tid] = agg[d];
     __syncthreads();
-    for (int j = 0; j < kScanLevels && (1 << j) < active; ++j) {
+    for (int j = 6; j < kScanLevels && (1 << j) < active; ++j) {
         const int off = 1 << j;
         if (tid >= off) {
             float o[D];
 #pragma unroll
             for (int d = 0; d < D; ++d) o[d] = buf[cur][d][tid - off];
-            matvec_acc<D>(T + (int64_t)(1 + j) * D * D, o, agg);
+            matvec_acc<D>(T + (1 + j) * D * D, o, agg);
         }
 #pragma unroll
         for (int d = 0; d < D; ++d) buf[cur ^ 1][d][tid] = agg[d];

@@ -20,59 +20,52 @@ constexpr int kMaxRes = 8;
 
 struct ResInfo {
     int n_fft, hop, n_frames, n_bins;
-    int64_t tw_off, win_off, perm_off;  // float offsets into the tables buffer (tw: n_fft float2, win: n_fft floats, perm: n_fft ints)
+    int64_t tw_off, win_off;  // float offsets into the tables buffer (tw: n_fft float2, win: n_fft floats)
     int frames_per_wg;                  // forward strip length
 };
 
-// position of natural index n in the digit-reversed DIT input order.
-// radices (first -> last stage): one radix-2 stage if log2(n_fft) is odd, then radix-4 stages.
-__device__ __forceinline__ int dit_pos(int n, int n_fft, int log2n) {
-    int M = n_fft, p = 0;
-    const int n4 = log2n >> 1;
-    for (int s = 0; s < n4; ++s) {  // last stages first
-        M >>= 2;
-        p += (n & 3) * M;
-        n >>= 2;
-    }
-    if (log2n & 1) p += (n & 1) * (M >> 1);
-    return p;
-}
-
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 
-// In-place forward DFT (e^{-i...}) of `buf` (n_fft float2 in LDS, input already digit-reversed).
-// tw[t] = (cos, -sin)(2 pi t / n_fft), t < n_fft.  All lanes of the workgroup participate.
-__device__ void lds_fft(float2* buf, const float2* __restrict__ tw, int n_fft, int log2n, int tid, int nthreads) {
-    int L = 1;
+// Forward DFT (e^{-i...}) of n_fft complex points held in LDS: Stockham autosort, radix-4 stages
+// (one radix-2 stage first when log2 n_fft is odd), natural order in AND out, ping-pong between
+// `a` (input) and `b`.  Every stage reads a[j + r n/4] for consecutive j (conflict-free) and the
+// result pointer is returned.  tw[t] = (cos, -sin)(2 pi t / n_fft), t < n_fft.
+__device__ float2* lds_fft(float2* a, float2* b, const float2* __restrict__ tw, int n_fft, int log2n, int tid, int nthreads) {
+    int Ns = 1;
     if (log2n & 1) {
-        for (int b = tid; b < n_fft / 2; b += nthreads) {
-            const float2 a0 = buf[2 * b], a1 = buf[2 * b + 1];
-            buf[2 * b] = make_float2(a0.x + a1.x, a0.y + a1.y);
-            buf[2 * b + 1] = make_float2(a0.x - a1.x, a0.y - a1.y);
+        const int h = n_fft >> 1;
+        for (int j = tid; j < h; j += nthreads) {
+            const float2 u0 = a[j], u1 = a[j + h];
+            b[2 * j] = make_float2(u0.x + u1.x, u0.y + u1.y);
+            b[2 * j + 1] = make_float2(u0.x - u1.x, u0.y - u1.y);
         }
-        L = 2;
+        float2* t = a; a = b; b = t;
+        Ns = 2;
         __syncthreads();
     }
-    for (; L < n_fft; L <<= 2) {
-        const int tstep = n_fft / (4 * L);
-        for (int b = tid; b < n_fft / 4; b += nthreads) {
-            const int j = b & (L - 1);
-            const int base = ((b - j) << 2) + j;
-            float2 a0 = buf[base], a1 = buf[base + L], a2 = buf[base + 2 * L], a3 = buf[base + 3 * L];
-            if (j) {
-                a1 = cmul(a1, tw[j * tstep]);
-                a2 = cmul(a2, tw[2 * j * tstep]);
-                a3 = cmul(a3, tw[3 * j * tstep]);
+    const int q = n_fft >> 2;
+    for (; Ns < n_fft; Ns <<= 2) {
+        const int tstep = n_fft / (4 * Ns);
+        for (int j = tid; j < q; j += nthreads) {
+            const int k = j & (Ns - 1);
+            float2 u0 = a[j], u1 = a[j + q], u2 = a[j + 2 * q], u3 = a[j + 3 * q];
+            if (k) {
+                u1 = cmul(u1, tw[k * tstep]);
+                u2 = cmul(u2, tw[2 * k * tstep]);
+                u3 = cmul(u3, tw[3 * k * tstep]);
             }
-            const float2 s02 = make_float2(a0.x + a2.x, a0.y + a2.y), d02 = make_float2(a0.x - a2.x, a0.y - a2.y);
-            const float2 s13 = make_float2(a1.x + a3.x, a1.y + a3.y), d13 = make_float2(a1.x - a3.x, a1.y - a3.y);
-            buf[base] = make_float2(s02.x + s13.x, s02.y + s13.y);
-            buf[base + L] = make_float2(d02.x + d13.y, d02.y - d13.x);  // d02 - i d13
-            buf[base + 2 * L] = make_float2(s02.x - s13.x, s02.y - s13.y);
-            buf[base + 3 * L] = make_float2(d02.x - d13.y, d02.y + d13.x);  // d02 + i d13
+            const float2 s02 = make_float2(u0.x + u2.x, u0.y + u2.y), d02 = make_float2(u0.x - u2.x, u0.y - u2.y);
+            const float2 s13 = make_float2(u1.x + u3.x, u1.y + u3.y), d13 = make_float2(u1.x - u3.x, u1.y - u3.y);
+            const int base = ((j - k) << 2) + k;
+            b[base] = make_float2(s02.x + s13.x, s02.y + s13.y);
+            b[base + Ns] = make_float2(d02.x + d13.y, d02.y - d13.x);  // d02 - i d13
+            b[base + 2 * Ns] = make_float2(s02.x - s13.x, s02.y - s13.y);
+            b[base + 3 * Ns] = make_float2(d02.x - d13.y, d02.y + d13.x);  // d02 + i d13
         }
+        float2* t = a; a = b; b = t;
         __syncthreads();
     }
+    return a;
 }
 
 __device__ __forceinline__ int64_t reflect_index(int64_t i, int64_t n) {
@@ -81,15 +74,15 @@ __device__ __forceinline__ int64_t reflect_index(int64_t i, int64_t n) {
     return i;
 }
 
-// load frame f of (x, y) as z = w (x + i y) into digit-reversed positions
+// load frame f of (x, y) as z = w (x + i y), natural order
 __device__ __forceinline__ void load_frame(float2* buf, const float* __restrict__ x, const float* __restrict__ y,
-                                           const float* __restrict__ win, const int* __restrict__ perm, int f,
-                                           const ResInfo& r, int64_t n, int tid, int nthreads) {
+                                           const float* __restrict__ win, int f, const ResInfo& r, int64_t n, int tid,
+                                           int nthreads) {
     const int64_t start = (int64_t)f * r.hop - r.n_fft / 2;
     for (int k = tid; k < r.n_fft; k += nthreads) {
         const int64_t i = reflect_index(start + k, n);
         const float w = win[k];
-        buf[perm[k]] = make_float2(w * x[i], w * y[i]);
+        buf[k] = make_float2(w * x[i], w * y[i]);
     }
 }
 
@@ -116,37 +109,40 @@ __device__ __forceinline__ void split_xy(const float2* buf, int k, int n_fft, fl
 
 constexpr int stft_threads(int n_fft) { return n_fft <= 512 ? 128 : (n_fft <= 2048 ? 512 : 1024); }
 
+constexpr float kLn2 = 0.6931471805599453f;
+
 template <int NFFT>
 __global__ __launch_bounds__(stft_threads(NFFT)) void k_stft_fwd(StftArgs a) {
     constexpr int THREADS = stft_threads(NFFT);
-    __shared__ __attribute__((aligned(16))) float2 buf[NFFT];
+    __shared__ __attribute__((aligned(16))) float2 bufA[NFFT];
+    __shared__ __attribute__((aligned(16))) float2 bufB[NFFT];
     __shared__ float red[16][4];
     const int tid = threadIdx.x, row = blockIdx.y;
     const ResInfo r = a.r;
     const float2* tw = reinterpret_cast<const float2*>(a.tables + r.tw_off);
     const float* win = a.tables + r.win_off;
-    const int* perm = reinterpret_cast<const int*>(a.tables + r.perm_off);
     const float* x = a.pred + (int64_t)row * a.n;
     const float* y = a.target + (int64_t)row * a.n;
     float s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f;
     const int f0 = blockIdx.x * r.frames_per_wg;
     for (int f = f0; f < f0 + r.frames_per_wg && f < r.n_frames; ++f) {
-        load_frame(buf, x, y, win, perm, f, r, a.n, tid, THREADS);
+        load_frame(bufA, x, y, win, f, r, a.n, tid, THREADS);
         __syncthreads();
-        lds_fft(buf, tw, r.n_fft, a.log2n, tid, THREADS);
+        const float2* Z = lds_fft(bufA, bufB, tw, NFFT, a.log2n, tid, THREADS);
         for (int k = tid; k < r.n_bins; k += THREADS) {
             float2 X, Y;
-            split_xy(buf, k, r.n_fft, X, Y);
+            split_xy(Z, k, NFFT, X, Y);
             const float xm = sqrtf(fmaxf(X.x * X.x + X.y * X.y, a.eps));
             const float ym = sqrtf(fmaxf(Y.x * Y.x + Y.y * Y.y, a.eps));
             const float d = ym - xm;
             s1 = fmaf(d, d, s1);
             s2 = fmaf(ym, ym, s2);
-            s3 += fabsf(logf(xm) - logf(ym));
+            s3 += fabsf(__builtin_amdgcn_logf(xm) - __builtin_amdgcn_logf(ym));  // log2; scaled by ln2 below
             s4 += fabsf(d);
         }
         __syncthreads();
     }
+    s3 *= kLn2;
     const int wave = tid >> 6, lane = tid & 63;
     s1 = wave_sum(s1); s2 = wave_sum(s2); s3 = wave_sum(s3); s4 = wave_sum(s4);
     if (lane == 0) { red[wave][0] = s1; red[wave][1] = s2; red[wave][2] = s3; red[wave][3] = s4; }
@@ -158,82 +154,82 @@ __global__ __launch_bounds__(stft_threads(NFFT)) void k_stft_fwd(StftArgs a) {
     }
 }
 
-// cotangent of the packed spectrum for frame f -> accumulated into hbuf as He (first frame) or i*He (second)
-__device__ __forceinline__ void accumulate_dx(const float2* buf, float2* hbuf, const StftArgs& a, const float* coef,
-                                              bool second, int tid, int nthreads) {
-    const ResInfo& r = a.r;
-    const float c_sc = coef[0], c_log = coef[1], c_lin = coef[2];
-    for (int k = tid; k < r.n_bins; k += nthreads) {
-        float2 X, Y;
-        split_xy(buf, k, r.n_fft, X, Y);
-        const float p2 = X.x * X.x + X.y * X.y;
-        const float xm = sqrtf(fmaxf(p2, a.eps));
-        const float ym = sqrtf(fmaxf(Y.x * Y.x + Y.y * Y.y, a.eps));
-        float g = c_sc * (xm - ym);
-        const float dl = logf(xm) - logf(ym);
-        g += c_log * ((dl > 0.f) - (dl < 0.f)) / xm;
-        g += c_lin * ((xm > ym) - (xm < ym));
-        // through sqrt(clamp(|X|^2, eps)): zero below the clamp
-        const float s = (p2 >= a.eps) ? g / xm : 0.0f;
-        float2 G = make_float2(s * X.x, s * X.y);
-        // Hermitian extension whose inverse DFT is the real cotangent frame
-        const bool edge = (k == 0) || (k == r.n_fft / 2);
-        float2 hk = edge ? make_float2(G.x, 0.f) : make_float2(0.5f * G.x, 0.5f * G.y);
-        float2 hn = make_float2(hk.x, -hk.y);
-        if (second) {  // multiply by i
-            hk = make_float2(-hk.y, hk.x);
-            hn = make_float2(-hn.y, hn.x);
-        }
-        const int kn = (r.n_fft - k) & (r.n_fft - 1);
-        if (second) {
-            hbuf[k].x += hk.x; hbuf[k].y += hk.y;
-            if (!edge) { hbuf[kn].x += hn.x; hbuf[kn].y += hn.y; }
-        } else {
-            hbuf[k] = hk;
-            if (!edge) hbuf[kn] = hn;
-        }
-    }
+// cotangent G[k] = dL/dX[k] of the prediction's half spectrum for the frame whose packed FFT is Z
+__device__ __forceinline__ float2 spectrum_cotangent(const float2* Z, int k, int n_fft, const StftArgs& a, const float* coef) {
+    float2 X, Y;
+    split_xy(Z, k, n_fft, X, Y);
+    const float p2 = X.x * X.x + X.y * X.y;
+    const float xm = sqrtf(fmaxf(p2, a.eps));
+    const float ym = sqrtf(fmaxf(Y.x * Y.x + Y.y * Y.y, a.eps));
+    float g = coef[0] * (xm - ym);
+    const float dl = __builtin_amdgcn_logf(xm) - __builtin_amdgcn_logf(ym);
+    g += coef[1] * ((dl > 0.f) - (dl < 0.f)) / xm;
+    g += coef[2] * ((xm > ym) - (xm < ym));
+    const float s = (p2 >= a.eps) ? g / xm : 0.0f;  // through sqrt(clamp(|X|^2, eps)): zero below the clamp
+    return make_float2(s * X.x, s * X.y);
 }
 
-template <int NFFT>
+// Backward.  The real cotangent frame is Re IDFT of the half spectrum G, i.e. the IDFT of its
+// Hermitian extension He (He[k] = G[k]/2, He[N-k] = conj(G[k])/2, real at k = 0, N/2), and
+// IDFT(h) = conj(FFT(conj(h))).  PAIR: two frames share one complex inverse FFT (He_a + i He_b).
+template <int NFFT, bool PAIR>
 __global__ __launch_bounds__(stft_threads(NFFT)) void k_stft_bwd(StftArgs a) {
     constexpr int THREADS = stft_threads(NFFT);
-    __shared__ __attribute__((aligned(16))) float2 buf[NFFT];
-    __shared__ __attribute__((aligned(16))) float2 hbuf[NFFT];
+    __shared__ __attribute__((aligned(16))) float2 bufA[NFFT];
+    __shared__ __attribute__((aligned(16))) float2 bufB[NFFT];
+    __shared__ __attribute__((aligned(16))) float2 bufH[PAIR ? NFFT : 1];
     const ResInfo r = a.r;
     const int tid = threadIdx.x, row = blockIdx.y;
     const float2* tw = reinterpret_cast<const float2*>(a.tables + r.tw_off);
     const float* win = a.tables + r.win_off;
-    const int* perm = reinterpret_cast<const int*>(a.tables + r.perm_off);
     const float* x = a.pred + (int64_t)row * a.n;
     const float* y = a.target + (int64_t)row * a.n;
     const float* coef = a.coef + (int64_t)row * 4;
     float* gx = a.grad_pred + (int64_t)row * a.n;
-    const int fa = 2 * blockIdx.x, fb = fa + 1;
-    const bool have_b = fb < r.n_frames;
+    const int fa = PAIR ? 2 * blockIdx.x : blockIdx.x, fb = fa + 1;
+    const bool have_b = PAIR && fb < r.n_frames;
+    const int64_t sa = (int64_t)fa * r.hop - NFFT / 2, sb = (int64_t)fb * r.hop - NFFT / 2;
 
-    load_frame(buf, x, y, win, perm, fa, r, a.n, tid, THREADS);
+    load_frame(bufA, x, y, win, fa, r, a.n, tid, THREADS);
     __syncthreads();
-    lds_fft(buf, tw, r.n_fft, a.log2n, tid, THREADS);
-    accumulate_dx(buf, hbuf, a, coef, false, tid, THREADS);
-    __syncthreads();
-    if (have_b) {
-        load_frame(buf, x, y, win, perm, fb, r, a.n, tid, THREADS);
-        __syncthreads();
-        lds_fft(buf, tw, r.n_fft, a.log2n, tid, THREADS);
-        accumulate_dx(buf, hbuf, a, coef, true, tid, THREADS);
-        __syncthreads();
-    }
-    // inverse DFT via conj(FFT(conj(.))): r1 + i r2
-    for (int k = tid; k < r.n_fft; k += THREADS) {
-        const float2 h = hbuf[k];
-        buf[perm[k]] = make_float2(h.x, -h.y);
+    float2* Z = lds_fft(bufA, bufB, tw, NFFT, a.log2n, tid, THREADS);
+    float2* O = (Z == bufA) ? bufB : bufA;       // the buffer the forward result is NOT in
+    float2* H = PAIR ? bufH : O;                 // where conj(He) is assembled
+    for (int k = tid; k <= NFFT / 2; k += THREADS) {
+        const float2 G = spectrum_cotangent(Z, k, NFFT, a, coef);
+        const bool edge = (k == 0) || (k == NFFT / 2);
+        // conj(He): He[k] = G/2 -> (Gx/2, -Gy/2); He[N-k] = conj(G)/2 -> (Gx/2, +Gy/2)
+        H[k] = edge ? make_float2(G.x, 0.f) : make_float2(0.5f * G.x, -0.5f * G.y);
+        if (!edge) H[NFFT - k] = make_float2(0.5f * G.x, 0.5f * G.y);
     }
     __syncthreads();
-    lds_fft(buf, tw, r.n_fft, a.log2n, tid, THREADS);
-    const int64_t sa = (int64_t)fa * r.hop - r.n_fft / 2, sb = (int64_t)fb * r.hop - r.n_fft / 2;
-    for (int k = tid; k < r.n_fft; k += THREADS) {
-        const float2 v = buf[k];
+    if (PAIR) {
+        if (have_b) {
+            load_frame(bufA, x, y, win, fb, r, a.n, tid, THREADS);
+            __syncthreads();
+            Z = lds_fft(bufA, bufB, tw, NFFT, a.log2n, tid, THREADS);
+            for (int k = tid; k <= NFFT / 2; k += THREADS) {
+                const float2 G = spectrum_cotangent(Z, k, NFFT, a, coef);
+                const bool edge = (k == 0) || (k == NFFT / 2);
+                // conj(i He_b): i He[k] = i G/2 = (-Gy/2, Gx/2) -> conj = (-Gy/2, -Gx/2);
+                //               i He[N-k] = i conj(G)/2 = (Gy/2, Gx/2) -> conj = (Gy/2, -Gx/2)
+                if (edge) {
+                    H[k].y -= G.x;  // i * Re(G) -> conj -> (0, -Gx)
+                } else {
+                    H[k].x += -0.5f * G.y; H[k].y += -0.5f * G.x;
+                    H[NFFT - k].x += 0.5f * G.y; H[NFFT - k].y += -0.5f * G.x;
+                }
+            }
+            __syncthreads();
+        }
+        O = bufA;  // both work buffers are free again
+    } else {
+        O = Z;     // forward result no longer needed
+    }
+    // FFT(conj(h)) = conj(r_a + i r_b)  =>  r_a = Re, r_b = -Im
+    const float2* R = lds_fft(H, O, tw, NFFT, a.log2n, tid, THREADS);
+    for (int k = tid; k < NFFT; k += THREADS) {
+        const float2 v = R[k];
         const float w = win[k];
         unsafeAtomicAdd(&gx[reflect_index(sa + k, a.n)], w * v.x);
         if (have_b) unsafeAtomicAdd(&gx[reflect_index(sb + k, a.n)], -w * v.y);
@@ -241,10 +237,9 @@ __global__ __launch_bounds__(stft_threads(NFFT)) void k_stft_bwd(StftArgs a) {
 }
 
 // ---- tables: twiddles (cos, -sin) and the (centre-padded) periodic Hann window -------------------
-__global__ void k_stft_tables(float* tables, ResInfo r, int win_length, int log2n) {
+__global__ void k_stft_tables(float* tables, ResInfo r, int win_length) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= r.n_fft) return;
-    reinterpret_cast<int*>(tables + r.perm_off)[t] = dit_pos(t, r.n_fft, log2n);
     const double ang = 6.283185307179586476925 * (double)t / (double)r.n_fft;
     tables[r.tw_off + 2 * t] = (float)cos(ang);
     tables[r.tw_off + 2 * t + 1] = (float)(-sin(ang));
@@ -271,46 +266,58 @@ struct LossArgs {
     float w_sc, w_log, w_lin;
     int sc_per_example;
 };
-// one workgroup of 64 lanes; deterministic
-__global__ __launch_bounds__(64) void k_mrstft_reduce(LossArgs a) {
+// stage 1: one 64-lane workgroup per (row, resolution) folds that row's strip partials (fp64, fixed order)
+__global__ __launch_bounds__(64) void k_mrstft_rowsums(LossArgs a) {
+    const int tid = threadIdx.x, row = blockIdx.x, res = blockIdx.y;
+    const float* p = a.part + a.part_off[res] + (int64_t)row * a.n_groups[res] * 4;
+    double s[4] = {0, 0, 0, 0};
+    for (int g = tid; g < a.n_groups[res]; g += 64) {
+        const float4 v = *reinterpret_cast<const float4*>(p + (int64_t)g * 4);
+        s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        for (int m = 32; m >= 1; m >>= 1) s[q] += __shfl_xor(s[q], m);
+    if (tid == 0) {
+        float* o = a.sums + ((int64_t)res * a.rows + row) * 4;
+        o[0] = (float)s[0]; o[1] = (float)s[1]; o[2] = (float)s[2]; o[3] = (float)s[3];
+    }
+}
+// stage 2: loss scalar + per-row backward coefficients (without dL/dloss, applied by k_scale_coef)
+__global__ __launch_bounds__(64) void k_mrstft_final(LossArgs a) {
     __shared__ double rs[kMaxRes][4];
     const int tid = threadIdx.x;
-    double total = 0.0;
-    for (int res = 0; res < a.n_res; ++res) {
-        double tot[4] = {0, 0, 0, 0};
-        double sc_acc = 0.0;
+    if (tid < a.n_res) {
+        const int res = tid;
+        double tot[4] = {0, 0, 0, 0}, sc_acc = 0.0;
         for (int row = 0; row < a.rows; ++row) {
-            double s[4] = {0, 0, 0, 0};
-            const float* p = a.part + a.part_off[res] + (int64_t)row * a.n_groups[res] * 4;
-            for (int g = tid; g < a.n_groups[res]; g += 64)
-                for (int q = 0; q < 4; ++q) s[q] += (double)p[(int64_t)g * 4 + q];
-            for (int q = 0; q < 4; ++q) {
-                for (int m = 32; m >= 1; m >>= 1) s[q] += __shfl_xor(s[q], m);
-                tot[q] += s[q];
-            }
-            if (tid < 4) a.sums[((int64_t)res * a.rows + row) * 4 + tid] = (float)s[tid];
-            sc_acc += sqrt(s[0]) / sqrt(s[1]);
+            const float* sm = a.sums + ((int64_t)res * a.rows + row) * 4;
+            for (int q = 0; q < 4; ++q) tot[q] += (double)sm[q];
+            sc_acc += sqrt((double)sm[0]) / sqrt((double)sm[1]);
         }
+        for (int q = 0; q < 4; ++q) rs[res][q] = tot[q];
         const double sc = a.sc_per_example ? sc_acc / a.rows : sqrt(tot[0]) / sqrt(tot[1]);
-        total += a.w_sc * sc + a.w_log * tot[2] / a.count[res] + a.w_lin * tot[3] / a.count[res];
-        if (tid < 4) rs[res][tid] = tot[tid];
+        rs[res][3] = a.w_sc * sc + a.w_log * tot[2] / a.count[res] + a.w_lin * tot[3] / a.count[res];
     }
     __syncthreads();
-    if (tid == 0) a.loss[0] = (float)(total / a.n_res);
-    // backward coefficients (without the upstream dL/dloss, applied by k_mrstft_coef)
-    for (int res = 0; res < a.n_res; ++res)
-        for (int row = tid; row < a.rows; row += 64) {
-            const float* s = a.sums + ((int64_t)res * a.rows + row) * 4;
-            double c_sc;
-            if (a.sc_per_example) c_sc = a.w_sc / ((double)a.rows * sqrt((double)s[0]) * sqrt((double)s[1]));
-            else c_sc = a.w_sc / (sqrt(rs[res][0]) * sqrt(rs[res][1]));
-            if (!(c_sc == c_sc) || c_sc > 1e30) c_sc = 0.0;  // identical signals: 0/0 -> no SC gradient
-            float* c = a.coef + ((int64_t)res * a.rows + row) * 4;
-            c[0] = (float)(c_sc / a.n_res);
-            c[1] = (float)(a.w_log / a.count[res] / a.n_res);
-            c[2] = (float)(a.w_lin / a.count[res] / a.n_res);
-            c[3] = 0.f;
-        }
+    if (tid == 0) {
+        double total = 0.0;
+        for (int res = 0; res < a.n_res; ++res) total += rs[res][3];
+        a.loss[0] = (float)(total / a.n_res);
+    }
+    for (int i = tid; i < a.n_res * a.rows; i += 64) {
+        const int res = i / a.rows;
+        const float* sm = a.sums + (int64_t)i * 4;
+        double c_sc;
+        if (a.sc_per_example) c_sc = a.w_sc / ((double)a.rows * sqrt((double)sm[0]) * sqrt((double)sm[1]));
+        else c_sc = a.w_sc / (sqrt(rs[res][0]) * sqrt(rs[res][1]));
+        if (!(c_sc == c_sc) || c_sc > 1e30) c_sc = 0.0;  // identical signals: 0/0 -> no SC gradient
+        float* c = a.coef + (int64_t)i * 4;
+        c[0] = (float)(c_sc / a.n_res);
+        c[1] = (float)(a.w_log / a.count[res] / a.n_res);
+        c[2] = (float)(a.w_lin / a.count[res] / a.n_res);
+        c[3] = 0.f;
+    }
 }
 __global__ void k_scale_coef(const float* coef, const float* grad_loss, float* out, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -352,8 +359,6 @@ Plan make_plan(const mst_mrstft_desc* d) {
         r.tw_off = t;
         t += 2 * (int64_t)nf;
         r.win_off = t;
-        t += nf;
-        r.perm_off = t;
         t += nf;
         p.log2n[i] = lg;
         p.win[i] = d->win_length[i];
@@ -399,7 +404,7 @@ extern "C" int mst_mrstft_init_tables(const mst_mrstft_desc* d, void* tables, vo
     if (!p.ok || !tables) return hipErrorInvalidValue;
     hipStream_t stream = (hipStream_t)stream_;
     for (int i = 0; i < d->n_res; ++i)
-        hipLaunchKernelGGL(k_stft_tables, dim3((p.res[i].n_fft + 255) / 256), dim3(256), 0, stream, (float*)tables, p.res[i], p.win[i], p.log2n[i]);
+        hipLaunchKernelGGL(k_stft_tables, dim3((p.res[i].n_fft + 255) / 256), dim3(256), 0, stream, (float*)tables, p.res[i], p.win[i]);
     return (int)hipGetLastError();
 }
 
@@ -438,7 +443,8 @@ extern "C" int mst_mrstft_forward(const mst_mrstft_desc* d, const float* pred, c
         la.part_off[i] = p.part_off[i];
         la.count[i] = (float)((double)d->rows * p.res[i].n_bins * p.res[i].n_frames);
     }
-    hipLaunchKernelGGL(k_mrstft_reduce, dim3(1), dim3(64), 0, stream, la);
+    hipLaunchKernelGGL(k_mrstft_rowsums, dim3(d->rows, d->n_res), dim3(64), 0, stream, la);
+    hipLaunchKernelGGL(k_mrstft_final, dim3(1), dim3(64), 0, stream, la);
     return (int)hipGetLastError();
 }
 
@@ -465,8 +471,12 @@ extern "C" int mst_mrstft_backward(const mst_mrstft_desc* d, const float* pred, 
         a.log2n = p.log2n[i];
         a.n = d->n_samples;
         a.eps = d->eps;
-        const dim3 grid((a.r.n_frames + 1) / 2, d->rows);
-#define MST_LAUNCH_BWD(NF) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stft_bwd<NF>), grid, dim3(stft_threads(NF)), 0, stream, a)
+        // three LDS buffers (pairing two frames per inverse FFT) fit up to n_fft = 4096; 8192 runs one frame per workgroup
+        const bool pair = a.r.n_fft <= 4096;
+        const dim3 grid(pair ? (a.r.n_frames + 1) / 2 : a.r.n_frames, d->rows);
+#define MST_LAUNCH_BWD(NF)                                                                                             \
+    if (NF <= 4096) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stft_bwd<NF, (NF <= 4096)>), grid, dim3(stft_threads(NF)), 0, stream, a); \
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stft_bwd<NF, false>), grid, dim3(stft_threads(NF)), 0, stream, a)
         MST_FOR_NFFT(a.r.n_fft, MST_LAUNCH_BWD)
     }
     return (int)hipGetLastError();
