@@ -80,21 +80,11 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const float* __restrict__
     }
     // 2. inclusive Hillis-Steele over lanes (levels beyond the populated lanes are skipped)
     const int active = (nc + K - 1) / K;
-    const int lane = tid & 63;
-    // levels 0..5 stay inside the wave: shuffles, no LDS round trip, no barrier
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-        const int off = 1 << j;
-        float o[D];
-#pragma unroll
-        for (int d = 0; d < D; ++d) o[d] = __shfl_up(agg[d], off);
-        if (lane >= off) matvec_acc<D>(T + (1 + j) * D * D, o, agg);
-    }
     int cur = 0;
 #pragma unroll
     for (int d = 0; d < D; ++d) buf[0][d][tid] = agg[d];
     __syncthreads();
-    for (int j = 6; j < kScanLevels && (1 << j) < active; ++j) {
+    for (int j = 0; j < kScanLevels && (1 << j) < active; ++j) {
         const int off = 1 << j;
         if (tid >= off) {
             float o[D];
