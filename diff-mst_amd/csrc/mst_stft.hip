@@ -26,15 +26,31 @@ struct ResInfo {
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 
-// Forward DFT (e^{-i...}) of n_fft complex points held in LDS: Stockham autosort, radix-4 stages
-// (one radix-2 stage first when log2 n_fft is odd), natural order in AND out, ping-pong between
-// `a` (input) and `b`.  Every stage reads a[j + r n/4] for consecutive j (conflict-free) and the
-// result pointer is returned.  tw[t] = (cos, -sin)(2 pi t / n_fft), t < n_fft.
-__device__ float2* lds_fft(float2* a, float2* b, const float2* __restrict__ tw, int n_fft, int log2n, int tid, int nthreads) {
+// Forward DFT (e^{-i...}) of NFFT complex points held in LDS: Stockham autosort, radix-4 stages
+// (one radix-2 stage first when log2 NFFT is odd), natural order in AND out, ping-pong between
+// `a` (input) and `b`; the result pointer is returned.  Every stage reads a[j + r n/4] for
+// consecutive j (conflict-free).  Twiddles come from a two-level table staged in LDS
+// (w^t = coarse[t >> 6] * fine[t & 63], 1.5 KB instead of 64 KB at n = 8192) so that no stage waits
+// on a global load; w^2t and w^3t are formed by multiplication.
+template <int NFFT>
+struct Twiddles {
+    float2 coarse[NFFT / 64];
+    float2 fine[64];
+};
+template <int NFFT>
+__device__ __forceinline__ void stage_twiddles(Twiddles<NFFT>& T, const float2* __restrict__ tw, int tid, int nthreads) {
+    for (int i = tid; i < NFFT / 64; i += nthreads) T.coarse[i] = tw[i * 64];
+    for (int i = tid; i < 64; i += nthreads) T.fine[i] = tw[i];
+}
+template <int NFFT, int THREADS>
+__device__ __forceinline__ float2* lds_fft(float2* a, float2* b, const Twiddles<NFFT>& T, int tid) {
+    constexpr int LOG2N = (NFFT == 128) ? 7 : (NFFT == 256) ? 8 : (NFFT == 512) ? 9 : (NFFT == 1024) ? 10
+                        : (NFFT == 2048) ? 11 : (NFFT == 4096) ? 12 : 13;
     int Ns = 1;
-    if (log2n & 1) {
-        const int h = n_fft >> 1;
-        for (int j = tid; j < h; j += nthreads) {
+    if (LOG2N & 1) {
+        constexpr int h = NFFT >> 1;
+#pragma unroll
+        for (int j = tid; j < h; j += THREADS) {
             const float2 u0 = a[j], u1 = a[j + h];
             b[2 * j] = make_float2(u0.x + u1.x, u0.y + u1.y);
             b[2 * j + 1] = make_float2(u0.x - u1.x, u0.y - u1.y);
@@ -43,16 +59,22 @@ __device__ float2* lds_fft(float2* a, float2* b, const float2* __restrict__ tw, 
         Ns = 2;
         __syncthreads();
     }
-    const int q = n_fft >> 2;
-    for (; Ns < n_fft; Ns <<= 2) {
-        const int tstep = n_fft / (4 * Ns);
-        for (int j = tid; j < q; j += nthreads) {
+    constexpr int q = NFFT >> 2;
+#pragma unroll 1
+    for (; Ns < NFFT; Ns <<= 2) {
+        const int tstep = NFFT / (4 * Ns);
+#pragma unroll
+        for (int j = tid; j < q; j += THREADS) {
             const int k = j & (Ns - 1);
             float2 u0 = a[j], u1 = a[j + q], u2 = a[j + 2 * q], u3 = a[j + 3 * q];
-            if (k) {
-                u1 = cmul(u1, tw[k * tstep]);
-                u2 = cmul(u2, tw[2 * k * tstep]);
-                u3 = cmul(u3, tw[3 * k * tstep]);
+            if (Ns > 1) {
+                const int t = k * tstep;
+                const float2 w1 = cmul(T.coarse[t >> 6], T.fine[t & 63]);
+                const float2 w2 = cmul(w1, w1);
+                const float2 w3 = cmul(w2, w1);
+                u1 = cmul(u1, w1);
+                u2 = cmul(u2, w2);
+                u3 = cmul(u3, w3);
             }
             const float2 s02 = make_float2(u0.x + u2.x, u0.y + u2.y), d02 = make_float2(u0.x - u2.x, u0.y - u2.y);
             const float2 s13 = make_float2(u1.x + u3.x, u1.y + u3.y), d13 = make_float2(u1.x - u3.x, u1.y - u3.y);
@@ -117,9 +139,10 @@ __global__ __launch_bounds__(stft_threads(NFFT)) void k_stft_fwd(StftArgs a) {
     __shared__ __attribute__((aligned(16))) float2 bufA[NFFT];
     __shared__ __attribute__((aligned(16))) float2 bufB[NFFT];
     __shared__ float red[16][4];
+    __shared__ Twiddles<NFFT> twd;
     const int tid = threadIdx.x, row = blockIdx.y;
     const ResInfo r = a.r;
-    const float2* tw = reinterpret_cast<const float2*>(a.tables + r.tw_off);
+    stage_twiddles<NFFT>(twd, reinterpret_cast<const float2*>(a.tables + r.tw_off), tid, THREADS);
     const float* win = a.tables + r.win_off;
     const float* x = a.pred + (int64_t)row * a.n;
     const float* y = a.target + (int64_t)row * a.n;
@@ -128,7 +151,7 @@ __global__ __launch_bounds__(stft_threads(NFFT)) void k_stft_fwd(StftArgs a) {
     for (int f = f0; f < f0 + r.frames_per_wg && f < r.n_frames; ++f) {
         load_frame(bufA, x, y, win, f, r, a.n, tid, THREADS);
         __syncthreads();
-        const float2* Z = lds_fft(bufA, bufB, tw, NFFT, a.log2n, tid, THREADS);
+        const float2* Z = lds_fft<NFFT, THREADS>(bufA, bufB, twd, tid);
         for (int k = tid; k < r.n_bins; k += THREADS) {
             float2 X, Y;
             split_xy(Z, k, NFFT, X, Y);
@@ -178,9 +201,10 @@ __global__ __launch_bounds__(stft_threads(NFFT)) void k_stft_bwd(StftArgs a) {
     __shared__ __attribute__((aligned(16))) float2 bufA[NFFT];
     __shared__ __attribute__((aligned(16))) float2 bufB[NFFT];
     __shared__ __attribute__((aligned(16))) float2 bufH[PAIR ? NFFT : 1];
+    __shared__ Twiddles<NFFT> twd;
     const ResInfo r = a.r;
     const int tid = threadIdx.x, row = blockIdx.y;
-    const float2* tw = reinterpret_cast<const float2*>(a.tables + r.tw_off);
+    stage_twiddles<NFFT>(twd, reinterpret_cast<const float2*>(a.tables + r.tw_off), tid, THREADS);
     const float* win = a.tables + r.win_off;
     const float* x = a.pred + (int64_t)row * a.n;
     const float* y = a.target + (int64_t)row * a.n;
@@ -192,7 +216,7 @@ __global__ __launch_bounds__(stft_threads(NFFT)) void k_stft_bwd(StftArgs a) {
 
     load_frame(bufA, x, y, win, fa, r, a.n, tid, THREADS);
     __syncthreads();
-    float2* Z = lds_fft(bufA, bufB, tw, NFFT, a.log2n, tid, THREADS);
+    float2* Z = lds_fft<NFFT, THREADS>(bufA, bufB, twd, tid);
     float2* O = (Z == bufA) ? bufB : bufA;       // the buffer the forward result is NOT in
     float2* H = PAIR ? bufH : O;                 // where conj(He) is assembled
     for (int k = tid; k <= NFFT / 2; k += THREADS) {
@@ -207,7 +231,7 @@ __global__ __launch_bounds__(stft_threads(NFFT)) void k_stft_bwd(StftArgs a) {
         if (have_b) {
             load_frame(bufA, x, y, win, fb, r, a.n, tid, THREADS);
             __syncthreads();
-            Z = lds_fft(bufA, bufB, tw, NFFT, a.log2n, tid, THREADS);
+            Z = lds_fft<NFFT, THREADS>(bufA, bufB, twd, tid);
             for (int k = tid; k <= NFFT / 2; k += THREADS) {
                 const float2 G = spectrum_cotangent(Z, k, NFFT, a, coef);
                 const bool edge = (k == 0) || (k == NFFT / 2);
@@ -227,7 +251,7 @@ __global__ __launch_bounds__(stft_threads(NFFT)) void k_stft_bwd(StftArgs a) {
         O = Z;     // forward result no longer needed
     }
     // FFT(conj(h)) = conj(r_a + i r_b)  =>  r_a = Re, r_b = -Im
-    const float2* R = lds_fft(H, O, tw, NFFT, a.log2n, tid, THREADS);
+    const float2* R = lds_fft<NFFT, THREADS>(H, O, twd, tid);
     for (int k = tid; k < NFFT; k += THREADS) {
         const float2 v = R[k];
         const float w = win[k];
