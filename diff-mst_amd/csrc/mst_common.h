@@ -14,8 +14,8 @@ constexpr int kStates = 2 * kSections; // DF2T state of the whole cascade
 constexpr int kWG = 256;               // lanes per workgroup in the streaming kernels
 constexpr int kEqChunk = 64;           // samples one lane filters sequentially (EQ kernels)
 constexpr int kCompChunk = 8;          // samples one lane owns in the compressor kernels
-constexpr int kScanThreads = 1024;     // lanes per row in the carry-scan kernels
-constexpr int kScanLevels = 10;        // log2(kScanThreads)
+constexpr int kScanThreads = 512;      // lanes per row in the carry-scan kernels
+constexpr int kScanLevels = 9;         // log2(kScanThreads)
 constexpr int kPow = 1 + kScanLevels;  // matrices per scan table: M, then M^(K*2^j)
 
 // ---- per-filter-row constants ("rc"), written by k_prep, floats -------------------------------

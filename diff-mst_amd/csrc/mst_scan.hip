@@ -8,20 +8,56 @@
 
 namespace mst {
 
+// number of leading columns of row i that can be non-zero (cascade matrices are block lower-triangular)
 template <int D>
-__device__ __forceinline__ void matvec_acc(const float* __restrict__ M, const float* v, float* acc) {
-    // acc += M v ; M row-major D x D, uniform address
+__device__ __forceinline__ constexpr int row_cols(int i) { return D == 12 ? 2 * (i / 2 + 1) : D; }
+
+// acc += M v ; M row-major D x D in LDS (16-byte aligned), read with explicit 16-byte loads.
+// The address is wave-uniform, so every read is an LDS broadcast: 24 ds_read_b128 per 12x12 matvec.
+template <int D>
+__device__ __forceinline__ void matvec_acc(const float* M, const float* v, float* acc) {
+    if (D == 2) {
+        const float4 m = *reinterpret_cast<const float4*>(M);
+        acc[0] = fmaf(m.x, v[0], fmaf(m.y, v[1], acc[0]));
+        acc[1] = fmaf(m.z, v[0], fmaf(m.w, v[1], acc[1]));
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < D; ++i) {
         float s = acc[i];
 #pragma unroll
-        for (int j = 0; j < D; ++j) {
-            if (D == 12 && (j / 2) > (i / 2)) continue;  // cascade matrices are block lower-triangular
-            s = fmaf(M[i * D + j], v[j], s);
+        for (int c = 0; c < row_cols<D>(i); c += 4) {
+            const float4 m = *reinterpret_cast<const float4*>(M + i * D + c);
+            s = fmaf(m.x, v[c], s);
+            s = fmaf(m.y, v[c + 1], s);
+            if (c + 2 < row_cols<D>(i)) {
+                s = fmaf(m.z, v[c + 2], s);
+                s = fmaf(m.w, v[c + 3], s);
+            }
         }
         acc[i] = s;
     }
 }
+// the single-chunk matrix kept in registers for the sequential fold / replay loops
+template <int D>
+struct RegMat {
+    float m[D][D];
+    __device__ __forceinline__ void load(const float* M) {
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int c = 0; c < D; ++c) m[i][c] = (c < row_cols<D>(i)) ? M[i * D + c] : 0.0f;
+    }
+    __device__ __forceinline__ void acc(const float* v, float* out) const {
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            float s = out[i];
+#pragma unroll
+            for (int c = 0; c < row_cols<D>(i); ++c) s = fmaf(m[i][c], v[c], s);
+            out[i] = s;
+        }
+    }
+};
 
 // z, s0: [row][D][nc_pad].  tab: [table_row][kPow][D*D], table_row = (row / tab_div) * tab_mod + row % tab_mod
 // KT > 0: K == KT known at compile time - all of a lane's chunk states are fetched up front (one
@@ -54,6 +90,8 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const float* __restrict__
         }
     }
     __syncthreads();  // table staged
+    RegMat<D> M1;
+    M1.load(T);
     float agg[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) agg[d] = 0.0f;
@@ -63,7 +101,7 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const float* __restrict__
             float nv[D];
 #pragma unroll
             for (int d = 0; d < D; ++d) nv[d] = zl[k][d];
-            matvec_acc<D>(T, agg, nv);
+            M1.acc(agg, nv);
 #pragma unroll
             for (int d = 0; d < D; ++d) agg[d] = nv[d];
         }
@@ -73,7 +111,7 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const float* __restrict__
             float nv[D];
 #pragma unroll
             for (int d = 0; d < D; ++d) nv[d] = (i < nc) ? zr[(int64_t)d * nc_pad + cidx(i)] : 0.0f;
-            matvec_acc<D>(T, agg, nv);
+            M1.acc(agg, nv);
 #pragma unroll
             for (int d = 0; d < D; ++d) agg[d] = nv[d];
         }
@@ -113,7 +151,7 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const float* __restrict__
             float nv[D];
 #pragma unroll
             for (int d = 0; d < D; ++d) nv[d] = zl[k][d];
-            matvec_acc<D>(T, st, nv);
+            M1.acc(st, nv);
 #pragma unroll
             for (int d = 0; d < D; ++d) st[d] = nv[d];
         }
@@ -128,7 +166,7 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const float* __restrict__
                 sr[(int64_t)d * nc_pad + c] = st[d];
                 nv[d] = zr[(int64_t)d * nc_pad + c];
             }
-            matvec_acc<D>(T, st, nv);
+            M1.acc(st, nv);
 #pragma unroll
             for (int d = 0; d < D; ++d) st[d] = nv[d];
         }
@@ -142,6 +180,7 @@ static void launch_scan_k(dim3 grid, hipStream_t stream, const float* z, float* 
     if (K == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan<D, REV, 1>), grid, block, 0, stream, z, s0, tab, tab_div, tab_mod, nc, nc_pad, K);
     else if (K == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan<D, REV, 2>), grid, block, 0, stream, z, s0, tab, tab_div, tab_mod, nc, nc_pad, K);
     else if (K == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan<D, REV, 4>), grid, block, 0, stream, z, s0, tab, tab_div, tab_mod, nc, nc_pad, K);
+    else if (K == 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan<D, REV, 8>), grid, block, 0, stream, z, s0, tab, tab_div, tab_mod, nc, nc_pad, K);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan<D, REV, 0>), grid, block, 0, stream, z, s0, tab, tab_div, tab_mod, nc, nc_pad, K);
 }
 void launch_scan12(bool reverse, const float* z, float* s0, const float* tab, int nch, int nc, int nc_pad, int K, int nsig,
