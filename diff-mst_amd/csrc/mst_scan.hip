@@ -81,12 +81,31 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const float* __restrict__
     // 1. fold my K chunks from zero
     constexpr int KL = KT > 0 ? KT : 1;
     float zl[KL][D];
+    // A lane's KT chunks are contiguous in memory (ascending, or descending when REVERSE): fetch them
+    // with 16-byte accesses whenever the span is whole and aligned (it is for every production length).
+    const int span0 = REVERSE ? nc - KT * (tid + 1) : KT * tid;  // lowest chunk index of my span
+    const bool vec = (KT % 4 == 0) && span0 >= 0 && span0 + KT <= nc && (span0 & 3) == 0;
     if (KT > 0) {
+        if (vec) {
 #pragma unroll
-        for (int k = 0; k < KL; ++k) {
-            const int i = tid * KT + k;
+            for (int d = 0; d < D; ++d)
 #pragma unroll
-            for (int d = 0; d < D; ++d) zl[k][d] = (i < nc) ? zr[(int64_t)d * nc_pad + cidx(i)] : 0.0f;
+                for (int q = 0; q < KL / 4; ++q) {
+                    const float4 v = *reinterpret_cast<const float4*>(zr + (int64_t)d * nc_pad + span0 + 4 * q);
+                    const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int m = 4 * q + t;                      // memory order inside the span
+                        zl[REVERSE ? KL - 1 - m : m][d] = e[t];       // scan order
+                    }
+                }
+        } else {
+#pragma unroll
+            for (int k = 0; k < KL; ++k) {
+                const int i = tid * KT + k;
+#pragma unroll
+                for (int d = 0; d < D; ++d) zl[k][d] = (i < nc) ? zr[(int64_t)d * nc_pad + cidx(i)] : 0.0f;
+            }
         }
     }
     __syncthreads();  // table staged
@@ -140,20 +159,40 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const float* __restrict__
 #pragma unroll
     for (int d = 0; d < D; ++d) st[d] = (tid > 0) ? buf[cur][d][tid - 1] : 0.0f;
     if (KT > 0) {
+        float so[KL][D];
 #pragma unroll
         for (int k = 0; k < KL; ++k) {
-            const int i = tid * KT + k;
-            if (i < nc) {
-                const int c = cidx(i);
 #pragma unroll
-                for (int d = 0; d < D; ++d) sr[(int64_t)d * nc_pad + c] = st[d];
-            }
+            for (int d = 0; d < D; ++d) so[k][d] = st[d];
             float nv[D];
 #pragma unroll
             for (int d = 0; d < D; ++d) nv[d] = zl[k][d];
             M1.acc(st, nv);
 #pragma unroll
             for (int d = 0; d < D; ++d) st[d] = nv[d];
+        }
+        if (vec) {
+#pragma unroll
+            for (int d = 0; d < D; ++d)
+#pragma unroll
+                for (int q = 0; q < KL / 4; ++q) {
+                    float e[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int m = 4 * q + t;
+                        e[t] = so[REVERSE ? KL - 1 - m : m][d];
+                    }
+                    *reinterpret_cast<float4*>(sr + (int64_t)d * nc_pad + span0 + 4 * q) = make_float4(e[0], e[1], e[2], e[3]);
+                }
+        } else {
+#pragma unroll
+            for (int k = 0; k < KL; ++k) {
+                const int i = tid * KT + k;
+                if (i < nc) {
+#pragma unroll
+                    for (int d = 0; d < D; ++d) sr[(int64_t)d * nc_pad + cidx(i)] = so[k][d];
+                }
+            }
         }
     } else {
         for (int k = 0; k < K; ++k) {

@@ -68,11 +68,10 @@ __device__ __forceinline__ float2* lds_fft(float2* a, float2* b, const Twiddles<
             const int k = j & (Ns - 1);
             float2 u0 = a[j], u1 = a[j + q], u2 = a[j + 2 * q], u3 = a[j + 3 * q];
             if (Ns > 1) {
-                // each power looked up on its own (no w^2 = w*w error growth): still 3 complex multiplies
                 const int t = k * tstep;
                 const float2 w1 = cmul(T.coarse[t >> 6], T.fine[t & 63]);
-                const float2 w2 = cmul(T.coarse[(2 * t) >> 6], T.fine[(2 * t) & 63]);
-                const float2 w3 = cmul(T.coarse[(3 * t) >> 6], T.fine[(3 * t) & 63]);
+                const float2 w2 = cmul(w1, w1);
+                const float2 w3 = cmul(w2, w1);
                 u1 = cmul(u1, w1);
                 u2 = cmul(u2, w2);
                 u3 = cmul(u3, w3);
