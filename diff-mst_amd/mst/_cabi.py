@@ -75,6 +75,11 @@ SIGNATURES = {
     "mst_peak_normalize_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int64]),
     "mst_peak_normalize_forward": (C.c_int, [_P, _P, C.c_int32, C.c_int64, _P, C.c_size_t, _P]),
     "mst_peak_normalize_backward": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int64, _P, C.c_size_t, _P]),
+    "mst_afloss_tables_bytes": (C.c_size_t, []),
+    "mst_afloss_init_tables": (C.c_int, [_P, _P]),
+    "mst_afloss_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int64]),
+    "mst_afloss_forward": (C.c_int, [_P, _P, C.c_int32, C.c_int64, C.POINTER(C.c_float), _P, _P, _P, _P, C.c_size_t, _P]),
+    "mst_afloss_backward": (C.c_int, [_P, _P, C.c_int32, C.c_int64, C.POINTER(C.c_float), _P, _P, _P, _P, _P, C.c_size_t, _P]),
 }
 
 

@@ -130,3 +130,91 @@ class MultiResolutionSTFTLoss(torch.nn.Module):
 
     def forward(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
         return _MrstftFunction.apply(x, y, self.cfg)
+
+
+# ------------------------------------------------------------------------------------------------
+# AudioFeatureLoss
+# ------------------------------------------------------------------------------------------------
+AF_KEYS = ("mix-rms", "mix-crest_factor", "mix-stereo_width", "mix-stereo_imbalance", "mix-barkspectrum")
+_AF_CACHE = {}
+
+
+def _af_constants(device, sample_rate):
+    """(twiddle/window tables, Bark filterbank) on `device`; built once."""
+    key = (str(device), int(sample_rate))
+    c = _AF_CACHE.get(key)
+    if c is None:
+        from .filter import barkscale_fbanks
+
+        lib = _hip.lib()
+        tables = torch.empty(lib.mst_afloss_tables_bytes() // 4, dtype=torch.float32, device=device)
+        with torch.cuda.device(device):
+            _hip.check(lib.mst_afloss_init_tables(_cabi.ptr(tables), _hip.current_stream_ptr(device)), "mst_afloss_init_tables")
+        fb = barkscale_fbanks(16385, 20.0, 20000.0, 24, sample_rate).contiguous().to(device)  # reference mst/loss.py:88
+        c = _AF_CACHE[key] = (tables, fb)
+    return c
+
+
+class _AudioFeatureFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target, weights, sample_rate):
+        _hip.require_cuda(pred, target)
+        lib = _hip.lib()
+        if pred.dim() != 3 or pred.shape[1] != 2 or pred.shape != target.shape:
+            raise ValueError("AudioFeatureLoss expects (bs, 2, seq_len) input and target of equal shape")
+        x = pred.float().contiguous()
+        y = target.float().contiguous()
+        bs, _, n = x.shape
+        dev = x.device
+        tables, fb = _af_constants(dev, sample_rate)
+        nbytes = lib.mst_afloss_workspace_bytes(bs, n)
+        if nbytes == 0:
+            raise ValueError("AudioFeatureLoss needs seq_len > 16384 (reflect padding of the 32768-point Bark STFT)")
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        losses = torch.empty(5, dtype=torch.float32, device=dev)
+        w = (ctypes.c_float * 5)(*[float(v) for v in weights])
+        with torch.cuda.device(dev):
+            _hip.check(lib.mst_afloss_forward(_cabi.ptr(x), _cabi.ptr(y), bs, n, w, _cabi.ptr(tables), _cabi.ptr(fb),
+                                              _cabi.ptr(losses), _cabi.ptr(ws), nbytes, _hip.current_stream_ptr(dev)),
+                       "mst_afloss_forward")
+        ctx.meta = (bs, n, w, nbytes, pred.shape)
+        ctx.save_for_backward(x, y, tables, fb, ws)
+        return losses
+
+    @staticmethod
+    def backward(ctx, grad_losses):
+        x, y, tables, fb, ws = ctx.saved_tensors
+        bs, n, w, nbytes, shape = ctx.meta
+        lib = _hip.lib()
+        dev = x.device
+        g = grad_losses.float().contiguous()
+        gx = torch.empty_like(x)
+        with torch.cuda.device(dev):
+            _hip.check(lib.mst_afloss_backward(_cabi.ptr(x), _cabi.ptr(y), bs, n, w, _cabi.ptr(tables), _cabi.ptr(fb), _cabi.ptr(g),
+                                               _cabi.ptr(gx), _cabi.ptr(ws), nbytes, _hip.current_stream_ptr(dev)),
+                       "mst_afloss_backward")
+        return gx.view(shape), None, None, None
+
+
+class AudioFeatureLoss(torch.nn.Module):
+    """Drop-in for reference ``mst.loss.AudioFeatureLoss`` (:198-260).
+
+    ``forward(input, target)`` returns ``{key: weight * mse(feature(input), feature(target))}`` with the
+    reference's five keys (``System`` sums ``val.mean()`` over them, mst/system.py:334-336).  All five
+    features and their gradients are computed by the kernels of ``csrc/mst_af.hip`` in one pass.
+    """
+
+    def __init__(self, weights: List[float], sample_rate: int, stem_separation: bool = False, use_clap: bool = False) -> None:
+        super().__init__()
+        self.weights = weights
+        self.sample_rate = sample_rate
+        self.stem_separation = stem_separation
+        self.sources_list = ["mix"]
+        self.source_weights = [1.0]
+        self.use_clap = use_clap
+        self.transform_names = ["rms", "crest_factor", "stereo_width", "stereo_imbalance", "barkspectrum"]
+        assert len(self.transform_names) == len(weights)
+
+    def forward(self, input: torch.Tensor, target: torch.Tensor):
+        losses = _AudioFeatureFunction.apply(input, target, tuple(self.weights), self.sample_rate)
+        return {key: losses[i] for i, key in enumerate(AF_KEYS)}

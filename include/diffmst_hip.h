@@ -140,6 +140,25 @@ int mst_peak_normalize_forward(const float* x, float* y, int32_t bs, int64_t n_s
 int mst_peak_normalize_backward(const float* x, const float* grad_y, float* grad_x, int32_t bs, int64_t n_samples,
                                 void* workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * AudioFeatureLoss (reference mst/loss.py:198-260): five weighted MSE terms between features of
+ * pred and target, both dense (bs, 2, n_samples): rms, crest factor, stereo width, stereo imbalance
+ * (:127-195) and the 24-band Bark spectrum of mid/side (:62-124; STFT 32768 / hop 8192 / Hann).
+ *   weights5     host array of the five weights, in that order
+ *   filterbank   device (16385, 24) fp32 = barkscale_fbanks(16385, 20, 20000, 24, sample_rate)
+ *                (reference mst/filter.py:107-161; a constant table built by the host wrapper)
+ *   losses5      device, the five weighted losses in the reference's key order */
+size_t mst_afloss_tables_bytes(void);
+int mst_afloss_init_tables(void* tables, void* stream);
+size_t mst_afloss_workspace_bytes(int32_t bs, int64_t n_samples);
+int mst_afloss_forward(const float* pred, const float* target, int32_t bs, int64_t n_samples, const float* weights5,
+                       const void* tables, const float* filterbank, float* losses5, void* workspace,
+                       size_t workspace_bytes, void* stream);
+/* grad_losses5: device, dL/d(loss_k); grad_pred (bs, 2, n_samples) is overwritten. */
+int mst_afloss_backward(const float* pred, const float* target, int32_t bs, int64_t n_samples, const float* weights5,
+                        const void* tables, const float* filterbank, const float* grad_losses5, float* grad_pred,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

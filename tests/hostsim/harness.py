@@ -94,3 +94,31 @@ def mrstft(pred, target, resolutions, w_sc=1.0, w_log_mag=1.0, w_lin_mag=0.0, sc
                                      _cabi.ptr(ws), wb, None) == 0
         out["grad_pred"] = gx.view_as(pred)
     return out
+
+
+def afloss(pred, target, weights, sample_rate=44100, grad=True, grad_losses=None):
+    """(bs, 2, n) CPU tensors -> dict(losses (5,), grad_pred)."""
+    from mst import _cabi
+    from mst.filter import barkscale_fbanks
+
+    L = lib()
+    x, y = pred.contiguous().float(), target.contiguous().float()
+    bs, _, n = x.shape
+    tables = torch.zeros(L.mst_afloss_tables_bytes() // 4)
+    assert L.mst_afloss_init_tables(_cabi.ptr(tables), None) == 0
+    fb = barkscale_fbanks(16385, 20.0, 20000.0, 24, sample_rate).contiguous()
+    wb = L.mst_afloss_workspace_bytes(bs, n)
+    assert wb > 0
+    ws = torch.zeros(wb // 4)
+    w = (C.c_float * 5)(*weights)
+    losses = torch.zeros(5)
+    assert L.mst_afloss_forward(_cabi.ptr(x), _cabi.ptr(y), bs, n, w, _cabi.ptr(tables), _cabi.ptr(fb), _cabi.ptr(losses),
+                                _cabi.ptr(ws), wb, None) == 0
+    out = dict(losses=losses.clone())
+    if grad:
+        g = torch.ones(5) if grad_losses is None else grad_losses.float()
+        gx = torch.full_like(x, float("nan"))
+        assert L.mst_afloss_backward(_cabi.ptr(x), _cabi.ptr(y), bs, n, w, _cabi.ptr(tables), _cabi.ptr(fb), _cabi.ptr(g),
+                                     _cabi.ptr(gx), _cabi.ptr(ws), wb, None) == 0
+        out["grad_pred"] = gx
+    return out

@@ -143,3 +143,98 @@ def test_peak_normalize(dev):
         ref.backward(g)
         assert rel(xd.grad[:2], ref_in.grad[:2]) < 1e-5
         assert torch.isfinite(xd.grad).all()
+
+
+# ------------------------------------------------------------------------------------------------
+# AudioFeatureLoss
+# ------------------------------------------------------------------------------------------------
+AF_WEIGHTS = [0.1, 0.001, 1.0, 1.0, 0.1]  # reference configs/models/unpaired+feat.yaml:55-60
+
+
+def test_afloss_golden(dev, golden_dir):
+    """Fixture produced by the REAL reference mst.loss.AudioFeatureLoss (tests/golden/make_golden.py)."""
+    import numpy as np
+    import os
+
+    from mst.loss import AF_KEYS, AudioFeatureLoss
+
+    g = np.load(os.path.join(golden_dir, "af_loss.npz"))
+    x = torch.from_numpy(g["input"]).to(dev).requires_grad_(True)
+    y = torch.from_numpy(g["target"]).to(dev)
+    ld = AudioFeatureLoss(weights=list(g["weights"]), sample_rate=44100)(x, y)
+    assert tuple(ld.keys()) == AF_KEYS
+    for k in AF_KEYS:
+        ref = float(g["loss." + k])
+        assert abs(ld[k].item() - ref) <= 2e-5 * abs(ref) + 1e-12, (k, ld[k].item(), ref)
+    sum(v.mean() for v in ld.values()).backward()  # reference mst/system.py:334-336
+    gsub = torch.from_numpy(g["grad_input_sub"])
+    assert rel(x.grad[..., ::16], gsub) < 2e-4
+    assert abs(x.grad.double().pow(2).sum().sqrt().item() - float(g["grad_input_l2"])) / float(g["grad_input_l2"]) < 2e-4
+
+
+@pytest.mark.parametrize("bs,n", [(2, 131072), (4, 262144), (1, 16385), (3, 50001)])
+def test_afloss_three_way(bs, n, dev):
+    from mst.loss import AF_KEYS, AudioFeatureLoss
+    from oracle import loss_restated as ol
+
+    torch.manual_seed(n + bs)
+    x = 0.2 * torch.randn(bs, 2, n)
+    x[:, 1] = 0.6 * x[:, 1] + 0.3 * x[:, 0]
+    y = 0.3 * torch.randn(bs, 2, n) * torch.tensor([1.0, 0.5]).view(1, 2, 1)
+    gw = torch.tensor([1.0, 2.0, 0.5, 1.5, 1.0])
+    xd = x.to(dev).requires_grad_(True)
+    ld = AudioFeatureLoss(AF_WEIGHTS, 44100)(xd, y.to(dev))
+    vals = torch.stack([ld[k] for k in AF_KEYS])
+    (vals * gw.to(dev)).sum().backward()
+    res = {}
+    for dt in (torch.float32, torch.float64):
+        xo = x.clone().to(dt).requires_grad_(True)
+        lo = ol.audio_feature_loss(xo, y.to(dt), AF_WEIGHTS)
+        vo = torch.stack([lo[k] for k in ol.AF_KEYS])
+        (vo * gw.to(dt)).sum().backward()
+        res[dt] = (vo.detach().double(), xo.grad)
+    v64, g64 = res[torch.float64]
+    v32, g32 = res[torch.float32]
+    err = ((vals.detach().cpu().double() - v64).abs() / v64.abs().clamp_min(1e-30))
+    err32 = ((v32 - v64).abs() / v64.abs().clamp_min(1e-30))
+    print(f"\n[af {bs}x2x{n}] loss rel err hip {err.tolist()} ref32 {err32.tolist()}; grad hip-f64 {rel(xd.grad, g64):.2e} ref32-f64 {rel(g32, g64):.2e}")
+    assert (err <= 3 * err32 + 2e-5).all()
+    assert rel(xd.grad, g64) <= 3 * rel(g32, g64) + 2e-5
+
+
+def test_afloss_known_answers(dev):
+    """L = R => width 0; silent left => imbalance +1; identical input and target => all five losses 0."""
+    from mst.loss import AF_KEYS, AudioFeatureLoss
+
+    torch.manual_seed(0)
+    n = 40000
+    f = AudioFeatureLoss([1.0] * 5, 44100)
+    a = torch.randn(2, 2, n).to(dev)
+    z = f(a, a)
+    assert all(abs(z[k].item()) < 1e-10 for k in AF_KEYS)
+    mono = a.clone()
+    mono[:, 1] = mono[:, 0]           # width(mono) = 0
+    wide = a.clone()
+    wide[:, 1] = -wide[:, 0]          # sum channel silent => width = mean(4 L^2) / clamp(0, 1e-8)
+    ld = f(mono, wide)
+    e = (4 * a[:, 0] ** 2).mean(dim=-1) / 1e-8
+    assert abs(ld["mix-stereo_width"].item() - (e ** 2).mean().item()) / (e ** 2).mean().item() < 1e-4
+    left_silent = a.clone()
+    left_silent[:, 0] = 0.0           # imbalance = +1
+    right_silent = a.clone()
+    right_silent[:, 1] = 0.0          # imbalance = -1
+    assert abs(f(left_silent, right_silent)["mix-stereo_imbalance"].item() - 4.0) < 1e-5
+    sq = torch.ones(1, 2, n, device=dev)
+    sq[..., ::2] = -1.0               # +-1 square wave: crest factor 0 dB
+    half = 0.5 * sq                   # same crest factor
+    assert abs(f(sq, half)["mix-crest_factor"].item()) < 1e-8
+
+
+def test_afloss_input_validation(dev):
+    from mst.loss import AudioFeatureLoss
+
+    f = AudioFeatureLoss(AF_WEIGHTS, 44100)
+    with pytest.raises(ValueError):
+        f(torch.zeros(1, 2, 1000, device=dev), torch.zeros(1, 2, 1000, device=dev))
+    with pytest.raises(AssertionError):
+        AudioFeatureLoss([1.0] * 6, 44100)  # reference asserts len(weights) == 5 (mst/loss.py:236)
