@@ -1,0 +1,84 @@
+"""The UNCHANGED kernel sources, run on the CPU by the host-side HIP simulator (tests/hostsim), against
+the oracle.  Small sizes: this checks indexing / scan / carry / adjoint logic without a GPU; the parity
+tests proper are the `-m gpu` ones."""
+import os
+import sys
+
+import pytest
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "hostsim"))
+import harness  # noqa: E402
+from oracle import console_restated as oc  # noqa: E402
+from oracle import loss_restated as ol  # noqa: E402
+from util import FULL, rel, short_ir  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def ranges():
+    harness.lib()  # builds tests/hostsim/build/libdiffmst_hostsim.so
+    return oc.param_ranges(44100)
+
+
+def test_console_forward_backward_small(ranges):
+    torch.manual_seed(1)
+    bs, T, n = 1, 2, 5003  # ragged: not a multiple of 4, 8 or 64; longer than both look-aheads
+    tracks = 0.1 * torch.randn(bs, T, n)
+    tp, fp, mp = torch.rand(bs, T, 27), torch.rand(bs, 25), torch.rand(bs, 26)
+    tp, mp = short_ir(tp, mp)
+    tp[..., 21] *= 0.2
+    mp[..., 20] *= 0.2
+    gmix, gmixed = torch.randn(bs, 2, n), torch.randn(bs, 2, T, n)
+    out = harness.console(ranges, tracks, tp, fp, mp, FULL, grad_mix=gmix, grad_mixed=gmixed, want_grad_tracks=True)
+    assert out["status"] == 0
+    tr = tracks.double().requires_grad_(True)
+    a, b = tp.double().requires_grad_(True), mp.double().requires_grad_(True)
+    mixed, mix, *_ = oc.console_forward(tr, a, fp.double(), b, **FULL)
+    ((mix * gmix.double()).sum() + (mixed * gmixed.double()).sum()).backward()
+    _, truth, *_ = oc.console_forward(tracks.double(), tp.double(), fp.double(), mp.double(), time_domain=True, **FULL)
+    assert rel(out["mix"], truth) < 1e-4
+    assert rel(out["mixed"], mixed) < 1e-3
+    assert rel(out["grad_tracks"], tr.grad) < 1e-2
+    assert rel(out["grad_tp"], a.grad) < 2e-2
+    assert rel(out["grad_mp"], b.grad) < 2e-2
+
+
+def test_console_status_flag(ranges):
+    tp, fp, mp = torch.rand(1, 1, 27), torch.rand(1, 25), torch.rand(1, 26)
+    mp[0, 24] = 1.5
+    tp[0, 0, 26] = -0.5
+    out = harness.console(ranges, torch.zeros(1, 1, 300), tp, fp, mp, FULL, want_mixed=False)
+    from mst import _desc
+
+    assert str(_desc.status_to_error(out["status"])) == "Parameter send_db of effect fx_bus is out of range."
+
+
+def test_mrstft_small():
+    torch.manual_seed(0)
+    x = 0.3 * torch.randn(1, 2, 3000)
+    y = 0.5 * x + 0.2 * torch.randn(1, 2, 3000)
+    res = ((512, 256, 512), (256, 50, 200), (2048, 1024, 2048))
+    out = harness.mrstft(x, y, res, w_sc=1.0, w_log_mag=0.0)
+    xo = x.double().requires_grad_(True)
+    lo = ol.mrstft_loss(xo, y.double(), res, w_sc=1.0, w_log_mag=0.0)
+    lo.backward()
+    assert abs(out["loss"].item() - lo.item()) / lo.item() < 1e-6
+    assert rel(out["grad_pred"], xo.grad) < 1e-5
+    full = harness.mrstft(x, y, res, grad=False)
+    assert abs(full["loss"].item() - ol.mrstft_loss(x.double(), y.double(), res).item()) < 1e-5
+
+
+def test_afloss_small():
+    torch.manual_seed(0)
+    n = 17000  # just above the 16384-sample reflect pad: 3 frames
+    w = [0.1, 0.001, 1.0, 1.0, 0.1]
+    a = 0.2 * torch.randn(1, 2, n)
+    b = 0.3 * torch.randn(1, 2, n) * torch.tensor([1.0, 0.6]).view(1, 2, 1)
+    gl = torch.tensor([1.0, 2.0, 0.5, 1.5, 1.0])
+    out = harness.afloss(a, b, w, grad_losses=gl)
+    ao = a.double().requires_grad_(True)
+    ld = ol.audio_feature_loss(ao, b.double(), w)
+    vals = torch.stack([ld[k] for k in ol.AF_KEYS])
+    (vals * gl.double()).sum().backward()
+    assert ((out["losses"].double() - vals.detach()).abs() / vals.detach().abs() < 5e-5).all()
+    assert rel(out["grad_pred"], ao.grad) < 1e-5
