@@ -53,6 +53,27 @@ __device__ __forceinline__ void ld8s(const float* row, int64_t i, int64_t n, flo
     const float4 a = load4_shift(row, i, n), b = load4_shift(row, i + 4, n);
     v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
 }
+__device__ __forceinline__ void st8(float* row, int64_t i, int64_t n, const float* v);
+// Unguarded variants for interior lanes of aligned rows (the overwhelmingly common case): no bounds or
+// alignment tests, two plain 16-byte accesses.
+__device__ __forceinline__ void ld8f(const float* row, int64_t i, float* v) {
+    const float4 a = *reinterpret_cast<const float4*>(row + i), b = *reinterpret_cast<const float4*>(row + i + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void st8f(float* row, int64_t i, const float* v) {
+    *reinterpret_cast<float4*>(row + i) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(row + i + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+// FAST selects them at compile time inside the kernels: LD8(fast, ...) etc.
+template <bool FAST> __device__ __forceinline__ void LD8(const float* row, int64_t i, int64_t n, float* v) {
+    if (FAST) ld8f(row, i, v); else ld8(row, i, n, v);
+}
+template <bool FAST> __device__ __forceinline__ void LD8S(const float* row, int64_t i, int64_t n, float* v) {
+    if (FAST) ld8f(row, i, v); else ld8s(row, i, n, v);
+}
+template <bool FAST> __device__ __forceinline__ void ST8(float* row, int64_t i, int64_t n, const float* v) {
+    if (FAST) st8f(row, i, v); else st8(row, i, n, v);
+}
 __device__ __forceinline__ void st8(float* row, int64_t i, int64_t n, const float* v) {
     store4(row, i, n, make_float4(v[0], v[1], v[2], v[3]));
     store4(row, i + 4, n, make_float4(v[4], v[5], v[6], v[7]));
@@ -103,17 +124,17 @@ __device__ __forceinline__ float block_carry(const float* __restrict__ agg, int 
 
 // ---- forward: zero-state end value of the smoother per 2048-sample block ---------------------------
 // u: [(row*NCH+ch)][stride]; zs: [row][nc_pad]
-template <int NCH>
-__global__ __launch_bounds__(kWG) void k_comp_zs(const float* __restrict__ u, int64_t stride, const float* __restrict__ rc,
-                                                 float* __restrict__ zs, int nc_pad, int64_t n) {
+template <int NCH, bool FAST>
+__device__ __forceinline__ void comp_zs_body(const float* __restrict__ u, int64_t stride, const float* __restrict__ rc,
+                                             float* __restrict__ zs, int nc_pad, int64_t n) {
     const int row = blockIdx.y, chunk = blockIdx.x * kWG + threadIdx.x;
     const int64_t i0 = (int64_t)chunk * CC;
     const CompK k = load_comp(rc + (int64_t)row * RC_STRIDE);
     float side[CC];
-    ld8(u + (int64_t)(row * NCH) * stride, i0, n, side);
+    LD8<FAST>(u + (int64_t)(row * NCH) * stride, i0, n, side);
     if (NCH == 2) {
         float o[CC];
-        ld8(u + (int64_t)(row * NCH + 1) * stride, i0, n, o);
+        LD8<FAST>(u + (int64_t)(row * NCH + 1) * stride, i0, n, o);
 #pragma unroll
         for (int i = 0; i < CC; ++i) side[i] += o[i];
     }
@@ -131,9 +152,17 @@ __global__ __launch_bounds__(kWG) void k_comp_zs(const float* __restrict__ u, in
     const float enter = block_enter<false>(acc, a, log2a, 0.0f, lds, threadIdx.x);
     if (threadIdx.x == kWG - 1) zs[(int64_t)row * gridDim.x + blockIdx.x] = fmaf(a, enter, acc);
 }
+template <int NCH>
+__global__ __launch_bounds__(kWG) void k_comp_zs(const float* __restrict__ u, int64_t stride, const float* __restrict__ rc,
+                                                 float* __restrict__ zs, int nc_pad, int64_t n) {
+    // whole-workgroup decision: every sample this block touches is in range (rows are 16-byte aligned)
+    if ((int64_t)(blockIdx.x + 1) * kWG * CC <= n) comp_zs_body<NCH, true>(u, stride, rc, zs, nc_pad, n);
+    else comp_zs_body<NCH, false>(u, stride, rc, zs, nc_pad, n);
+}
 
 // ---- forward: tracks.  grid (nblk, bs).  Accumulates the stereo bus over the T tracks of mix b.
-__global__ __launch_bounds__(kWG) void k_apply_tracks(TrackApplyArgs a) {
+template <bool FAST>
+__device__ __forceinline__ void apply_tracks_body(const TrackApplyArgs& a) {
     __shared__ float lds[8];
     const int b = blockIdx.y, chunk = blockIdx.x * kWG + threadIdx.x;
     const int64_t i0 = (int64_t)chunk * CC;
@@ -149,8 +178,8 @@ __global__ __launch_bounds__(kWG) void k_apply_tracks(TrackApplyArgs a) {
         if (a.comp_on) {
             const CompK k = load_comp(rc);
             float x[CC], xd[CC], g[CC];
-            ld8(urow, i0, a.n, x);
-            ld8s(urow, i0 - a.lookahead, a.n, xd);
+            LD8<FAST>(urow, i0, a.n, x);
+            LD8S<FAST>(urow, i0 - a.lookahead, a.n, xd);
             float z = 0.0f;
 #pragma unroll
             for (int i = 0; i < CC; ++i) {
@@ -167,9 +196,9 @@ __global__ __launch_bounds__(kWG) void k_apply_tracks(TrackApplyArgs a) {
                 g[i] = s;
                 y[i] = xd[i] * lin_gain(s, k);
             }
-            if (a.gs) st8(a.gs + (int64_t)row * a.stride, i0, a.n, g);
+            if (a.gs) ST8<FAST>(a.gs + (int64_t)row * a.stride, i0, a.n, g);
         } else {
-            ld8(urow, i0, a.n, y);
+            LD8<FAST>(urow, i0, a.n, y);
         }
 #pragma unroll
         for (int i = 0; i < CC; ++i) {
@@ -183,16 +212,25 @@ __global__ __launch_bounds__(kWG) void k_apply_tracks(TrackApplyArgs a) {
                 ml[i] = pl * y[i];
                 mr[i] = pr * y[i];
             }
-            st8(a.mixed + (((int64_t)b * 2 + 0) * a.T + t) * a.n, i0, a.n, ml);
-            st8(a.mixed + (((int64_t)b * 2 + 1) * a.T + t) * a.n, i0, a.n, mr);
+            ST8<FAST>(a.mixed + (((int64_t)b * 2 + 0) * a.T + t) * a.n, i0, a.n, ml);
+            ST8<FAST>(a.mixed + (((int64_t)b * 2 + 1) * a.T + t) * a.n, i0, a.n, mr);
         }
     }
-    st8(a.bus + ((int64_t)b * 2 + 0) * a.bus_stride, i0, a.n, accL);
-    st8(a.bus + ((int64_t)b * 2 + 1) * a.bus_stride, i0, a.n, accR);
+    ST8<FAST>(a.bus + ((int64_t)b * 2 + 0) * a.bus_stride, i0, a.n, accL);
+    ST8<FAST>(a.bus + ((int64_t)b * 2 + 1) * a.bus_stride, i0, a.n, accR);
+}
+__device__ __forceinline__ bool block_interior(int64_t n, int lookahead, int aligned) {
+    const int64_t lo = (int64_t)blockIdx.x * kWG * CC, hi = lo + (int64_t)kWG * CC;
+    return aligned && lo - lookahead >= 0 && hi + lookahead <= n;
+}
+__global__ __launch_bounds__(kWG) void k_apply_tracks(TrackApplyArgs a) {
+    if (block_interior(a.n, a.lookahead, a.aligned)) apply_tracks_body<true>(a);
+    else apply_tracks_body<false>(a);
 }
 
 // ---- forward: master bus.  grid (nblk, bs).  out = delay(v) * G * gout  (stereo-linked)
-__global__ __launch_bounds__(kWG) void k_apply_master(MasterApplyArgs a) {
+template <bool FAST>
+__device__ __forceinline__ void apply_master_body(const MasterApplyArgs& a) {
     __shared__ float lds[8];
     const int b = blockIdx.y, chunk = blockIdx.x * kWG + threadIdx.x;
     const int64_t i0 = (int64_t)chunk * CC;
@@ -204,10 +242,10 @@ __global__ __launch_bounds__(kWG) void k_apply_master(MasterApplyArgs a) {
     if (a.comp_on) {
         const CompK k = load_comp(rc);
         float l[CC], r[CC], g[CC];
-        ld8(v0, i0, a.n, l);
-        ld8(v1, i0, a.n, r);
-        ld8s(v0, i0 - a.lookahead, a.n, yl);
-        ld8s(v1, i0 - a.lookahead, a.n, yr);
+        LD8<FAST>(v0, i0, a.n, l);
+        LD8<FAST>(v1, i0, a.n, r);
+        LD8S<FAST>(v0, i0 - a.lookahead, a.n, yl);
+        LD8S<FAST>(v1, i0 - a.lookahead, a.n, yr);
         float z = 0.0f;
 #pragma unroll
         for (int i = 0; i < CC; ++i) {
@@ -226,34 +264,38 @@ __global__ __launch_bounds__(kWG) void k_apply_master(MasterApplyArgs a) {
             yl[i] *= G;
             yr[i] *= G;
         }
-        if (a.gs) st8(a.gs + (int64_t)b * a.stride, i0, a.n, g);
+        if (a.gs) ST8<FAST>(a.gs + (int64_t)b * a.stride, i0, a.n, g);
     } else {
-        ld8(v0, i0, a.n, yl);
-        ld8(v1, i0, a.n, yr);
+        LD8<FAST>(v0, i0, a.n, yl);
+        LD8<FAST>(v1, i0, a.n, yr);
 #pragma unroll
         for (int i = 0; i < CC; ++i) {
             yl[i] *= gout;
             yr[i] *= gout;
         }
     }
-    st8(a.out + ((int64_t)b * 2 + 0) * a.out_stride, i0, a.n, yl);
-    st8(a.out + ((int64_t)b * 2 + 1) * a.out_stride, i0, a.n, yr);
+    ST8<FAST>(a.out + ((int64_t)b * 2 + 0) * a.out_stride, i0, a.n, yl);
+    ST8<FAST>(a.out + ((int64_t)b * 2 + 1) * a.out_stride, i0, a.n, yr);
+}
+__global__ __launch_bounds__(kWG) void k_apply_master(MasterApplyArgs a) {
+    if (block_interior(a.n, a.lookahead, a.aligned)) apply_master_body<true>(a);
+    else apply_master_body<false>(a);
 }
 
 // ---- backward ------------------------------------------------------------------------------------
 // upstream cotangent of the compressor output y for 8 samples starting at i (may run past either end)
-template <bool MASTER>
+template <bool MASTER, bool FAST>
 __device__ __forceinline__ void load_gy(const CompBwdArgs& a, int row, const float* rc, int64_t i, float* gl, float* gr) {
     // raw upstream cotangents per stereo channel: grad_mix (MASTER) or grad_bus (+ grad_mixed_tracks)
     const int b = MASTER ? row : row / a.T;
     float l[CC], r[CC];
-    ld8s(a.gup + ((int64_t)b * 2 + 0) * a.gup_stride, i, a.n, l);
-    ld8s(a.gup + ((int64_t)b * 2 + 1) * a.gup_stride, i, a.n, r);
+    LD8S<FAST>(a.gup + ((int64_t)b * 2 + 0) * a.gup_stride, i, a.n, l);
+    LD8S<FAST>(a.gup + ((int64_t)b * 2 + 1) * a.gup_stride, i, a.n, r);
     if (!MASTER && a.gmixed) {
         const int t = row % a.T;
         float ml[CC], mr[CC];
-        ld8s(a.gmixed + (((int64_t)b * 2 + 0) * a.T + t) * a.n, i, a.n, ml);
-        ld8s(a.gmixed + (((int64_t)b * 2 + 1) * a.T + t) * a.n, i, a.n, mr);
+        LD8S<FAST>(a.gmixed + (((int64_t)b * 2 + 0) * a.T + t) * a.n, i, a.n, ml);
+        LD8S<FAST>(a.gmixed + (((int64_t)b * 2 + 1) * a.T + t) * a.n, i, a.n, mr);
 #pragma unroll
         for (int q = 0; q < CC; ++q) {
             l[q] += ml[q];
@@ -268,8 +310,8 @@ __device__ __forceinline__ void load_gy(const CompBwdArgs& a, int row, const flo
 }
 
 // zero-state (from the right) end value of the adjoint smoother q[n] = dgs[n] + a q[n+1]
-template <bool MASTER>
-__global__ __launch_bounds__(kWG) void k_comp_bwd_zs(CompBwdArgs a) {
+template <bool MASTER, bool FAST>
+__device__ __forceinline__ void comp_bwd_zs_body(const CompBwdArgs& a) {
     constexpr int NCH = MASTER ? 2 : 1;
     __shared__ float lds[8];
     const int row = blockIdx.y, chunk = blockIdx.x * kWG + threadIdx.x;
@@ -277,10 +319,10 @@ __global__ __launch_bounds__(kWG) void k_comp_bwd_zs(CompBwdArgs a) {
     const float* rc = a.rc + (int64_t)row * RC_STRIDE;
     const CompK k = load_comp(rc);
     float gl[CC], gr[CC], xd0[CC], xd1[CC], g[CC];
-    load_gy<MASTER>(a, row, rc, i0, gl, gr);
-    ld8s(a.u + (int64_t)(row * NCH) * a.stride, i0 - a.lookahead, a.n, xd0);
-    if (MASTER) ld8s(a.u + (int64_t)(row * NCH + 1) * a.stride, i0 - a.lookahead, a.n, xd1);
-    ld8(a.gs + (int64_t)row * a.stride, i0, a.n, g);
+    load_gy<MASTER, FAST>(a, row, rc, i0, gl, gr);
+    LD8S<FAST>(a.u + (int64_t)(row * NCH) * a.stride, i0 - a.lookahead, a.n, xd0);
+    if (MASTER) LD8S<FAST>(a.u + (int64_t)(row * NCH + 1) * a.stride, i0 - a.lookahead, a.n, xd1);
+    LD8<FAST>(a.gs + (int64_t)row * a.stride, i0, a.n, g);
     const float pl = rc[RC_PANL], pr = rc[RC_PANR];  // master: both = output-fader gain
     float acc = 0.0f;
 #pragma unroll
@@ -294,9 +336,14 @@ __global__ __launch_bounds__(kWG) void k_comp_bwd_zs(CompBwdArgs a) {
     const float enter = block_enter<true>(acc, ac, l2a, 0.0f, lds, threadIdx.x);
     if (threadIdx.x == 0) a.zq[(int64_t)row * gridDim.x + blockIdx.x] = fmaf(ac, enter, acc);
 }
-
 template <bool MASTER>
-__global__ __launch_bounds__(kWG) void k_comp_bwd_run(CompBwdArgs a) {
+__global__ __launch_bounds__(kWG) void k_comp_bwd_zs(CompBwdArgs a) {
+    if (block_interior(a.n, a.lookahead, a.aligned)) comp_bwd_zs_body<MASTER, true>(a);
+    else comp_bwd_zs_body<MASTER, false>(a);
+}
+
+template <bool MASTER, bool FAST>
+__device__ __forceinline__ void comp_bwd_run_body(const CompBwdArgs& a) {
     constexpr int NCH = MASTER ? 2 : 1;
     __shared__ float red[4][CP_COUNT];  // red[0] doubles as the 8-float scan scratch
     const int tid = threadIdx.x, row = blockIdx.y, chunk = blockIdx.x * kWG + tid;
@@ -308,22 +355,22 @@ __global__ __launch_bounds__(kWG) void k_comp_bwd_run(CompBwdArgs a) {
 #pragma unroll
     for (int i = 0; i < CP_COUNT; ++i) p[i] = 0.0f;
     float gl[CC], gr[CC], du0[CC], du1[CC];
-    load_gy<MASTER>(a, row, rc, i0, gl, gr);
+    load_gy<MASTER, FAST>(a, row, rc, i0, gl, gr);
     const float pl = rc[RC_PANL], pr = rc[RC_PANR];  // master: both = output-fader gain
 
     if (a.comp_on) {
         const CompK k = load_comp(rc);
         float x0[CC], x1[CC], xd0[CC], xd1[CC], g[CC], gF[CC], glF[CC], grF[CC];
-        ld8(u0, i0, a.n, x0);
-        ld8s(u0, i0 - a.lookahead, a.n, xd0);
+        LD8<FAST>(u0, i0, a.n, x0);
+        LD8S<FAST>(u0, i0 - a.lookahead, a.n, xd0);
         if (MASTER) {
-            ld8(u1, i0, a.n, x1);
-            ld8s(u1, i0 - a.lookahead, a.n, xd1);
+            LD8<FAST>(u1, i0, a.n, x1);
+            LD8S<FAST>(u1, i0 - a.lookahead, a.n, xd1);
         }
-        ld8(a.gs + (int64_t)row * a.stride, i0, a.n, g);
+        LD8<FAST>(a.gs + (int64_t)row * a.stride, i0, a.n, g);
         // look-ahead branch: du[i] += gy[i+L] * G[i+L]
-        ld8s(a.gs + (int64_t)row * a.stride, i0 + a.lookahead, a.n, gF);
-        load_gy<MASTER>(a, row, rc, i0 + a.lookahead, glF, grF);
+        LD8S<FAST>(a.gs + (int64_t)row * a.stride, i0 + a.lookahead, a.n, gF);
+        load_gy<MASTER, FAST>(a, row, rc, i0 + a.lookahead, glF, grF);
         const float g_prev0 = (i0 > 0 && i0 - 1 < a.n) ? a.gs[(int64_t)row * a.stride + i0 - 1] : 0.0f;
         float dgsv[CC], Gv[CC];
         float zq = 0.0f;
@@ -383,8 +430,8 @@ __global__ __launch_bounds__(kWG) void k_comp_bwd_run(CompBwdArgs a) {
         }
     } else {
         float x0[CC], x1[CC];
-        ld8(u0, i0, a.n, x0);
-        if (MASTER) ld8(u1, i0, a.n, x1);
+        LD8<FAST>(u0, i0, a.n, x0);
+        if (MASTER) LD8<FAST>(u1, i0, a.n, x1);
 #pragma unroll
         for (int i = 0; i < CC; ++i) {
             du0[i] = MASTER ? pl * gl[i] : pl * gl[i] + pr * gr[i];
@@ -398,8 +445,8 @@ __global__ __launch_bounds__(kWG) void k_comp_bwd_run(CompBwdArgs a) {
             }
         }
     }
-    st8(a.du + (int64_t)(row * NCH) * a.stride, i0, a.n, du0);
-    if (MASTER) st8(a.du + (int64_t)(row * NCH + 1) * a.stride, i0, a.n, du1);
+    ST8<FAST>(a.du + (int64_t)(row * NCH) * a.stride, i0, a.n, du0);
+    if (MASTER) ST8<FAST>(a.du + (int64_t)(row * NCH + 1) * a.stride, i0, a.n, du1);
 
     const int wave = tid >> 6, lane = tid & 63;
 #pragma unroll
@@ -410,6 +457,11 @@ __global__ __launch_bounds__(kWG) void k_comp_bwd_run(CompBwdArgs a) {
     __syncthreads();
     if (tid < CP_COUNT)
         a.part[((int64_t)row * gridDim.x + blockIdx.x) * CP_COUNT + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+}
+template <bool MASTER>
+__global__ __launch_bounds__(kWG) void k_comp_bwd_run(CompBwdArgs a) {
+    if (block_interior(a.n, a.lookahead, a.aligned)) comp_bwd_run_body<MASTER, true>(a);
+    else comp_bwd_run_body<MASTER, false>(a);
 }
 
 // ---- launch helpers ---------------------------------------------------------------------------------

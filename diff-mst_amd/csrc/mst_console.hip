@@ -36,6 +36,7 @@ extern "C" int mst_console_forward(const mst_console_desc* d, const float* track
     float* ws = (float*)workspace;
     const int64_t n = L.N, Ns = round_up(L.N, 4);
     const bool save = d->flags & MST_SAVE_FOR_BACKWARD;
+    const int aligned = (n % 4 == 0) && !((uintptr_t)mix & 15) && !((uintptr_t)mixed_tracks & 15);
     const bool t_comp = d->flags & MST_USE_TRACK_COMPRESSOR;
     const bool m_on = d->flags & MST_USE_MASTER_BUS;
     const bool o_on = d->flags & MST_USE_OUTPUT_FADER;
@@ -56,7 +57,7 @@ extern "C" int mst_console_forward(const mst_console_desc* d, const float* track
     const bool bus_is_mix = !m_on && !o_on;
     TrackApplyArgs ta{ws + L.u_t, Ns, ws + L.rc_t, ws + L.zS_t, (save && t_comp) ? ws + L.gs_t : nullptr,
                       bus_is_mix ? mix : ws + L.bus, bus_is_mix ? n : Ns, mixed_tracks,
-                      L.T, L.ncC_pad, d->track_lookahead, t_comp ? 1 : 0, n};
+                      L.T, L.ncC_pad, d->track_lookahead, t_comp ? 1 : 0, n, aligned};
     launch_apply_tracks(ta, L.bs, stream);
 
     // ---- master bus
@@ -66,10 +67,10 @@ extern "C" int mst_console_forward(const mst_console_desc* d, const float* track
         launch_cascade(EQ_FWD, true, ws + L.bus, Ns, ws + L.v_m, Ns, ws + L.rc_m, 2, ws + L.sE_m, nullptr, L.ncE_pad, n, 2 * L.bs, stream);
         launch_comp_zs(2, ws + L.v_m, Ns, ws + L.rc_m, ws + L.zS_m, L.ncC_pad, n, L.bs, stream);
         MasterApplyArgs ma{ws + L.v_m, Ns, ws + L.rc_m, ws + L.zS_m, save ? ws + L.gs_m : nullptr, mix, n,
-                           L.ncC_pad, d->master_lookahead, 1, n};
+                           L.ncC_pad, d->master_lookahead, 1, n, aligned};
         launch_apply_master(ma, L.bs, stream);
     } else if (o_on) {
-        MasterApplyArgs ma{ws + L.bus, Ns, ws + L.rc_m, nullptr, nullptr, mix, n, L.ncC_pad, 0, 0, n};
+        MasterApplyArgs ma{ws + L.bus, Ns, ws + L.rc_m, nullptr, nullptr, mix, n, L.ncC_pad, 0, 0, n, aligned};
         launch_apply_master(ma, L.bs, stream);
     }
     return (int)hipGetLastError();
@@ -91,13 +92,14 @@ extern "C" int mst_console_backward(const mst_console_desc* d, const float* trac
     const bool m_on = d->flags & MST_USE_MASTER_BUS;
     const bool o_on = d->flags & MST_USE_OUTPUT_FADER;
     (void)tracks;
+    const int aligned = (n % 4 == 0) && !((uintptr_t)grad_mix & 15) && !((uintptr_t)grad_mixed_tracks & 15);
 
     // ---- master bus: compressor adjoint, EQ adjoint (-> grad of the stereo bus), coefficient sums
     const float* gbus = grad_mix;  // cotangent of the stereo bus as seen by the track stage
     int64_t gbus_stride = n;
     if (m_on) {
         CompBwdArgs ca{ws + L.v_m, Ns, ws + L.gs_m, ws + L.rc_m, nullptr, ws + L.zQ_m, ws + L.du_m, ws + L.cp_m,
-                       grad_mix, n, nullptr, 1, L.ncC_pad, d->master_lookahead, 1, n};
+                       grad_mix, n, nullptr, 1, L.ncC_pad, d->master_lookahead, 1, n, aligned};
         launch_comp_bwd(true, false, ca, L.bs, stream);
         ca.s0 = ws + L.zQ_m;
         launch_comp_bwd(true, true, ca, L.bs, stream);
@@ -111,7 +113,7 @@ extern "C" int mst_console_backward(const mst_console_desc* d, const float* trac
         gbus_stride = Ns;
     } else if (o_on) {
         CompBwdArgs ca{ws + L.bus, Ns, nullptr, ws + L.rc_m, nullptr, nullptr, ws + L.dbus, ws + L.cp_m,
-                       grad_mix, n, nullptr, 1, L.ncC_pad, 0, 0, n};
+                       grad_mix, n, nullptr, 1, L.ncC_pad, 0, 0, n, aligned};
         launch_comp_bwd(true, true, ca, L.bs, stream);
         gbus = ws + L.dbus;
         gbus_stride = Ns;
@@ -122,7 +124,7 @@ extern "C" int mst_console_backward(const mst_console_desc* d, const float* trac
     // ---- tracks
     {
         CompBwdArgs ca{ws + L.u_t, Ns, ws + L.gs_t, ws + L.rc_t, nullptr, ws + L.zQ_t, ws + L.du_t, ws + L.cp_t,
-                       gbus, gbus_stride, grad_mixed_tracks, L.T, L.ncC_pad, d->track_lookahead, t_comp ? 1 : 0, n};
+                       gbus, gbus_stride, grad_mixed_tracks, L.T, L.ncC_pad, d->track_lookahead, t_comp ? 1 : 0, n, aligned};
         if (t_comp) {
             launch_comp_bwd(false, false, ca, L.R, stream);
             ca.s0 = ws + L.zQ_t;

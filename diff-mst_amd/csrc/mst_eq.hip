@@ -5,7 +5,7 @@
 // rFFT/irFFT per row) with a time-domain, chunk-parallel linear recurrence:
 //
 //   every lane owns kEqChunk consecutive samples of one signal row; the 256 lanes of a workgroup
-//   cover a 16384-sample tile, staged through LDS in 32-sample slabs so that HBM sees only
+//   cover a 16384-sample tile, staged through LDS in 16-sample slabs (next slab prefetched into registers) so that HBM sees only
 //   coalesced 16-byte accesses while each lane reads its own contiguous slab.
 //     *_zs   : run the chunk from ZERO state, keep only the 12-float end state  (z)
 //     scan   : (mst_scan.hip) s0[c+1] = M s0[c] + z[c] gives every chunk's true start state
@@ -18,34 +18,46 @@
 
 namespace mst {
 
-constexpr int kSlab = 32;         // samples per lane per LDS stage
-constexpr int kLdw = kSlab + 4;   // padded LDS row: conflict-free ds_read_b128 / ds_write_b128
+constexpr int kSlab = 16;         // samples per lane per LDS stage
+constexpr int kLdw = kSlab + 4;   // padded LDS row (5 x 16 B, odd): conflict-free ds_read_b128 / ds_write_b128
 constexpr int kNSlab = kEqChunk / kSlab;
+constexpr int kSlabVec = kSlab / 4;              // float4 per lane per slab
+constexpr int kFetch = kWG * kSlabVec / kWG;     // float4 each thread moves per slab (= kSlabVec)
 
-// coalesced global -> LDS (lane-major rows).  Tile = kWG lanes x kEqChunk samples; slab j.
-__device__ __forceinline__ void slab_load(float* __restrict__ tile, const float* __restrict__ row, int64_t tile_base,
-                                          int j, int64_t n, int tid) {
+// A slab (kWG lanes x kSlab samples) travels HBM -> registers -> LDS in two steps so that the NEXT slab's
+// global loads are in flight while the current one is being filtered (all workgroups of these kernels
+// are resident at once and would otherwise alternate, in lockstep, between a pure-memory and a
+// pure-ALU phase).
+struct SlabRegs {
+    float4 v[kFetch];
+};
+__device__ __forceinline__ void slab_fetch(SlabRegs& r, const float* __restrict__ row, int64_t tile_base, int j, int64_t n, int tid) {
 #pragma unroll
-    for (int r = 0; r < (kWG * kSlab / 4) / kWG; ++r) {
-        const int q = tid + kWG * r;       // float4 index inside the slab image
-        const int lane = q / (kSlab / 4);  // owning lane
-        const int i = (q % (kSlab / 4)) * 4;
-        const int64_t g = tile_base + (int64_t)lane * kEqChunk + j * kSlab + i;
-        *reinterpret_cast<float4*>(&tile[lane * kLdw + i]) = load4(row, g, n);
+    for (int q0 = 0; q0 < kFetch; ++q0) {
+        const int q = tid + kWG * q0;      // float4 index inside the slab image
+        const int lane = q / kSlabVec;     // owning lane
+        const int i = (q % kSlabVec) * 4;
+        r.v[q0] = load4(row, tile_base + (int64_t)lane * kEqChunk + j * kSlab + i, n);
+    }
+}
+__device__ __forceinline__ void slab_stash(const SlabRegs& r, float* __restrict__ tile, int tid) {
+#pragma unroll
+    for (int q0 = 0; q0 < kFetch; ++q0) {
+        const int q = tid + kWG * q0;
+        *reinterpret_cast<float4*>(&tile[(q / kSlabVec) * kLdw + (q % kSlabVec) * 4]) = r.v[q0];
     }
 }
 __device__ __forceinline__ void slab_store(const float* __restrict__ tile, float* __restrict__ row, int64_t tile_base,
                                            int j, int64_t n, int tid) {
 #pragma unroll
-    for (int r = 0; r < (kWG * kSlab / 4) / kWG; ++r) {
-        const int q = tid + kWG * r;
-        const int lane = q / (kSlab / 4);
-        const int i = (q % (kSlab / 4)) * 4;
-        const int64_t g = tile_base + (int64_t)lane * kEqChunk + j * kSlab + i;
-        store4(row, g, n, *reinterpret_cast<const float4*>(&tile[lane * kLdw + i]));
+    for (int q0 = 0; q0 < kFetch; ++q0) {
+        const int q = tid + kWG * q0;
+        const int lane = q / kSlabVec;
+        const int i = (q % kSlabVec) * 4;
+        store4(row, tile_base + (int64_t)lane * kEqChunk + j * kSlab + i, n,
+               *reinterpret_cast<const float4*>(&tile[lane * kLdw + i]));
     }
 }
-
 
 // MODE_RUN = false: zero-state pass, writes z[sig][12][nc_pad]
 // MODE_RUN = true : true pass from s0[sig][12][nc_pad], writes out
@@ -59,6 +71,12 @@ __global__ __launch_bounds__(kWG) void k_cascade(const float* __restrict__ in, i
     const int tid = threadIdx.x, sig = blockIdx.y;
     const int64_t tile_base = (int64_t)blockIdx.x * kWG * kEqChunk;
     const int chunk = blockIdx.x * kWG + tid;
+    const float* inrow = in + (int64_t)sig * in_stride;
+    float* outrow = MODE_RUN ? out + (int64_t)sig * out_stride : nullptr;
+    auto order = [](int jj) { return (DIR == EQ_FWD) ? jj : kNSlab - 1 - jj; };
+    SlabRegs pre;
+    slab_fetch(pre, inrow, tile_base, order(0), n, tid);  // first slab in flight while constants load
+
     const float* coef = rc + (int64_t)(sig / nch) * RC_STRIDE + RC_SOS;
     float c[5 * kSections];
 #pragma unroll
@@ -67,15 +85,13 @@ __global__ __launch_bounds__(kWG) void k_cascade(const float* __restrict__ in, i
 #pragma unroll
     for (int i = 0; i < kStates; ++i)
         st[i] = MODE_RUN ? s0[((int64_t)sig * kStates + i) * nc_pad + chunk] : 0.0f;
-
-    const float* inrow = in + (int64_t)sig * in_stride;
-    float* outrow = MODE_RUN ? out + (int64_t)sig * out_stride : nullptr;
     float* mine = &tile[tid * kLdw];
 
     for (int jj = 0; jj < kNSlab; ++jj) {
-        const int j = (DIR == EQ_FWD) ? jj : kNSlab - 1 - jj;
-        slab_load(tile, inrow, tile_base, j, n, tid);
+        const int j = order(jj);
+        slab_stash(pre, tile, tid);
         __syncthreads();
+        if (jj + 1 < kNSlab) slab_fetch(pre, inrow, tile_base, order(jj + 1), n, tid);
         if (DIR == EQ_FWD) {
 #pragma unroll
             for (int i4 = 0; i4 < kSlab; i4 += 4) {
@@ -100,7 +116,7 @@ __global__ __launch_bounds__(kWG) void k_cascade(const float* __restrict__ in, i
         __syncthreads();
         if (MODE_RUN) {
             slab_store(tile, outrow, tile_base, j, n, tid);
-            __syncthreads();
+            __syncthreads();  // the image is read by other lanes' stores before the next stash overwrites it
         }
     }
     if (!MODE_RUN) {
@@ -141,9 +157,12 @@ __global__ __launch_bounds__(kWG) void k_allpole_zs(const float* __restrict__ u,
     for (int s = 0; s < kSections; ++s) wa1[s] = wa2[s] = wb1[s] = wb2[s] = 0.0f;
     const float* urow = u + (int64_t)sig * u_stride;
     float* mine = &tile[tid * kLdw];
+    SlabRegs pre;
+    slab_fetch(pre, urow, tile_base, 0, n, tid);
     for (int j = 0; j < kNSlab; ++j) {
-        slab_load(tile, urow, tile_base, j, n, tid);
+        slab_stash(pre, tile, tid);
         __syncthreads();
+        if (j + 1 < kNSlab) slab_fetch(pre, urow, tile_base, j + 1, n, tid);
 #pragma unroll 4
         for (int i = 0; i < kSlab; ++i) {
             const float x = mine[i];
@@ -199,10 +218,17 @@ __global__ __launch_bounds__(kWG) void k_coefgrad(const float* __restrict__ u, i
     const float* grow = g + (int64_t)sig * g_stride;
     float* mu = &tile_u[tid * kLdw];
     float* mg = &tile_g[tid * kLdw];
+    SlabRegs pu, pg;
+    slab_fetch(pu, urow, tile_base, 0, n, tid);
+    slab_fetch(pg, grow, tile_base, 0, n, tid);
     for (int j = 0; j < kNSlab; ++j) {
-        slab_load(tile_u, urow, tile_base, j, n, tid);
-        slab_load(tile_g, grow, tile_base, j, n, tid);
+        slab_stash(pu, tile_u, tid);
+        slab_stash(pg, tile_g, tid);
         __syncthreads();
+        if (j + 1 < kNSlab) {
+            slab_fetch(pu, urow, tile_base, j + 1, n, tid);
+            slab_fetch(pg, grow, tile_base, j + 1, n, tid);
+        }
 #pragma unroll 2
         for (int i = 0; i < kSlab; ++i) {
             const float x = mu[i], gg = mg[i];

@@ -62,6 +62,7 @@ struct TrackApplyArgs {
     float* mixed;        // (bs, 2, T, n) out or null
     int T, nc_pad, lookahead, comp_on;
     int64_t n;
+    int aligned;         // every row base / stride is 16-byte aligned: interior blocks skip all guards
 };
 struct MasterApplyArgs {
     const float* v;      // (bs*2, stride) master EQ output (or the raw bus when the master bus is off)
@@ -73,6 +74,7 @@ struct MasterApplyArgs {
     int64_t out_stride;
     int nc_pad, lookahead, comp_on;
     int64_t n;
+    int aligned;
 };
 // One argument block for tracks (NCH = 1) and master (NCH = 2).
 struct CompBwdArgs {
@@ -89,6 +91,7 @@ struct CompBwdArgs {
     const float* gmixed;  // tracks only: grad wrt mixed_tracks (bs,2,T,n) or null
     int T, nc_pad, lookahead, comp_on;
     int64_t n;
+    int aligned;
 };
 void launch_comp_zs(int nch, const float* u, int64_t stride, const float* rc, float* zs, int nc_pad, int64_t n, int rows,
                     hipStream_t stream);
