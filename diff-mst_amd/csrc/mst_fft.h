@@ -1,5 +1,10 @@
 // mst_fft.h - complex FFT of a power-of-two length held in LDS, for the spectrogram losses.
 //
+// STATUS (round 1): NOT used by the shipped kernels.  Measured on MI355X at BASELINE cfg #2 this register
+// radix-8/16 formulation was SLOWER than the radix-4 Stockham of mst_stft.hip (fwd 94/60/40 us vs
+// 64/43/45 us for n_fft 8192/2048/512): 210-256 VGPRs leave 2 waves per SIMD and the LDS latency of
+// each pass is no longer hidden.  Kept as the starting point for a radix-8, 4-waves/SIMD variant.
+//
 // Stockham autosort (natural order in and out, ping-pong between two LDS buffers) with the
 // butterflies done IN REGISTERS at radix 8 / 16: a 512-point transform is three radix-8 passes by one
 // 64-lane wave, 2048 = 8*16*16 and 8192 = 2*16*16*16 by N/16 lanes - three to four LDS round trips

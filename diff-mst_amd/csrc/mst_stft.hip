@@ -12,7 +12,7 @@
 // epilogue is fused - no spectrogram ever reaches HBM.  Backward recomputes the forward tile,
 // forms dL/dX, and returns two frames' time-domain cotangents per complex FFT; the overlap-add
 // (incl. the reflect-padding fold-back) uses hardware float atomics into grad_pred.
-#include "mst_fft.h"
+#include "mst_common.h"
 
 namespace mst {
 
@@ -21,13 +21,74 @@ constexpr int kMaxRes = 8;
 struct ResInfo {
     int n_fft, hop, n_frames, n_bins;
     int64_t tw_off, win_off;  // float offsets into the tables buffer (tw: n_fft float2, win: n_fft floats)
-    int frames_per_slot;      // forward: consecutive frames handled by one slot of a workgroup
+    int frames_per_wg;                  // forward strip length
 };
 
-// Workgroup geometry: a transform is owned by TPF = FftPlan<N>::tpf lanes (one radix-16 butterfly per
-// lane and pass); small transforms run several frames ("slots") side by side in one workgroup.
-constexpr int stft_slots(int n_fft) { return n_fft <= 512 ? 4 : (n_fft <= 1024 ? 2 : 1); }
-template <int N> constexpr int stft_threads() { return FftPlan<N>::tpf * stft_slots(N); }
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+
+// Forward DFT (e^{-i...}) of NFFT complex points held in LDS: Stockham autosort, radix-4 stages
+// (one radix-2 stage first when log2 NFFT is odd), natural order in AND out, ping-pong between
+// `a` (input) and `b`; the result pointer is returned.  Every stage reads a[j + r n/4] for
+// consecutive j (conflict-free).  Twiddles come from a two-level table staged in LDS
+// (w^t = coarse[t >> 6] * fine[t & 63], 1.5 KB instead of 64 KB at n = 8192) so that no stage waits
+// on a global load; w^2t and w^3t are formed by multiplication.
+template <int NFFT>
+struct Twiddles {
+    float2 coarse[NFFT / 64];
+    float2 fine[64];
+};
+template <int NFFT>
+__device__ __forceinline__ void stage_twiddles(Twiddles<NFFT>& T, const float2* __restrict__ tw, int tid, int nthreads) {
+    for (int i = tid; i < NFFT / 64; i += nthreads) T.coarse[i] = tw[i * 64];
+    for (int i = tid; i < 64; i += nthreads) T.fine[i] = tw[i];
+}
+template <int NFFT, int THREADS>
+__device__ __forceinline__ float2* lds_fft(float2* a, float2* b, const Twiddles<NFFT>& T, int tid) {
+    constexpr int LOG2N = (NFFT == 128) ? 7 : (NFFT == 256) ? 8 : (NFFT == 512) ? 9 : (NFFT == 1024) ? 10
+                        : (NFFT == 2048) ? 11 : (NFFT == 4096) ? 12 : 13;
+    int Ns = 1;
+    if (LOG2N & 1) {
+        constexpr int h = NFFT >> 1;
+#pragma unroll
+        for (int j = tid; j < h; j += THREADS) {
+            const float2 u0 = a[j], u1 = a[j + h];
+            b[2 * j] = make_float2(u0.x + u1.x, u0.y + u1.y);
+            b[2 * j + 1] = make_float2(u0.x - u1.x, u0.y - u1.y);
+        }
+        float2* t = a; a = b; b = t;
+        Ns = 2;
+        __syncthreads();
+    }
+    constexpr int q = NFFT >> 2;
+#pragma unroll 1
+    for (; Ns < NFFT; Ns <<= 2) {
+        const int tstep = NFFT / (4 * Ns);
+#pragma unroll
+        for (int j = tid; j < q; j += THREADS) {
+            const int k = j & (Ns - 1);
+            float2 u0 = a[j], u1 = a[j + q], u2 = a[j + 2 * q], u3 = a[j + 3 * q];
+            if (Ns > 1) {
+                const int t = k * tstep;
+                const float2 w1 = cmul(T.coarse[t >> 6], T.fine[t & 63]);
+                const float2 w2 = cmul(w1, w1);
+                const float2 w3 = cmul(w2, w1);
+                u1 = cmul(u1, w1);
+                u2 = cmul(u2, w2);
+                u3 = cmul(u3, w3);
+            }
+            const float2 s02 = make_float2(u0.x + u2.x, u0.y + u2.y), d02 = make_float2(u0.x - u2.x, u0.y - u2.y);
+            const float2 s13 = make_float2(u1.x + u3.x, u1.y + u3.y), d13 = make_float2(u1.x - u3.x, u1.y - u3.y);
+            const int base = ((j - k) << 2) + k;
+            b[base] = make_float2(s02.x + s13.x, s02.y + s13.y);
+            b[base + Ns] = make_float2(d02.x + d13.y, d02.y - d13.x);  // d02 - i d13
+            b[base + 2 * Ns] = make_float2(s02.x - s13.x, s02.y - s13.y);
+            b[base + 3 * Ns] = make_float2(d02.x - d13.y, d02.y + d13.x);  // d02 + i d13
+        }
+        float2* t = a; a = b; b = t;
+        __syncthreads();
+    }
+    return a;
+}
 
 __device__ __forceinline__ int64_t reflect_index(int64_t i, int64_t n) {
     if (i < 0) i = -i;
@@ -35,20 +96,15 @@ __device__ __forceinline__ int64_t reflect_index(int64_t i, int64_t n) {
     return i;
 }
 
-// frame f of (x, y) as z = w (x + i y) in natural order (padded LDS indexing); zeros when !valid
-template <int N, int TPF>
+// load frame f of (x, y) as z = w (x + i y), natural order
 __device__ __forceinline__ void load_frame(float2* buf, const float* __restrict__ x, const float* __restrict__ y,
-                                           const float* __restrict__ win, int f, int hop, int64_t n, bool valid, int lane) {
-    const int64_t start = (int64_t)f * hop - N / 2;
-#pragma unroll 4
-    for (int k = lane; k < N; k += TPF) {
-        float2 v = make_float2(0.f, 0.f);
-        if (valid) {
-            const int64_t i = reflect_index(start + k, n);
-            const float w = win[k];
-            v = make_float2(w * x[i], w * y[i]);
-        }
-        buf[lds_pad(k)] = v;
+                                           const float* __restrict__ win, int f, const ResInfo& r, int64_t n, int tid,
+                                           int nthreads) {
+    const int64_t start = (int64_t)f * r.hop - r.n_fft / 2;
+    for (int k = tid; k < r.n_fft; k += nthreads) {
+        const int64_t i = reflect_index(start + k, n);
+        const float w = win[k];
+        buf[k] = make_float2(w * x[i], w * y[i]);
     }
 }
 
@@ -67,56 +123,52 @@ struct StftArgs {
 };
 
 // separate the two real spectra packed in one complex FFT
-template <int N>
-__device__ __forceinline__ void split_xy(const float2* buf, int k, float2& X, float2& Y) {
-    const float2 zk = buf[lds_pad(k)], zn = buf[lds_pad((N - k) & (N - 1))];
+__device__ __forceinline__ void split_xy(const float2* buf, int k, int n_fft, float2& X, float2& Y) {
+    const float2 zk = buf[k], zn = buf[(n_fft - k) & (n_fft - 1)];
     X = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
     Y = make_float2(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
 }
 
+constexpr int stft_threads(int n_fft) { return n_fft <= 512 ? 128 : (n_fft <= 2048 ? 512 : 1024); }
+
 constexpr float kLn2 = 0.6931471805599453f;
 
-template <int N>
-__global__ __launch_bounds__(stft_threads<N>()) void k_stft_fwd(StftArgs a) {
-    constexpr int TPF = FftPlan<N>::tpf, SLOTS = stft_slots(N), THREADS = TPF * SLOTS, PN = lds_padded(N);
-    __shared__ __attribute__((aligned(16))) float2 bufs[SLOTS * 2 * PN];
-    __shared__ float red[THREADS / 64][4];
-    const int tid = threadIdx.x, row = blockIdx.y, slot = tid / TPF, lane = tid % TPF;
+template <int NFFT>
+__global__ __launch_bounds__(stft_threads(NFFT)) void k_stft_fwd(StftArgs a) {
+    constexpr int THREADS = stft_threads(NFFT);
+    __shared__ __attribute__((aligned(16))) float2 bufA[NFFT];
+    __shared__ __attribute__((aligned(16))) float2 bufB[NFFT];
+    __shared__ float red[16][4];
+    __shared__ Twiddles<NFFT> twd;
+    const int tid = threadIdx.x, row = blockIdx.y;
     const ResInfo r = a.r;
-    LaneTw<N> twd;
-    twd.init(reinterpret_cast<const float2*>(a.tables + r.tw_off), lane);
+    stage_twiddles<NFFT>(twd, reinterpret_cast<const float2*>(a.tables + r.tw_off), tid, THREADS);
     const float* win = a.tables + r.win_off;
     const float* x = a.pred + (int64_t)row * a.n;
     const float* y = a.target + (int64_t)row * a.n;
-    float2* A = bufs + slot * 2 * PN;
-    float2* B = A + PN;
     float s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f;
-    const int f0 = (blockIdx.x * SLOTS + slot) * r.frames_per_slot;
-    for (int it = 0; it < r.frames_per_slot; ++it) {
-        const int f = f0 + it;
-        const bool valid = f < r.n_frames;
-        load_frame<N, TPF>(A, x, y, win, f, r.hop, a.n, valid, lane);
+    const int f0 = blockIdx.x * r.frames_per_wg;
+    for (int f = f0; f < f0 + r.frames_per_wg && f < r.n_frames; ++f) {
+        load_frame(bufA, x, y, win, f, r, a.n, tid, THREADS);
         __syncthreads();
-        const float2* Z = lds_fft<N>(A, B, twd, lane);
-        if (valid) {
-            for (int k = lane; k < r.n_bins; k += TPF) {
-                float2 X, Y;
-                split_xy<N>(Z, k, X, Y);
-                const float xm = __builtin_amdgcn_sqrtf(fmaxf(X.x * X.x + X.y * X.y, a.eps));
-                const float ym = __builtin_amdgcn_sqrtf(fmaxf(Y.x * Y.x + Y.y * Y.y, a.eps));
-                const float d = ym - xm;
-                s1 = fmaf(d, d, s1);
-                s2 = fmaf(ym, ym, s2);
-                s3 += fabsf(__builtin_amdgcn_logf(xm) - __builtin_amdgcn_logf(ym));  // log2; scaled by ln2 below
-                s4 += fabsf(d);
-            }
+        const float2* Z = lds_fft<NFFT, THREADS>(bufA, bufB, twd, tid);
+        for (int k = tid; k < r.n_bins; k += THREADS) {
+            float2 X, Y;
+            split_xy(Z, k, NFFT, X, Y);
+            const float xm = sqrtf(fmaxf(X.x * X.x + X.y * X.y, a.eps));
+            const float ym = sqrtf(fmaxf(Y.x * Y.x + Y.y * Y.y, a.eps));
+            const float d = ym - xm;
+            s1 = fmaf(d, d, s1);
+            s2 = fmaf(ym, ym, s2);
+            s3 += fabsf(__builtin_amdgcn_logf(xm) - __builtin_amdgcn_logf(ym));  // log2; scaled by ln2 below
+            s4 += fabsf(d);
         }
         __syncthreads();
     }
     s3 *= kLn2;
-    const int wave = tid >> 6, wl = tid & 63;
+    const int wave = tid >> 6, lane = tid & 63;
     s1 = wave_sum(s1); s2 = wave_sum(s2); s3 = wave_sum(s3); s4 = wave_sum(s4);
-    if (wl == 0) { red[wave][0] = s1; red[wave][1] = s2; red[wave][2] = s3; red[wave][3] = s4; }
+    if (lane == 0) { red[wave][0] = s1; red[wave][1] = s2; red[wave][2] = s3; red[wave][3] = s4; }
     __syncthreads();
     if (tid < 4) {
         float v = 0.f;
@@ -126,93 +178,85 @@ __global__ __launch_bounds__(stft_threads<N>()) void k_stft_fwd(StftArgs a) {
 }
 
 // cotangent G[k] = dL/dX[k] of the prediction's half spectrum for the frame whose packed FFT is Z
-template <int N>
-__device__ __forceinline__ float2 spectrum_cotangent(const float2* Z, int k, const StftArgs& a, const float* coef) {
+__device__ __forceinline__ float2 spectrum_cotangent(const float2* Z, int k, int n_fft, const StftArgs& a, const float* coef) {
     float2 X, Y;
-    split_xy<N>(Z, k, X, Y);
+    split_xy(Z, k, n_fft, X, Y);
     const float p2 = X.x * X.x + X.y * X.y;
-    const float xm = __builtin_amdgcn_sqrtf(fmaxf(p2, a.eps));
-    const float ym = __builtin_amdgcn_sqrtf(fmaxf(Y.x * Y.x + Y.y * Y.y, a.eps));
-    const float rx = __builtin_amdgcn_rcpf(xm);
+    const float xm = sqrtf(fmaxf(p2, a.eps));
+    const float ym = sqrtf(fmaxf(Y.x * Y.x + Y.y * Y.y, a.eps));
     float g = coef[0] * (xm - ym);
     const float dl = __builtin_amdgcn_logf(xm) - __builtin_amdgcn_logf(ym);
-    g += coef[1] * ((dl > 0.f) - (dl < 0.f)) * rx;
+    g += coef[1] * ((dl > 0.f) - (dl < 0.f)) / xm;
     g += coef[2] * ((xm > ym) - (xm < ym));
-    const float s = (p2 >= a.eps) ? g * rx : 0.0f;  // through sqrt(clamp(|X|^2, eps)): zero below the clamp
+    const float s = (p2 >= a.eps) ? g / xm : 0.0f;  // through sqrt(clamp(|X|^2, eps)): zero below the clamp
     return make_float2(s * X.x, s * X.y);
 }
 
 // Backward.  The real cotangent frame is Re IDFT of the half spectrum G, i.e. the IDFT of its
 // Hermitian extension He (He[k] = G[k]/2, He[N-k] = conj(G[k])/2, real at k = 0, N/2), and
 // IDFT(h) = conj(FFT(conj(h))).  PAIR: two frames share one complex inverse FFT (He_a + i He_b).
-template <int N, bool PAIR>
-__global__ __launch_bounds__(stft_threads<N>()) void k_stft_bwd(StftArgs a) {
-    constexpr int TPF = FftPlan<N>::tpf, SLOTS = stft_slots(N), THREADS = TPF * SLOTS, PN = lds_padded(N);
-    constexpr int NBUF = PAIR ? 3 : 2;
-    __shared__ __attribute__((aligned(16))) float2 bufs[SLOTS * NBUF * PN];
+template <int NFFT, bool PAIR>
+__global__ __launch_bounds__(stft_threads(NFFT)) void k_stft_bwd(StftArgs a) {
+    constexpr int THREADS = stft_threads(NFFT);
+    __shared__ __attribute__((aligned(16))) float2 bufA[NFFT];
+    __shared__ __attribute__((aligned(16))) float2 bufB[NFFT];
+    __shared__ __attribute__((aligned(16))) float2 bufH[PAIR ? NFFT : 1];
+    __shared__ Twiddles<NFFT> twd;
     const ResInfo r = a.r;
-    const int tid = threadIdx.x, row = blockIdx.y, slot = tid / TPF, lane = tid % TPF;
-    LaneTw<N> twd;
-    twd.init(reinterpret_cast<const float2*>(a.tables + r.tw_off), lane);
+    const int tid = threadIdx.x, row = blockIdx.y;
+    stage_twiddles<NFFT>(twd, reinterpret_cast<const float2*>(a.tables + r.tw_off), tid, THREADS);
     const float* win = a.tables + r.win_off;
     const float* x = a.pred + (int64_t)row * a.n;
     const float* y = a.target + (int64_t)row * a.n;
     const float* coef = a.coef + (int64_t)row * 4;
     float* gx = a.grad_pred + (int64_t)row * a.n;
-    float2* A = bufs + slot * NBUF * PN;
-    float2* B = A + PN;
-    const int unit = blockIdx.x * SLOTS + slot;  // frame (or frame pair) index
-    const int fa = PAIR ? 2 * unit : unit, fb = fa + 1;
-    const bool have_a = fa < r.n_frames, have_b = PAIR && fb < r.n_frames;
-    const int64_t sa = (int64_t)fa * r.hop - N / 2, sb = (int64_t)fb * r.hop - N / 2;
+    const int fa = PAIR ? 2 * blockIdx.x : blockIdx.x, fb = fa + 1;
+    const bool have_b = PAIR && fb < r.n_frames;
+    const int64_t sa = (int64_t)fa * r.hop - NFFT / 2, sb = (int64_t)fb * r.hop - NFFT / 2;
 
-    load_frame<N, TPF>(A, x, y, win, fa, r.hop, a.n, have_a, lane);
+    load_frame(bufA, x, y, win, fa, r, a.n, tid, THREADS);
     __syncthreads();
-    float2* Z = lds_fft<N>(A, B, twd, lane);
-    float2* O = (Z == A) ? B : A;         // the buffer the forward result is NOT in
-    float2* H = PAIR ? A + 2 * PN : O;    // where conj(He) is assembled
-    for (int k = lane; k <= N / 2; k += TPF) {
-        const float2 G = spectrum_cotangent<N>(Z, k, a, coef);
-        const bool edge = (k == 0) || (k == N / 2);
+    float2* Z = lds_fft<NFFT, THREADS>(bufA, bufB, twd, tid);
+    float2* O = (Z == bufA) ? bufB : bufA;       // the buffer the forward result is NOT in
+    float2* H = PAIR ? bufH : O;                 // where conj(He) is assembled
+    for (int k = tid; k <= NFFT / 2; k += THREADS) {
+        const float2 G = spectrum_cotangent(Z, k, NFFT, a, coef);
+        const bool edge = (k == 0) || (k == NFFT / 2);
         // conj(He): He[k] = G/2 -> (Gx/2, -Gy/2); He[N-k] = conj(G)/2 -> (Gx/2, +Gy/2)
-        H[lds_pad(k)] = edge ? make_float2(G.x, 0.f) : make_float2(0.5f * G.x, -0.5f * G.y);
-        if (!edge) H[lds_pad(N - k)] = make_float2(0.5f * G.x, 0.5f * G.y);
+        H[k] = edge ? make_float2(G.x, 0.f) : make_float2(0.5f * G.x, -0.5f * G.y);
+        if (!edge) H[NFFT - k] = make_float2(0.5f * G.x, 0.5f * G.y);
     }
     __syncthreads();
     if (PAIR) {
-        load_frame<N, TPF>(A, x, y, win, fb, r.hop, a.n, have_b, lane);
-        __syncthreads();
-        Z = lds_fft<N>(A, B, twd, lane);
         if (have_b) {
-            for (int k = lane; k <= N / 2; k += TPF) {
-                const float2 G = spectrum_cotangent<N>(Z, k, a, coef);
-                const bool edge = (k == 0) || (k == N / 2);
-                // conj(i He_b): i He[k] = i G/2 -> conj = (-Gy/2, -Gx/2);  i He[N-k] = i conj(G)/2 -> conj = (Gy/2, -Gx/2)
+            load_frame(bufA, x, y, win, fb, r, a.n, tid, THREADS);
+            __syncthreads();
+            Z = lds_fft<NFFT, THREADS>(bufA, bufB, twd, tid);
+            for (int k = tid; k <= NFFT / 2; k += THREADS) {
+                const float2 G = spectrum_cotangent(Z, k, NFFT, a, coef);
+                const bool edge = (k == 0) || (k == NFFT / 2);
+                // conj(i He_b): i He[k] = i G/2 = (-Gy/2, Gx/2) -> conj = (-Gy/2, -Gx/2);
+                //               i He[N-k] = i conj(G)/2 = (Gy/2, Gx/2) -> conj = (Gy/2, -Gx/2)
                 if (edge) {
-                    H[lds_pad(k)].y -= G.x;
+                    H[k].y -= G.x;  // i * Re(G) -> conj -> (0, -Gx)
                 } else {
-                    float2 h = H[lds_pad(k)];
-                    H[lds_pad(k)] = make_float2(h.x - 0.5f * G.y, h.y - 0.5f * G.x);
-                    h = H[lds_pad(N - k)];
-                    H[lds_pad(N - k)] = make_float2(h.x + 0.5f * G.y, h.y - 0.5f * G.x);
+                    H[k].x += -0.5f * G.y; H[k].y += -0.5f * G.x;
+                    H[NFFT - k].x += 0.5f * G.y; H[NFFT - k].y += -0.5f * G.x;
                 }
             }
+            __syncthreads();
         }
-        __syncthreads();
-        O = A;  // both work buffers are free again
+        O = bufA;  // both work buffers are free again
     } else {
-        O = Z;  // forward result no longer needed
+        O = Z;     // forward result no longer needed
     }
     // FFT(conj(h)) = conj(r_a + i r_b)  =>  r_a = Re, r_b = -Im
-    const float2* R = lds_fft<N>(H, O, twd, lane);
-    if (have_a) {
-#pragma unroll 4
-        for (int k = lane; k < N; k += TPF) {
-            const float2 v = R[lds_pad(k)];
-            const float w = win[k];
-            unsafeAtomicAdd(&gx[reflect_index(sa + k, a.n)], w * v.x);
-            if (have_b) unsafeAtomicAdd(&gx[reflect_index(sb + k, a.n)], -w * v.y);
-        }
+    const float2* R = lds_fft<NFFT, THREADS>(H, O, twd, tid);
+    for (int k = tid; k < NFFT; k += THREADS) {
+        const float2 v = R[k];
+        const float w = win[k];
+        unsafeAtomicAdd(&gx[reflect_index(sa + k, a.n)], w * v.x);
+        if (have_b) unsafeAtomicAdd(&gx[reflect_index(sb + k, a.n)], -w * v.y);
     }
 }
 
@@ -343,10 +387,9 @@ Plan make_plan(const mst_mrstft_desc* d) {
         p.log2n[i] = lg;
         p.win[i] = d->win_length[i];
         // aim for >= ~2000 workgroups per launch (256 CUs x several resident) but cap the strip at 8 frames
-        const int slots = stft_slots(nf);
-        int fps = (int)(((int64_t)r.n_frames * d->rows) / (2048 * slots));
-        r.frames_per_slot = fps < 1 ? 1 : (fps > 8 ? 8 : fps);
-        p.n_groups[i] = (r.n_frames + r.frames_per_slot * slots - 1) / (r.frames_per_slot * slots);
+        int fpw = (int)(((int64_t)r.n_frames * d->rows) / 2048);
+        r.frames_per_wg = fpw < 1 ? 1 : (fpw > 8 ? 8 : fpw);
+        p.n_groups[i] = (r.n_frames + r.frames_per_wg - 1) / r.frames_per_wg;
         p.part_off[i] = po;
         po += (int64_t)d->rows * p.n_groups[i] * 4;
     }
@@ -418,7 +461,7 @@ extern "C" int mst_mrstft_forward(const mst_mrstft_desc* d, const float* pred, c
         a.n = d->n_samples;
         a.eps = d->eps;
         const dim3 grid(p.n_groups[i], d->rows);
-#define MST_LAUNCH_FWD(NF) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stft_fwd<NF>), grid, dim3(stft_threads<NF>()), 0, stream, a)
+#define MST_LAUNCH_FWD(NF) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stft_fwd<NF>), grid, dim3(stft_threads(NF)), 0, stream, a)
         MST_FOR_NFFT(a.r.n_fft, MST_LAUNCH_FWD)
         la.n_groups[i] = p.n_groups[i];
         la.part_off[i] = p.part_off[i];
@@ -452,14 +495,12 @@ extern "C" int mst_mrstft_backward(const mst_mrstft_desc* d, const float* pred, 
         a.log2n = p.log2n[i];
         a.n = d->n_samples;
         a.eps = d->eps;
-        // three LDS buffers (pairing two frames per inverse FFT) fit up to n_fft = 4096; 8192 runs one frame per slot
+        // three LDS buffers (pairing two frames per inverse FFT) fit up to n_fft = 4096; 8192 runs one frame per workgroup
         const bool pair = a.r.n_fft <= 4096;
-        const int units = pair ? (a.r.n_frames + 1) / 2 : a.r.n_frames;
-        const int slots = stft_slots(a.r.n_fft);
-        const dim3 grid((units + slots - 1) / slots, d->rows);
+        const dim3 grid(pair ? (a.r.n_frames + 1) / 2 : a.r.n_frames, d->rows);
 #define MST_LAUNCH_BWD(NF)                                                                                             \
-    if (NF <= 4096) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stft_bwd<NF, (NF <= 4096)>), grid, dim3(stft_threads<NF>()), 0, stream, a); \
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stft_bwd<NF, false>), grid, dim3(stft_threads<NF>()), 0, stream, a)
+    if (NF <= 4096) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stft_bwd<NF, (NF <= 4096)>), grid, dim3(stft_threads(NF)), 0, stream, a); \
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stft_bwd<NF, false>), grid, dim3(stft_threads(NF)), 0, stream, a)
         MST_FOR_NFFT(a.r.n_fft, MST_LAUNCH_BWD)
     }
     return (int)hipGetLastError();
