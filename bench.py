@@ -33,6 +33,17 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 BYTES_PER_MIX = 8 * N * (T + 2) + 24 * N
 
 
+def measured_traffic():
+    """HBM bytes per step from the committed rocprofv3 PMC passes of this same command (profiles/), or None.
+    bench.py cannot run the profiler on itself; the figure is refreshed whenever the kernels change."""
+    path = os.path.join(ROOT, "profiles", "round1_traffic.json")
+    try:
+        with open(path) as f:
+            return float(json.load(f)["hbm_bytes_per_step_raw"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def shard_batch(global_batch: int, rank: int, world: int):
     """Contiguous batch-axis shard owned by `rank`: mixes [lo, hi)."""
     per = global_batch // world
@@ -191,8 +202,9 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "kernel": "whole step (console fwd+bwd + MR-STFT fwd+bwd kernel sequence), HIP-event time per step",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(),
+                "kernel": "whole step = the ~37 back-to-back kernels of console fwd+bwd + MR-STFT fwd+bwd (no single kernel "
+                          "exceeds 13 % of the step, see profiles/round1_summary.md); HIP-event time per step",
                 "algorithmic_bytes_per_step": BS * BYTES_PER_MIX, "gpu_ms_per_step": gpu_ms_per_step, "stages": stages,
             },
         }
