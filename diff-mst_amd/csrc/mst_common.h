@@ -43,6 +43,8 @@ constexpr float kLn10Over20 = 0.11512925464970229f;  // d/dg 10^(g/20) = that * 
 constexpr float kCompEps = 1e-8f;                     // clamp of |side chain|
 
 __host__ __device__ inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
+// filter (parameter) row of signal row `sig`: rows below `split` are mono tracks, the rest stereo pairs
+__host__ __device__ inline int filter_row(int sig, int split) { return sig < split ? sig : split + ((sig - split) >> 1); }
 
 // ---- one DF2T biquad step: y = b0 x + s1; s1' = b1 x - a1 y + s2; s2' = b2 x - a2 y ---------
 template <typename T>
@@ -172,18 +174,20 @@ inline Layout make_layout(const mst_console_desc* d) {
         return at;
     };
     const int64_t R = L.R, B = L.bs, N = round_up(L.N, 4);
-    L.rc_t = take(R * RC_STRIDE);
-    L.rc_m = take(B * RC_STRIDE);
-    L.powF_t = take(R * kPow * 144);
-    L.powF_m = take(B * kPow * 144);
-    L.powA_t = take(R * kPow * 144);
-    L.powA_m = take(B * kPow * 144);
-    L.powP_t = take(R * 12 * kPow * 4);
-    L.powP_m = take(B * 12 * kPow * 4);
-    L.u_t = take(R * N);
+    // Track rows come first and the master rows follow IN THE SAME ARRAY wherever a kernel can serve
+    // both in one launch (signal rows [0,R) = tracks, [R, R+2bs) = master L/R; filter rows [0,R), [R,R+bs)).
+    L.rc_t = take((R + B) * RC_STRIDE);
+    L.rc_m = L.rc_t + R * RC_STRIDE;
+    L.powF_t = take((R + B) * kPow * 144);
+    L.powF_m = L.powF_t + R * kPow * 144;
+    L.powA_t = take((R + B) * kPow * 144);
+    L.powA_m = L.powA_t + R * kPow * 144;
+    L.powP_t = take((R + B) * 12 * kPow * 4);
+    L.powP_m = L.powP_t + R * 12 * kPow * 4;
+    L.u_t = take((R + 2 * B) * N);
+    L.v_m = L.u_t + R * N;
     L.gs_t = take(R * N);
     L.bus = take(B * 2 * N);
-    L.v_m = take(B * 2 * N);
     L.gs_m = take(B * N);
     L.zE_t = take(R * 12 * L.ncE_pad);
     L.sE_t = take(R * 12 * L.ncE_pad);
@@ -193,9 +197,9 @@ inline Layout make_layout(const mst_console_desc* d) {
     L.sS_t = take(R * L.ncC_pad);
     L.zS_m = take(B * L.ncC_pad);
     L.sS_m = take(B * L.ncC_pad);
-    L.du_m = take(B * 2 * N);
+    L.du_t = take((R + 2 * B) * N);
+    L.du_m = L.du_t + R * N;
     L.dbus = take(B * 2 * N);
-    L.du_t = take(R * N);
     L.zQ_t = take(R * L.ncC_pad);
     L.sQ_t = take(R * L.ncC_pad);
     L.zQ_m = take(B * L.ncC_pad);
@@ -204,14 +208,14 @@ inline Layout make_layout(const mst_console_desc* d) {
     L.sA_t = take(R * 12 * L.ncE_pad);
     L.zA_m = take(B * 2 * 12 * L.ncE_pad);
     L.sA_m = take(B * 2 * 12 * L.ncE_pad);
-    L.zP_t = take(R * 24 * L.ncE_pad);
-    L.sP_t = take(R * 24 * L.ncE_pad);
-    L.zP_m = take(B * 2 * 24 * L.ncE_pad);
-    L.sP_m = take(B * 2 * 24 * L.ncE_pad);
+    L.zP_t = take((R + 2 * B) * 24 * L.ncE_pad);
+    L.zP_m = L.zP_t + R * 24 * L.ncE_pad;
+    L.sP_t = take((R + 2 * B) * 24 * L.ncE_pad);
+    L.sP_m = L.sP_t + R * 24 * L.ncE_pad;
     L.cp_t = take(R * L.nblkC * CP_COUNT);
     L.cp_m = take(B * L.nblkC * CP_COUNT);
-    L.ep_t = take(R * L.nblkE * EP_COUNT);
-    L.ep_m = take(B * 2 * L.nblkE * EP_COUNT);
+    L.ep_t = take((R + 2 * B) * L.nblkE * EP_COUNT);
+    L.ep_m = L.ep_t + R * L.nblkE * EP_COUNT;
     L.total = o;
     return L;
 }

@@ -41,16 +41,15 @@ extern "C" int mst_console_forward(const mst_console_desc* d, const float* track
     const bool m_on = d->flags & MST_USE_MASTER_BUS;
     const bool o_on = d->flags & MST_USE_OUTPUT_FADER;
 
-    hipMemsetAsync(status, 0, sizeof(int32_t), stream);
     PrepArgs pa{track_params, fx_bus_params, master_bus_params, ws + L.rc_t, ws + L.rc_m,
                 ws + L.powF_t, ws + L.powF_m, ws + L.powA_t, ws + L.powA_m, ws + L.powP_t, ws + L.powP_m,
                 status, L.R, L.bs, L.KE, *d};
     launch_prep(pa, stream);
 
     // ---- tracks: EQ (zs -> carry scan -> run), compressor smoother (zs -> scan), apply + pan + bus sum
-    launch_cascade(EQ_FWD, false, tracks, d->track_row_stride, nullptr, 0, ws + L.rc_t, 1, nullptr, ws + L.zE_t, L.ncE_pad, n, L.R, stream);
-    launch_scan12(false, ws + L.zE_t, ws + L.sE_t, ws + L.powF_t, 1, L.ncE, L.ncE_pad, L.KE, L.R, stream);
-    launch_cascade(EQ_FWD, true, tracks, d->track_row_stride, ws + L.u_t, Ns, ws + L.rc_t, 1, ws + L.sE_t, nullptr, L.ncE_pad, n, L.R, stream);
+    launch_cascade(EQ_FWD, false, tracks, d->track_row_stride, nullptr, 0, ws + L.rc_t, L.R, nullptr, ws + L.zE_t, L.ncE_pad, n, L.R, stream);
+    launch_scan12(false, ws + L.zE_t, ws + L.sE_t, ws + L.powF_t, L.R, L.ncE, L.ncE_pad, L.KE, L.R, stream);
+    launch_cascade(EQ_FWD, true, tracks, d->track_row_stride, ws + L.u_t, Ns, ws + L.rc_t, L.R, ws + L.sE_t, nullptr, L.ncE_pad, n, L.R, stream);
     if (t_comp) {
         launch_comp_zs(1, ws + L.u_t, Ns, ws + L.rc_t, ws + L.zS_t, L.ncC_pad, n, L.R, stream);
     }
@@ -62,9 +61,9 @@ extern "C" int mst_console_forward(const mst_console_desc* d, const float* track
 
     // ---- master bus
     if (m_on) {
-        launch_cascade(EQ_FWD, false, ws + L.bus, Ns, nullptr, 0, ws + L.rc_m, 2, nullptr, ws + L.zE_m, L.ncE_pad, n, 2 * L.bs, stream);
-        launch_scan12(false, ws + L.zE_m, ws + L.sE_m, ws + L.powF_m, 2, L.ncE, L.ncE_pad, L.KE, 2 * L.bs, stream);
-        launch_cascade(EQ_FWD, true, ws + L.bus, Ns, ws + L.v_m, Ns, ws + L.rc_m, 2, ws + L.sE_m, nullptr, L.ncE_pad, n, 2 * L.bs, stream);
+        launch_cascade(EQ_FWD, false, ws + L.bus, Ns, nullptr, 0, ws + L.rc_m, 0, nullptr, ws + L.zE_m, L.ncE_pad, n, 2 * L.bs, stream);
+        launch_scan12(false, ws + L.zE_m, ws + L.sE_m, ws + L.powF_m, 0, L.ncE, L.ncE_pad, L.KE, 2 * L.bs, stream);
+        launch_cascade(EQ_FWD, true, ws + L.bus, Ns, ws + L.v_m, Ns, ws + L.rc_m, 0, ws + L.sE_m, nullptr, L.ncE_pad, n, 2 * L.bs, stream);
         launch_comp_zs(2, ws + L.v_m, Ns, ws + L.rc_m, ws + L.zS_m, L.ncC_pad, n, L.bs, stream);
         MasterApplyArgs ma{ws + L.v_m, Ns, ws + L.rc_m, ws + L.zS_m, save ? ws + L.gs_m : nullptr, mix, n,
                            L.ncC_pad, d->master_lookahead, 1, n, aligned};
@@ -94,7 +93,13 @@ extern "C" int mst_console_backward(const mst_console_desc* d, const float* trac
     (void)tracks;
     const int aligned = (n % 4 == 0) && !((uintptr_t)grad_mix & 15) && !((uintptr_t)grad_mixed_tracks & 15);
 
-    // ---- master bus: compressor adjoint, EQ adjoint (-> grad of the stereo bus), coefficient sums
+    // ---- all-pole states of the coefficient-gradient pass depend only on what forward saved: one
+    // launch covers the track rows and the master rows (signal rows [0,R) and [R,R+2bs) of the same arrays)
+    const int nsig_all = L.R + (m_on ? 2 * L.bs : 0);
+    launch_allpole_zs(ws + L.u_t, Ns, ws + L.rc_t, L.R, ws + L.zP_t, L.ncE_pad, n, nsig_all, stream);
+    launch_scan2(ws + L.zP_t, ws + L.sP_t, ws + L.powP_t, L.R, L.ncE, L.ncE_pad, L.KE, nsig_all, stream);
+
+    // ---- master bus: compressor adjoint, EQ adjoint (-> grad of the stereo bus)
     const float* gbus = grad_mix;  // cotangent of the stereo bus as seen by the track stage
     int64_t gbus_stride = n;
     if (m_on) {
@@ -103,12 +108,9 @@ extern "C" int mst_console_backward(const mst_console_desc* d, const float* trac
         launch_comp_bwd(true, false, ca, L.bs, stream);
         ca.s0 = ws + L.zQ_m;
         launch_comp_bwd(true, true, ca, L.bs, stream);
-        launch_cascade(EQ_ADJ, false, ws + L.du_m, Ns, nullptr, 0, ws + L.rc_m, 2, nullptr, ws + L.zA_m, L.ncE_pad, n, 2 * L.bs, stream);
-        launch_scan12(true, ws + L.zA_m, ws + L.sA_m, ws + L.powA_m, 2, L.ncE, L.ncE_pad, L.KE, 2 * L.bs, stream);
-        launch_cascade(EQ_ADJ, true, ws + L.du_m, Ns, ws + L.dbus, Ns, ws + L.rc_m, 2, ws + L.sA_m, nullptr, L.ncE_pad, n, 2 * L.bs, stream);
-        launch_allpole_zs(ws + L.v_m, Ns, ws + L.rc_m, 2, ws + L.zP_m, L.ncE_pad, n, 2 * L.bs, stream);
-        launch_scan2(ws + L.zP_m, ws + L.sP_m, ws + L.powP_m, 2, L.ncE, L.ncE_pad, L.KE, 2 * L.bs, stream);
-        launch_coefgrad(ws + L.v_m, Ns, ws + L.du_m, Ns, ws + L.rc_m, 2, ws + L.sP_m, L.ncE_pad, ws + L.ep_m, n, 2 * L.bs, stream);
+        launch_cascade(EQ_ADJ, false, ws + L.du_m, Ns, nullptr, 0, ws + L.rc_m, 0, nullptr, ws + L.zA_m, L.ncE_pad, n, 2 * L.bs, stream);
+        launch_scan12(true, ws + L.zA_m, ws + L.sA_m, ws + L.powA_m, 0, L.ncE, L.ncE_pad, L.KE, 2 * L.bs, stream);
+        launch_cascade(EQ_ADJ, true, ws + L.du_m, Ns, ws + L.dbus, Ns, ws + L.rc_m, 0, ws + L.sA_m, nullptr, L.ncE_pad, n, 2 * L.bs, stream);
         gbus = ws + L.dbus;
         gbus_stride = Ns;
     } else if (o_on) {
@@ -130,13 +132,12 @@ extern "C" int mst_console_backward(const mst_console_desc* d, const float* trac
             ca.s0 = ws + L.zQ_t;
         }
         launch_comp_bwd(false, true, ca, L.R, stream);
-        launch_allpole_zs(ws + L.u_t, Ns, ws + L.rc_t, 1, ws + L.zP_t, L.ncE_pad, n, L.R, stream);
-        launch_scan2(ws + L.zP_t, ws + L.sP_t, ws + L.powP_t, 1, L.ncE, L.ncE_pad, L.KE, L.R, stream);
-        launch_coefgrad(ws + L.u_t, Ns, ws + L.du_t, Ns, ws + L.rc_t, 1, ws + L.sP_t, L.ncE_pad, ws + L.ep_t, n, L.R, stream);
+        // coefficient-gradient sums for the track rows and (same launch) the master rows
+        launch_coefgrad(ws + L.u_t, Ns, ws + L.du_t, Ns, ws + L.rc_t, L.R, ws + L.sP_t, L.ncE_pad, ws + L.ep_t, n, nsig_all, stream);
         if (grad_tracks) {
-            launch_cascade(EQ_ADJ, false, ws + L.du_t, Ns, nullptr, 0, ws + L.rc_t, 1, nullptr, ws + L.zA_t, L.ncE_pad, n, L.R, stream);
-            launch_scan12(true, ws + L.zA_t, ws + L.sA_t, ws + L.powA_t, 1, L.ncE, L.ncE_pad, L.KE, L.R, stream);
-            launch_cascade(EQ_ADJ, true, ws + L.du_t, Ns, grad_tracks, n, ws + L.rc_t, 1, ws + L.sA_t, nullptr, L.ncE_pad, n, L.R, stream);
+            launch_cascade(EQ_ADJ, false, ws + L.du_t, Ns, nullptr, 0, ws + L.rc_t, L.R, nullptr, ws + L.zA_t, L.ncE_pad, n, L.R, stream);
+            launch_scan12(true, ws + L.zA_t, ws + L.sA_t, ws + L.powA_t, L.R, L.ncE, L.ncE_pad, L.KE, L.R, stream);
+            launch_cascade(EQ_ADJ, true, ws + L.du_t, Ns, grad_tracks, n, ws + L.rc_t, L.R, ws + L.sA_t, nullptr, L.ncE_pad, n, L.R, stream);
         }
     }
     PrepBwdArgs pb{track_params, master_bus_params, ws + L.rc_t, ws + L.rc_m, ws + L.cp_t, ws + L.cp_m, ws + L.ep_t, ws + L.ep_m,

@@ -64,7 +64,7 @@ __device__ __forceinline__ void slab_store(const float* __restrict__ tile, float
 template <int DIR, bool MODE_RUN>
 __global__ __launch_bounds__(kWG) void k_cascade(const float* __restrict__ in, int64_t in_stride,
                                                  float* __restrict__ out, int64_t out_stride,
-                                                 const float* __restrict__ rc, int nch,
+                                                 const float* __restrict__ rc, int split,
                                                  const float* __restrict__ s0, float* __restrict__ z,
                                                  int nc_pad, int64_t n) {
     __shared__ __attribute__((aligned(16))) float tile[kWG * kLdw];
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(kWG) void k_cascade(const float* __restrict__ in, i
     SlabRegs pre;
     slab_fetch(pre, inrow, tile_base, order(0), n, tid);  // first slab in flight while constants load
 
-    const float* coef = rc + (int64_t)(sig / nch) * RC_STRIDE + RC_SOS;
+    const float* coef = rc + (int64_t)filter_row(sig, split) * RC_STRIDE + RC_SOS;
     float c[5 * kSections];
 #pragma unroll
     for (int i = 0; i < 5 * kSections; ++i) c[i] = coef[i];
@@ -144,14 +144,14 @@ __device__ __forceinline__ void load_ap(const float* coef, ApCoef& k) {
 
 // zero-state end states of the 12 all-pole filters per lane chunk: z[sig][24][nc_pad]
 __global__ __launch_bounds__(kWG) void k_allpole_zs(const float* __restrict__ u, int64_t u_stride,
-                                                    const float* __restrict__ rc, int nch, float* __restrict__ z,
+                                                    const float* __restrict__ rc, int split, float* __restrict__ z,
                                                     int nc_pad, int64_t n) {
     __shared__ __attribute__((aligned(16))) float tile[kWG * kLdw];
     const int tid = threadIdx.x, sig = blockIdx.y;
     const int64_t tile_base = (int64_t)blockIdx.x * kWG * kEqChunk;
     const int chunk = blockIdx.x * kWG + tid;
     ApCoef k;
-    load_ap(rc + (int64_t)(sig / nch) * RC_STRIDE + RC_SOS, k);
+    load_ap(rc + (int64_t)filter_row(sig, split) * RC_STRIDE + RC_SOS, k);
     float wa1[kSections], wa2[kSections], wb1[kSections], wb2[kSections];
 #pragma unroll
     for (int s = 0; s < kSections; ++s) wa1[s] = wa2[s] = wb1[s] = wb2[s] = 0.0f;
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(kWG) void k_allpole_zs(const float* __restrict__ u,
 // coefficient-gradient partial sums: part[sig][block][30] = {db0 db1 db2 da1 da2} x 6 sections
 __global__ __launch_bounds__(kWG) void k_coefgrad(const float* __restrict__ u, int64_t u_stride,
                                                   const float* __restrict__ g, int64_t g_stride,
-                                                  const float* __restrict__ rc, int nch,
+                                                  const float* __restrict__ rc, int split,
                                                   const float* __restrict__ s0, int nc_pad,
                                                   float* __restrict__ part, int64_t n) {
     __shared__ __attribute__((aligned(16))) float tile_u[kWG * kLdw];
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(kWG) void k_coefgrad(const float* __restrict__ u, i
     const int64_t tile_base = (int64_t)blockIdx.x * kWG * kEqChunk;
     const int chunk = blockIdx.x * kWG + tid;
     ApCoef k;
-    load_ap(rc + (int64_t)(sig / nch) * RC_STRIDE + RC_SOS, k);
+    load_ap(rc + (int64_t)filter_row(sig, split) * RC_STRIDE + RC_SOS, k);
     float wa1[kSections], wa2[kSections], wb1[kSections], wb2[kSections];
 #pragma unroll
     for (int s = 0; s < kSections; ++s) {
@@ -263,29 +263,29 @@ __global__ __launch_bounds__(kWG) void k_coefgrad(const float* __restrict__ u, i
 
 // ---- host-side launch helpers (called from mst_console.hip) --------------------------------------
 void launch_cascade(int dir, bool run, const float* in, int64_t in_stride, float* out, int64_t out_stride,
-                    const float* rc, int nch, const float* s0, float* z, int nc_pad, int64_t n, int nsig,
+                    const float* rc, int split, const float* s0, float* z, int nc_pad, int64_t n, int nsig,
                     hipStream_t stream) {
     dim3 grid(nc_pad / kWG, nsig), block(kWG);
     if (dir == EQ_FWD && !run)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cascade<EQ_FWD, false>), grid, block, 0, stream, in, in_stride, out, out_stride, rc, nch, s0, z, nc_pad, n);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cascade<EQ_FWD, false>), grid, block, 0, stream, in, in_stride, out, out_stride, rc, split, s0, z, nc_pad, n);
     else if (dir == EQ_FWD && run)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cascade<EQ_FWD, true>), grid, block, 0, stream, in, in_stride, out, out_stride, rc, nch, s0, z, nc_pad, n);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cascade<EQ_FWD, true>), grid, block, 0, stream, in, in_stride, out, out_stride, rc, split, s0, z, nc_pad, n);
     else if (dir == EQ_ADJ && !run)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cascade<EQ_ADJ, false>), grid, block, 0, stream, in, in_stride, out, out_stride, rc, nch, s0, z, nc_pad, n);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cascade<EQ_ADJ, false>), grid, block, 0, stream, in, in_stride, out, out_stride, rc, split, s0, z, nc_pad, n);
     else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cascade<EQ_ADJ, true>), grid, block, 0, stream, in, in_stride, out, out_stride, rc, nch, s0, z, nc_pad, n);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cascade<EQ_ADJ, true>), grid, block, 0, stream, in, in_stride, out, out_stride, rc, split, s0, z, nc_pad, n);
 }
 
-void launch_allpole_zs(const float* u, int64_t u_stride, const float* rc, int nch, float* z, int nc_pad, int64_t n,
+void launch_allpole_zs(const float* u, int64_t u_stride, const float* rc, int split, float* z, int nc_pad, int64_t n,
                        int nsig, hipStream_t stream) {
     dim3 grid(nc_pad / kWG, nsig), block(kWG);
-    hipLaunchKernelGGL(k_allpole_zs, grid, block, 0, stream, u, u_stride, rc, nch, z, nc_pad, n);
+    hipLaunchKernelGGL(k_allpole_zs, grid, block, 0, stream, u, u_stride, rc, split, z, nc_pad, n);
 }
 
-void launch_coefgrad(const float* u, int64_t u_stride, const float* g, int64_t g_stride, const float* rc, int nch,
+void launch_coefgrad(const float* u, int64_t u_stride, const float* g, int64_t g_stride, const float* rc, int split,
                      const float* s0, int nc_pad, float* part, int64_t n, int nsig, hipStream_t stream) {
     dim3 grid(nc_pad / kWG, nsig), block(kWG);
-    hipLaunchKernelGGL(k_coefgrad, grid, block, 0, stream, u, u_stride, g, g_stride, rc, nch, s0, nc_pad, part, n);
+    hipLaunchKernelGGL(k_coefgrad, grid, block, 0, stream, u, u_stride, g, g_stride, rc, split, s0, nc_pad, part, n);
 }
 
 }  // namespace mst

@@ -6,6 +6,8 @@
 namespace mst {
 
 enum { EQ_FWD = 0, EQ_ADJ = 1 };
+// `split` arguments: signal rows below it are mono (tracks, one filter row each), rows from it on are stereo
+// pairs sharing a filter row (master buses).  Tracks-only launch: split = nsig; master-only: split = 0.
 
 // ---- mst_params.hip
 struct PrepArgs {
@@ -39,16 +41,16 @@ void launch_prep_bwd(const PrepBwdArgs& a, hipStream_t stream);
 
 // ---- mst_eq.hip
 void launch_cascade(int dir, bool run, const float* in, int64_t in_stride, float* out, int64_t out_stride, const float* rc,
-                    int nch, const float* s0, float* z, int nc_pad, int64_t n, int nsig, hipStream_t stream);
-void launch_allpole_zs(const float* u, int64_t u_stride, const float* rc, int nch, float* z, int nc_pad, int64_t n, int nsig,
+                    int split, const float* s0, float* z, int nc_pad, int64_t n, int nsig, hipStream_t stream);
+void launch_allpole_zs(const float* u, int64_t u_stride, const float* rc, int split, float* z, int nc_pad, int64_t n, int nsig,
                        hipStream_t stream);
-void launch_coefgrad(const float* u, int64_t u_stride, const float* g, int64_t g_stride, const float* rc, int nch,
+void launch_coefgrad(const float* u, int64_t u_stride, const float* g, int64_t g_stride, const float* rc, int split,
                      const float* s0, int nc_pad, float* part, int64_t n, int nsig, hipStream_t stream);
 
 // ---- mst_scan.hip
-void launch_scan12(bool reverse, const float* z, float* s0, const float* tab, int nch, int nc, int nc_pad, int K, int nsig,
+void launch_scan12(bool reverse, const float* z, float* s0, const float* tab, int split, int nc, int nc_pad, int K, int nsig,
                    hipStream_t stream);
-void launch_scan2(const float* z, float* s0, const float* tab, int nch, int nc, int nc_pad, int K, int nsig, hipStream_t stream);
+void launch_scan2(const float* z, float* s0, const float* tab, int split, int nc, int nc_pad, int K, int nsig, hipStream_t stream);
 
 // ---- mst_comp.hip
 struct TrackApplyArgs {

@@ -59,19 +59,19 @@ struct RegMat {
     }
 };
 
-// z, s0: [row][D][nc_pad].  tab: [table_row][kPow][D*D], table_row = (row / tab_div) * tab_mod + row % tab_mod
+// z, s0: [row][D][nc_pad].  tab: [table_row][kPow][D*D]; row = sig * sub + f, table_row = filter_row(sig, split) * sub + f
 // KT > 0: K == KT known at compile time - all of a lane's chunk states are fetched up front (one
 // memory round trip instead of K dependent ones) and the fold / replay loops are unrolled.
 template <int D, bool REVERSE, int KT>
 __global__ __launch_bounds__(kScanThreads) void k_scan(const float* __restrict__ z, float* __restrict__ s0,
-                                                       const float* __restrict__ tab, int tab_div, int tab_mod,
+                                                       const float* __restrict__ tab, int sub, int split,
                                                        int nc, int nc_pad, int Krt) {
     __shared__ float buf[2][D][kScanThreads];
     __shared__ __attribute__((aligned(16))) float T[kPow * D * D];  // this row's power table, staged once
     const int tid = threadIdx.x, row = blockIdx.x;
     const int K = KT > 0 ? KT : Krt;
     {
-        const float* Tg = tab + ((int64_t)(row / tab_div) * tab_mod + (row % tab_mod)) * kPow * D * D;
+        const float* Tg = tab + ((int64_t)filter_row(row / sub, split) * sub + (row % sub)) * kPow * D * D;
         for (int i = tid; i < kPow * D * D; i += kScanThreads) T[i] = Tg[i];
     }
     const float* zr = z + (int64_t)row * D * nc_pad;
@@ -213,22 +213,22 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const float* __restrict__
 }
 
 template <int D, bool REV>
-static void launch_scan_k(dim3 grid, hipStream_t stream, const float* z, float* s0, const float* tab, int tab_div, int tab_mod,
+static void launch_scan_k(dim3 grid, hipStream_t stream, const float* z, float* s0, const float* tab, int sub, int split,
                           int nc, int nc_pad, int K) {
     const dim3 block(kScanThreads);
-    if (K == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan<D, REV, 1>), grid, block, 0, stream, z, s0, tab, tab_div, tab_mod, nc, nc_pad, K);
-    else if (K == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan<D, REV, 2>), grid, block, 0, stream, z, s0, tab, tab_div, tab_mod, nc, nc_pad, K);
-    else if (K == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan<D, REV, 4>), grid, block, 0, stream, z, s0, tab, tab_div, tab_mod, nc, nc_pad, K);
-    else if (K == 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan<D, REV, 8>), grid, block, 0, stream, z, s0, tab, tab_div, tab_mod, nc, nc_pad, K);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan<D, REV, 0>), grid, block, 0, stream, z, s0, tab, tab_div, tab_mod, nc, nc_pad, K);
+    if (K == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan<D, REV, 1>), grid, block, 0, stream, z, s0, tab, sub, split, nc, nc_pad, K);
+    else if (K == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan<D, REV, 2>), grid, block, 0, stream, z, s0, tab, sub, split, nc, nc_pad, K);
+    else if (K == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan<D, REV, 4>), grid, block, 0, stream, z, s0, tab, sub, split, nc, nc_pad, K);
+    else if (K == 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan<D, REV, 8>), grid, block, 0, stream, z, s0, tab, sub, split, nc, nc_pad, K);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan<D, REV, 0>), grid, block, 0, stream, z, s0, tab, sub, split, nc, nc_pad, K);
 }
-void launch_scan12(bool reverse, const float* z, float* s0, const float* tab, int nch, int nc, int nc_pad, int K, int nsig,
+void launch_scan12(bool reverse, const float* z, float* s0, const float* tab, int split, int nc, int nc_pad, int K, int nsig,
                    hipStream_t stream) {
-    if (reverse) launch_scan_k<12, true>(dim3(nsig), stream, z, s0, tab, nch, 1, nc, nc_pad, K);
-    else launch_scan_k<12, false>(dim3(nsig), stream, z, s0, tab, nch, 1, nc, nc_pad, K);
+    if (reverse) launch_scan_k<12, true>(dim3(nsig), stream, z, s0, tab, 1, split, nc, nc_pad, K);
+    else launch_scan_k<12, false>(dim3(nsig), stream, z, s0, tab, 1, split, nc, nc_pad, K);
 }
-void launch_scan2(const float* z, float* s0, const float* tab, int nch, int nc, int nc_pad, int K, int nsig, hipStream_t stream) {
-    launch_scan_k<2, false>(dim3(nsig * 12), stream, z, s0, tab, nch * 12, 12, nc, nc_pad, K);
+void launch_scan2(const float* z, float* s0, const float* tab, int split, int nc, int nc_pad, int K, int nsig, hipStream_t stream) {
+    launch_scan_k<2, false>(dim3(nsig * 12), stream, z, s0, tab, 12, split, nc, nc_pad, K);
 }
 
 }  // namespace mst

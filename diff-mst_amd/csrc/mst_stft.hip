@@ -115,6 +115,7 @@ struct StftArgs {
     float* part;           // forward: (rows, n_groups, 4) partial sums {S1, S2, S3, S4}
     const float* sums;     // backward: (rows, 4) reduced sums of this resolution
     const float* coef;     // backward: (rows, 4) per-row gradient coefficients {c_sc, c_log, c_lin, -}
+    const float* grad_loss; // backward: upstream dL/dloss (one device float), folded into the coefficients
     float* grad_pred;      // backward: (rows, n), accumulated with float atomics
     ResInfo r;
     int log2n;
@@ -208,7 +209,8 @@ __global__ __launch_bounds__(stft_threads(NFFT)) void k_stft_bwd(StftArgs a) {
     const float* win = a.tables + r.win_off;
     const float* x = a.pred + (int64_t)row * a.n;
     const float* y = a.target + (int64_t)row * a.n;
-    const float* coef = a.coef + (int64_t)row * 4;
+    const float gl = a.grad_loss[0];
+    const float coef[3] = {a.coef[(int64_t)row * 4] * gl, a.coef[(int64_t)row * 4 + 1] * gl, a.coef[(int64_t)row * 4 + 2] * gl};
     float* gx = a.grad_pred + (int64_t)row * a.n;
     const int fa = PAIR ? 2 * blockIdx.x : blockIdx.x, fb = fa + 1;
     const bool have_b = PAIR && fb < r.n_frames;
@@ -290,36 +292,39 @@ struct LossArgs {
     float w_sc, w_log, w_lin;
     int sc_per_example;
 };
-// stage 1: one 64-lane workgroup per (row, resolution) folds that row's strip partials (fp64, fixed order)
-__global__ __launch_bounds__(64) void k_mrstft_rowsums(LossArgs a) {
-    const int tid = threadIdx.x, row = blockIdx.x, res = blockIdx.y;
-    const float* p = a.part + a.part_off[res] + (int64_t)row * a.n_groups[res] * 4;
-    double s[4] = {0, 0, 0, 0};
-    for (int g = tid; g < a.n_groups[res]; g += 64) {
-        const float4 v = *reinterpret_cast<const float4*>(p + (int64_t)g * 4);
-        s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-        for (int m = 32; m >= 1; m >>= 1) s[q] += __shfl_xor(s[q], m);
-    if (tid == 0) {
-        float* o = a.sums + ((int64_t)res * a.rows + row) * 4;
-        o[0] = (float)s[0]; o[1] = (float)s[1]; o[2] = (float)s[2]; o[3] = (float)s[3];
-    }
-}
-// stage 2: loss scalar + per-row backward coefficients (without dL/dloss, applied by k_scale_coef)
-__global__ __launch_bounds__(64) void k_mrstft_final(LossArgs a) {
+// Reduction of the strip partials + loss scalar + per-row backward coefficients, one 1024-lane workgroup:
+// wave w folds the partials of (resolution, row) pairs w, w+16, ... (fp64, fixed order), then a handful of
+// lanes finish.  Deterministic.
+__global__ __launch_bounds__(1024) void k_mrstft_final(LossArgs a) {
     __shared__ double rs[kMaxRes][4];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int npairs = a.n_res * a.rows;
+    for (int pr = wave; pr < npairs; pr += 16) {
+        const int res = pr / a.rows, row = pr % a.rows;
+        const float* p = a.part + a.part_off[res] + (int64_t)row * a.n_groups[res] * 4;
+        double s[4] = {0, 0, 0, 0};
+        for (int g = lane; g < a.n_groups[res]; g += 64) {
+            const float4 v = *reinterpret_cast<const float4*>(p + (int64_t)g * 4);
+            s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            for (int m = 32; m >= 1; m >>= 1) s[q] += __shfl_xor(s[q], m);
+        if (lane == 0) {
+            float* o = a.sums + (int64_t)pr * 4;
+            o[0] = (float)s[0]; o[1] = (float)s[1]; o[2] = (float)s[2]; o[3] = (float)s[3];
+        }
+    }
+    __syncthreads();
     if (tid < a.n_res) {
         const int res = tid;
         double tot[4] = {0, 0, 0, 0}, sc_acc = 0.0;
         for (int row = 0; row < a.rows; ++row) {
-            const float* sm = a.sums + ((int64_t)res * a.rows + row) * 4;
+            const volatile float* sm = a.sums + ((int64_t)res * a.rows + row) * 4;
             for (int q = 0; q < 4; ++q) tot[q] += (double)sm[q];
             sc_acc += sqrt((double)sm[0]) / sqrt((double)sm[1]);
         }
-        for (int q = 0; q < 4; ++q) rs[res][q] = tot[q];
+        for (int q = 0; q < 3; ++q) rs[res][q] = tot[q];
         const double sc = a.sc_per_example ? sc_acc / a.rows : sqrt(tot[0]) / sqrt(tot[1]);
         rs[res][3] = a.w_sc * sc + a.w_log * tot[2] / a.count[res] + a.w_lin * tot[3] / a.count[res];
     }
@@ -329,9 +334,9 @@ __global__ __launch_bounds__(64) void k_mrstft_final(LossArgs a) {
         for (int res = 0; res < a.n_res; ++res) total += rs[res][3];
         a.loss[0] = (float)(total / a.n_res);
     }
-    for (int i = tid; i < a.n_res * a.rows; i += 64) {
+    for (int i = tid; i < npairs; i += 1024) {
         const int res = i / a.rows;
-        const float* sm = a.sums + (int64_t)i * 4;
+        const volatile float* sm = a.sums + (int64_t)i * 4;
         double c_sc;
         if (a.sc_per_example) c_sc = a.w_sc / ((double)a.rows * sqrt((double)sm[0]) * sqrt((double)sm[1]));
         else c_sc = a.w_sc / (sqrt(rs[res][0]) * sqrt(rs[res][1]));
@@ -342,10 +347,6 @@ __global__ __launch_bounds__(64) void k_mrstft_final(LossArgs a) {
         c[2] = (float)(a.w_lin / a.count[res] / a.n_res);
         c[3] = 0.f;
     }
-}
-__global__ void k_scale_coef(const float* coef, const float* grad_loss, float* out, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = coef[i] * grad_loss[0];
 }
 
 }  // namespace mst
@@ -467,8 +468,7 @@ extern "C" int mst_mrstft_forward(const mst_mrstft_desc* d, const float* pred, c
         la.part_off[i] = p.part_off[i];
         la.count[i] = (float)((double)d->rows * p.res[i].n_bins * p.res[i].n_frames);
     }
-    hipLaunchKernelGGL(k_mrstft_rowsums, dim3(d->rows, d->n_res), dim3(64), 0, stream, la);
-    hipLaunchKernelGGL(k_mrstft_final, dim3(1), dim3(64), 0, stream, la);
+    hipLaunchKernelGGL(k_mrstft_final, dim3(1), dim3(1024), 0, stream, la);
     return (int)hipGetLastError();
 }
 
@@ -480,8 +480,6 @@ extern "C" int mst_mrstft_backward(const mst_mrstft_desc* d, const float* pred, 
     if (workspace_bytes < (size_t)p.ws_floats * sizeof(float)) return hipErrorInvalidValue;
     hipStream_t stream = (hipStream_t)stream_;
     float* ws = (float*)workspace;
-    const int nc = d->n_res * d->rows * 4;
-    hipLaunchKernelGGL(k_scale_coef, dim3((nc + 255) / 256), dim3(256), 0, stream, ws + p.coef_off, grad_loss, ws + p.coefs_off, nc);
     hipMemsetAsync(grad_pred, 0, (size_t)d->rows * d->n_samples * sizeof(float), stream);
     for (int i = 0; i < d->n_res; ++i) {
         StftArgs a{};
@@ -489,7 +487,8 @@ extern "C" int mst_mrstft_backward(const mst_mrstft_desc* d, const float* pred, 
         a.target = target;
         a.tables = (const float*)tables;
         a.sums = ws + p.sums_off + (int64_t)i * d->rows * 4;
-        a.coef = ws + p.coefs_off + (int64_t)i * d->rows * 4;
+        a.coef = ws + p.coef_off + (int64_t)i * d->rows * 4;
+        a.grad_loss = grad_loss;
         a.grad_pred = grad_pred;
         a.r = p.res[i];
         a.log2n = p.log2n[i];

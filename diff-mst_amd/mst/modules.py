@@ -132,7 +132,7 @@ class _ConsoleFunction(torch.autograd.Function):
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         mix = torch.empty(bs, 2, n, dtype=torch.float32, device=dev)
         mixed = torch.empty(bs, 2, n_tracks, n, dtype=torch.float32, device=dev) if want_mixed else None
-        status = torch.empty(1, dtype=torch.int32, device=dev)
+        status = console._status_word(dev)
         with torch.cuda.device(dev):
             rc = lib.mst_console_forward(
                 ctypes.byref(desc), _cabi.ptr(rows), _cabi.ptr(tp), _cabi.ptr(fp), _cabi.ptr(mp), _cabi.ptr(mix),
@@ -242,28 +242,37 @@ class AdvancedMixConsole(torch.nn.Module):
         if validate not in ("sync", "deferred"):
             raise ValueError("validate must be 'sync' or 'deferred'")
         self.validate = validate
-        self._pending_status = []
+        self._status = {}
         self._affine_cache = {}
 
     # ------------------------------------------------------------------ validation
+    def _status_word(self, device) -> torch.Tensor:
+        """One persistent int32 per device that the kernels only ever raise (atomic max): zeroed once here,
+        read (and cleared) by the host - no per-call fill launch."""
+        key = str(device)
+        t = self._status.get(key)
+        if t is None:
+            t = self._status[key] = torch.zeros(1, dtype=torch.int32, device=device)
+        return t
+
     def _note_status(self, status: torch.Tensor):
         if self.validate == "sync":
-            err = _desc.status_to_error(int(status.item()))
-            if err is not None:
-                raise err
-        else:
-            self._pending_status.append(status)
-            if len(self._pending_status) > 64:
-                self.check_parameters()
+            code = int(status.item())
+            if code:
+                status.zero_()
+                raise _desc.status_to_error(code)
 
     def check_parameters(self):
-        """Raise the reference's ValueError if any deferred range check failed."""
-        pending, self._pending_status = self._pending_status, []
-        if pending:
-            worst = int(torch.stack(pending).max().item())
-            err = _desc.status_to_error(worst)
-            if err is not None:
-                raise err
+        """Raise the reference's ValueError if any range check since the last call failed (deferred mode)."""
+        worst = 0
+        for t in self._status.values():
+            code = int(t.item())
+            if code:
+                t.zero_()
+                worst = max(worst, code)
+        err = _desc.status_to_error(worst)
+        if err is not None:
+            raise err
 
     # ------------------------------------------------------------------ parameter dictionaries
     def _affine(self, index, device):

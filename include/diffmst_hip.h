@@ -49,7 +49,8 @@ extern "C" {
  *        1 + 27 + k      fx-bus parameter index k out of range  (:394-422)
  *        1 + 52 + k      master-bus parameter index k           (:424-460)
  * the smallest code wins (atomic max of 1000-code), which is the reference's dictionary
- * iteration order (:79-97).  The launcher zeroes *status itself. */
+ * iteration order (:79-97).  *status is only ever raised (atomic max): the caller zeroes it once and may let
+ * several calls accumulate into it before reading (deferred validation). */
 
 typedef struct mst_console_desc {
     int32_t bs;
