@@ -122,57 +122,6 @@ __device__ __forceinline__ float block_carry(const float* __restrict__ agg, int 
     return S;
 }
 
-// Batched variants: TB independent recurrences (the tracks of one mix) share every shuffle round and barrier.
-template <int TB>
-__device__ __forceinline__ void block_enter_batch(const float* z, const float* a, const float* log2a, const float* S, float* out,
-                                                  float (*lds)[8], int tid) {
-    const int lane = tid & 63, wave = tid >> 6;
-    float v[TB], p[TB];
-#pragma unroll
-    for (int b = 0; b < TB; ++b) { v[b] = z[b]; p[b] = a[b]; }
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-#pragma unroll
-        for (int b = 0; b < TB; ++b) {
-            const float o = __shfl_up(v[b], d);
-            if (lane >= d) v[b] = fmaf(p[b], o, v[b]);
-            p[b] *= p[b];
-        }
-    }
-    if (lane == 63) {
-#pragma unroll
-        for (int b = 0; b < TB; ++b) lds[b][wave] = v[b];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int b = 0; b < TB; ++b) {
-        float sw = S[b];
-        for (int w = 0; w < wave; ++w) sw = fmaf(p[b], sw, lds[b][w]);
-        float ex = __shfl_up(v[b], 1);
-        if (lane == 0) ex = 0.0f;
-        out[b] = fmaf(__builtin_amdgcn_exp2f((float)lane * log2a[b]), sw, ex);
-    }
-    __syncthreads();
-}
-template <int TB>
-__device__ __forceinline__ void block_carry_batch(const float* const* agg, int blk, const float* log2a, float* S, float (*lds)[8], int tid) {
-    float acc[TB];
-#pragma unroll
-    for (int b = 0; b < TB; ++b) {
-        acc[b] = 0.0f;
-        for (int j = blk - 1 - tid; j >= 0; j -= kWG) acc[b] += __builtin_amdgcn_exp2f((float)(blk - 1 - j) * 256.0f * log2a[b]) * agg[b][j];
-        acc[b] = wave_sum(acc[b]);
-    }
-    if ((tid & 63) == 0) {
-#pragma unroll
-        for (int b = 0; b < TB; ++b) lds[b][4 + (tid >> 6)] = acc[b];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int b = 0; b < TB; ++b) S[b] = (lds[b][4] + lds[b][5]) + (lds[b][6] + lds[b][7]);
-    __syncthreads();
-}
-
 // ---- forward: zero-state end value of the smoother per 2048-sample block ---------------------------
 // u: [(row*NCH+ch)][stride]; zs: [row][nc_pad]
 template <int NCH, bool FAST>
@@ -212,85 +161,59 @@ __global__ __launch_bounds__(kWG) void k_comp_zs(const float* __restrict__ u, in
 }
 
 // ---- forward: tracks.  grid (nblk, bs).  Accumulates the stereo bus over the T tracks of mix b.
-// Tracks are handled kTB at a time: their loads are issued together and their envelope scans share
-// shuffle rounds and barriers (the loop over tracks was a chain of dependent round trips).
-constexpr int kTB = 4;
 template <bool FAST>
 __device__ __forceinline__ void apply_tracks_body(const TrackApplyArgs& a) {
-    __shared__ float lds[kTB][8];
-    const int b = blockIdx.y, chunk = blockIdx.x * kWG + threadIdx.x, tid = threadIdx.x;
+    __shared__ float lds[8];
+    const int b = blockIdx.y, chunk = blockIdx.x * kWG + threadIdx.x;
     const int64_t i0 = (int64_t)chunk * CC;
     float accL[CC], accR[CC];
 #pragma unroll
     for (int i = 0; i < CC; ++i) accL[i] = accR[i] = 0.0f;
-    for (int t0 = 0; t0 < a.T; t0 += kTB) {
-        float g[kTB][CC], xd[kTB][CC];  // g: compressor input, then gain-computer output, then smoothed gain
-        float z[kTB], ac[kTB], l2a[kTB], S[kTB], st[kTB];
-        const float* agg[kTB];
-        const float* rcs[kTB];
-#pragma unroll
-        for (int q = 0; q < kTB; ++q) {
-            const int t = (t0 + q < a.T) ? t0 + q : a.T - 1;  // tail lanes of the batch redo the last track (discarded)
-            const int row = b * a.T + t;
-            rcs[q] = a.rc + (int64_t)row * RC_STRIDE;
-            const float* urow = a.u + (int64_t)row * a.stride;
-            LD8<FAST>(urow, i0, a.n, g[q]);
-            if (a.comp_on) LD8S<FAST>(urow, i0 - a.lookahead, a.n, xd[q]);
-            agg[q] = a.s0 + (int64_t)row * gridDim.x;
-            ac[q] = rcs[q][RC_ALPHA_C];
-            l2a[q] = rcs[q][RC_LOG2A_C];
-        }
+    for (int t = 0; t < a.T; ++t) {
+        const int row = b * a.T + t;
+        const float* rc = a.rc + (int64_t)row * RC_STRIDE;
+        const float pl = rc[RC_PANL], pr = rc[RC_PANR];
+        const float* urow = a.u + (int64_t)row * a.stride;
+        float y[CC];
         if (a.comp_on) {
-#pragma unroll
-            for (int q = 0; q < kTB; ++q) {
-                const CompK k = load_comp(rcs[q]);
-                float zz = 0.0f;
-#pragma unroll
-                for (int i = 0; i < CC; ++i) {
-                    float d;
-                    g[q][i] = k.oma * gain_computer(g[q][i], k, d);
-                    zz = fmaf(k.alpha, zz, g[q][i]);
-                }
-                z[q] = zz;
-            }
-            block_carry_batch<kTB>(agg, blockIdx.x, l2a, S, lds, tid);
-            block_enter_batch<kTB>(z, ac, l2a, S, st, lds, tid);
-        }
-#pragma unroll
-        for (int q = 0; q < kTB; ++q) {
-            if (t0 + q >= a.T) break;
-            const int t = t0 + q, row = b * a.T + t;
-            const float pl = rcs[q][RC_PANL], pr = rcs[q][RC_PANR];
-            float y[CC];
-            if (a.comp_on) {
-                const CompK k = load_comp(rcs[q]);
-                float s = st[q];
-#pragma unroll
-                for (int i = 0; i < CC; ++i) {
-                    s = fmaf(k.alpha, s, g[q][i]);
-                    g[q][i] = s;
-                    y[i] = xd[q][i] * lin_gain(s, k);
-                }
-                if (a.gs) ST8<FAST>(a.gs + (int64_t)row * a.stride, i0, a.n, g[q]);
-            } else {
-#pragma unroll
-                for (int i = 0; i < CC; ++i) y[i] = g[q][i];
-            }
+            const CompK k = load_comp(rc);
+            float x[CC], xd[CC], g[CC];
+            LD8<FAST>(urow, i0, a.n, x);
+            LD8S<FAST>(urow, i0 - a.lookahead, a.n, xd);
+            float z = 0.0f;
 #pragma unroll
             for (int i = 0; i < CC; ++i) {
-                accL[i] = fmaf(pl, y[i], accL[i]);
-                accR[i] = fmaf(pr, y[i], accR[i]);
+                float d;
+                g[i] = k.oma * gain_computer(x[i], k, d);
+                z = fmaf(k.alpha, z, g[i]);
             }
-            if (a.mixed) {
-                float ml[CC], mr[CC];
+            const float ac = rc[RC_ALPHA_C], l2a = rc[RC_LOG2A_C];
+            const float S = block_carry<false>(a.s0 + (int64_t)row * gridDim.x, blockIdx.x, gridDim.x, l2a, lds, threadIdx.x);
+            float s = block_enter<false>(z, ac, l2a, S, lds, threadIdx.x);
 #pragma unroll
-                for (int i = 0; i < CC; ++i) {
-                    ml[i] = pl * y[i];
-                    mr[i] = pr * y[i];
-                }
-                ST8<FAST>(a.mixed + (((int64_t)b * 2 + 0) * a.T + t) * a.n, i0, a.n, ml);
-                ST8<FAST>(a.mixed + (((int64_t)b * 2 + 1) * a.T + t) * a.n, i0, a.n, mr);
+            for (int i = 0; i < CC; ++i) {
+                s = fmaf(k.alpha, s, g[i]);
+                g[i] = s;
+                y[i] = xd[i] * lin_gain(s, k);
             }
+            if (a.gs) ST8<FAST>(a.gs + (int64_t)row * a.stride, i0, a.n, g);
+        } else {
+            LD8<FAST>(urow, i0, a.n, y);
+        }
+#pragma unroll
+        for (int i = 0; i < CC; ++i) {
+            accL[i] = fmaf(pl, y[i], accL[i]);
+            accR[i] = fmaf(pr, y[i], accR[i]);
+        }
+        if (a.mixed) {
+            float ml[CC], mr[CC];
+#pragma unroll
+            for (int i = 0; i < CC; ++i) {
+                ml[i] = pl * y[i];
+                mr[i] = pr * y[i];
+            }
+            ST8<FAST>(a.mixed + (((int64_t)b * 2 + 0) * a.T + t) * a.n, i0, a.n, ml);
+            ST8<FAST>(a.mixed + (((int64_t)b * 2 + 1) * a.T + t) * a.n, i0, a.n, mr);
         }
     }
     ST8<FAST>(a.bus + ((int64_t)b * 2 + 0) * a.bus_stride, i0, a.n, accL);

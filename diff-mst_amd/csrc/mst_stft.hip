@@ -292,39 +292,36 @@ struct LossArgs {
     float w_sc, w_log, w_lin;
     int sc_per_example;
 };
-// Reduction of the strip partials + loss scalar + per-row backward coefficients, one 1024-lane workgroup:
-// wave w folds the partials of (resolution, row) pairs w, w+16, ... (fp64, fixed order), then a handful of
-// lanes finish.  Deterministic.
-__global__ __launch_bounds__(1024) void k_mrstft_final(LossArgs a) {
-    __shared__ double rs[kMaxRes][4];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int npairs = a.n_res * a.rows;
-    for (int pr = wave; pr < npairs; pr += 16) {
-        const int res = pr / a.rows, row = pr % a.rows;
-        const float* p = a.part + a.part_off[res] + (int64_t)row * a.n_groups[res] * 4;
-        double s[4] = {0, 0, 0, 0};
-        for (int g = lane; g < a.n_groups[res]; g += 64) {
-            const float4 v = *reinterpret_cast<const float4*>(p + (int64_t)g * 4);
-            s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            for (int m = 32; m >= 1; m >>= 1) s[q] += __shfl_xor(s[q], m);
-        if (lane == 0) {
-            float* o = a.sums + (int64_t)pr * 4;
-            o[0] = (float)s[0]; o[1] = (float)s[1]; o[2] = (float)s[2]; o[3] = (float)s[3];
-        }
+// stage 1: one 64-lane workgroup per (row, resolution) folds that row's strip partials (fp64, fixed order)
+__global__ __launch_bounds__(64) void k_mrstft_rowsums(LossArgs a) {
+    const int tid = threadIdx.x, row = blockIdx.x, res = blockIdx.y;
+    const float* p = a.part + a.part_off[res] + (int64_t)row * a.n_groups[res] * 4;
+    double s[4] = {0, 0, 0, 0};
+    for (int g = tid; g < a.n_groups[res]; g += 64) {
+        const float4 v = *reinterpret_cast<const float4*>(p + (int64_t)g * 4);
+        s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
     }
-    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        for (int m = 32; m >= 1; m >>= 1) s[q] += __shfl_xor(s[q], m);
+    if (tid == 0) {
+        float* o = a.sums + ((int64_t)res * a.rows + row) * 4;
+        o[0] = (float)s[0]; o[1] = (float)s[1]; o[2] = (float)s[2]; o[3] = (float)s[3];
+    }
+}
+// stage 2: loss scalar + per-row backward coefficients (without dL/dloss, applied by k_scale_coef)
+__global__ __launch_bounds__(64) void k_mrstft_final(LossArgs a) {
+    __shared__ double rs[kMaxRes][4];
+    const int tid = threadIdx.x;
     if (tid < a.n_res) {
         const int res = tid;
         double tot[4] = {0, 0, 0, 0}, sc_acc = 0.0;
         for (int row = 0; row < a.rows; ++row) {
-            const volatile float* sm = a.sums + ((int64_t)res * a.rows + row) * 4;
+            const float* sm = a.sums + ((int64_t)res * a.rows + row) * 4;
             for (int q = 0; q < 4; ++q) tot[q] += (double)sm[q];
             sc_acc += sqrt((double)sm[0]) / sqrt((double)sm[1]);
         }
-        for (int q = 0; q < 3; ++q) rs[res][q] = tot[q];
+        for (int q = 0; q < 4; ++q) rs[res][q] = tot[q];
         const double sc = a.sc_per_example ? sc_acc / a.rows : sqrt(tot[0]) / sqrt(tot[1]);
         rs[res][3] = a.w_sc * sc + a.w_log * tot[2] / a.count[res] + a.w_lin * tot[3] / a.count[res];
     }
@@ -334,9 +331,9 @@ __global__ __launch_bounds__(1024) void k_mrstft_final(LossArgs a) {
         for (int res = 0; res < a.n_res; ++res) total += rs[res][3];
         a.loss[0] = (float)(total / a.n_res);
     }
-    for (int i = tid; i < npairs; i += 1024) {
+    for (int i = tid; i < a.n_res * a.rows; i += 64) {
         const int res = i / a.rows;
-        const volatile float* sm = a.sums + (int64_t)i * 4;
+        const float* sm = a.sums + (int64_t)i * 4;
         double c_sc;
         if (a.sc_per_example) c_sc = a.w_sc / ((double)a.rows * sqrt((double)sm[0]) * sqrt((double)sm[1]));
         else c_sc = a.w_sc / (sqrt(rs[res][0]) * sqrt(rs[res][1]));
@@ -348,7 +345,6 @@ __global__ __launch_bounds__(1024) void k_mrstft_final(LossArgs a) {
         c[3] = 0.f;
     }
 }
-
 }  // namespace mst
 
 // ======================================================================================= C ABI
@@ -468,7 +464,8 @@ extern "C" int mst_mrstft_forward(const mst_mrstft_desc* d, const float* pred, c
         la.part_off[i] = p.part_off[i];
         la.count[i] = (float)((double)d->rows * p.res[i].n_bins * p.res[i].n_frames);
     }
-    hipLaunchKernelGGL(k_mrstft_final, dim3(1), dim3(1024), 0, stream, la);
+    hipLaunchKernelGGL(k_mrstft_rowsums, dim3(d->rows, d->n_res), dim3(64), 0, stream, la);
+    hipLaunchKernelGGL(k_mrstft_final, dim3(1), dim3(64), 0, stream, la);
     return (int)hipGetLastError();
 }
 
