@@ -2,6 +2,7 @@
 // launch sequences behind them.  No allocation, no host sync: everything is enqueued on the
 // caller's stream over the caller's workspace.
 #include "mst_kernels.h"
+#include <cstdlib>
 
 namespace mst {
 static int check_desc(const mst_console_desc* d) {
@@ -12,6 +13,36 @@ static int check_desc(const mst_console_desc* d) {
     if ((d->track_lookahead & 3) || (d->master_lookahead & 3) || d->track_lookahead < 0 || d->master_lookahead < 0)
         return hipErrorInvalidValue;
     return hipSuccess;
+}
+}  // namespace mst
+
+namespace mst {
+AuxPool* aux_pool() {
+    static AuxPool pools[16];
+    static int state[16] = {0};  // 0 = untried, 1 = ready, -1 = unavailable
+    static const bool disabled = getenv("MST_AUX_STREAMS") == nullptr;  // opt-in: measured slower on MI355X (round 1)
+    if (disabled) return nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    if (state[dev] == 0) {
+        AuxPool& p = pools[dev];
+        bool ok = hipEventCreateWithFlags(&p.fork, hipEventDisableTiming) == hipSuccess;
+        for (int i = 0; i < AuxPool::kStreams && ok; ++i) {
+            ok = hipStreamCreateWithFlags(&p.s[i], hipStreamNonBlocking) == hipSuccess &&
+                 hipEventCreateWithFlags(&p.join[i], hipEventDisableTiming) == hipSuccess;
+        }
+        p.ok = ok;
+        state[dev] = ok ? 1 : -1;
+    }
+    return state[dev] == 1 ? &pools[dev] : nullptr;
+}
+void aux_fork(AuxPool* p, hipStream_t main, int k) {
+    (void)hipEventRecord(p->fork, main);
+    (void)hipStreamWaitEvent(p->s[k], p->fork, 0);
+}
+void aux_join(AuxPool* p, hipStream_t main, int k) {
+    (void)hipEventRecord(p->join[k], p->s[k]);
+    (void)hipStreamWaitEvent(main, p->join[k], 0);
 }
 }  // namespace mst
 

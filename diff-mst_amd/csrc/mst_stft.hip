@@ -12,7 +12,7 @@
 // epilogue is fused - no spectrogram ever reaches HBM.  Backward recomputes the forward tile,
 // forms dL/dX, and returns two frames' time-domain cotangents per complex FFT; the overlap-add
 // (incl. the reflect-padding fold-back) uses hardware float atomics into grad_pred.
-#include "mst_common.h"
+#include "mst_kernels.h"
 
 namespace mst {
 
@@ -447,7 +447,14 @@ extern "C" int mst_mrstft_forward(const mst_mrstft_desc* d, const float* pred, c
     la.w_log = d->w_log_mag;
     la.w_lin = d->w_lin_mag;
     la.sc_per_example = d->sc_per_example;
+    // the resolutions are independent: run them side by side on auxiliary streams (a 1-workgroup-per-CU
+    // n_fft = 8192 launch leaves room for the small-transform workgroups), join before the reduction
+    AuxPool* aux = d->n_res > 1 ? aux_pool() : nullptr;
+    hipStream_t main_stream = stream;
     for (int i = 0; i < d->n_res; ++i) {
+        const int ak = i % (AuxPool::kStreams + 1);  // 0 = caller's stream
+        if (aux && ak > 0) aux_fork(aux, main_stream, ak - 1);
+        stream = (aux && ak > 0) ? aux->s[ak - 1] : main_stream;
         StftArgs a{};
         a.pred = pred;
         a.target = target;
@@ -463,7 +470,9 @@ extern "C" int mst_mrstft_forward(const mst_mrstft_desc* d, const float* pred, c
         la.n_groups[i] = p.n_groups[i];
         la.part_off[i] = p.part_off[i];
         la.count[i] = (float)((double)d->rows * p.res[i].n_bins * p.res[i].n_frames);
+        if (aux && ak > 0) aux_join(aux, main_stream, ak - 1);
     }
+    stream = main_stream;
     hipLaunchKernelGGL(k_mrstft_rowsums, dim3(d->rows, d->n_res), dim3(64), 0, stream, la);
     hipLaunchKernelGGL(k_mrstft_final, dim3(1), dim3(64), 0, stream, la);
     return (int)hipGetLastError();
@@ -478,7 +487,12 @@ extern "C" int mst_mrstft_backward(const mst_mrstft_desc* d, const float* pred, 
     hipStream_t stream = (hipStream_t)stream_;
     float* ws = (float*)workspace;
     hipMemsetAsync(grad_pred, 0, (size_t)d->rows * d->n_samples * sizeof(float), stream);
+    AuxPool* aux = d->n_res > 1 ? aux_pool() : nullptr;
+    hipStream_t main_stream = stream;
     for (int i = 0; i < d->n_res; ++i) {
+        const int ak = i % (AuxPool::kStreams + 1);
+        if (aux && ak > 0) aux_fork(aux, main_stream, ak - 1);
+        stream = (aux && ak > 0) ? aux->s[ak - 1] : main_stream;
         StftArgs a{};
         a.pred = pred;
         a.target = target;
@@ -498,6 +512,8 @@ extern "C" int mst_mrstft_backward(const mst_mrstft_desc* d, const float* pred, 
     if (NF <= 4096) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stft_bwd<NF, (NF <= 4096)>), grid, dim3(stft_threads(NF)), 0, stream, a); \
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stft_bwd<NF, false>), grid, dim3(stft_threads(NF)), 0, stream, a)
         MST_FOR_NFFT(a.r.n_fft, MST_LAUNCH_BWD)
+        if (aux && ak > 0) aux_join(aux, main_stream, ak - 1);
     }
+    stream = main_stream;
     return (int)hipGetLastError();
 }
