@@ -11,7 +11,9 @@ namespace mst {
 
 constexpr int kSections = 6;           // low shelf, 4 peaking, high shelf (reference mst/modules.py:125-143)
 constexpr int kStates = 2 * kSections; // DF2T state of the whole cascade
-constexpr int kWG = 256;               // lanes per workgroup in the streaming kernels
+constexpr int kWG = 256;               // lanes per workgroup in the compressor kernels
+constexpr int kEqWG = 64;              // lanes per workgroup in the EQ kernels: ONE wave per 4096-sample tile, so
+                                       // a CU hosts many independent tiles at different phases (no lockstep)
 constexpr int kEqChunk = 64;           // samples one lane filters sequentially (EQ kernels)
 constexpr int kCompChunk = 8;          // samples one lane owns in the compressor kernels
 constexpr int kScanThreads = 512;      // lanes per row in the carry-scan kernels
@@ -160,10 +162,10 @@ inline Layout make_layout(const mst_console_desc* d) {
     L.R = d->bs * d->n_tracks;
     L.N = d->n_samples;
     L.ncE = (int)((L.N + kEqChunk - 1) / kEqChunk);
-    L.ncE_pad = (int)round_up(L.ncE, kWG);
+    L.ncE_pad = (int)round_up(L.ncE, 256);
     L.ncC = (int)((L.N + kCompChunk - 1) / kCompChunk);
     L.ncC_pad = (int)round_up(L.ncC, kWG);
-    L.nblkE = L.ncE_pad / kWG;
+    L.nblkE = L.ncE_pad / kEqWG;
     L.nblkC = L.ncC_pad / kWG;
     L.KE = (L.ncE + kScanThreads - 1) / kScanThreads;
     L.KC = (L.ncC + kScanThreads - 1) / kScanThreads;

@@ -9,42 +9,12 @@
 // like the EQ states.  The track "apply" kernel loops over the tracks of one mix so the stereo
 // bus is accumulated in registers and written once (no (bs,2,T,N) intermediate unless asked for).
 #include "mst_kernels.h"
+#include "mst_compdev.h"
 
 namespace mst {
 
 constexpr int CC = kCompChunk;
 
-struct CompK {
-    float thr, kappa, knee, hw, inv2w, invw, alpha, oma, mk;
-};
-__device__ __forceinline__ CompK load_comp(const float* rc) {
-    CompK k;
-    k.thr = rc[RC_THR];
-    k.kappa = rc[RC_KAPPA];
-    k.knee = rc[RC_KNEE];
-    k.hw = 0.5f * k.knee;
-    k.invw = 1.0f / k.knee;
-    k.inv2w = 0.5f * k.invw;
-    k.alpha = rc[RC_ALPHA];
-    k.oma = 1.0f - k.alpha;
-    k.mk = rc[RC_MAKEUP];
-    return k;
-}
-// static curve: returns g_c = kappa * f(x_db - thr); d = x_db - thr is handed back
-__device__ __forceinline__ float gain_computer(float side, const CompK& k, float& d) {
-    const float ax = fmaxf(fabsf(side), kCompEps);
-    d = kDbPerLog2 * __builtin_amdgcn_logf(ax) - k.thr;
-    float f = 0.0f;
-    if (d > k.hw) f = d;
-    else if (d >= -k.hw) {
-        const float t = d + k.hw;
-        f = t * t * k.inv2w;
-    }
-    return k.kappa * f;
-}
-__device__ __forceinline__ float lin_gain(float gs, const CompK& k) {
-    return __builtin_amdgcn_exp2f((gs + k.mk) * kLog2PerDb);
-}
 __device__ __forceinline__ void ld8(const float* row, int64_t i, int64_t n, float* v) {
     const float4 a = load4(row, i, n), b = load4(row, i + 4, n);
     v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;

@@ -80,10 +80,11 @@ extern "C" int mst_console_forward(const mst_console_desc* d, const float* track
     // ---- tracks: EQ (zs -> carry scan -> run), compressor smoother (zs -> scan), apply + pan + bus sum
     launch_cascade(EQ_FWD, false, tracks, d->track_row_stride, nullptr, 0, ws + L.rc_t, L.R, nullptr, ws + L.zE_t, L.ncE_pad, n, L.R, stream);
     launch_scan12(false, ws + L.zE_t, ws + L.sE_t, ws + L.powF_t, L.R, L.ncE, L.ncE_pad, L.KE, L.R, stream);
-    launch_cascade(EQ_FWD, true, tracks, d->track_row_stride, ws + L.u_t, Ns, ws + L.rc_t, L.R, ws + L.sE_t, nullptr, L.ncE_pad, n, L.R, stream);
-    if (t_comp) {
-        launch_comp_zs(1, ws + L.u_t, Ns, ws + L.rc_t, ws + L.zS_t, L.ncC_pad, n, L.R, stream);
-    }
+    if (t_comp)  // EQ run fused with the gain computer + per-block envelope aggregates
+        launch_cascade_run_gc(tracks, d->track_row_stride, ws + L.u_t, Ns, ws + L.rc_t, L.R, ws + L.sE_t, L.ncE_pad, n, L.R,
+                              ws + L.zS_t, L.nblkC, stream);
+    else
+        launch_cascade(EQ_FWD, true, tracks, d->track_row_stride, ws + L.u_t, Ns, ws + L.rc_t, L.R, ws + L.sE_t, nullptr, L.ncE_pad, n, L.R, stream);
     const bool bus_is_mix = !m_on && !o_on;
     TrackApplyArgs ta{ws + L.u_t, Ns, ws + L.rc_t, ws + L.zS_t, (save && t_comp) ? ws + L.gs_t : nullptr,
                       bus_is_mix ? mix : ws + L.bus, bus_is_mix ? n : Ns, mixed_tracks,

@@ -4,8 +4,8 @@
 // mst/modules.py:237, 293; SURVEY A.3-A.4: twelve 2^19-point coefficient rFFTs + signal
 // rFFT/irFFT per row) with a time-domain, chunk-parallel linear recurrence:
 //
-//   every lane owns kEqChunk consecutive samples of one signal row; the 256 lanes of a workgroup
-//   cover a 16384-sample tile, staged through LDS in 16-sample slabs (next slab prefetched into registers) so that HBM sees only
+//   every lane owns kEqChunk consecutive samples of one signal row; the 64 lanes of a (one-wave) workgroup
+//   cover a 4096-sample tile, staged through LDS in 16-sample slabs (next slab prefetched into registers) so that HBM sees only
 //   coalesced 16-byte accesses while each lane reads its own contiguous slab.
 //     *_zs   : run the chunk from ZERO state, keep only the 12-float end state  (z)
 //     scan   : (mst_scan.hip) s0[c+1] = M s0[c] + z[c] gives every chunk's true start state
@@ -15,6 +15,7 @@
 //   dL/da_kj = -<g, S^j (1/A_k) u>  (u = EQ output, g = its cotangent): twelve independent 2-state
 //   all-pole recurrences on u, same zs / scan / run structure (k_allpole_zs, k_coefgrad).
 #include "mst_kernels.h"
+#include "mst_compdev.h"
 
 namespace mst {
 
@@ -22,9 +23,9 @@ constexpr int kSlab = 16;         // samples per lane per LDS stage
 constexpr int kLdw = kSlab + 4;   // padded LDS row (5 x 16 B, odd): conflict-free ds_read_b128 / ds_write_b128
 constexpr int kNSlab = kEqChunk / kSlab;
 constexpr int kSlabVec = kSlab / 4;              // float4 per lane per slab
-constexpr int kFetch = kWG * kSlabVec / kWG;     // float4 each thread moves per slab (= kSlabVec)
+constexpr int kFetch = kEqWG * kSlabVec / kEqWG;     // float4 each thread moves per slab (= kSlabVec)
 
-// A slab (kWG lanes x kSlab samples) travels HBM -> registers -> LDS in two steps so that the NEXT slab's
+// A slab (kEqWG lanes x kSlab samples) travels HBM -> registers -> LDS in two steps so that the NEXT slab's
 // global loads are in flight while the current one is being filtered (all workgroups of these kernels
 // are resident at once and would otherwise alternate, in lockstep, between a pure-memory and a
 // pure-ALU phase).
@@ -34,7 +35,7 @@ struct SlabRegs {
 __device__ __forceinline__ void slab_fetch(SlabRegs& r, const float* __restrict__ row, int64_t tile_base, int j, int64_t n, int tid) {
 #pragma unroll
     for (int q0 = 0; q0 < kFetch; ++q0) {
-        const int q = tid + kWG * q0;      // float4 index inside the slab image
+        const int q = tid + kEqWG * q0;      // float4 index inside the slab image
         const int lane = q / kSlabVec;     // owning lane
         const int i = (q % kSlabVec) * 4;
         r.v[q0] = load4(row, tile_base + (int64_t)lane * kEqChunk + j * kSlab + i, n);
@@ -43,7 +44,7 @@ __device__ __forceinline__ void slab_fetch(SlabRegs& r, const float* __restrict_
 __device__ __forceinline__ void slab_stash(const SlabRegs& r, float* __restrict__ tile, int tid) {
 #pragma unroll
     for (int q0 = 0; q0 < kFetch; ++q0) {
-        const int q = tid + kWG * q0;
+        const int q = tid + kEqWG * q0;
         *reinterpret_cast<float4*>(&tile[(q / kSlabVec) * kLdw + (q % kSlabVec) * 4]) = r.v[q0];
     }
 }
@@ -51,7 +52,7 @@ __device__ __forceinline__ void slab_store(const float* __restrict__ tile, float
                                            int j, int64_t n, int tid) {
 #pragma unroll
     for (int q0 = 0; q0 < kFetch; ++q0) {
-        const int q = tid + kWG * q0;
+        const int q = tid + kEqWG * q0;
         const int lane = q / kSlabVec;
         const int i = (q % kSlabVec) * 4;
         store4(row, tile_base + (int64_t)lane * kEqChunk + j * kSlab + i, n,
@@ -61,16 +62,20 @@ __device__ __forceinline__ void slab_store(const float* __restrict__ tile, float
 
 // MODE_RUN = false: zero-state pass, writes z[sig][12][nc_pad]
 // MODE_RUN = true : true pass from s0[sig][12][nc_pad], writes out
-template <int DIR, bool MODE_RUN>
-__global__ __launch_bounds__(kWG) void k_cascade(const float* __restrict__ in, int64_t in_stride,
+// FUSE_GC (forward run of mono rows only): the compressor's static curve is evaluated on the fresh EQ
+// output and the zero-state envelope end value of every 2048-sample compressor block (= 32 lanes) is
+// written to zs_comp[sig][block] - this replaces the separate k_comp_zs pass over the EQ output.
+template <int DIR, bool MODE_RUN, bool FUSE_GC = false>
+__global__ __launch_bounds__(kEqWG) void k_cascade(const float* __restrict__ in, int64_t in_stride,
                                                  float* __restrict__ out, int64_t out_stride,
                                                  const float* __restrict__ rc, int split,
                                                  const float* __restrict__ s0, float* __restrict__ z,
-                                                 int nc_pad, int64_t n) {
-    __shared__ __attribute__((aligned(16))) float tile[kWG * kLdw];
+                                                 int nc_pad, int64_t n, float* __restrict__ zs_comp = nullptr,
+                                                 int nblk_comp = 0) {
+    __shared__ __attribute__((aligned(16))) float tile[kEqWG * kLdw];
     const int tid = threadIdx.x, sig = blockIdx.y;
-    const int64_t tile_base = (int64_t)blockIdx.x * kWG * kEqChunk;
-    const int chunk = blockIdx.x * kWG + tid;
+    const int64_t tile_base = (int64_t)blockIdx.x * kEqWG * kEqChunk;
+    const int chunk = blockIdx.x * kEqWG + tid;
     const float* inrow = in + (int64_t)sig * in_stride;
     float* outrow = MODE_RUN ? out + (int64_t)sig * out_stride : nullptr;
     auto order = [](int jj) { return (DIR == EQ_FWD) ? jj : kNSlab - 1 - jj; };
@@ -86,6 +91,9 @@ __global__ __launch_bounds__(kWG) void k_cascade(const float* __restrict__ in, i
     for (int i = 0; i < kStates; ++i)
         st[i] = MODE_RUN ? s0[((int64_t)sig * kStates + i) * nc_pad + chunk] : 0.0f;
     float* mine = &tile[tid * kLdw];
+    CompK ck{};
+    float zacc = 0.0f;
+    if (FUSE_GC) ck = load_comp(rc + (int64_t)filter_row(sig, split) * RC_STRIDE);
 
     for (int jj = 0; jj < kNSlab; ++jj) {
         const int j = order(jj);
@@ -101,6 +109,13 @@ __global__ __launch_bounds__(kWG) void k_cascade(const float* __restrict__ in, i
                 v.z = cascade_step<float>(v.z, c, st);
                 v.w = cascade_step<float>(v.w, c, st);
                 if (MODE_RUN) *reinterpret_cast<float4*>(&mine[i4]) = v;
+                if (FUSE_GC) {
+                    float dd;
+                    zacc = fmaf(ck.alpha, zacc, ck.oma * gain_computer(v.x, ck, dd));
+                    zacc = fmaf(ck.alpha, zacc, ck.oma * gain_computer(v.y, ck, dd));
+                    zacc = fmaf(ck.alpha, zacc, ck.oma * gain_computer(v.z, ck, dd));
+                    zacc = fmaf(ck.alpha, zacc, ck.oma * gain_computer(v.w, ck, dd));
+                }
             }
         } else {
 #pragma unroll
@@ -123,6 +138,20 @@ __global__ __launch_bounds__(kWG) void k_cascade(const float* __restrict__ in, i
 #pragma unroll
         for (int i = 0; i < kStates; ++i) z[((int64_t)sig * kStates + i) * nc_pad + chunk] = st[i];
     }
+    if (FUSE_GC) {
+        // fold the 32 lane values of each 2048-sample block: v_l += a64^d v_(l-d) inside 32-lane segments
+        const float l2a64 = 8.0f * rc[(int64_t)filter_row(sig, split) * RC_STRIDE + RC_LOG2A_C];  // log2(alpha^64)
+        float p = __builtin_amdgcn_exp2f(l2a64);
+        const int l32 = tid & 31;
+#pragma unroll
+        for (int d = 1; d < 32; d <<= 1) {
+            const float o = __shfl_up(zacc, d);
+            if (l32 >= d) zacc = fmaf(p, o, zacc);
+            p *= p;
+        }
+        const int blk = chunk >> 5;  // (kEqChunk * 32) = 2048 samples per compressor block
+        if (l32 == 31 && blk < nblk_comp) zs_comp[(int64_t)sig * nblk_comp + blk] = zacc;
+    }
 }
 
 // ---- all-pole bank for the coefficient gradients ------------------------------------------------
@@ -143,13 +172,13 @@ __device__ __forceinline__ void load_ap(const float* coef, ApCoef& k) {
 }
 
 // zero-state end states of the 12 all-pole filters per lane chunk: z[sig][24][nc_pad]
-__global__ __launch_bounds__(kWG) void k_allpole_zs(const float* __restrict__ u, int64_t u_stride,
+__global__ __launch_bounds__(kEqWG) void k_allpole_zs(const float* __restrict__ u, int64_t u_stride,
                                                     const float* __restrict__ rc, int split, float* __restrict__ z,
                                                     int nc_pad, int64_t n) {
-    __shared__ __attribute__((aligned(16))) float tile[kWG * kLdw];
+    __shared__ __attribute__((aligned(16))) float tile[kEqWG * kLdw];
     const int tid = threadIdx.x, sig = blockIdx.y;
-    const int64_t tile_base = (int64_t)blockIdx.x * kWG * kEqChunk;
-    const int chunk = blockIdx.x * kWG + tid;
+    const int64_t tile_base = (int64_t)blockIdx.x * kEqWG * kEqChunk;
+    const int chunk = blockIdx.x * kEqWG + tid;
     ApCoef k;
     load_ap(rc + (int64_t)filter_row(sig, split) * RC_STRIDE + RC_SOS, k);
     float wa1[kSections], wa2[kSections], wb1[kSections], wb2[kSections];
@@ -189,17 +218,17 @@ __global__ __launch_bounds__(kWG) void k_allpole_zs(const float* __restrict__ u,
 }
 
 // coefficient-gradient partial sums: part[sig][block][30] = {db0 db1 db2 da1 da2} x 6 sections
-__global__ __launch_bounds__(kWG) void k_coefgrad(const float* __restrict__ u, int64_t u_stride,
+__global__ __launch_bounds__(kEqWG) void k_coefgrad(const float* __restrict__ u, int64_t u_stride,
                                                   const float* __restrict__ g, int64_t g_stride,
                                                   const float* __restrict__ rc, int split,
                                                   const float* __restrict__ s0, int nc_pad,
                                                   float* __restrict__ part, int64_t n) {
-    __shared__ __attribute__((aligned(16))) float tile_u[kWG * kLdw];
-    __shared__ __attribute__((aligned(16))) float tile_g[kWG * kLdw];
-    __shared__ float red[4][EP_COUNT];
+    __shared__ __attribute__((aligned(16))) float tile_u[kEqWG * kLdw];
+    __shared__ __attribute__((aligned(16))) float tile_g[kEqWG * kLdw];
+    __shared__ float red[kEqWG / 64][EP_COUNT];
     const int tid = threadIdx.x, sig = blockIdx.y;
-    const int64_t tile_base = (int64_t)blockIdx.x * kWG * kEqChunk;
-    const int chunk = blockIdx.x * kWG + tid;
+    const int64_t tile_base = (int64_t)blockIdx.x * kEqWG * kEqChunk;
+    const int chunk = blockIdx.x * kEqWG + tid;
     ApCoef k;
     load_ap(rc + (int64_t)filter_row(sig, split) * RC_STRIDE + RC_SOS, k);
     float wa1[kSections], wa2[kSections], wb1[kSections], wb2[kSections];
@@ -257,34 +286,45 @@ __global__ __launch_bounds__(kWG) void k_coefgrad(const float* __restrict__ u, i
         if (lane == 0) red[wave][i] = v;
     }
     __syncthreads();
-    if (tid < EP_COUNT)
-        part[((int64_t)sig * gridDim.x + blockIdx.x) * EP_COUNT + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    if (tid < EP_COUNT) {
+        float v = red[0][tid];
+        for (int w = 1; w < kEqWG / 64; ++w) v += red[w][tid];
+        part[((int64_t)sig * gridDim.x + blockIdx.x) * EP_COUNT + tid] = v;
+    }
 }
 
 // ---- host-side launch helpers (called from mst_console.hip) --------------------------------------
 void launch_cascade(int dir, bool run, const float* in, int64_t in_stride, float* out, int64_t out_stride,
                     const float* rc, int split, const float* s0, float* z, int nc_pad, int64_t n, int nsig,
                     hipStream_t stream) {
-    dim3 grid(nc_pad / kWG, nsig), block(kWG);
+    dim3 grid(nc_pad / kEqWG, nsig), block(kEqWG);
     if (dir == EQ_FWD && !run)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cascade<EQ_FWD, false>), grid, block, 0, stream, in, in_stride, out, out_stride, rc, split, s0, z, nc_pad, n);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cascade<EQ_FWD, false>), grid, block, 0, stream, in, in_stride, out, out_stride, rc, split, s0, z, nc_pad, n, (float*)nullptr, 0);
     else if (dir == EQ_FWD && run)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cascade<EQ_FWD, true>), grid, block, 0, stream, in, in_stride, out, out_stride, rc, split, s0, z, nc_pad, n);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cascade<EQ_FWD, true>), grid, block, 0, stream, in, in_stride, out, out_stride, rc, split, s0, z, nc_pad, n, (float*)nullptr, 0);
     else if (dir == EQ_ADJ && !run)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cascade<EQ_ADJ, false>), grid, block, 0, stream, in, in_stride, out, out_stride, rc, split, s0, z, nc_pad, n);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cascade<EQ_ADJ, false>), grid, block, 0, stream, in, in_stride, out, out_stride, rc, split, s0, z, nc_pad, n, (float*)nullptr, 0);
     else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cascade<EQ_ADJ, true>), grid, block, 0, stream, in, in_stride, out, out_stride, rc, split, s0, z, nc_pad, n);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cascade<EQ_ADJ, true>), grid, block, 0, stream, in, in_stride, out, out_stride, rc, split, s0, z, nc_pad, n, (float*)nullptr, 0);
+}
+
+void launch_cascade_run_gc(const float* in, int64_t in_stride, float* out, int64_t out_stride, const float* rc, int split,
+                           const float* s0, int nc_pad, int64_t n, int nsig, float* zs_comp, int nblk_comp, hipStream_t stream) {
+    static_assert(kEqChunk * 32 == kWG * kCompChunk, "a compressor block must be 32 EQ lanes");
+    dim3 grid(nc_pad / kEqWG, nsig), block(kEqWG);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cascade<EQ_FWD, true, true>), grid, block, 0, stream, in, in_stride, out, out_stride, rc, split,
+                       s0, (float*)nullptr, nc_pad, n, zs_comp, nblk_comp);
 }
 
 void launch_allpole_zs(const float* u, int64_t u_stride, const float* rc, int split, float* z, int nc_pad, int64_t n,
                        int nsig, hipStream_t stream) {
-    dim3 grid(nc_pad / kWG, nsig), block(kWG);
+    dim3 grid(nc_pad / kEqWG, nsig), block(kEqWG);
     hipLaunchKernelGGL(k_allpole_zs, grid, block, 0, stream, u, u_stride, rc, split, z, nc_pad, n);
 }
 
 void launch_coefgrad(const float* u, int64_t u_stride, const float* g, int64_t g_stride, const float* rc, int split,
                      const float* s0, int nc_pad, float* part, int64_t n, int nsig, hipStream_t stream) {
-    dim3 grid(nc_pad / kWG, nsig), block(kWG);
+    dim3 grid(nc_pad / kEqWG, nsig), block(kEqWG);
     hipLaunchKernelGGL(k_coefgrad, grid, block, 0, stream, u, u_stride, g, g_stride, rc, split, s0, nc_pad, part, n);
 }
 

@@ -42,6 +42,9 @@ void launch_prep_bwd(const PrepBwdArgs& a, hipStream_t stream);
 // ---- mst_eq.hip
 void launch_cascade(int dir, bool run, const float* in, int64_t in_stride, float* out, int64_t out_stride, const float* rc,
                     int split, const float* s0, float* z, int nc_pad, int64_t n, int nsig, hipStream_t stream);
+// forward run of mono rows fused with the compressor's zero-state block aggregates (replaces k_comp_zs<1>)
+void launch_cascade_run_gc(const float* in, int64_t in_stride, float* out, int64_t out_stride, const float* rc, int split,
+                           const float* s0, int nc_pad, int64_t n, int nsig, float* zs_comp, int nblk_comp, hipStream_t stream);
 void launch_allpole_zs(const float* u, int64_t u_stride, const float* rc, int split, float* z, int nc_pad, int64_t n, int nsig,
                        hipStream_t stream);
 void launch_coefgrad(const float* u, int64_t u_stride, const float* g, int64_t g_stride, const float* rc, int split,
