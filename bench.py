@@ -177,7 +177,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
-    # stage split of one step on the launch stream (HIP events; kernels run on torch's current stream)
+    # stage split of one step on the launch stream (HIP events; kernels run on torch's current stream).
+    # Two un-stamped steps are enqueued first so that the host is ahead of the GPU, as in the timed loop.
+    step()
+    step()
     step(stamp=True)
     torch.cuda.synchronize()
     stages = {"console_fwd_ms": ev["s"].elapsed_time(ev["fwd"]), "loss_fwd_ms": ev["fwd"].elapsed_time(ev["loss"]),
