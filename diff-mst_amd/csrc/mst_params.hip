@@ -16,10 +16,13 @@ namespace mst {
 // ---------------------------------------------------------------------------------------------
 __device__ void design_section_f32(int kind, float gain_db, float freq, float q, float sr, float* out) {
 #pragma clang fp contract(off)
-    const float A = (float)pow(10.0, (double)(gain_db / 40.0f));
+    // 10^x = 2^(x log2 10) in fp64: far below one fp32 ulp from the correctly rounded value, and much cheaper than pow()
+    const float A = (float)exp2((double)(gain_db / 40.0f) * 3.321928094887362);
     const float w0 = 6.283185307179586f * (freq / sr);
-    const float sn = (float)sin((double)w0);
-    const float cw = (float)cos((double)w0);
+    double sn64, cw64;
+    sincos((double)w0, &sn64, &cw64);
+    const float sn = (float)sn64;
+    const float cw = (float)cw64;
     const float alpha = sn / (2.0f * q);
     const float sA = sqrtf(A);
     float b0, b1, b2, a0, a1, a2;
@@ -78,11 +81,13 @@ __device__ inline D3 dfun(D3 a, double f, double fp) { return D3{f, {a.d[0] * fp
 
 __device__ void design_section_dual(int kind, double gain_db, double freq, double q, double sr, D3* out) {
     D3 g{gain_db, {1, 0, 0}}, f{freq, {0, 1, 0}}, qq{q, {0, 0, 1}};
-    const double Av = pow(10.0, gain_db / 40.0);
+    const double Av = exp2(gain_db / 40.0 * 3.321928094887362);
     D3 A = dfun(g, Av, Av * 2.302585092994046 / 40.0);
     D3 w0 = dscale(f, 6.283185307179586 / sr);
-    D3 sn = dfun(w0, sin(w0.v), cos(w0.v));
-    D3 cw = dfun(w0, cos(w0.v), -sin(w0.v));
+    double snv, csv;
+    sincos(w0.v, &snv, &csv);
+    D3 sn = dfun(w0, snv, csv);
+    D3 cw = dfun(w0, csv, -snv);
     D3 alpha = sn / dscale(qq, 2.0);
     const double sAv = sqrt(Av);
     D3 sA = dfun(A, sAv, 0.5 / sAv);
@@ -199,11 +204,11 @@ __global__ __launch_bounds__(320) void k_prep(PrepArgs a) {
 #pragma clang fp contract(off)
         float gin = 1.0f;
         const int gi = is_master ? 25 : 0;
-        if (gin_on) gin = (float)pow(10.0, (double)(denorm(p[gi], lo[gi], hi[gi]) / 20.0f));
+        if (gin_on) gin = (float)exp2((double)(denorm(p[gi], lo[gi], hi[gi]) / 20.0f) * 3.321928094887362);
         rc[RC_GIN] = gin;
         if (is_master) {
             float gout = 1.0f;
-            if (d.flags & MST_USE_OUTPUT_FADER) gout = (float)pow(10.0, (double)(denorm(p[24], lo[24], hi[24]) / 20.0f));
+            if (d.flags & MST_USE_OUTPUT_FADER) gout = (float)exp2((double)(denorm(p[24], lo[24], hi[24]) / 20.0f) * 3.321928094887362);
             rc[RC_PANL] = gout;
             rc[RC_PANR] = gout;
         } else {
