@@ -21,8 +21,7 @@ constexpr int kMaxRes = 8;
 struct ResInfo {
     int n_fft, hop, n_frames, n_bins;
     int64_t tw_off, win_off;  // float offsets into the tables buffer (tw: n_fft float2, win: n_fft floats)
-    int n_groups;                       // forward: workgroups per row; group g owns frames [g F / G, (g+1) F / G)
-    int n_units_bwd;                    // backward: workgroups per row (each owns a balanced strip of frames / frame pairs)
+    int frames_per_wg;                  // forward strip length
 };
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
@@ -149,9 +148,8 @@ __global__ __launch_bounds__(stft_threads(NFFT)) void k_stft_fwd(StftArgs a) {
     const float* x = a.pred + (int64_t)row * a.n;
     const float* y = a.target + (int64_t)row * a.n;
     float s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f;
-    const int f0 = (int)(((int64_t)blockIdx.x * r.n_frames) / r.n_groups);
-    const int f1 = (int)(((int64_t)(blockIdx.x + 1) * r.n_frames) / r.n_groups);
-    for (int f = f0; f < f1; ++f) {
+    const int f0 = blockIdx.x * r.frames_per_wg;
+    for (int f = f0; f < f0 + r.frames_per_wg && f < r.n_frames; ++f) {
         load_frame(bufA, x, y, win, f, r, a.n, tid, THREADS);
         __syncthreads();
         const float2* Z = lds_fft<NFFT, THREADS>(bufA, bufB, twd, tid);
@@ -214,12 +212,7 @@ __global__ __launch_bounds__(stft_threads(NFFT)) void k_stft_bwd(StftArgs a) {
     const float gl = a.grad_loss[0];
     const float coef[3] = {a.coef[(int64_t)row * 4] * gl, a.coef[(int64_t)row * 4 + 1] * gl, a.coef[(int64_t)row * 4 + 2] * gl};
     float* gx = a.grad_pred + (int64_t)row * a.n;
-    const int n_units = PAIR ? (r.n_frames + 1) / 2 : r.n_frames;
-    const int u0 = (int)(((int64_t)blockIdx.x * n_units) / r.n_units_bwd);
-    const int u1 = (int)(((int64_t)(blockIdx.x + 1) * n_units) / r.n_units_bwd);
-    for (int unit = u0; unit < u1; ++unit) {
-    __syncthreads();  // LDS of the previous unit fully consumed
-    const int fa = PAIR ? 2 * unit : unit, fb = fa + 1;
+    const int fa = PAIR ? 2 * blockIdx.x : blockIdx.x, fb = fa + 1;
     const bool have_b = PAIR && fb < r.n_frames;
     const int64_t sa = (int64_t)fa * r.hop - NFFT / 2, sb = (int64_t)fb * r.hop - NFFT / 2;
 
@@ -266,7 +259,6 @@ __global__ __launch_bounds__(stft_threads(NFFT)) void k_stft_bwd(StftArgs a) {
         const float w = win[k];
         unsafeAtomicAdd(&gx[reflect_index(sa + k, a.n)], w * v.x);
         if (have_b) unsafeAtomicAdd(&gx[reflect_index(sb + k, a.n)], -w * v.y);
-    }
     }
 }
 
@@ -393,30 +385,8 @@ Plan make_plan(const mst_mrstft_desc* d) {
         p.win[i] = d->win_length[i];
         // aim for >= ~2000 workgroups per launch (256 CUs x several resident) but cap the strip at 8 frames
         int fpw = (int)(((int64_t)r.n_frames * d->rows) / 2048);
-        fpw = fpw < 1 ? 1 : (fpw > 8 ? 8 : fpw);
-        // Workgroups resident per launch round: 256 CUs x (LDS-limited) workgroups per CU.  A grid that is a
-        // hair over a whole number of rounds pays a full extra round for the stragglers (65 frames x 16 rows of
-        // n_fft 8192 = 1040 workgroups at one per CU = 4.06 rounds): trim such grids to the whole number and let
-        // a few workgroups take one frame more (strips are balanced to +-1 frame).
-        const int lds_fwd = 2 * nf * 8 + 2048, lds_bwd = (nf <= 4096 ? 3 : 2) * nf * 8 + 2048;
-        auto trim = [&](int groups, int lds_bytes, int threads) {
-            int per_cu = (160 * 1024) / lds_bytes;
-            const int by_waves = 32 / ((threads + 63) / 64);
-            if (per_cu > by_waves) per_cu = by_waves;
-            if (per_cu < 1) per_cu = 1;
-            const int64_t round_sz = 256LL * per_cu, total = (int64_t)groups * d->rows;
-            const int64_t whole = total / round_sz;
-            if (whole >= 1 && (total - whole * round_sz) * 8 < round_sz) {  // < 1/8 of a round spills over
-                const int g = (int)((whole * round_sz) / d->rows);
-                if (g >= 1) return g;
-            }
-            return groups;
-        };
-        const int threads = nf <= 512 ? 128 : (nf <= 2048 ? 512 : 1024);
-        r.n_groups = trim((r.n_frames + fpw - 1) / fpw, lds_fwd, threads);
-        const int units = nf <= 4096 ? (r.n_frames + 1) / 2 : r.n_frames;
-        r.n_units_bwd = trim(units, lds_bwd, threads);
-        p.n_groups[i] = r.n_groups;
+        r.frames_per_wg = fpw < 1 ? 1 : (fpw > 8 ? 8 : fpw);
+        p.n_groups[i] = (r.n_frames + r.frames_per_wg - 1) / r.frames_per_wg;
         p.part_off[i] = po;
         po += (int64_t)d->rows * p.n_groups[i] * 4;
     }
@@ -537,8 +507,7 @@ extern "C" int mst_mrstft_backward(const mst_mrstft_desc* d, const float* pred, 
         a.eps = d->eps;
         // three LDS buffers (pairing two frames per inverse FFT) fit up to n_fft = 4096; 8192 runs one frame per workgroup
         const bool pair = a.r.n_fft <= 4096;
-        const dim3 grid(a.r.n_units_bwd, d->rows);
-        (void)pair;
+        const dim3 grid(pair ? (a.r.n_frames + 1) / 2 : a.r.n_frames, d->rows);
 #define MST_LAUNCH_BWD(NF)                                                                                             \
     if (NF <= 4096) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stft_bwd<NF, (NF <= 4096)>), grid, dim3(stft_threads(NF)), 0, stream, a); \
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stft_bwd<NF, false>), grid, dim3(stft_threads(NF)), 0, stream, a)
