@@ -13,6 +13,7 @@
 // forms dL/dX, and returns two frames' time-domain cotangents per complex FFT; the overlap-add
 // (incl. the reflect-padding fold-back) uses hardware float atomics into grad_pred.
 #include "mst_kernels.h"
+#include <cstdlib>
 
 namespace mst {
 
@@ -383,9 +384,10 @@ Plan make_plan(const mst_mrstft_desc* d) {
         t += nf;
         p.log2n[i] = lg;
         p.win[i] = d->win_length[i];
-        // aim for >= ~2000 workgroups per launch (256 CUs x several resident) but cap the strip at 8 frames
-        int fpw = (int)(((int64_t)r.n_frames * d->rows) / 2048);
-        r.frames_per_wg = fpw < 1 ? 1 : (fpw > 8 ? 8 : fpw);
+        // strips of 2 frames measured best on MI355X at cfg #2 (1: 423, 2: 411, 4: 443, 8: 455, 16: 566 us per
+        // fwd+bwd); MST_STFT_FPW overrides for experiments
+        r.frames_per_wg = ((int64_t)r.n_frames * d->rows >= 1024) ? 2 : 1;
+        if (const char* e = getenv("MST_STFT_FPW")) r.frames_per_wg = atoi(e) > 0 ? atoi(e) : r.frames_per_wg;
         p.n_groups[i] = (r.n_frames + r.frames_per_wg - 1) / r.frames_per_wg;
         p.part_off[i] = po;
         po += (int64_t)d->rows * p.n_groups[i] * 4;
