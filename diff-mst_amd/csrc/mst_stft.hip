@@ -196,17 +196,27 @@ __device__ __forceinline__ float2 spectrum_cotangent(const float2* Z, int k, int
 
 // Backward.  The real cotangent frame is Re IDFT of the half spectrum G, i.e. the IDFT of its
 // Hermitian extension He (He[k] = G[k]/2, He[N-k] = conj(G[k])/2, real at k = 0, N/2), and
-// IDFT(h) = conj(FFT(conj(h))).  PAIR: two frames share one complex inverse FFT (He_a + i He_b).
+// IDFT(h) = conj(FFT(conj(h))).
+//   PAIR  (n_fft <= 4096, three LDS buffers): two frames share one complex inverse FFT (He_a + i He_b).
+//   !PAIR (n_fft = 8192, two LDS buffers): the real-output inverse is done with a HALF-size complex FFT:
+//         y_even + i y_odd = IDFT_M(A + i Bq),  A[k] = H[k] + conj(H[M-k]),  Bq[k] = (H[k] - conj(H[M-k])) conj(W_N^k).
 template <int NFFT, bool PAIR>
 __global__ __launch_bounds__(stft_threads(NFFT)) void k_stft_bwd(StftArgs a) {
     constexpr int THREADS = stft_threads(NFFT);
+    constexpr int M = NFFT / 2;
     __shared__ __attribute__((aligned(16))) float2 bufA[NFFT];
     __shared__ __attribute__((aligned(16))) float2 bufB[NFFT];
     __shared__ __attribute__((aligned(16))) float2 bufH[PAIR ? NFFT : 1];
     __shared__ Twiddles<NFFT> twd;
+    __shared__ Twiddles<PAIR ? 64 : M> twh;  // half-size transform's twiddles (!PAIR only)
     const ResInfo r = a.r;
     const int tid = threadIdx.x, row = blockIdx.y;
-    stage_twiddles<NFFT>(twd, reinterpret_cast<const float2*>(a.tables + r.tw_off), tid, THREADS);
+    const float2* twg = reinterpret_cast<const float2*>(a.tables + r.tw_off);
+    stage_twiddles<NFFT>(twd, twg, tid, THREADS);
+    if constexpr (!PAIR) {  // W_M^t = W_N^(2t)
+        for (int i = tid; i < M / 64; i += THREADS) twh.coarse[i] = twg[2 * 64 * i];
+        for (int i = tid; i < 64; i += THREADS) twh.fine[i] = twg[2 * i];
+    }
     const float* win = a.tables + r.win_off;
     const float* x = a.pred + (int64_t)row * a.n;
     const float* y = a.target + (int64_t)row * a.n;
@@ -220,17 +230,17 @@ __global__ __launch_bounds__(stft_threads(NFFT)) void k_stft_bwd(StftArgs a) {
     load_frame(bufA, x, y, win, fa, r, a.n, tid, THREADS);
     __syncthreads();
     float2* Z = lds_fft<NFFT, THREADS>(bufA, bufB, twd, tid);
-    float2* O = (Z == bufA) ? bufB : bufA;       // the buffer the forward result is NOT in
-    float2* H = PAIR ? bufH : O;                 // where conj(He) is assembled
-    for (int k = tid; k <= NFFT / 2; k += THREADS) {
-        const float2 G = spectrum_cotangent(Z, k, NFFT, a, coef);
-        const bool edge = (k == 0) || (k == NFFT / 2);
-        // conj(He): He[k] = G/2 -> (Gx/2, -Gy/2); He[N-k] = conj(G)/2 -> (Gx/2, +Gy/2)
-        H[k] = edge ? make_float2(G.x, 0.f) : make_float2(0.5f * G.x, -0.5f * G.y);
-        if (!edge) H[NFFT - k] = make_float2(0.5f * G.x, 0.5f * G.y);
-    }
-    __syncthreads();
-    if (PAIR) {
+    float2* O = (Z == bufA) ? bufB : bufA;  // the buffer the forward result is NOT in
+    if constexpr (PAIR) {
+        float2* H = bufH;  // conj(He) is assembled here
+        for (int k = tid; k <= NFFT / 2; k += THREADS) {
+            const float2 G = spectrum_cotangent(Z, k, NFFT, a, coef);
+            const bool edge = (k == 0) || (k == NFFT / 2);
+            // conj(He): He[k] = G/2 -> (Gx/2, -Gy/2); He[N-k] = conj(G)/2 -> (Gx/2, +Gy/2)
+            H[k] = edge ? make_float2(G.x, 0.f) : make_float2(0.5f * G.x, -0.5f * G.y);
+            if (!edge) H[NFFT - k] = make_float2(0.5f * G.x, 0.5f * G.y);
+        }
+        __syncthreads();
         if (have_b) {
             load_frame(bufA, x, y, win, fb, r, a.n, tid, THREADS);
             __syncthreads();
@@ -238,10 +248,9 @@ __global__ __launch_bounds__(stft_threads(NFFT)) void k_stft_bwd(StftArgs a) {
             for (int k = tid; k <= NFFT / 2; k += THREADS) {
                 const float2 G = spectrum_cotangent(Z, k, NFFT, a, coef);
                 const bool edge = (k == 0) || (k == NFFT / 2);
-                // conj(i He_b): i He[k] = i G/2 = (-Gy/2, Gx/2) -> conj = (-Gy/2, -Gx/2);
-                //               i He[N-k] = i conj(G)/2 = (Gy/2, Gx/2) -> conj = (Gy/2, -Gx/2)
+                // conj(i He_b): i He[k] = i G/2 -> conj = (-Gy/2, -Gx/2);  i He[N-k] = i conj(G)/2 -> conj = (Gy/2, -Gx/2)
                 if (edge) {
-                    H[k].y -= G.x;  // i * Re(G) -> conj -> (0, -Gx)
+                    H[k].y -= G.x;
                 } else {
                     H[k].x += -0.5f * G.y; H[k].y += -0.5f * G.x;
                     H[NFFT - k].x += 0.5f * G.y; H[NFFT - k].y += -0.5f * G.x;
@@ -249,17 +258,43 @@ __global__ __launch_bounds__(stft_threads(NFFT)) void k_stft_bwd(StftArgs a) {
             }
             __syncthreads();
         }
-        O = bufA;  // both work buffers are free again
+        // FFT(conj(h)) = conj(r_a + i r_b)  =>  r_a = Re, r_b = -Im
+        const float2* R = lds_fft<NFFT, THREADS>(H, bufA, twd, tid);
+        for (int k = tid; k < NFFT; k += THREADS) {
+            const float2 v = R[k];
+            const float w = win[k];
+            unsafeAtomicAdd(&gx[reflect_index(sa + k, a.n)], w * v.x);
+            if (have_b) unsafeAtomicAdd(&gx[reflect_index(sb + k, a.n)], -w * v.y);
+        }
     } else {
-        O = Z;     // forward result no longer needed
-    }
-    // FFT(conj(h)) = conj(r_a + i r_b)  =>  r_a = Re, r_b = -Im
-    const float2* R = lds_fft<NFFT, THREADS>(H, O, twd, tid);
-    for (int k = tid; k < NFFT; k += THREADS) {
-        const float2 v = R[k];
-        const float w = win[k];
-        unsafeAtomicAdd(&gx[reflect_index(sa + k, a.n)], w * v.x);
-        if (have_b) unsafeAtomicAdd(&gx[reflect_index(sb + k, a.n)], -w * v.y);
+        // pair (k, M-k), k = 0..M/2, of the first-half Hermitian spectrum H[0..M] (H[k] = G[k]/2 inside, real at the ends)
+        for (int k = tid; k <= M / 2; k += THREADS) {
+            float2 Hk = spectrum_cotangent(Z, k, NFFT, a, coef), Hm = spectrum_cotangent(Z, M - k, NFFT, a, coef);
+            if (k == 0) {
+                // V[0] = (H0 + HM) + i (H0 - HM), both real; store conj
+                O[0] = make_float2(Hk.x + Hm.x, -(Hk.x - Hm.x));
+            } else {
+                Hk = make_float2(0.5f * Hk.x, 0.5f * Hk.y);
+                Hm = make_float2(0.5f * Hm.x, 0.5f * Hm.y);
+                const float2 w = cmul(twd.coarse[k >> 6], twd.fine[k & 63]);  // W_N^k ; W_N^(M-k) = -conj(W_N^k)
+                const float2 Ak = make_float2(Hk.x + Hm.x, Hk.y - Hm.y);                                  // H[k] + conj(H[M-k])
+                const float2 Bk = cmul(make_float2(Hk.x - Hm.x, Hk.y + Hm.y), make_float2(w.x, -w.y));    // (..)(conj W^k)
+                O[k] = make_float2(Ak.x - Bk.y, -(Ak.y + Bk.x));                                         // conj(A + i Bq)
+                if (k != M / 2) {
+                    const float2 Am = make_float2(Hm.x + Hk.x, Hm.y - Hk.y);
+                    const float2 Bm = cmul(make_float2(Hm.x - Hk.x, Hm.y + Hk.y), make_float2(-w.x, -w.y));
+                    O[M - k] = make_float2(Am.x - Bm.y, -(Am.y + Bm.x));
+                }
+            }
+        }
+        __syncthreads();
+        // half-size forward FFT of conj(V): result = conj(y_even + i y_odd)
+        const float2* R = lds_fft<M, THREADS>(O, Z, twh, tid);
+        for (int m = tid; m < M; m += THREADS) {
+            const float2 v = R[m];
+            unsafeAtomicAdd(&gx[reflect_index(sa + 2 * m, a.n)], win[2 * m] * v.x);
+            unsafeAtomicAdd(&gx[reflect_index(sa + 2 * m + 1, a.n)], -win[2 * m + 1] * v.y);
+        }
     }
 }
 
