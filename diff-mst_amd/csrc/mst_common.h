@@ -19,6 +19,9 @@ constexpr int kCompChunk = 8;          // samples one lane owns in the compresso
 constexpr int kScanThreads = 512;      // lanes per row in the carry-scan kernels
 constexpr int kScanLevels = 9;         // log2(kScanThreads)
 constexpr int kPow = 1 + kScanLevels;  // matrices per scan table: M, then M^(K*2^j)
+constexpr int kTile = kEqWG * kEqChunk;  // samples one single-wave workgroup of the EQ kernels covers (4096)
+constexpr int kPow1 = 12;              // in-wave scan tables: M^(2^j), j = 0..5 lanes of a tile, 6..11 tiles of a row
+constexpr int kMaxTiles1 = 64;         // rows of up to 64 tiles (262144 samples) scan in-wave (no carry-scan kernel)
 
 // ---- per-filter-row constants ("rc"), written by k_prep, floats -------------------------------
 constexpr int RC_SOS = 0;      // 6 x {b0 b1 b2 a1 a2}; section 0's b carries the input-fader gain
@@ -67,10 +70,13 @@ __device__ __forceinline__ float biquad_step<float>(float x, const float* c, flo
 }
 
 // forward cascade, state st[2k], st[2k+1] for section k
+#ifndef MST_DBG_SECTIONS
+#define MST_DBG_SECTIONS kSections  // timing diagnostics only: fewer sections = less math, wrong results
+#endif
 template <typename T>
 __device__ __forceinline__ T cascade_step(T x, const T* c, T* st) {
 #pragma unroll
-    for (int k = 0; k < kSections; ++k) x = biquad_step<T>(x, c + 5 * k, st[2 * k], st[2 * k + 1]);
+    for (int k = 0; k < MST_DBG_SECTIONS; ++k) x = biquad_step<T>(x, c + 5 * k, st[2 * k], st[2 * k + 1]);
     return x;
 }
 
@@ -139,6 +145,8 @@ struct Layout {
     int ncC, ncC_pad;        // compressor lane-chunks per row
     int nblkE, nblkC;        // workgroups per row in EQ / compressor kernels
     int KE, KC;              // chunks per scan thread
+    int ntE;                 // 4096-sample EQ tiles per row
+    int eq1;                 // 1: EQ carries scanned inside the zs / run kernels, 0: separate carry-scan kernel
     // offsets
     int64_t rc_t, rc_m;                  // row constants
     int64_t powF_t, powF_m;              // forward cascade scan tables  rows x kPow x 144
@@ -152,6 +160,8 @@ struct Layout {
     int64_t zA_t, sA_t, zA_m, sA_m;      // EQ-adjoint chunk states
     int64_t zP_t, sP_t, zP_m, sP_m;      // all-pole (coefficient-gradient) chunk states
     int64_t cp_t, cp_m, ep_t, ep_m;      // partial sums
+    int64_t pow1F_t, pow1F_m, pow1A_t, pow1A_m;  // in-wave scan tables rows x kPow1 x 144
+    int64_t aggF_t, aggF_m, aggA_t, aggA_m;      // tile aggregates sigrows x 12 x kMaxTiles1 (forward / adjoint cascade)
     int64_t total;                       // floats
 };
 
@@ -169,6 +179,8 @@ inline Layout make_layout(const mst_console_desc* d) {
     L.nblkC = L.ncC_pad / kWG;
     L.KE = (L.ncE + kScanThreads - 1) / kScanThreads;
     L.KC = (L.ncC + kScanThreads - 1) / kScanThreads;
+    L.ntE = (int)((L.N + kTile - 1) / kTile);
+    L.eq1 = (L.ntE <= kMaxTiles1 && !(d->flags & MST_DEV_MULTIPASS_EQ)) ? 1 : 0;
     int64_t o = 0;
     auto take = [&](int64_t n) {
         int64_t at = o;
@@ -218,6 +230,14 @@ inline Layout make_layout(const mst_console_desc* d) {
     L.cp_m = take(B * L.nblkC * CP_COUNT);
     L.ep_t = take((R + 2 * B) * L.nblkE * EP_COUNT);
     L.ep_m = L.ep_t + R * L.nblkE * EP_COUNT;
+    L.pow1F_t = take((R + B) * kPow1 * 144);
+    L.pow1F_m = L.pow1F_t + R * kPow1 * 144;
+    L.pow1A_t = take((R + B) * kPow1 * 144);
+    L.pow1A_m = L.pow1A_t + R * kPow1 * 144;
+    L.aggF_t = take((R + 2 * B) * kStates * kMaxTiles1);
+    L.aggF_m = L.aggF_t + R * kStates * kMaxTiles1;
+    L.aggA_t = take((R + 2 * B) * kStates * kMaxTiles1);
+    L.aggA_m = L.aggA_t + R * kStates * kMaxTiles1;
     L.total = o;
     return L;
 }

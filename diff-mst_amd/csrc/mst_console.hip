@@ -74,17 +74,22 @@ extern "C" int mst_console_forward(const mst_console_desc* d, const float* track
 
     PrepArgs pa{track_params, fx_bus_params, master_bus_params, ws + L.rc_t, ws + L.rc_m,
                 ws + L.powF_t, ws + L.powF_m, ws + L.powA_t, ws + L.powA_m, ws + L.powP_t, ws + L.powP_m,
-                status, L.R, L.bs, L.KE, *d};
+                ws + L.pow1F_t, ws + L.pow1F_m, ws + L.pow1A_t, ws + L.pow1A_m, status, L.R, L.bs, L.KE, L.eq1, *d};
     launch_prep(pa, stream);
 
     // ---- tracks: EQ (zs -> carry scan -> run), compressor smoother (zs -> scan), apply + pan + bus sum
-    launch_cascade(EQ_FWD, false, tracks, d->track_row_stride, nullptr, 0, ws + L.rc_t, L.R, nullptr, ws + L.zE_t, L.ncE_pad, n, L.R, stream);
-    launch_scan12(false, ws + L.zE_t, ws + L.sE_t, ws + L.powF_t, L.R, L.ncE, L.ncE_pad, L.KE, L.R, stream);
+    // L.eq1: the carries are scanned inside the zs / run kernels (the run kernel reads the zs kernel's states directly)
+    const float* p1F_t = L.eq1 ? ws + L.pow1F_t : nullptr;
+    const float* p1F_m = L.eq1 ? ws + L.pow1F_m : nullptr;
+    const float* sE_t = L.eq1 ? ws + L.zE_t : ws + L.sE_t;
+    const float* sE_m = L.eq1 ? ws + L.zE_m : ws + L.sE_m;
+    launch_cascade(EQ_FWD, false, tracks, d->track_row_stride, nullptr, 0, ws + L.rc_t, L.R, nullptr, ws + L.zE_t, L.ncE_pad, n, L.R, stream, p1F_t, L.ntE, ws + L.aggF_t);
+    if (!L.eq1) launch_scan12(false, ws + L.zE_t, ws + L.sE_t, ws + L.powF_t, L.R, L.ncE, L.ncE_pad, L.KE, L.R, stream);
     if (t_comp)  // EQ run fused with the gain computer + per-block envelope aggregates
-        launch_cascade_run_gc(tracks, d->track_row_stride, ws + L.u_t, Ns, ws + L.rc_t, L.R, ws + L.sE_t, L.ncE_pad, n, L.R,
-                              ws + L.zS_t, L.nblkC, stream);
+        launch_cascade_run_gc(tracks, d->track_row_stride, ws + L.u_t, Ns, ws + L.rc_t, L.R, sE_t, L.ncE_pad, n, L.R,
+                              ws + L.zS_t, L.nblkC, stream, p1F_t, L.ntE, ws + L.aggF_t);
     else
-        launch_cascade(EQ_FWD, true, tracks, d->track_row_stride, ws + L.u_t, Ns, ws + L.rc_t, L.R, ws + L.sE_t, nullptr, L.ncE_pad, n, L.R, stream);
+        launch_cascade(EQ_FWD, true, tracks, d->track_row_stride, ws + L.u_t, Ns, ws + L.rc_t, L.R, sE_t, nullptr, L.ncE_pad, n, L.R, stream, p1F_t, L.ntE, ws + L.aggF_t);
     const bool bus_is_mix = !m_on && !o_on;
     TrackApplyArgs ta{ws + L.u_t, Ns, ws + L.rc_t, ws + L.zS_t, (save && t_comp) ? ws + L.gs_t : nullptr,
                       bus_is_mix ? mix : ws + L.bus, bus_is_mix ? n : Ns, mixed_tracks,
@@ -93,9 +98,9 @@ extern "C" int mst_console_forward(const mst_console_desc* d, const float* track
 
     // ---- master bus
     if (m_on) {
-        launch_cascade(EQ_FWD, false, ws + L.bus, Ns, nullptr, 0, ws + L.rc_m, 0, nullptr, ws + L.zE_m, L.ncE_pad, n, 2 * L.bs, stream);
-        launch_scan12(false, ws + L.zE_m, ws + L.sE_m, ws + L.powF_m, 0, L.ncE, L.ncE_pad, L.KE, 2 * L.bs, stream);
-        launch_cascade(EQ_FWD, true, ws + L.bus, Ns, ws + L.v_m, Ns, ws + L.rc_m, 0, ws + L.sE_m, nullptr, L.ncE_pad, n, 2 * L.bs, stream);
+        launch_cascade(EQ_FWD, false, ws + L.bus, Ns, nullptr, 0, ws + L.rc_m, 0, nullptr, ws + L.zE_m, L.ncE_pad, n, 2 * L.bs, stream, p1F_m, L.ntE, ws + L.aggF_m);
+        if (!L.eq1) launch_scan12(false, ws + L.zE_m, ws + L.sE_m, ws + L.powF_m, 0, L.ncE, L.ncE_pad, L.KE, 2 * L.bs, stream);
+        launch_cascade(EQ_FWD, true, ws + L.bus, Ns, ws + L.v_m, Ns, ws + L.rc_m, 0, sE_m, nullptr, L.ncE_pad, n, 2 * L.bs, stream, p1F_m, L.ntE, ws + L.aggF_m);
         launch_comp_zs(2, ws + L.v_m, Ns, ws + L.rc_m, ws + L.zS_m, L.ncC_pad, n, L.bs, stream);
         MasterApplyArgs ma{ws + L.v_m, Ns, ws + L.rc_m, ws + L.zS_m, save ? ws + L.gs_m : nullptr, mix, n,
                            L.ncC_pad, d->master_lookahead, 1, n, aligned};
@@ -140,9 +145,11 @@ extern "C" int mst_console_backward(const mst_console_desc* d, const float* trac
         launch_comp_bwd(true, false, ca, L.bs, stream);
         ca.s0 = ws + L.zQ_m;
         launch_comp_bwd(true, true, ca, L.bs, stream);
-        launch_cascade(EQ_ADJ, false, ws + L.du_m, Ns, nullptr, 0, ws + L.rc_m, 0, nullptr, ws + L.zA_m, L.ncE_pad, n, 2 * L.bs, stream);
-        launch_scan12(true, ws + L.zA_m, ws + L.sA_m, ws + L.powA_m, 0, L.ncE, L.ncE_pad, L.KE, 2 * L.bs, stream);
-        launch_cascade(EQ_ADJ, true, ws + L.du_m, Ns, ws + L.dbus, Ns, ws + L.rc_m, 0, ws + L.sA_m, nullptr, L.ncE_pad, n, 2 * L.bs, stream);
+        const float* p1A_m = L.eq1 ? ws + L.pow1A_m : nullptr;
+        launch_cascade(EQ_ADJ, false, ws + L.du_m, Ns, nullptr, 0, ws + L.rc_m, 0, nullptr, ws + L.zA_m, L.ncE_pad, n, 2 * L.bs, stream, p1A_m, L.ntE, ws + L.aggA_m);
+        if (!L.eq1) launch_scan12(true, ws + L.zA_m, ws + L.sA_m, ws + L.powA_m, 0, L.ncE, L.ncE_pad, L.KE, 2 * L.bs, stream);
+        launch_cascade(EQ_ADJ, true, ws + L.du_m, Ns, ws + L.dbus, Ns, ws + L.rc_m, 0, L.eq1 ? ws + L.zA_m : ws + L.sA_m, nullptr, L.ncE_pad, n,
+                       2 * L.bs, stream, p1A_m, L.ntE, ws + L.aggA_m);
         gbus = ws + L.dbus;
         gbus_stride = Ns;
     } else if (o_on) {
@@ -152,7 +159,7 @@ extern "C" int mst_console_backward(const mst_console_desc* d, const float* trac
         gbus = ws + L.dbus;
         gbus_stride = Ns;
     } else {
-        hipMemsetAsync(ws + L.cp_m, 0, (size_t)L.bs * L.nblkC * CP_COUNT * sizeof(float), stream);
+        (void)hipMemsetAsync(ws + L.cp_m, 0, (size_t)L.bs * L.nblkC * CP_COUNT * sizeof(float), stream);
     }
 
     // ---- tracks
@@ -167,9 +174,11 @@ extern "C" int mst_console_backward(const mst_console_desc* d, const float* trac
         // coefficient-gradient sums for the track rows and (same launch) the master rows
         launch_coefgrad(ws + L.u_t, Ns, ws + L.du_t, Ns, ws + L.rc_t, L.R, ws + L.sP_t, L.ncE_pad, ws + L.ep_t, n, nsig_all, stream);
         if (grad_tracks) {
-            launch_cascade(EQ_ADJ, false, ws + L.du_t, Ns, nullptr, 0, ws + L.rc_t, L.R, nullptr, ws + L.zA_t, L.ncE_pad, n, L.R, stream);
-            launch_scan12(true, ws + L.zA_t, ws + L.sA_t, ws + L.powA_t, L.R, L.ncE, L.ncE_pad, L.KE, L.R, stream);
-            launch_cascade(EQ_ADJ, true, ws + L.du_t, Ns, grad_tracks, n, ws + L.rc_t, L.R, ws + L.sA_t, nullptr, L.ncE_pad, n, L.R, stream);
+            const float* p1A_t = L.eq1 ? ws + L.pow1A_t : nullptr;
+            launch_cascade(EQ_ADJ, false, ws + L.du_t, Ns, nullptr, 0, ws + L.rc_t, L.R, nullptr, ws + L.zA_t, L.ncE_pad, n, L.R, stream, p1A_t, L.ntE, ws + L.aggA_t);
+            if (!L.eq1) launch_scan12(true, ws + L.zA_t, ws + L.sA_t, ws + L.powA_t, L.R, L.ncE, L.ncE_pad, L.KE, L.R, stream);
+            launch_cascade(EQ_ADJ, true, ws + L.du_t, Ns, grad_tracks, n, ws + L.rc_t, L.R, L.eq1 ? ws + L.zA_t : ws + L.sA_t, nullptr, L.ncE_pad,
+                           n, L.R, stream, p1A_t, L.ntE, ws + L.aggA_t);
         }
     }
     PrepBwdArgs pb{track_params, master_bus_params, ws + L.rc_t, ws + L.rc_m, ws + L.cp_t, ws + L.cp_m, ws + L.ep_t, ws + L.ep_m,

@@ -10,16 +10,24 @@
 //     *_zs   : run the chunk from ZERO state, keep only the 12-float end state  (z)
 //     scan   : (mst_scan.hip) s0[c+1] = M s0[c] + z[c] gives every chunk's true start state
 //     *_run  : re-run the chunk from its true start state and emit the output
+//   SCAN1 (rows of <= 64 tiles): no scan kernel.  The zs kernel scans its 64 lane states in-wave with
+//   M^(2^j) and writes every chunk's end state GIVEN A ZERO STATE AT THE TILE START; the run kernel scans
+//   the <= 63 preceding tile aggregates of its row in-wave with M^(64 2^j) for the state S entering its
+//   tile, and starts lane l from  (end state of lane l-1) + M^l S.
 //   The adjoint (reverse-time) cascade uses the same skeleton with time reversed.
 //   Coefficient gradients use the forward-only identity  dL/db_kj = <g, S^j (1/B_k) u>,
 //   dL/da_kj = -<g, S^j (1/A_k) u>  (u = EQ output, g = its cotangent): twelve independent 2-state
 //   all-pole recurrences on u, same zs / scan / run structure (k_allpole_zs, k_coefgrad).
 #include "mst_kernels.h"
+#include "mst_mat.h"
 #include "mst_compdev.h"
 
 namespace mst {
 
-constexpr int kSlab = 16;         // samples per lane per LDS stage
+#ifndef MST_EQ_SLAB
+#define MST_EQ_SLAB 16
+#endif
+constexpr int kSlab = MST_EQ_SLAB;  // samples per lane per LDS stage
 constexpr int kLdw = kSlab + 4;   // padded LDS row (5 x 16 B, odd): conflict-free ds_read_b128 / ds_write_b128
 constexpr int kNSlab = kEqChunk / kSlab;
 constexpr int kSlabVec = kSlab / 4;              // float4 per lane per slab
@@ -65,13 +73,14 @@ __device__ __forceinline__ void slab_store(const float* __restrict__ tile, float
 // FUSE_GC (forward run of mono rows only): the compressor's static curve is evaluated on the fresh EQ
 // output and the zero-state envelope end value of every 2048-sample compressor block (= 32 lanes) is
 // written to zs_comp[sig][block] - this replaces the separate k_comp_zs pass over the EQ output.
-template <int DIR, bool MODE_RUN, bool FUSE_GC = false>
+template <int DIR, bool MODE_RUN, bool FUSE_GC = false, bool SCAN1 = false>
 __global__ __launch_bounds__(kEqWG) void k_cascade(const float* __restrict__ in, int64_t in_stride,
                                                  float* __restrict__ out, int64_t out_stride,
                                                  const float* __restrict__ rc, int split,
                                                  const float* __restrict__ s0, float* __restrict__ z,
                                                  int nc_pad, int64_t n, float* __restrict__ zs_comp = nullptr,
-                                                 int nblk_comp = 0) {
+                                                 int nblk_comp = 0, const float* __restrict__ pw1 = nullptr, int ntiles = 0,
+                                                 float* __restrict__ agg = nullptr) {
     __shared__ __attribute__((aligned(16))) float tile[kEqWG * kLdw];
     const int tid = threadIdx.x, sig = blockIdx.y;
     const int64_t tile_base = (int64_t)blockIdx.x * kEqWG * kEqChunk;
@@ -87,9 +96,41 @@ __global__ __launch_bounds__(kEqWG) void k_cascade(const float* __restrict__ in,
 #pragma unroll
     for (int i = 0; i < 5 * kSections; ++i) c[i] = coef[i];
     float st[kStates];
+    const int pos = DIR == EQ_FWD ? tid : kEqWG - 1 - tid;  // position of my chunk in recurrence order inside the tile
+    const float* tab = SCAN1 ? pw1 + (int64_t)filter_row(sig, split) * kPow1 * 144 : nullptr;
+    static_assert(kTabFloats <= kEqWG * kLdw, "a scan table is staged through the slab buffer");
+    TabRegs tlo, thi;  // M^(2^j): j = 0..5 (lanes of a tile) and j = 6..11 (tiles of a row)
+    if (SCAN1) tab_fetch(tlo, tab, tid);
+    if (MODE_RUN && SCAN1) {
+        tab_fetch(thi, tab + kTabFloats, tid);
+        // s0 = the zs kernel's in-tile end states.  Mine starts from my predecessor lane's ...
+        const int nb = DIR == EQ_FWD ? chunk - 1 : chunk + 1;
 #pragma unroll
-    for (int i = 0; i < kStates; ++i)
-        st[i] = MODE_RUN ? s0[((int64_t)sig * kStates + i) * nc_pad + chunk] : 0.0f;
+        for (int i = 0; i < kStates; ++i) st[i] = pos > 0 ? s0[((int64_t)sig * kStates + i) * nc_pad + nb] : 0.0f;
+        // ... + M^pos S, S = state entering the tile = scan over the aggregates of the preceding tiles
+        const int wt = DIR == EQ_FWD ? (int)blockIdx.x : ntiles - 1 - (int)blockIdx.x;  // my tile in recurrence order
+        if (wt > 0) {
+            float zz[kStates], v[kStates];  // lane q looks at the tile at recurrence position q
+#pragma unroll
+            for (int d = 0; d < kStates; ++d) zz[d] = tid < wt ? agg[((int64_t)sig * kStates + d) * kMaxTiles1 + tid] : 0.0f;
+            tab_stash(thi, tile, tid);
+            __syncthreads();
+            wave_scan12<false>(zz, tile, tid, wt);
+#pragma unroll
+            for (int d = 0; d < kStates; ++d) v[d] = __shfl(zz[d], wt - 1);
+            __syncthreads();
+            tab_stash(tlo, tile, tid);
+            __syncthreads();
+            apply_pow12(v, tile, pos);
+#pragma unroll
+            for (int d = 0; d < kStates; ++d) st[d] += v[d];
+            __syncthreads();  // the slab image overwrites the table next
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < kStates; ++i)
+            st[i] = MODE_RUN ? s0[((int64_t)sig * kStates + i) * nc_pad + chunk] : 0.0f;
+    }
     float* mine = &tile[tid * kLdw];
     CompK ck{};
     float zacc = 0.0f;
@@ -135,6 +176,16 @@ __global__ __launch_bounds__(kEqWG) void k_cascade(const float* __restrict__ in,
         }
     }
     if (!MODE_RUN) {
+        if (SCAN1) {
+            tab_stash(tlo, tile, tid);  // the slab buffer is free now
+            __syncthreads();
+            wave_scan12<DIR == EQ_ADJ>(st, tile, pos, kEqWG);
+            if (pos == kEqWG - 1) {  // tile aggregate, indexed by the tile's position in recurrence order
+                const int wt = DIR == EQ_FWD ? (int)blockIdx.x : ntiles - 1 - (int)blockIdx.x;
+#pragma unroll
+                for (int i = 0; i < kStates; ++i) agg[((int64_t)sig * kStates + i) * kMaxTiles1 + wt] = st[i];
+            }
+        }
 #pragma unroll
         for (int i = 0; i < kStates; ++i) z[((int64_t)sig * kStates + i) * nc_pad + chunk] = st[i];
     }
@@ -294,26 +345,41 @@ __global__ __launch_bounds__(kEqWG) void k_coefgrad(const float* __restrict__ u,
 }
 
 // ---- host-side launch helpers (called from mst_console.hip) --------------------------------------
-void launch_cascade(int dir, bool run, const float* in, int64_t in_stride, float* out, int64_t out_stride,
-                    const float* rc, int split, const float* s0, float* z, int nc_pad, int64_t n, int nsig,
-                    hipStream_t stream) {
-    dim3 grid(nc_pad / kEqWG, nsig), block(kEqWG);
-    if (dir == EQ_FWD && !run)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cascade<EQ_FWD, false>), grid, block, 0, stream, in, in_stride, out, out_stride, rc, split, s0, z, nc_pad, n, (float*)nullptr, 0);
-    else if (dir == EQ_FWD && run)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cascade<EQ_FWD, true>), grid, block, 0, stream, in, in_stride, out, out_stride, rc, split, s0, z, nc_pad, n, (float*)nullptr, 0);
-    else if (dir == EQ_ADJ && !run)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cascade<EQ_ADJ, false>), grid, block, 0, stream, in, in_stride, out, out_stride, rc, split, s0, z, nc_pad, n, (float*)nullptr, 0);
-    else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cascade<EQ_ADJ, true>), grid, block, 0, stream, in, in_stride, out, out_stride, rc, split, s0, z, nc_pad, n, (float*)nullptr, 0);
+// pw1 != nullptr selects the SCAN1 kernels (rows of ntiles <= kMaxTiles1 tiles): `z` then receives, and `s0` must be,
+// the zs launch's in-tile end states, and no carry-scan launch goes in between.
+void launch_cascade(int dir, bool run, const float* in, int64_t in_stride, float* out, int64_t out_stride, const float* rc,
+                    int split, const float* s0, float* z, int nc_pad, int64_t n, int nsig, hipStream_t stream, const float* pw1,
+                    int ntiles, float* agg) {
+    const dim3 grid(pw1 ? ntiles : nc_pad / kEqWG, nsig), block(kEqWG);
+    float* const nozs = nullptr;
+#define MST_LAUNCH_CASCADE(D, R, S) \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cascade<D, R, false, S>), grid, block, 0, stream, in, in_stride, out, out_stride, rc, \
+                       split, s0, z, nc_pad, n, nozs, 0, pw1, ntiles, agg)
+    if (pw1) {
+        if (dir == EQ_FWD && !run) MST_LAUNCH_CASCADE(EQ_FWD, false, true);
+        else if (dir == EQ_FWD) MST_LAUNCH_CASCADE(EQ_FWD, true, true);
+        else if (!run) MST_LAUNCH_CASCADE(EQ_ADJ, false, true);
+        else MST_LAUNCH_CASCADE(EQ_ADJ, true, true);
+    } else {
+        if (dir == EQ_FWD && !run) MST_LAUNCH_CASCADE(EQ_FWD, false, false);
+        else if (dir == EQ_FWD) MST_LAUNCH_CASCADE(EQ_FWD, true, false);
+        else if (!run) MST_LAUNCH_CASCADE(EQ_ADJ, false, false);
+        else MST_LAUNCH_CASCADE(EQ_ADJ, true, false);
+    }
+#undef MST_LAUNCH_CASCADE
 }
 
 void launch_cascade_run_gc(const float* in, int64_t in_stride, float* out, int64_t out_stride, const float* rc, int split,
-                           const float* s0, int nc_pad, int64_t n, int nsig, float* zs_comp, int nblk_comp, hipStream_t stream) {
+                           const float* s0, int nc_pad, int64_t n, int nsig, float* zs_comp, int nblk_comp, hipStream_t stream,
+                           const float* pw1, int ntiles, float* agg) {
     static_assert(kEqChunk * 32 == kWG * kCompChunk, "a compressor block must be 32 EQ lanes");
-    dim3 grid(nc_pad / kEqWG, nsig), block(kEqWG);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cascade<EQ_FWD, true, true>), grid, block, 0, stream, in, in_stride, out, out_stride, rc, split,
-                       s0, (float*)nullptr, nc_pad, n, zs_comp, nblk_comp);
+    const dim3 grid(pw1 ? ntiles : nc_pad / kEqWG, nsig), block(kEqWG);
+    if (pw1)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cascade<EQ_FWD, true, true, true>), grid, block, 0, stream, in, in_stride, out, out_stride,
+                           rc, split, s0, (float*)nullptr, nc_pad, n, zs_comp, nblk_comp, pw1, ntiles, agg);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cascade<EQ_FWD, true, true, false>), grid, block, 0, stream, in, in_stride, out, out_stride,
+                           rc, split, s0, (float*)nullptr, nc_pad, n, zs_comp, nblk_comp, pw1, ntiles, agg);
 }
 
 void launch_allpole_zs(const float* u, int64_t u_stride, const float* rc, int split, float* z, int nc_pad, int64_t n,

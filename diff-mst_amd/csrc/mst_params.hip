@@ -252,6 +252,19 @@ __global__ __launch_bounds__(320) void k_prep(PrepArgs a) {
         cur ^= 1;
     }
     if (mat_lane) pw[0 * 144 + e] = (float)mats[grp][cur][e];
+    if (a.eq1) {
+        // in-wave scans: M^(2^j), j = 0..kPow1-1 (M = one-chunk transition), by repeated squaring
+        float* pw1 = grp == 0 ? (is_master ? a.pow1F_m + (int64_t)mrow * kPow1 * 144 : a.pow1F_t + (int64_t)row * kPow1 * 144)
+                              : (is_master ? a.pow1A_m + (int64_t)mrow * kPow1 * 144 : a.pow1A_t + (int64_t)row * kPow1 * 144);
+        for (int j = 0; j < kPow1; ++j) {
+            if (mat_lane) pw1[j * 144 + e] = (float)mats[grp][cur][e];
+            if (j + 1 < kPow1) {
+                if (mat_lane) mat12_mul(mats[grp][cur], mats[grp][cur], mats[grp][cur ^ 1], e);
+                __syncthreads();
+                cur ^= 1;
+            }
+        }
+    } else {
     // acc (slot 2) = cur^KE by binary exponentiation; `cur`/`cur^1` ping-pong the running square
     if (mat_lane) mats[grp][2][e] = (e / 12 == e % 12) ? 1.0 : 0.0;
     __syncthreads();
@@ -282,6 +295,7 @@ __global__ __launch_bounds__(320) void k_prep(PrepArgs a) {
             __syncthreads();
             src = dst;
         }
+    }
     }
 
     // ---- all-pole filters used by the coefficient-gradient pass: f = 2k (1/A_k), 2k+1 (1/B_k)

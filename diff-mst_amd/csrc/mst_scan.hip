@@ -5,39 +5,10 @@
 // Hillis-Steele scan over the 1024 lane aggregates uses the precomputed powers M^(K 2^j)
 // (uniform per row => scalar loads), then each lane replays its K chunks from its true start.
 #include "mst_kernels.h"
+#include "mst_mat.h"
 
 namespace mst {
 
-// number of leading columns of row i that can be non-zero (cascade matrices are block lower-triangular)
-template <int D>
-__device__ __forceinline__ constexpr int row_cols(int i) { return D == 12 ? 2 * (i / 2 + 1) : D; }
-
-// acc += M v ; M row-major D x D in LDS (16-byte aligned), read with explicit 16-byte loads.
-// The address is wave-uniform, so every read is an LDS broadcast: 24 ds_read_b128 per 12x12 matvec.
-template <int D>
-__device__ __forceinline__ void matvec_acc(const float* M, const float* v, float* acc) {
-    if (D == 2) {
-        const float4 m = *reinterpret_cast<const float4*>(M);
-        acc[0] = fmaf(m.x, v[0], fmaf(m.y, v[1], acc[0]));
-        acc[1] = fmaf(m.z, v[0], fmaf(m.w, v[1], acc[1]));
-        return;
-    }
-#pragma unroll
-    for (int i = 0; i < D; ++i) {
-        float s = acc[i];
-#pragma unroll
-        for (int c = 0; c < row_cols<D>(i); c += 4) {
-            const float4 m = *reinterpret_cast<const float4*>(M + i * D + c);
-            s = fmaf(m.x, v[c], s);
-            s = fmaf(m.y, v[c + 1], s);
-            if (c + 2 < row_cols<D>(i)) {
-                s = fmaf(m.z, v[c + 2], s);
-                s = fmaf(m.w, v[c + 3], s);
-            }
-        }
-        acc[i] = s;
-    }
-}
 // the single-chunk matrix kept in registers for the sequential fold / replay loops
 template <int D>
 struct RegMat {

@@ -523,7 +523,7 @@ extern "C" int mst_mrstft_backward(const mst_mrstft_desc* d, const float* pred, 
     if (workspace_bytes < (size_t)p.ws_floats * sizeof(float)) return hipErrorInvalidValue;
     hipStream_t stream = (hipStream_t)stream_;
     float* ws = (float*)workspace;
-    hipMemsetAsync(grad_pred, 0, (size_t)d->rows * d->n_samples * sizeof(float), stream);
+    (void)hipMemsetAsync(grad_pred, 0, (size_t)d->rows * d->n_samples * sizeof(float), stream);
     AuxPool* aux = d->n_res > 1 ? aux_pool() : nullptr;
     hipStream_t main_stream = stream;
     for (int i = 0; i < d->n_res; ++i) {

@@ -20,6 +20,7 @@ USE_FX_BUS = 0x10
 USE_MASTER_BUS = 0x20
 USE_OUTPUT_FADER = 0x40
 SAVE_FOR_BACKWARD = 0x100
+DEV_MULTIPASS_EQ = 0x200
 
 ABI_VERSION = 1
 

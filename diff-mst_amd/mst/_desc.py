@@ -1,6 +1,8 @@
 """Build the C-ABI console descriptor from the console's ``param_ranges`` (host logic, no device work)."""
 from __future__ import annotations
 
+import os
+
 from . import _cabi
 
 EQ_BANDS = ("low_shelf", "band0", "band1", "band2", "band3", "high_shelf")
@@ -50,6 +52,8 @@ def flag_word(save_for_backward: bool = False, **flags) -> int:
             word |= bit
     if save_for_backward:
         word |= _cabi.SAVE_FOR_BACKWARD
+    if os.environ.get("MST_MULTIPASS_EQ"):  # developer A/B switch (include/diffmst_hip.h MST_DEV_MULTIPASS_EQ)
+        word |= _cabi.DEV_MULTIPASS_EQ
     return word
 
 

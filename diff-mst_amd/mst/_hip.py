@@ -7,7 +7,8 @@ import os
 from . import _cabi
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_PKG_ROOT, "lib", "libdiffmst_hip.so")
+# MST_HIP_LIB: developer override to load an A/B build of the same library (still no fallback)
+LIB_PATH = os.environ.get("MST_HIP_LIB") or os.path.join(_PKG_ROOT, "lib", "libdiffmst_hip.so")
 _lib = None
 
 

@@ -43,6 +43,9 @@ extern "C" {
 #define MST_USE_MASTER_BUS 0x20u
 #define MST_USE_OUTPUT_FADER 0x40u
 #define MST_SAVE_FOR_BACKWARD 0x100u /* keep intermediates in the workspace for mst_console_backward */
+#define MST_DEV_MULTIPASS_EQ 0x200u /* developer/test switch: keep the EQ carry scan in its own kernel (zero-state pass,
+                                       carry scan, run) even when a row is short enough (<= 262144 samples) for the
+                                       in-wave scans of the two-kernel path; longer rows always take three kernels */
 
 /* *status after mst_console_forward: 0 = all parameters in [0,1]; otherwise 1000 - code with
  * code = 1 + k           track parameter index k out of range   (reference mst/modules.py:353-392)

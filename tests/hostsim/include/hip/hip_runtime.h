@@ -167,6 +167,18 @@ static inline float unsafeAtomicAdd(float* p, float v) {
 static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 
+// agent-scope atomics, wave votes and scalar helpers of the single-pass kernels
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#define __hip_atomic_store(p, v, order, scope) __atomic_store_n((p), (v), (order))
+#define __hip_atomic_load(p, order, scope) __atomic_load_n((p), (order))
+static inline int __all(int pred) {
+    int v = pred ? 1 : 0;
+    for (int m = 32; m >= 1; m >>= 1) v &= hostsim::shfl_idx(v, (hostsim::t_tid & 63u) ^ (unsigned)m);
+    return v;
+}
+static inline int __builtin_amdgcn_readfirstlane(int v) { return hostsim::shfl_idx(v, 0u); }
+static inline void __builtin_amdgcn_s_sleep(int) { std::this_thread::yield(); }
+
 // raw gfx950 transcendental builtins used by the kernels
 static inline float __builtin_amdgcn_logf(float x) { return log2f(x); }
 static inline float __builtin_amdgcn_exp2f(float x) { return exp2f(x); }

@@ -43,6 +43,24 @@ def test_console_forward_backward_small(ranges):
     assert rel(out["grad_mp"], b.grad) < 2e-2
 
 
+def test_console_inwave_scan_eq_matches_three_kernel_eq(ranges):
+    """EQ carries scanned inside the zs / run kernels (tile aggregates, in-wave scans) vs zs / scan / run on the same
+    inputs: 5 tiles per row, ragged tail, forward and both adjoint cascades (master and grad_tracks)."""
+    torch.manual_seed(3)
+    bs, T, n = 1, 2, 4 * 4096 + 777
+    tracks = 0.1 * torch.randn(bs, T, n)
+    tp, fp, mp = torch.rand(bs, T, 27), torch.rand(bs, 25), torch.rand(bs, 26)
+    gmix = torch.randn(bs, 2, n)
+    a = harness.console(ranges, tracks, tp, fp, mp, FULL, grad_mix=gmix, want_mixed=False, want_grad_tracks=True)
+    b = harness.console(ranges, tracks, tp, fp, mp, FULL, grad_mix=gmix, want_mixed=False, want_grad_tracks=True,
+                        multipass_eq=True)
+    assert a["status"] == 0 and b["status"] == 0
+    assert rel(a["mix"], b["mix"]) < 2e-6
+    assert rel(a["grad_tracks"], b["grad_tracks"]) < 2e-5
+    assert rel(a["grad_tp"], b["grad_tp"]) < 1e-4
+    assert rel(a["grad_mp"], b["grad_mp"]) < 1e-4
+
+
 def test_console_status_flag(ranges):
     tp, fp, mp = torch.rand(1, 1, 27), torch.rand(1, 25), torch.rand(1, 26)
     mp[0, 24] = 1.5
