@@ -47,6 +47,9 @@ constexpr float kLog2PerDb = 0.16609640474436813f;   // log2(10)/20
 constexpr float kLn10Over20 = 0.11512925464970229f;  // d/dg 10^(g/20) = that * 10^(g/20)
 constexpr float kCompEps = 1e-8f;                     // clamp of |side chain|
 
+// two fp32 lanes in one 64-bit register pair: arithmetic on it compiles to v_pk_fma_f32 / v_pk_mul_f32
+typedef float f2 __attribute__((vector_size(8)));
+
 __host__ __device__ inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 // filter (parameter) row of signal row `sig`: rows below `split` are mono tracks, the rest stereo pairs
 __host__ __device__ inline int filter_row(int sig, int split) { return sig < split ? sig : split + ((sig - split) >> 1); }

@@ -17,11 +17,13 @@ static int check_desc(const mst_console_desc* d) {
 }  // namespace mst
 
 namespace mst {
-AuxPool* aux_pool() {
+AuxPool* aux_pool(int feature) {
     static AuxPool pools[16];
     static int state[16] = {0};  // 0 = untried, 1 = ready, -1 = unavailable
-    static const bool disabled = getenv("MST_AUX_STREAMS") == nullptr;  // opt-in: measured slower on MI355X (round 1)
-    if (disabled) return nullptr;
+    // opt-in bit mask (MST_AUX_STREAMS): 1 = the STFT resolutions side by side (measured slower on MI355X, round 1),
+    // 2 = the all-pole pass of the console backward beside the master-bus chain
+    static const int enabled = getenv("MST_AUX_STREAMS") ? atoi(getenv("MST_AUX_STREAMS")) : 0;
+    if (!(enabled & feature)) return nullptr;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
     if (state[dev] == 0) {
@@ -133,8 +135,16 @@ extern "C" int mst_console_backward(const mst_console_desc* d, const float* trac
     // ---- all-pole states of the coefficient-gradient pass depend only on what forward saved: one
     // launch covers the track rows and the master rows (signal rows [0,R) and [R,R+2bs) of the same arrays)
     const int nsig_all = L.R + (m_on ? 2 * L.bs : 0);
-    launch_allpole_zs(ws + L.u_t, Ns, ws + L.rc_t, L.R, ws + L.zP_t, L.ncE_pad, n, nsig_all, stream);
-    launch_scan2(ws + L.zP_t, ws + L.sP_t, ws + L.powP_t, L.R, L.ncE, L.ncE_pad, L.KE, nsig_all, stream);
+    // They are independent of the (latency-bound, few-row) master chain below: with MST_AUX_STREAMS they run
+    // beside it on an auxiliary stream and are joined before the coefficient-gradient launch.
+    AuxPool* aux = m_on ? aux_pool(2) : nullptr;
+    hipStream_t side = stream;
+    if (aux) {
+        aux_fork(aux, stream, 0);
+        side = aux->s[0];
+    }
+    launch_allpole_zs(ws + L.u_t, Ns, ws + L.rc_t, L.R, ws + L.zP_t, L.ncE_pad, n, nsig_all, side);
+    launch_scan2(ws + L.zP_t, ws + L.sP_t, ws + L.powP_t, L.R, L.ncE, L.ncE_pad, L.KE, nsig_all, side);
 
     // ---- master bus: compressor adjoint, EQ adjoint (-> grad of the stereo bus)
     const float* gbus = grad_mix;  // cotangent of the stereo bus as seen by the track stage
@@ -171,6 +181,7 @@ extern "C" int mst_console_backward(const mst_console_desc* d, const float* trac
             ca.s0 = ws + L.zQ_t;
         }
         launch_comp_bwd(false, true, ca, L.R, stream);
+        if (aux) aux_join(aux, stream, 0);
         // coefficient-gradient sums for the track rows and (same launch) the master rows
         launch_coefgrad(ws + L.u_t, Ns, ws + L.du_t, Ns, ws + L.rc_t, L.R, ws + L.sP_t, L.ncE_pad, ws + L.ep_t, n, nsig_all, stream);
         if (grad_tracks) {

@@ -68,6 +68,32 @@ __device__ __forceinline__ void slab_store(const float* __restrict__ tile, float
     }
 }
 
+// Build-time variants of the staging pipeline (A/B on the GPU; defaults are the measured best):
+//   MST_EQ_PREFETCH  1: the next slab's global loads are issued before the current slab is filtered
+//                    0: each slab is fetched when it is needed (fewer live registers)
+//   MST_EQ_SCHEDBAR  1: a scheduling barrier closes every slab iteration (single-wave workgroups have no
+//                       real barrier, and the compiler otherwise hoists the staging of ALL slabs above the math)
+#ifndef MST_EQ_PREFETCH
+#define MST_EQ_PREFETCH 1
+#endif
+#ifndef MST_EQ_SCHEDBAR
+#define MST_EQ_SCHEDBAR 0
+#endif
+__device__ __forceinline__ void slab_first(SlabRegs& r, const float* __restrict__ row, int64_t tile_base, int j, int64_t n, int tid) {
+    if (MST_EQ_PREFETCH) slab_fetch(r, row, tile_base, j, n, tid);
+}
+__device__ __forceinline__ void slab_enter(SlabRegs& r, const float* __restrict__ row, int64_t tile_base, int j, int64_t n, int tid) {
+    if (!MST_EQ_PREFETCH) slab_fetch(r, row, tile_base, j, n, tid);
+}
+__device__ __forceinline__ void slab_next(SlabRegs& r, const float* __restrict__ row, int64_t tile_base, int j, bool valid, int64_t n, int tid) {
+    if (MST_EQ_PREFETCH && valid) slab_fetch(r, row, tile_base, j, n, tid);
+}
+__device__ __forceinline__ void slab_fence() {
+#if MST_EQ_SCHEDBAR
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+
 // MODE_RUN = false: zero-state pass, writes z[sig][12][nc_pad]
 // MODE_RUN = true : true pass from s0[sig][12][nc_pad], writes out
 // FUSE_GC (forward run of mono rows only): the compressor's static curve is evaluated on the fresh EQ
@@ -89,7 +115,7 @@ __global__ __launch_bounds__(kEqWG) void k_cascade(const float* __restrict__ in,
     float* outrow = MODE_RUN ? out + (int64_t)sig * out_stride : nullptr;
     auto order = [](int jj) { return (DIR == EQ_FWD) ? jj : kNSlab - 1 - jj; };
     SlabRegs pre;
-    slab_fetch(pre, inrow, tile_base, order(0), n, tid);  // first slab in flight while constants load
+    slab_first(pre, inrow, tile_base, order(0), n, tid);  // first slab in flight while constants load
 
     const float* coef = rc + (int64_t)filter_row(sig, split) * RC_STRIDE + RC_SOS;
     float c[5 * kSections];
@@ -100,7 +126,7 @@ __global__ __launch_bounds__(kEqWG) void k_cascade(const float* __restrict__ in,
     const float* tab = SCAN1 ? pw1 + (int64_t)filter_row(sig, split) * kPow1 * 144 : nullptr;
     static_assert(kTabFloats <= kEqWG * kLdw, "a scan table is staged through the slab buffer");
     TabRegs tlo, thi;  // M^(2^j): j = 0..5 (lanes of a tile) and j = 6..11 (tiles of a row)
-    if (SCAN1) tab_fetch(tlo, tab, tid);
+    if (SCAN1 && !MODE_RUN) tab_fetch(tlo, tab, tid);
     if (MODE_RUN && SCAN1) {
         tab_fetch(thi, tab + kTabFloats, tid);
         // s0 = the zs kernel's in-tile end states.  Mine starts from my predecessor lane's ...
@@ -114,6 +140,7 @@ __global__ __launch_bounds__(kEqWG) void k_cascade(const float* __restrict__ in,
 #pragma unroll
             for (int d = 0; d < kStates; ++d) zz[d] = tid < wt ? agg[((int64_t)sig * kStates + d) * kMaxTiles1 + tid] : 0.0f;
             tab_stash(thi, tile, tid);
+            tab_fetch(tlo, tab, tid);  // in flight during the scan over the tiles
             __syncthreads();
             wave_scan12<false>(zz, tile, tid, wt);
 #pragma unroll
@@ -138,9 +165,10 @@ __global__ __launch_bounds__(kEqWG) void k_cascade(const float* __restrict__ in,
 
     for (int jj = 0; jj < kNSlab; ++jj) {
         const int j = order(jj);
+        slab_enter(pre, inrow, tile_base, j, n, tid);
         slab_stash(pre, tile, tid);
         __syncthreads();
-        if (jj + 1 < kNSlab) slab_fetch(pre, inrow, tile_base, order(jj + 1), n, tid);
+        slab_next(pre, inrow, tile_base, order(jj + 1 < kNSlab ? jj + 1 : jj), jj + 1 < kNSlab, n, tid);
         if (DIR == EQ_FWD) {
 #pragma unroll
             for (int i4 = 0; i4 < kSlab; i4 += 4) {
@@ -174,6 +202,7 @@ __global__ __launch_bounds__(kEqWG) void k_cascade(const float* __restrict__ in,
             slab_store(tile, outrow, tile_base, j, n, tid);
             __syncthreads();  // the image is read by other lanes' stores before the next stash overwrites it
         }
+        slab_fence();
     }
     if (!MODE_RUN) {
         if (SCAN1) {
@@ -238,11 +267,12 @@ __global__ __launch_bounds__(kEqWG) void k_allpole_zs(const float* __restrict__ 
     const float* urow = u + (int64_t)sig * u_stride;
     float* mine = &tile[tid * kLdw];
     SlabRegs pre;
-    slab_fetch(pre, urow, tile_base, 0, n, tid);
+    slab_first(pre, urow, tile_base, 0, n, tid);
     for (int j = 0; j < kNSlab; ++j) {
+        slab_enter(pre, urow, tile_base, j, n, tid);
         slab_stash(pre, tile, tid);
         __syncthreads();
-        if (j + 1 < kNSlab) slab_fetch(pre, urow, tile_base, j + 1, n, tid);
+        slab_next(pre, urow, tile_base, j + 1, j + 1 < kNSlab, n, tid);
 #pragma unroll 4
         for (int i = 0; i < kSlab; ++i) {
             const float x = mine[i];
@@ -257,6 +287,7 @@ __global__ __launch_bounds__(kEqWG) void k_allpole_zs(const float* __restrict__ 
             }
         }
         __syncthreads();
+        slab_fence();
     }
 #pragma unroll
     for (int s = 0; s < kSections; ++s) {
@@ -280,54 +311,73 @@ __global__ __launch_bounds__(kEqWG) void k_coefgrad(const float* __restrict__ u,
     const int tid = threadIdx.x, sig = blockIdx.y;
     const int64_t tile_base = (int64_t)blockIdx.x * kEqWG * kEqChunk;
     const int chunk = blockIdx.x * kEqWG + tid;
-    ApCoef k;
-    load_ap(rc + (int64_t)filter_row(sig, split) * RC_STRIDE + RC_SOS, k);
-    float wa1[kSections], wa2[kSections], wb1[kSections], wb2[kSections];
+    // The two all-pole filters of a section, 1/A_k (lane .x) and 1/B_k (lane .y), advance as ONE packed
+    // recurrence  w = x*{1, 1/b0} - {a1, b1/b0} w1 - {a2, b2/b0} w2, and their five inner products with the
+    // cotangent accumulate in three packed sums: a section costs 1 v_pk_mul + 5 v_pk_fma per sample.
+    f2 k1[kSections], k2[kSections], kin[kSections];
+    {
+        const float* coef = rc + (int64_t)filter_row(sig, split) * RC_STRIDE + RC_SOS;
+#pragma unroll
+        for (int s = 0; s < kSections; ++s) {
+            const float ib0 = 1.0f / coef[5 * s];
+            k1[s] = f2{-coef[5 * s + 3], -(coef[5 * s + 1] / coef[5 * s])};
+            k2[s] = f2{-coef[5 * s + 4], -(coef[5 * s + 2] / coef[5 * s])};
+            kin[s] = f2{1.0f, ib0};
+        }
+    }
+    f2 w1[kSections], w2[kSections], a0[kSections], a1[kSections], a2[kSections];
 #pragma unroll
     for (int s = 0; s < kSections; ++s) {
         const int64_t base = ((int64_t)sig * 24 + 4 * s) * nc_pad + chunk;
-        wa1[s] = s0[base];
-        wa2[s] = s0[base + nc_pad];
-        wb1[s] = s0[base + 2 * (int64_t)nc_pad];
-        wb2[s] = s0[base + 3 * (int64_t)nc_pad];
+        w1[s] = f2{s0[base], s0[base + 2 * (int64_t)nc_pad]};
+        w2[s] = f2{s0[base + nc_pad], s0[base + 3 * (int64_t)nc_pad]};
+        a0[s] = a1[s] = a2[s] = f2{0.0f, 0.0f};
     }
-    float acc[EP_COUNT];
-#pragma unroll
-    for (int i = 0; i < EP_COUNT; ++i) acc[i] = 0.0f;
     const float* urow = u + (int64_t)sig * u_stride;
     const float* grow = g + (int64_t)sig * g_stride;
     float* mu = &tile_u[tid * kLdw];
     float* mg = &tile_g[tid * kLdw];
     SlabRegs pu, pg;
-    slab_fetch(pu, urow, tile_base, 0, n, tid);
-    slab_fetch(pg, grow, tile_base, 0, n, tid);
+    slab_first(pu, urow, tile_base, 0, n, tid);
+    slab_first(pg, grow, tile_base, 0, n, tid);
     for (int j = 0; j < kNSlab; ++j) {
+        slab_enter(pu, urow, tile_base, j, n, tid);
+        slab_enter(pg, grow, tile_base, j, n, tid);
         slab_stash(pu, tile_u, tid);
         slab_stash(pg, tile_g, tid);
         __syncthreads();
-        if (j + 1 < kNSlab) {
-            slab_fetch(pu, urow, tile_base, j + 1, n, tid);
-            slab_fetch(pg, grow, tile_base, j + 1, n, tid);
-        }
-#pragma unroll 2
-        for (int i = 0; i < kSlab; ++i) {
-            const float x = mu[i], gg = mg[i];
+        slab_next(pu, urow, tile_base, j + 1, j + 1 < kNSlab, n, tid);
+        slab_next(pg, grow, tile_base, j + 1, j + 1 < kNSlab, n, tid);
+#pragma unroll 1
+        for (int i4 = 0; i4 < kSlab; i4 += 4) {
+            const float4 xv = *reinterpret_cast<const float4*>(&mu[i4]);
+            const float4 gv = *reinterpret_cast<const float4*>(&mg[i4]);
+            const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, gs[4] = {gv.x, gv.y, gv.z, gv.w};
 #pragma unroll
-            for (int s = 0; s < kSections; ++s) {
-                const float wa = fmaf(-k.a2[s], wa2[s], fmaf(-k.a1[s], wa1[s], x));
-                const float wb = fmaf(-k.c2[s], wb2[s], fmaf(-k.c1[s], wb1[s], x * k.ib0[s]));
-                acc[5 * s + 0] = fmaf(gg, wb, acc[5 * s + 0]);
-                acc[5 * s + 1] = fmaf(gg, wb1[s], acc[5 * s + 1]);
-                acc[5 * s + 2] = fmaf(gg, wb2[s], acc[5 * s + 2]);
-                acc[5 * s + 3] = fmaf(-gg, wa1[s], acc[5 * s + 3]);
-                acc[5 * s + 4] = fmaf(-gg, wa2[s], acc[5 * s + 4]);
-                wa2[s] = wa1[s];
-                wa1[s] = wa;
-                wb2[s] = wb1[s];
-                wb1[s] = wb;
+            for (int t = 0; t < 4; ++t) {
+                const f2 xx = {xs[t], xs[t]}, gp = {gs[t], gs[t]}, gm = {-gs[t], gs[t]};
+#pragma unroll
+                for (int s = 0; s < kSections; ++s) {
+                    const f2 w = k2[s] * w2[s] + (k1[s] * w1[s] + xx * kin[s]);
+                    a0[s] += gp * w;       // .y: dL/db0
+                    a1[s] += gm * w1[s];   // .x: dL/da1   .y: dL/db1
+                    a2[s] += gm * w2[s];   // .x: dL/da2   .y: dL/db2
+                    w2[s] = w1[s];
+                    w1[s] = w;
+                }
             }
         }
         __syncthreads();
+        slab_fence();
+    }
+    float acc[EP_COUNT];
+#pragma unroll
+    for (int s = 0; s < kSections; ++s) {
+        acc[5 * s + 0] = a0[s][1];
+        acc[5 * s + 1] = a1[s][1];
+        acc[5 * s + 2] = a2[s][1];
+        acc[5 * s + 3] = a1[s][0];
+        acc[5 * s + 4] = a2[s][0];
     }
     // deterministic workgroup reduction: wave shuffle tree, then 4 wave partials in fixed order
     const int wave = tid >> 6, lane = tid & 63;

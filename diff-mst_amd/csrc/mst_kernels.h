@@ -124,7 +124,7 @@ struct AuxPool {
     hipEvent_t join[kStreams];
     bool ok;
 };
-AuxPool* aux_pool();  // nullptr when disabled or creation failed
+AuxPool* aux_pool(int feature);  // nullptr when that feature bit of MST_AUX_STREAMS is off or creation failed
 void aux_fork(AuxPool* p, hipStream_t main, int k);   // stream k waits for everything enqueued on `main` so far
 void aux_join(AuxPool* p, hipStream_t main, int k);   // `main` waits for everything enqueued on stream k so far
 

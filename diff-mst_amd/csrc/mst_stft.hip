@@ -486,7 +486,7 @@ extern "C" int mst_mrstft_forward(const mst_mrstft_desc* d, const float* pred, c
     la.sc_per_example = d->sc_per_example;
     // the resolutions are independent: run them side by side on auxiliary streams (a 1-workgroup-per-CU
     // n_fft = 8192 launch leaves room for the small-transform workgroups), join before the reduction
-    AuxPool* aux = d->n_res > 1 ? aux_pool() : nullptr;
+    AuxPool* aux = d->n_res > 1 ? aux_pool(1) : nullptr;
     hipStream_t main_stream = stream;
     for (int i = 0; i < d->n_res; ++i) {
         const int ak = i % (AuxPool::kStreams + 1);  // 0 = caller's stream
@@ -524,7 +524,7 @@ extern "C" int mst_mrstft_backward(const mst_mrstft_desc* d, const float* pred, 
     hipStream_t stream = (hipStream_t)stream_;
     float* ws = (float*)workspace;
     (void)hipMemsetAsync(grad_pred, 0, (size_t)d->rows * d->n_samples * sizeof(float), stream);
-    AuxPool* aux = d->n_res > 1 ? aux_pool() : nullptr;
+    AuxPool* aux = d->n_res > 1 ? aux_pool(1) : nullptr;
     hipStream_t main_stream = stream;
     for (int i = 0; i < d->n_res; ++i) {
         const int ak = i % (AuxPool::kStreams + 1);

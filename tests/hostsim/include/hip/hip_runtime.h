@@ -178,6 +178,7 @@ static inline int __all(int pred) {
 }
 static inline int __builtin_amdgcn_readfirstlane(int v) { return hostsim::shfl_idx(v, 0u); }
 static inline void __builtin_amdgcn_s_sleep(int) { std::this_thread::yield(); }
+static inline void __builtin_amdgcn_sched_barrier(int) {}
 
 // raw gfx950 transcendental builtins used by the kernels
 static inline float __builtin_amdgcn_logf(float x) { return log2f(x); }

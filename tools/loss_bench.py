@@ -5,8 +5,9 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "diff-mst_amd")]
 import torch
 from mst.loss import MultiResolutionSTFTLoss
 dev = torch.device("cuda:0")
-bs, n = 8, 262144
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+bs = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+n = int(sys.argv[3]) if len(sys.argv) > 3 else 262144
 torch.manual_seed(0)
 f = MultiResolutionSTFTLoss(fft_sizes=[512, 2048, 8192], hop_sizes=[256, 1024, 4096], win_lengths=[512, 2048, 8192])
 x = torch.randn(bs, 2, n, device=dev, requires_grad=True); y = torch.randn(bs, 2, n, device=dev)
@@ -18,4 +19,4 @@ e0.record()
 for _ in range(iters):
     x.grad = None; f(x, y).backward()
 e1.record(); torch.cuda.synchronize()
-print(f"mrstft fwd+bwd: {e0.elapsed_time(e1)/iters*1e3:.1f} us")
+print(f"mrstft bs={bs} n={n} fwd+bwd ms/step: {e0.elapsed_time(e1)/iters*1e3:.1f} us")
