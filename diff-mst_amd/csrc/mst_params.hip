@@ -140,7 +140,9 @@ __device__ __forceinline__ void mat12_mul(const double* A, const double* B, doub
     C[e] = acc;
 }
 
-// One workgroup (320 lanes) per filter row: rows [0,R) are tracks, [R,R+bs) master buses.
+// Two workgroups (320 lanes) per filter row: rows [0,R) are tracks, [R,R+bs) master buses.  Both design the
+// row (identical values, identical stores); workgroup y = 0 then builds the 12x12 cascade tables, y = 1 the
+// all-pole tables - two serial fp64 chains that would otherwise run back to back.
 __global__ __launch_bounds__(320) void k_prep(PrepArgs a) {
     __shared__ double mats[2][3][144];  // [fwd|adj][cur, tmp, acc]
     __shared__ float coef[32];
@@ -180,7 +182,7 @@ __global__ __launch_bounds__(320) void k_prep(PrepArgs a) {
                                denorm(p[i + 2], lo[i + 2], hi[i + 2]), sr, c);
         }
         for (int j = 0; j < 5; ++j) coef[5 * tid + j] = c[j];
-    } else if (tid == 6) {
+    } else if (tid == 64) {  // one wave per divergent fp64 branch: they run side by side
 #pragma clang fp contract(off)
         float thr = 0.f, kappa = 0.f, knee = 1.f, alpha = 0.f, mk = 0.f;
         if (comp_on) {
@@ -200,7 +202,7 @@ __global__ __launch_bounds__(320) void k_prep(PrepArgs a) {
         rc[RC_MAKEUP] = mk;
         rc[RC_ALPHA_C] = (float)pow((double)alpha, (double)kCompChunk);
         rc[RC_LOG2A_C] = alpha > 0.0f ? (float)((double)kCompChunk * log2((double)alpha)) : -1.0e30f;
-    } else if (tid == 7) {
+    } else if (tid == 128) {
 #pragma clang fp contract(off)
         float gin = 1.0f;
         const int gi = is_master ? 25 : 0;
@@ -229,6 +231,8 @@ __global__ __launch_bounds__(320) void k_prep(PrepArgs a) {
     // ---- one-sample transition matrices of the forward and the adjoint cascade (zero input)
     double c64[30];
     for (int i = 0; i < 30; ++i) c64[i] = (double)rc[RC_SOS + i];
+    const int part = blockIdx.y;
+    if (part == 0) {
     if (tid < 24) {
         const int which = tid / 12, col = tid % 12;
         double st[12];
@@ -298,9 +302,11 @@ __global__ __launch_bounds__(320) void k_prep(PrepArgs a) {
     }
     }
 
+    }  // part 0
+
     // ---- all-pole filters used by the coefficient-gradient pass: f = 2k (1/A_k), 2k+1 (1/B_k)
-    if (tid >= 288 && tid < 300) {
-        const int f = tid - 288, k = f >> 1;
+    if (part == 1 && tid < 12) {
+        const int f = tid, k = f >> 1;
         double c1, c2;
         if (f & 1) {
             c1 = c64[5 * k + 1] / c64[5 * k + 0];
@@ -340,9 +346,9 @@ __global__ __launch_bounds__(320) void k_prep(PrepArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// backward of the parameter maps.  One workgroup (64 lanes) per filter row.
+// backward of the parameter maps.  One workgroup (4 waves) per filter row.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_prep_bwd(PrepBwdArgs a) {
+__global__ __launch_bounds__(256) void k_prep_bwd(PrepBwdArgs a) {
     __shared__ double dsos[EP_COUNT];
     __shared__ double dcp[CP_COUNT];
     const int row = blockIdx.x, tid = threadIdx.x;
@@ -364,22 +370,47 @@ __global__ __launch_bounds__(64) void k_prep_bwd(PrepBwdArgs a) {
     const bool gin_on = is_master ? (d.flags & MST_USE_MASTER_BUS) : (d.flags & MST_USE_TRACK_INPUT_FADER);
     const bool chain_on = is_master ? (d.flags & MST_USE_MASTER_BUS) : true;  // does the EQ/gain stage exist
 
-    // deterministic reduction of the partial sums: lane-strided fp64 partials + a fixed shuffle tree
-    {
+    // deterministic reduction of the partial sums (wave 0).  All of a lane's loads are issued before anything is
+    // summed (one memory round trip instead of one per sum): lane l takes workgroup-partials l, l+64, ...
+    // as fp64, then a fixed shuffle tree folds the 64 lanes.
+    if (tid < 64) {
         const int nsig = is_master ? 2 : 1;
         const float* ep = is_master ? a.ep_m + ((int64_t)(mrow * 2) * a.nblkE) * EP_COUNT
                                     : a.ep_t + ((int64_t)row * a.nblkE) * EP_COUNT;
         const int nE = chain_on ? nsig * a.nblkE : 0;  // the two channels of a master row are adjacent
+        double se[EP_COUNT];
+#pragma unroll
+        for (int q = 0; q < EP_COUNT; ++q) se[q] = 0.0;
+        for (int b = tid; b < nE; b += 64) {
+            const float* pb = ep + (int64_t)b * EP_COUNT;  // 30 floats, 8-byte aligned
+            float2 v[EP_COUNT / 2];
+#pragma unroll
+            for (int q = 0; q < EP_COUNT / 2; ++q) v[q] = *reinterpret_cast<const float2*>(pb + 2 * q);
+#pragma unroll
+            for (int q = 0; q < EP_COUNT / 2; ++q) {
+                se[2 * q] += (double)v[q].x;
+                se[2 * q + 1] += (double)v[q].y;
+            }
+        }
+        const float* cp = is_master ? a.cp_m + ((int64_t)mrow * a.nblkC) * CP_COUNT : a.cp_t + ((int64_t)row * a.nblkC) * CP_COUNT;
+        double sc[CP_COUNT];
+#pragma unroll
+        for (int q = 0; q < CP_COUNT; ++q) sc[q] = 0.0;
+        for (int b = tid; b < a.nblkC; b += 64) {
+            const float4 v0 = *reinterpret_cast<const float4*>(cp + (int64_t)b * CP_COUNT);
+            const float4 v1 = *reinterpret_cast<const float4*>(cp + (int64_t)b * CP_COUNT + 4);
+            sc[0] += (double)v0.x; sc[1] += (double)v0.y; sc[2] += (double)v0.z; sc[3] += (double)v0.w;
+            sc[4] += (double)v1.x; sc[5] += (double)v1.y; sc[6] += (double)v1.z; sc[7] += (double)v1.w;
+        }
+#pragma unroll
         for (int q = 0; q < EP_COUNT; ++q) {
-            double s = 0.0;
-            for (int b = tid; b < nE; b += 64) s += (double)ep[(int64_t)b * EP_COUNT + q];
+            double s = se[q];
             for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
             if (tid == 0) dsos[q] = s;
         }
-        const float* cp = is_master ? a.cp_m + ((int64_t)mrow * a.nblkC) * CP_COUNT : a.cp_t + ((int64_t)row * a.nblkC) * CP_COUNT;
+#pragma unroll
         for (int q = 0; q < CP_COUNT; ++q) {
-            double s = 0.0;
-            for (int b = tid; b < a.nblkC; b += 64) s += (double)cp[(int64_t)b * CP_COUNT + q];
+            double s = sc[q];
             for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
             if (tid == 0) dcp[q] = s;
         }
@@ -401,7 +432,7 @@ __global__ __launch_bounds__(64) void k_prep_bwd(PrepBwdArgs a) {
                 g[i + v] = (float)(acc * (double)(hi[i + v] - lo[i + v]));
             }
         }
-    } else if (tid == 6) {
+    } else if (tid == 64) {  // one wave per divergent fp64 branch
         if (gin_on) {
             // d/d gin: section-0 numerator b' = gin*b  =>  sum_j dL/db'_j * b_j ;  b_j = b'_j / gin
             double acc = 0.0;
@@ -410,7 +441,7 @@ __global__ __launch_bounds__(64) void k_prep_bwd(PrepBwdArgs a) {
             // acc = gin * dL/dgin ; d gin / d gain_db = gin*ln10/20
             g[gi] = (float)(acc * (double)kLn10Over20 * (double)(hi[gi] - lo[gi]));
         }
-    } else if (tid == 7) {
+    } else if (tid == 128) {
         if (comp_on) {
             const double ratio = (double)denorm(p[cmp0 + 1], lo[cmp0 + 1], hi[cmp0 + 1]);
             const double att = (double)denorm(p[cmp0 + 2], lo[cmp0 + 2], hi[cmp0 + 2]);
@@ -423,7 +454,7 @@ __global__ __launch_bounds__(64) void k_prep_bwd(PrepBwdArgs a) {
             g[cmp0 + 4] = (float)(dcp[CP_KNEE] * (double)(hi[cmp0 + 4] - lo[cmp0 + 4]));
             g[cmp0 + 5] = (float)(dcp[CP_MAKEUP] * (double)(hi[cmp0 + 5] - lo[cmp0 + 5]));
         }
-    } else if (tid == 8) {
+    } else if (tid == 192) {
         if (is_master) {
             if (d.flags & MST_USE_OUTPUT_FADER) {
                 // CP_PANL holds sum(grad_out * out_before_fader); d gout/d db = gout*ln10/20
@@ -442,10 +473,10 @@ __global__ __launch_bounds__(64) void k_prep_bwd(PrepBwdArgs a) {
 }
 
 void launch_prep(const PrepArgs& a, hipStream_t stream) {
-    hipLaunchKernelGGL(k_prep, dim3(a.R + a.bs), dim3(320), 0, stream, a);
+    hipLaunchKernelGGL(k_prep, dim3(a.R + a.bs, 2), dim3(320), 0, stream, a);
 }
 void launch_prep_bwd(const PrepBwdArgs& a, hipStream_t stream) {
-    hipLaunchKernelGGL(k_prep_bwd, dim3(a.R + a.bs), dim3(64), 0, stream, a);
+    hipLaunchKernelGGL(k_prep_bwd, dim3(a.R + a.bs), dim3(256), 0, stream, a);
 }
 
 }  // namespace mst
