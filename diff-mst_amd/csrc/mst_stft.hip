@@ -91,6 +91,126 @@ __device__ __forceinline__ float2* lds_fft(float2* a, float2* b, const Twiddles<
     return a;
 }
 
+// ---- in-place variant (n_fft = 8192): ONE LDS buffer, so two workgroups share a CU ------------------
+// Measured on MI355X: the ping-pong 8192 kernels (1 workgroup of 1024 lanes per CU) lose only ~20 % per
+// workgroup when run with 512 lanes - they wait on barriers and LDS latency, not on throughput - so two
+// independent 512-lane workgroups per CU overlap each other's stalls.
+// (The forward kernel did not gain - 69-78 vs 62 us - and stays on the ping-pong transform by default.)
+//   fft_dif: decimation in frequency, natural order in, digit-reversed out (freq_pos() gives the slot of bin k)
+//   fft_dit: decimation in time, digit-reversed in (same map), natural order out
+// A leading (DIF) / trailing (DIT) radix-2 stage handles odd log2 n; the rest is radix-4.  Slots are bank-
+// swizzled (lds_swz) so that digit-reversed neighbours - consecutive bins - land in different banks.
+constexpr int ilog2(int n) { return n <= 1 ? 0 : 1 + ilog2(n >> 1); }
+template <int LOG2N>
+__device__ __forceinline__ int lds_swz(int a) { return a ^ ((a >> (LOG2N - 5)) & 31); }
+template <int DIGITS>
+__device__ __forceinline__ int rev4(int k) {  // reverse DIGITS base-4 digits
+    int r = 0;
+#pragma unroll
+    for (int i = 0; i < DIGITS; ++i) {
+        r = (r << 2) | (k & 3);
+        k >>= 2;
+    }
+    return r;
+}
+// slot (before swizzling) of bin k after fft_dif<N>, = slot sample k must be put in before fft_dit<N>
+template <int N>
+__device__ __forceinline__ int freq_pos(int k) {
+    constexpr int LG = ilog2(N);
+    if (LG & 1) return (k & 1) * (N / 2) + rev4<LG / 2>(k >> 1);
+    return rev4<LG / 2>(k);
+}
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+
+template <int N, int THREADS>
+__device__ __forceinline__ void fft_dif(float2* buf, const Twiddles<N>& T, int tid) {
+    constexpr int LG = ilog2(N);
+    constexpr bool ODD = LG & 1;
+    constexpr int M = ODD ? N / 2 : N;  // length of the radix-4 sub-transforms
+    if (ODD) {
+#pragma unroll
+        for (int j = tid; j < M; j += THREADS) {
+            const int p0 = lds_swz<LG>(j), p1 = lds_swz<LG>(j + M);
+            const float2 a = buf[p0], b = buf[p1];
+            buf[p0] = cadd(a, b);
+            buf[p1] = cmul(csub(a, b), cmul(T.coarse[j >> 6], T.fine[j & 63]));
+        }
+        __syncthreads();
+    }
+#pragma unroll 1
+    for (int L = M / 4; L >= 1; L >>= 2) {
+        const int tstep = N / (4 * L);
+#pragma unroll
+        for (int b = tid; b < N / 4; b += THREADS) {
+            const int h = ODD ? b / (M / 4) : 0, bb = ODD ? b % (M / 4) : b;
+            const int k = bb & (L - 1);
+            const int i0 = h * M + ((bb - k) << 2) + k;
+            const int p0 = lds_swz<LG>(i0), p1 = lds_swz<LG>(i0 + L), p2 = lds_swz<LG>(i0 + 2 * L), p3 = lds_swz<LG>(i0 + 3 * L);
+            const float2 u0 = buf[p0], u1 = buf[p1], u2 = buf[p2], u3 = buf[p3];
+            const float2 s02 = cadd(u0, u2), d02 = csub(u0, u2), s13 = cadd(u1, u3), d13 = csub(u1, u3);
+            float2 y1 = make_float2(d02.x + d13.y, d02.y - d13.x);  // d02 - i d13
+            float2 y2 = csub(s02, s13);
+            float2 y3 = make_float2(d02.x - d13.y, d02.y + d13.x);  // d02 + i d13
+            if (L > 1) {
+                const int t = k * tstep;
+                const float2 w1 = cmul(T.coarse[t >> 6], T.fine[t & 63]);
+                const float2 w2 = cmul(w1, w1);
+                y1 = cmul(y1, w1);
+                y2 = cmul(y2, w2);
+                y3 = cmul(y3, cmul(w2, w1));
+            }
+            buf[p0] = cadd(s02, s13);
+            buf[p1] = y1;
+            buf[p2] = y2;
+            buf[p3] = y3;
+        }
+        __syncthreads();
+    }
+}
+template <int N, int THREADS>
+__device__ __forceinline__ void fft_dit(float2* buf, const Twiddles<N>& T, int tid) {
+    constexpr int LG = ilog2(N);
+    constexpr bool ODD = LG & 1;
+    constexpr int M = ODD ? N / 2 : N;
+#pragma unroll 1
+    for (int L = 1; L < M; L <<= 2) {
+        const int tstep = N / (4 * L);
+#pragma unroll
+        for (int b = tid; b < N / 4; b += THREADS) {
+            const int h = ODD ? b / (M / 4) : 0, bb = ODD ? b % (M / 4) : b;
+            const int k = bb & (L - 1);
+            const int i0 = h * M + ((bb - k) << 2) + k;
+            const int p0 = lds_swz<LG>(i0), p1 = lds_swz<LG>(i0 + L), p2 = lds_swz<LG>(i0 + 2 * L), p3 = lds_swz<LG>(i0 + 3 * L);
+            float2 u0 = buf[p0], u1 = buf[p1], u2 = buf[p2], u3 = buf[p3];
+            if (L > 1) {
+                const int t = k * tstep;
+                const float2 w1 = cmul(T.coarse[t >> 6], T.fine[t & 63]);
+                const float2 w2 = cmul(w1, w1);
+                u1 = cmul(u1, w1);
+                u2 = cmul(u2, w2);
+                u3 = cmul(u3, cmul(w2, w1));
+            }
+            const float2 s02 = cadd(u0, u2), d02 = csub(u0, u2), s13 = cadd(u1, u3), d13 = csub(u1, u3);
+            buf[p0] = cadd(s02, s13);
+            buf[p1] = make_float2(d02.x + d13.y, d02.y - d13.x);
+            buf[p2] = csub(s02, s13);
+            buf[p3] = make_float2(d02.x - d13.y, d02.y + d13.x);
+        }
+        __syncthreads();
+    }
+    if (ODD) {
+#pragma unroll
+        for (int j = tid; j < M; j += THREADS) {
+            const int p0 = lds_swz<LG>(j), p1 = lds_swz<LG>(j + M);
+            const float2 a = buf[p0], b = cmul(buf[p1], cmul(T.coarse[j >> 6], T.fine[j & 63]));
+            buf[p0] = cadd(a, b);
+            buf[p1] = csub(a, b);
+        }
+        __syncthreads();
+    }
+}
+
 __device__ __forceinline__ int64_t reflect_index(int64_t i, int64_t n) {
     if (i < 0) i = -i;
     if (i >= n) i = 2 * (n - 1) - i;
@@ -124,14 +244,23 @@ struct StftArgs {
     float eps;
 };
 
+// bin k of a transform result: natural order (ping-pong kernels) or the swizzled digit-reversed slots of fft_dif
+template <int N, bool INPLACE>
+__device__ __forceinline__ float2 bin_at(const float2* buf, int k) {
+    return INPLACE ? buf[lds_swz<ilog2(N)>(freq_pos<N>(k))] : buf[k];
+}
 // separate the two real spectra packed in one complex FFT
-__device__ __forceinline__ void split_xy(const float2* buf, int k, int n_fft, float2& X, float2& Y) {
-    const float2 zk = buf[k], zn = buf[(n_fft - k) & (n_fft - 1)];
+template <int N, bool INPLACE>
+__device__ __forceinline__ void split_xy(const float2* buf, int k, float2& X, float2& Y) {
+    const float2 zk = bin_at<N, INPLACE>(buf, k), zn = bin_at<N, INPLACE>(buf, (N - k) & (N - 1));
     X = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
     Y = make_float2(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
 }
 
-constexpr int stft_threads(int n_fft) { return n_fft <= 512 ? 128 : (n_fft <= 2048 ? 512 : 1024); }
+#ifndef MST_STFT_T8192
+#define MST_STFT_T8192 1024
+#endif
+constexpr int stft_threads(int n_fft) { return n_fft <= 512 ? 128 : (n_fft <= 2048 ? 512 : (n_fft <= 4096 ? 1024 : MST_STFT_T8192)); }
 
 constexpr float kLn2 = 0.6931471805599453f;
 
@@ -156,7 +285,7 @@ __global__ __launch_bounds__(stft_threads(NFFT)) void k_stft_fwd(StftArgs a) {
         const float2* Z = lds_fft<NFFT, THREADS>(bufA, bufB, twd, tid);
         for (int k = tid; k < r.n_bins; k += THREADS) {
             float2 X, Y;
-            split_xy(Z, k, NFFT, X, Y);
+            split_xy<NFFT, false>(Z, k, X, Y);
             const float xm = sqrtf(fmaxf(X.x * X.x + X.y * X.y, a.eps));
             const float ym = sqrtf(fmaxf(Y.x * Y.x + Y.y * Y.y, a.eps));
             const float d = ym - xm;
@@ -180,9 +309,10 @@ __global__ __launch_bounds__(stft_threads(NFFT)) void k_stft_fwd(StftArgs a) {
 }
 
 // cotangent G[k] = dL/dX[k] of the prediction's half spectrum for the frame whose packed FFT is Z
-__device__ __forceinline__ float2 spectrum_cotangent(const float2* Z, int k, int n_fft, const StftArgs& a, const float* coef) {
+template <int N, bool INPLACE>
+__device__ __forceinline__ float2 spectrum_cotangent(const float2* Z, int k, const StftArgs& a, const float* coef) {
     float2 X, Y;
-    split_xy(Z, k, n_fft, X, Y);
+    split_xy<N, INPLACE>(Z, k, X, Y);
     const float p2 = X.x * X.x + X.y * X.y;
     const float xm = sqrtf(fmaxf(p2, a.eps));
     const float ym = sqrtf(fmaxf(Y.x * Y.x + Y.y * Y.y, a.eps));
@@ -234,7 +364,7 @@ __global__ __launch_bounds__(stft_threads(NFFT)) void k_stft_bwd(StftArgs a) {
     if constexpr (PAIR) {
         float2* H = bufH;  // conj(He) is assembled here
         for (int k = tid; k <= NFFT / 2; k += THREADS) {
-            const float2 G = spectrum_cotangent(Z, k, NFFT, a, coef);
+            const float2 G = spectrum_cotangent<NFFT, false>(Z, k, a, coef);
             const bool edge = (k == 0) || (k == NFFT / 2);
             // conj(He): He[k] = G/2 -> (Gx/2, -Gy/2); He[N-k] = conj(G)/2 -> (Gx/2, +Gy/2)
             H[k] = edge ? make_float2(G.x, 0.f) : make_float2(0.5f * G.x, -0.5f * G.y);
@@ -246,7 +376,7 @@ __global__ __launch_bounds__(stft_threads(NFFT)) void k_stft_bwd(StftArgs a) {
             __syncthreads();
             Z = lds_fft<NFFT, THREADS>(bufA, bufB, twd, tid);
             for (int k = tid; k <= NFFT / 2; k += THREADS) {
-                const float2 G = spectrum_cotangent(Z, k, NFFT, a, coef);
+                const float2 G = spectrum_cotangent<NFFT, false>(Z, k, a, coef);
                 const bool edge = (k == 0) || (k == NFFT / 2);
                 // conj(i He_b): i He[k] = i G/2 -> conj = (-Gy/2, -Gx/2);  i He[N-k] = i conj(G)/2 -> conj = (Gy/2, -Gx/2)
                 if (edge) {
@@ -269,7 +399,7 @@ __global__ __launch_bounds__(stft_threads(NFFT)) void k_stft_bwd(StftArgs a) {
     } else {
         // pair (k, M-k), k = 0..M/2, of the first-half Hermitian spectrum H[0..M] (H[k] = G[k]/2 inside, real at the ends)
         for (int k = tid; k <= M / 2; k += THREADS) {
-            float2 Hk = spectrum_cotangent(Z, k, NFFT, a, coef), Hm = spectrum_cotangent(Z, M - k, NFFT, a, coef);
+            float2 Hk = spectrum_cotangent<NFFT, false>(Z, k, a, coef), Hm = spectrum_cotangent<NFFT, false>(Z, M - k, a, coef);
             if (k == 0) {
                 // V[0] = (H0 + HM) + i (H0 - HM), both real; store conj
                 O[0] = make_float2(Hk.x + Hm.x, -(Hk.x - Hm.x));
@@ -295,6 +425,134 @@ __global__ __launch_bounds__(stft_threads(NFFT)) void k_stft_bwd(StftArgs a) {
             unsafeAtomicAdd(&gx[reflect_index(sa + 2 * m, a.n)], win[2 * m] * v.x);
             unsafeAtomicAdd(&gx[reflect_index(sa + 2 * m + 1, a.n)], -win[2 * m + 1] * v.y);
         }
+    }
+}
+
+// ---- the same two kernels on the in-place transform (used for n_fft = 8192) -------------------------
+constexpr int kIpThreads = 512;
+
+template <int NFFT>
+__device__ __forceinline__ void load_frame_ip(float2* buf, const float* __restrict__ x, const float* __restrict__ y,
+                                              const float* __restrict__ win, int f, const ResInfo& r, int64_t n, int tid) {
+    const int64_t start = (int64_t)f * r.hop - NFFT / 2;
+#pragma unroll 4
+    for (int k = tid; k < NFFT; k += kIpThreads) {
+        const int64_t i = reflect_index(start + k, n);
+        const float w = win[k];
+        buf[lds_swz<ilog2(NFFT)>(k)] = make_float2(w * x[i], w * y[i]);
+    }
+}
+
+template <int NFFT>
+__global__ __launch_bounds__(kIpThreads) void k_stft_fwd_ip(StftArgs a) {
+    constexpr int THREADS = kIpThreads;
+    __shared__ __attribute__((aligned(16))) float2 buf[NFFT];
+    __shared__ float red[THREADS / 64][4];
+    __shared__ Twiddles<NFFT> twd;
+    const int tid = threadIdx.x, row = blockIdx.y;
+    const ResInfo r = a.r;
+    stage_twiddles<NFFT>(twd, reinterpret_cast<const float2*>(a.tables + r.tw_off), tid, THREADS);
+    const float* win = a.tables + r.win_off;
+    const float* x = a.pred + (int64_t)row * a.n;
+    const float* y = a.target + (int64_t)row * a.n;
+    float s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f;
+    const int f0 = blockIdx.x * r.frames_per_wg;
+    for (int f = f0; f < f0 + r.frames_per_wg && f < r.n_frames; ++f) {
+        load_frame_ip<NFFT>(buf, x, y, win, f, r, a.n, tid);
+        __syncthreads();
+        fft_dif<NFFT, THREADS>(buf, twd, tid);
+        for (int k = tid; k < r.n_bins; k += THREADS) {
+            float2 X, Y;
+            split_xy<NFFT, true>(buf, k, X, Y);
+            const float xm = sqrtf(fmaxf(X.x * X.x + X.y * X.y, a.eps));
+            const float ym = sqrtf(fmaxf(Y.x * Y.x + Y.y * Y.y, a.eps));
+            const float d = ym - xm;
+            s1 = fmaf(d, d, s1);
+            s2 = fmaf(ym, ym, s2);
+            s3 += fabsf(__builtin_amdgcn_logf(xm) - __builtin_amdgcn_logf(ym));  // log2; scaled by ln2 below
+            s4 += fabsf(d);
+        }
+        __syncthreads();
+    }
+    s3 *= kLn2;
+    const int wave = tid >> 6, lane = tid & 63;
+    s1 = wave_sum(s1); s2 = wave_sum(s2); s3 = wave_sum(s3); s4 = wave_sum(s4);
+    if (lane == 0) { red[wave][0] = s1; red[wave][1] = s2; red[wave][2] = s3; red[wave][3] = s4; }
+    __syncthreads();
+    if (tid < 4) {
+        float v = 0.f;
+        for (int w = 0; w < THREADS / 64; ++w) v += red[w][tid];
+        a.part[((int64_t)row * gridDim.x + blockIdx.x) * 4 + tid] = v;
+    }
+}
+
+// one frame per workgroup; the real cotangent frame comes out of a HALF-size complex transform (see k_stft_bwd, !PAIR)
+template <int NFFT>
+__global__ __launch_bounds__(kIpThreads) void k_stft_bwd_ip(StftArgs a) {
+    constexpr int THREADS = kIpThreads;
+    constexpr int M = NFFT / 2;
+    constexpr int LGM = ilog2(M);
+    constexpr int PER = (M / 2 + 1 + THREADS - 1) / THREADS;  // (k, M-k) pairs per lane
+    __shared__ __attribute__((aligned(16))) float2 buf[NFFT];
+    __shared__ Twiddles<NFFT> twd;
+    __shared__ Twiddles<M> twh;
+    const ResInfo r = a.r;
+    const int tid = threadIdx.x, row = blockIdx.y;
+    const float2* twg = reinterpret_cast<const float2*>(a.tables + r.tw_off);
+    stage_twiddles<NFFT>(twd, twg, tid, THREADS);
+    for (int i = tid; i < M / 64; i += THREADS) twh.coarse[i] = twg[2 * 64 * i];  // W_M^t = W_N^(2t)
+    for (int i = tid; i < 64; i += THREADS) twh.fine[i] = twg[2 * i];
+    const float* win = a.tables + r.win_off;
+    const float* x = a.pred + (int64_t)row * a.n;
+    const float* y = a.target + (int64_t)row * a.n;
+    const float gl = a.grad_loss[0];
+    const float coef[3] = {a.coef[(int64_t)row * 4] * gl, a.coef[(int64_t)row * 4 + 1] * gl, a.coef[(int64_t)row * 4 + 2] * gl};
+    float* gx = a.grad_pred + (int64_t)row * a.n;
+    const int fa = blockIdx.x;
+    const int64_t sa = (int64_t)fa * r.hop - NFFT / 2;
+
+    load_frame_ip<NFFT>(buf, x, y, win, fa, r, a.n, tid);
+    __syncthreads();
+    fft_dif<NFFT, THREADS>(buf, twd, tid);
+    // conj(A + i Bq) for the pairs (k, M-k), k = 0..M/2, kept in registers until every lane has read its bins
+    float2 Vk[PER], Vm[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int k = tid + i * THREADS;
+        Vk[i] = Vm[i] = make_float2(0.f, 0.f);
+        if (k <= M / 2) {
+            float2 Hk = spectrum_cotangent<NFFT, true>(buf, k, a, coef), Hm = spectrum_cotangent<NFFT, true>(buf, M - k, a, coef);
+            if (k == 0) {
+                Vk[i] = make_float2(Hk.x + Hm.x, -(Hk.x - Hm.x));  // V[0] = (H0 + HM) + i (H0 - HM), both real; conj
+            } else {
+                Hk = make_float2(0.5f * Hk.x, 0.5f * Hk.y);
+                Hm = make_float2(0.5f * Hm.x, 0.5f * Hm.y);
+                const float2 w = cmul(twd.coarse[k >> 6], twd.fine[k & 63]);  // W_N^k ; W_N^(M-k) = -conj(W_N^k)
+                const float2 Ak = make_float2(Hk.x + Hm.x, Hk.y - Hm.y);
+                const float2 Bk = cmul(make_float2(Hk.x - Hm.x, Hk.y + Hm.y), make_float2(w.x, -w.y));
+                Vk[i] = make_float2(Ak.x - Bk.y, -(Ak.y + Bk.x));
+                const float2 Am = make_float2(Hm.x + Hk.x, Hm.y - Hk.y);
+                const float2 Bm = cmul(make_float2(Hm.x - Hk.x, Hm.y + Hk.y), make_float2(-w.x, -w.y));
+                Vm[i] = make_float2(Am.x - Bm.y, -(Am.y + Bm.x));
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int k = tid + i * THREADS;
+        if (k <= M / 2) {
+            buf[lds_swz<LGM>(freq_pos<M>(k))] = Vk[i];
+            if (k != 0 && k != M / 2) buf[lds_swz<LGM>(freq_pos<M>(M - k))] = Vm[i];
+        }
+    }
+    __syncthreads();
+    // half-size forward transform of conj(V): natural-order result = conj(y_even + i y_odd)
+    fft_dit<M, THREADS>(buf, twh, tid);
+    for (int m = tid; m < M; m += THREADS) {
+        const float2 v = buf[lds_swz<LGM>(m)];
+        unsafeAtomicAdd(&gx[reflect_index(sa + 2 * m, a.n)], win[2 * m] * v.x);
+        unsafeAtomicAdd(&gx[reflect_index(sa + 2 * m + 1, a.n)], -win[2 * m + 1] * v.y);
     }
 }
 
@@ -436,6 +694,14 @@ Plan make_plan(const mst_mrstft_desc* d) {
     p.ok = true;
     return p;
 }
+// n_fft = 8192: the backward runs on the in-place kernel (two workgroups per CU: 105 vs 128 us at cfg #2), the
+// forward stays on the two-buffer kernel (in place it measured 69-78 vs 62 us).  Developer switches for A/B:
+// MST_STFT_PINGPONG=1 -> two-buffer kernels everywhere; MST_STFT_INPLACE_FWD=1 -> in-place forward as well.
+static bool inplace_8192(bool forward) {
+    static const bool off = getenv("MST_STFT_PINGPONG") != nullptr;
+    static const bool fwd = getenv("MST_STFT_INPLACE_FWD") != nullptr;
+    return !off && (!forward || fwd);
+}
 #define MST_FOR_NFFT(nf, CALL) \
     switch (nf) {               \
         case 128: CALL(128); break;   \
@@ -503,7 +769,10 @@ extern "C" int mst_mrstft_forward(const mst_mrstft_desc* d, const float* pred, c
         a.eps = d->eps;
         const dim3 grid(p.n_groups[i], d->rows);
 #define MST_LAUNCH_FWD(NF) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stft_fwd<NF>), grid, dim3(stft_threads(NF)), 0, stream, a)
-        MST_FOR_NFFT(a.r.n_fft, MST_LAUNCH_FWD)
+        if (a.r.n_fft == 8192 && inplace_8192(true))
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stft_fwd_ip<8192>), grid, dim3(kIpThreads), 0, stream, a);
+        else
+            MST_FOR_NFFT(a.r.n_fft, MST_LAUNCH_FWD)
         la.n_groups[i] = p.n_groups[i];
         la.part_off[i] = p.part_off[i];
         la.count[i] = (float)((double)d->rows * p.res[i].n_bins * p.res[i].n_frames);
@@ -548,7 +817,10 @@ extern "C" int mst_mrstft_backward(const mst_mrstft_desc* d, const float* pred, 
 #define MST_LAUNCH_BWD(NF)                                                                                             \
     if (NF <= 4096) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stft_bwd<NF, (NF <= 4096)>), grid, dim3(stft_threads(NF)), 0, stream, a); \
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stft_bwd<NF, false>), grid, dim3(stft_threads(NF)), 0, stream, a)
-        MST_FOR_NFFT(a.r.n_fft, MST_LAUNCH_BWD)
+        if (a.r.n_fft == 8192 && inplace_8192(false))
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stft_bwd_ip<8192>), grid, dim3(kIpThreads), 0, stream, a);
+        else
+            MST_FOR_NFFT(a.r.n_fft, MST_LAUNCH_BWD)
         if (aux && ak > 0) aux_join(aux, main_stream, ak - 1);
     }
     stream = main_stream;

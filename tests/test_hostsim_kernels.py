@@ -86,6 +86,23 @@ def test_mrstft_small():
     assert abs(full["loss"].item() - ol.mrstft_loss(x.double(), y.double(), res).item()) < 1e-5
 
 
+def test_mrstft_8192_inplace_transform():
+    """n_fft = 8192 runs on the in-place kernels (fft_dif / fft_dit, digit-reversed slots, bank swizzle)."""
+    torch.manual_seed(5)
+    x = 0.3 * torch.randn(1, 1, 20000)
+    y = 0.6 * x + 0.2 * torch.randn(1, 1, 20000)
+    res = ((8192, 4096, 8192),)
+    full = harness.mrstft(x, y, res, grad=False)
+    assert abs(full["loss"].item() - ol.mrstft_loss(x.double(), y.double(), res).item()) < 1e-5
+    # gradient of the well-conditioned term only (d log|X| ~ 1/|X| is fp32-noise-limited, see the GPU tests)
+    out = harness.mrstft(x, y, res, w_sc=1.0, w_log_mag=0.0)
+    xo = x.double().requires_grad_(True)
+    lo = ol.mrstft_loss(xo, y.double(), res, w_sc=1.0, w_log_mag=0.0)
+    lo.backward()
+    assert abs(out["loss"].item() - lo.item()) / lo.item() < 1e-6
+    assert rel(out["grad_pred"], xo.grad) < 1e-5
+
+
 def test_afloss_small():
     torch.manual_seed(0)
     n = 17000  # just above the 16384-sample reflect pad: 3 frames
