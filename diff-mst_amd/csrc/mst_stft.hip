@@ -43,12 +43,13 @@ __device__ __forceinline__ void stage_twiddles(Twiddles<NFFT>& T, const float2* 
     for (int i = tid; i < NFFT / 64; i += nthreads) T.coarse[i] = tw[i * 64];
     for (int i = tid; i < 64; i += nthreads) T.fine[i] = tw[i];
 }
-template <int NFFT, int THREADS>
+// R2_DONE: the caller already applied the leading radix-2 stage while loading (load_frame<..., true>)
+template <int NFFT, int THREADS, bool R2_DONE = false>
 __device__ __forceinline__ float2* lds_fft(float2* a, float2* b, const Twiddles<NFFT>& T, int tid) {
     constexpr int LOG2N = (NFFT == 128) ? 7 : (NFFT == 256) ? 8 : (NFFT == 512) ? 9 : (NFFT == 1024) ? 10
                         : (NFFT == 2048) ? 11 : (NFFT == 4096) ? 12 : 13;
-    int Ns = 1;
-    if (LOG2N & 1) {
+    int Ns = ((LOG2N & 1) && R2_DONE) ? 2 : 1;
+    if ((LOG2N & 1) && !R2_DONE) {
         constexpr int h = NFFT >> 1;
 #pragma unroll
         for (int j = tid; j < h; j += THREADS) {
@@ -123,12 +124,12 @@ __device__ __forceinline__ int freq_pos(int k) {
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 
-template <int N, int THREADS>
+template <int N, int THREADS, bool R2_DONE = false>  // R2_DONE: the loader applied the leading radix-2 stage
 __device__ __forceinline__ void fft_dif(float2* buf, const Twiddles<N>& T, int tid) {
     constexpr int LG = ilog2(N);
     constexpr bool ODD = LG & 1;
     constexpr int M = ODD ? N / 2 : N;  // length of the radix-4 sub-transforms
-    if (ODD) {
+    if (ODD && !R2_DONE) {
 #pragma unroll
         for (int j = tid; j < M; j += THREADS) {
             const int p0 = lds_swz<LG>(j), p1 = lds_swz<LG>(j + M);
@@ -217,11 +218,24 @@ __device__ __forceinline__ int64_t reflect_index(int64_t i, int64_t n) {
     return i;
 }
 
-// load frame f of (x, y) as z = w (x + i y), natural order
+// load frame f of (x, y) as z = w (x + i y), natural order.
+// R2 (odd log2 n_fft): the transform's leading radix-2 stage is applied on the way in - points j and j + n/2
+// are fetched together and (z_j + z_(j+n/2), z_j - z_(j+n/2)) stored at 2j, 2j+1 - one LDS pass and one barrier less.
+template <bool R2>
 __device__ __forceinline__ void load_frame(float2* buf, const float* __restrict__ x, const float* __restrict__ y,
                                            const float* __restrict__ win, int f, const ResInfo& r, int64_t n, int tid,
                                            int nthreads) {
     const int64_t start = (int64_t)f * r.hop - r.n_fft / 2;
+    if (R2) {
+        const int h = r.n_fft / 2;
+        for (int j = tid; j < h; j += nthreads) {
+            const int64_t i0 = reflect_index(start + j, n), i1 = reflect_index(start + j + h, n);
+            const float w0 = win[j], w1 = win[j + h];
+            const float2 u0 = make_float2(w0 * x[i0], w0 * y[i0]), u1 = make_float2(w1 * x[i1], w1 * y[i1]);
+            *reinterpret_cast<float4*>(&buf[2 * j]) = make_float4(u0.x + u1.x, u0.y + u1.y, u0.x - u1.x, u0.y - u1.y);
+        }
+        return;
+    }
     for (int k = tid; k < r.n_fft; k += nthreads) {
         const int64_t i = reflect_index(start + k, n);
         const float w = win[k];
@@ -267,6 +281,7 @@ constexpr float kLn2 = 0.6931471805599453f;
 template <int NFFT>
 __global__ __launch_bounds__(stft_threads(NFFT)) void k_stft_fwd(StftArgs a) {
     constexpr int THREADS = stft_threads(NFFT);
+    constexpr bool kOddLog2 = ilog2(NFFT) & 1;
     __shared__ __attribute__((aligned(16))) float2 bufA[NFFT];
     __shared__ __attribute__((aligned(16))) float2 bufB[NFFT];
     __shared__ float red[16][4];
@@ -280,9 +295,9 @@ __global__ __launch_bounds__(stft_threads(NFFT)) void k_stft_fwd(StftArgs a) {
     float s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f;
     const int f0 = blockIdx.x * r.frames_per_wg;
     for (int f = f0; f < f0 + r.frames_per_wg && f < r.n_frames; ++f) {
-        load_frame(bufA, x, y, win, f, r, a.n, tid, THREADS);
+        load_frame<kOddLog2>(bufA, x, y, win, f, r, a.n, tid, THREADS);
         __syncthreads();
-        const float2* Z = lds_fft<NFFT, THREADS>(bufA, bufB, twd, tid);
+        const float2* Z = lds_fft<NFFT, THREADS, true>(bufA, bufB, twd, tid);
         for (int k = tid; k < r.n_bins; k += THREADS) {
             float2 X, Y;
             split_xy<NFFT, false>(Z, k, X, Y);
@@ -357,9 +372,10 @@ __global__ __launch_bounds__(stft_threads(NFFT)) void k_stft_bwd(StftArgs a) {
     const bool have_b = PAIR && fb < r.n_frames;
     const int64_t sa = (int64_t)fa * r.hop - NFFT / 2, sb = (int64_t)fb * r.hop - NFFT / 2;
 
-    load_frame(bufA, x, y, win, fa, r, a.n, tid, THREADS);
+    constexpr bool kOddLog2 = ilog2(NFFT) & 1;
+    load_frame<kOddLog2>(bufA, x, y, win, fa, r, a.n, tid, THREADS);
     __syncthreads();
-    float2* Z = lds_fft<NFFT, THREADS>(bufA, bufB, twd, tid);
+    float2* Z = lds_fft<NFFT, THREADS, true>(bufA, bufB, twd, tid);
     float2* O = (Z == bufA) ? bufB : bufA;  // the buffer the forward result is NOT in
     if constexpr (PAIR) {
         float2* H = bufH;  // conj(He) is assembled here
@@ -372,9 +388,9 @@ __global__ __launch_bounds__(stft_threads(NFFT)) void k_stft_bwd(StftArgs a) {
         }
         __syncthreads();
         if (have_b) {
-            load_frame(bufA, x, y, win, fb, r, a.n, tid, THREADS);
+            load_frame<kOddLog2>(bufA, x, y, win, fb, r, a.n, tid, THREADS);
             __syncthreads();
-            Z = lds_fft<NFFT, THREADS>(bufA, bufB, twd, tid);
+            Z = lds_fft<NFFT, THREADS, true>(bufA, bufB, twd, tid);
             for (int k = tid; k <= NFFT / 2; k += THREADS) {
                 const float2 G = spectrum_cotangent<NFFT, false>(Z, k, a, coef);
                 const bool edge = (k == 0) || (k == NFFT / 2);
@@ -431,15 +447,22 @@ __global__ __launch_bounds__(stft_threads(NFFT)) void k_stft_bwd(StftArgs a) {
 // ---- the same two kernels on the in-place transform (used for n_fft = 8192) -------------------------
 constexpr int kIpThreads = 512;
 
+// frame f as z = w (x + i y) with fft_dif's leading radix-2 stage applied on the way in (n_fft with odd log2):
+// slot j <- z_j + z_(j+n/2),  slot j + n/2 <- (z_j - z_(j+n/2)) W_n^j   (tw = the exactly rounded global table)
 template <int NFFT>
 __device__ __forceinline__ void load_frame_ip(float2* buf, const float* __restrict__ x, const float* __restrict__ y,
-                                              const float* __restrict__ win, int f, const ResInfo& r, int64_t n, int tid) {
+                                              const float* __restrict__ win, const float2* __restrict__ tw, int f,
+                                              const ResInfo& r, int64_t n, int tid) {
+    static_assert(ilog2(NFFT) & 1, "the fused radix-2 stage needs an odd log2 n_fft");
+    constexpr int LG = ilog2(NFFT), h = NFFT / 2;
     const int64_t start = (int64_t)f * r.hop - NFFT / 2;
 #pragma unroll 4
-    for (int k = tid; k < NFFT; k += kIpThreads) {
-        const int64_t i = reflect_index(start + k, n);
-        const float w = win[k];
-        buf[lds_swz<ilog2(NFFT)>(k)] = make_float2(w * x[i], w * y[i]);
+    for (int j = tid; j < h; j += kIpThreads) {
+        const int64_t i0 = reflect_index(start + j, n), i1 = reflect_index(start + j + h, n);
+        const float w0 = win[j], w1 = win[j + h];
+        const float2 u0 = make_float2(w0 * x[i0], w0 * y[i0]), u1 = make_float2(w1 * x[i1], w1 * y[i1]);
+        buf[lds_swz<LG>(j)] = cadd(u0, u1);
+        buf[lds_swz<LG>(j + h)] = cmul(csub(u0, u1), tw[j]);
     }
 }
 
@@ -458,9 +481,9 @@ __global__ __launch_bounds__(kIpThreads) void k_stft_fwd_ip(StftArgs a) {
     float s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f;
     const int f0 = blockIdx.x * r.frames_per_wg;
     for (int f = f0; f < f0 + r.frames_per_wg && f < r.n_frames; ++f) {
-        load_frame_ip<NFFT>(buf, x, y, win, f, r, a.n, tid);
+        load_frame_ip<NFFT>(buf, x, y, win, reinterpret_cast<const float2*>(a.tables + r.tw_off), f, r, a.n, tid);
         __syncthreads();
-        fft_dif<NFFT, THREADS>(buf, twd, tid);
+        fft_dif<NFFT, THREADS, true>(buf, twd, tid);
         for (int k = tid; k < r.n_bins; k += THREADS) {
             float2 X, Y;
             split_xy<NFFT, true>(buf, k, X, Y);
@@ -511,9 +534,9 @@ __global__ __launch_bounds__(kIpThreads) void k_stft_bwd_ip(StftArgs a) {
     const int fa = blockIdx.x;
     const int64_t sa = (int64_t)fa * r.hop - NFFT / 2;
 
-    load_frame_ip<NFFT>(buf, x, y, win, fa, r, a.n, tid);
+    load_frame_ip<NFFT>(buf, x, y, win, twg, fa, r, a.n, tid);
     __syncthreads();
-    fft_dif<NFFT, THREADS>(buf, twd, tid);
+    fft_dif<NFFT, THREADS, true>(buf, twd, tid);
     // conj(A + i Bq) for the pairs (k, M-k), k = 0..M/2, kept in registers until every lane has read its bins
     float2 Vk[PER], Vm[PER];
 #pragma unroll
