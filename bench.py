@@ -206,7 +206,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(),
-                "kernel": "whole step = the ~37 back-to-back kernels of console fwd+bwd + MR-STFT fwd+bwd (no single kernel "
+                "kernel": "whole step = the ~33 back-to-back kernels of console fwd+bwd + MR-STFT fwd+bwd (no single kernel "
                           "exceeds 13 % of the step, see profiles/round1_summary.md); HIP-event time per step",
                 "algorithmic_bytes_per_step": BS * BYTES_PER_MIX, "gpu_ms_per_step": gpu_ms_per_step, "stages": stages,
             },

@@ -1,9 +1,11 @@
 // mst_scan.hip - carry scans that turn per-chunk zero-state end states into true start states:
 //      s0[c+1] = M s0[c] + z[c]      (forward)       s0[c-1] = M s0[c] + z[c]   (reverse)
 // with a constant D x D matrix per row (D = 12 cascade, D = 2 all-pole, D = 1 envelope smoother).
-// One 1024-lane workgroup per row: each lane folds K consecutive chunks sequentially, a
-// Hillis-Steele scan over the 1024 lane aggregates uses the precomputed powers M^(K 2^j)
-// (uniform per row => scalar loads), then each lane replays its K chunks from its true start.
+// One 512-lane workgroup per row: each lane folds K consecutive chunks sequentially, a
+// Hillis-Steele scan over the 512 lane aggregates uses the precomputed powers M^(K 2^j)
+// (staged in LDS, every read a broadcast), then each lane replays its K chunks from its true start.
+// The EQ cascades of rows up to 262144 samples do NOT come here: their carries are scanned inside the
+// zs / run kernels (mst_eq.hip, SCAN1); this kernel serves the all-pole bank and longer rows.
 #include "mst_kernels.h"
 #include "mst_mat.h"
 

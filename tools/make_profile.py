@@ -50,8 +50,6 @@ def main(stats_steps, pmc_steps):
         "fetch_kb_per_step": fk, "write_kb_per_step": wk,
         "hbm_bytes_per_step_raw": (fk + wk) * 1024.0,
         "algorithmic_bytes_per_step": 218103808,
-        "per_kernel_fetch_kb_per_step": {k: v * f["per_step"] * 0 + v * (json.load(open(os.path.join(G, "r1_fetch.json")))["per_step"] and 1) for k, v in f["per_kernel_per_step"].items()},
-        "per_kernel_write_kb_per_step": w["per_kernel_per_step"],
         "note": "raw FETCH_SIZE/WRITE_SIZE (KB) summed over the mst:: kernels and divided by the steps executed (the one extra "
                 "no-grad console forward that builds the reference mix is included in the sum). Calibration on kernels with a "
                 "known byte count: k_comp_bwd_run<false> reads u + gs = 134 MB -> FETCH 148 MB, writes 67 MB -> WRITE 66 MB "
