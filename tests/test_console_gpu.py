@@ -259,6 +259,59 @@ def test_linearity_and_determinism_full_size(console, dev):
     del flags
 
 
+def test_inwave_scan_equals_carry_scan_kernel_full_size(console, dev, monkeypatch):
+    """The two EQ carry-resolution paths (in-wave scans, taken up to 262144 samples; separate carry-scan kernel,
+    taken beyond) on the SAME cfg #2-sized input, forward and backward: fp32 round-off apart."""
+    torch.manual_seed(21)
+    bs, T, n = 2, 8, 262144
+    tracks = 0.1 * torch.randn(bs, T, n)
+    tp, fp, mp = torch.rand(bs, T, 27), torch.rand(bs, 25), torch.rand(bs, 26)
+    gmix = torch.randn(bs, 2, n)
+    a = run_hip(console, dev, tracks, tp, fp, mp, FULL, gmix=gmix, grad_tracks=True)
+    monkeypatch.setenv("MST_MULTIPASS_EQ", "1")
+    b = run_hip(console, dev, tracks, tp, fp, mp, FULL, gmix=gmix, grad_tracks=True)
+    assert rel(a["mix"], b["mix"]) < 5e-6
+    # the cotangents pass the compressors' knees / abs(): 1e-6 differences of u move them by ~1e-3 in BOTH paths
+    # (each sits 3e-4 from float64, like the fp32 reference itself - tools/dbg_gtracks.py)
+    assert rel(a["g_tracks"], b["g_tracks"]) < 5e-3
+    assert rel(a["g_tp"], b["g_tp"]) < 5e-3 and rel(a["g_mp"], b["g_mp"]) < 5e-3
+
+
+def test_rows_longer_than_the_inwave_limit(console, dev):
+    """N = 2^19 + 5: 129 tiles per row, so the EQ goes through the carry-scan kernel; truth = float64 time domain
+    (the frequency-sampling reference at this length is the same filter)."""
+    torch.manual_seed(22)
+    bs, T, n = 1, 2, (1 << 19) + 5
+    tracks = 0.1 * torch.randn(bs, T, n)
+    tp, fp, mp = torch.rand(bs, T, 27), torch.rand(bs, 25), torch.rand(bs, 26)
+    gmix = torch.randn(bs, 2, n)
+    hip = run_hip(console, dev, tracks, tp, fp, mp, FULL, gmix=gmix)
+    r32 = run_oracle(tracks, tp, fp, mp, FULL, gmix=gmix)
+    r64 = run_oracle(tracks, tp, fp, mp, FULL, gmix=gmix, dtype=torch.float64)
+    assert rel(hip["mix"], r32["mix"]) < 1e-4
+    assert_three_way(hip, r32, r64, "g_tp", 3e-2)
+    assert_three_way(hip, r32, r64, "g_mp", 3e-2)
+
+
+def test_cfg3_shape_batch_independence(console, dev):
+    """SURVEY cfg #3 shape (bs 32, T 16, N 262144: 512 track rows, ~4 GB of workspace): one mix of the big batch
+    against the oracle run on that mix alone (mixes never interact), plus bitwise determinism."""
+    torch.manual_seed(23)
+    bs, T, n = 32, 16, 262144
+    tracks = 0.1 * torch.randn(bs, T, n)
+    tp, fp, mp = torch.rand(bs, T, 27), torch.rand(bs, 25), torch.rand(bs, 26)
+    gmix = torch.randn(bs, 2, n)
+    lean = type(console)(44100, materialize_mixed_tracks=False)
+    a = run_hip(lean, dev, tracks, tp, fp, mp, FULL, gmix=gmix)
+    b = run_hip(lean, dev, tracks, tp, fp, mp, FULL, gmix=gmix)
+    assert torch.equal(a["mix"], b["mix"]) and torch.equal(a["g_tp"], b["g_tp"]) and torch.equal(a["g_mp"], b["g_mp"])
+    assert torch.isfinite(a["g_tp"]).all() and torch.isfinite(a["g_mp"]).all()
+    i = 29
+    one = run_oracle(tracks[i:i + 1], tp[i:i + 1], fp[i:i + 1], mp[i:i + 1], FULL, gmix=gmix[i:i + 1])
+    assert rel(a["mix"][i:i + 1], one["mix"]) < 1e-4
+    assert rel(a["g_tp"][i:i + 1], one["g_tp"]) < 3e-2 and rel(a["g_mp"][i:i + 1], one["g_mp"]) < 3e-2
+
+
 def test_strided_tracks_like_system(console, dev):
     """System passes tracks[..., middle:] (reference mst/system.py:258): row stride != length."""
     torch.manual_seed(4)
