@@ -181,6 +181,7 @@ inline Layout make_layout(const mst_console_desc* d) {
     L.nblkE = L.ncE_pad / kEqWG;
     L.nblkC = L.ncC_pad / kWG;
     L.KE = (L.ncE + kScanThreads - 1) / kScanThreads;
+    if (L.KE > 8) L.KE = (int)round_up(L.KE, 8);  // whole 8-chunk sub-spans: aligned 16-byte state accesses in k_scan
     L.KC = (L.ncC + kScanThreads - 1) / kScanThreads;
     L.ntE = (int)((L.N + kTile - 1) / kTile);
     L.eq1 = (L.ntE <= kMaxTiles1 && !(d->flags & MST_DEV_MULTIPASS_EQ)) ? 1 : 0;

@@ -32,6 +32,55 @@ struct RegMat {
     }
 };
 
+// Eight consecutive chunk states (scan positions i0 .. i0+7 of a row; memory order is descending when REVERSE)
+// <-> registers, with 16-byte accesses whenever the span is whole and aligned.
+template <int D, bool REVERSE>
+__device__ __forceinline__ void span8_load(const float* __restrict__ zr, int nc, int nc_pad, int i0, float (*zl)[D]) {
+    const int lo = REVERSE ? nc - 8 - i0 : i0;  // lowest chunk index of the span
+    if (lo >= 0 && lo + 8 <= nc && (lo & 3) == 0) {
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const float4 v = *reinterpret_cast<const float4*>(zr + (int64_t)d * nc_pad + lo + 4 * q);
+                const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int t = 0; t < 4; ++t) zl[REVERSE ? 7 - (4 * q + t) : 4 * q + t][d] = e[t];
+            }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = i0 + k, c = REVERSE ? nc - 1 - i : i;
+#pragma unroll
+            for (int d = 0; d < D; ++d) zl[k][d] = (i < nc) ? zr[(int64_t)d * nc_pad + c] : 0.0f;
+        }
+    }
+}
+template <int D, bool REVERSE>
+__device__ __forceinline__ void span8_store(float* __restrict__ sr, int nc, int nc_pad, int i0, int count, float (*so)[D]) {
+    const int lo = REVERSE ? nc - 8 - i0 : i0;
+    if (count == 8 && lo >= 0 && lo + 8 <= nc && (lo & 3) == 0) {
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                float e[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) e[t] = so[REVERSE ? 7 - (4 * q + t) : 4 * q + t][d];
+                *reinterpret_cast<float4*>(sr + (int64_t)d * nc_pad + lo + 4 * q) = make_float4(e[0], e[1], e[2], e[3]);
+            }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = i0 + k, c = REVERSE ? nc - 1 - i : i;
+            if (k < count && i < nc) {
+#pragma unroll
+                for (int d = 0; d < D; ++d) sr[(int64_t)d * nc_pad + c] = so[k][d];
+            }
+        }
+    }
+}
+
 // z, s0: [row][D][nc_pad].  tab: [table_row][kPow][D*D]; row = sig * sub + f, table_row = filter_row(sig, split) * sub + f
 // KT > 0: K == KT known at compile time - all of a lane's chunk states are fetched up front (one
 // memory round trip instead of K dependent ones) and the fold / replay loops are unrolled.
@@ -98,14 +147,21 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const float* __restrict__
             for (int d = 0; d < D; ++d) agg[d] = nv[d];
         }
     } else {
-        for (int k = 0; k < K; ++k) {
-            const int i = tid * K + k;
-            float nv[D];
+        // any K: sub-spans of eight chunks, each fetched in one go (a lane's K chunks are contiguous)
+        for (int k0 = 0; k0 < K; k0 += 8) {
+            float z8[8][D];
+            span8_load<D, REVERSE>(zr, nc, nc_pad, tid * K + k0, z8);
 #pragma unroll
-            for (int d = 0; d < D; ++d) nv[d] = (i < nc) ? zr[(int64_t)d * nc_pad + cidx(i)] : 0.0f;
-            M1.acc(agg, nv);
+            for (int kk = 0; kk < 8; ++kk) {
+                if (k0 + kk < K) {
+                    float nv[D];
 #pragma unroll
-            for (int d = 0; d < D; ++d) agg[d] = nv[d];
+                    for (int d = 0; d < D; ++d) nv[d] = z8[kk][d];
+                    M1.acc(agg, nv);
+#pragma unroll
+                    for (int d = 0; d < D; ++d) agg[d] = nv[d];
+                }
+            }
         }
     }
     // 2. inclusive Hillis-Steele over lanes (levels beyond the populated lanes are skipped)
@@ -168,19 +224,25 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const float* __restrict__
             }
         }
     } else {
-        for (int k = 0; k < K; ++k) {
-            const int i = tid * K + k;
-            if (i >= nc) break;
-            const int c = cidx(i);
-            float nv[D];
+        for (int k0 = 0; k0 < K; k0 += 8) {
+            if (tid * K + k0 >= nc) break;
+            float z8[8][D], so8[8][D];
+            span8_load<D, REVERSE>(zr, nc, nc_pad, tid * K + k0, z8);
+            const int count = K - k0 < 8 ? K - k0 : 8;
 #pragma unroll
-            for (int d = 0; d < D; ++d) {
-                sr[(int64_t)d * nc_pad + c] = st[d];
-                nv[d] = zr[(int64_t)d * nc_pad + c];
+            for (int kk = 0; kk < 8; ++kk) {
+#pragma unroll
+                for (int d = 0; d < D; ++d) so8[kk][d] = st[d];
+                if (kk < count) {
+                    float nv[D];
+#pragma unroll
+                    for (int d = 0; d < D; ++d) nv[d] = z8[kk][d];
+                    M1.acc(st, nv);
+#pragma unroll
+                    for (int d = 0; d < D; ++d) st[d] = nv[d];
+                }
             }
-            M1.acc(st, nv);
-#pragma unroll
-            for (int d = 0; d < D; ++d) st[d] = nv[d];
+            span8_store<D, REVERSE>(sr, nc, nc_pad, tid * K + k0, count, so8);
         }
     }
 }

@@ -61,6 +61,25 @@ def test_console_inwave_scan_eq_matches_three_kernel_eq(ranges):
     assert rel(a["grad_mp"], b["grad_mp"]) < 1e-4
 
 
+def test_console_generic_scan_width(ranges):
+    """A row length for which a carry-scan lane owns K = 3 chunks (not one of the unrolled widths 1/2/4/8): the
+    sub-span path of k_scan, for the 12-state cascades (three-kernel EQ) and for the all-pole bank (both runs)."""
+    torch.manual_seed(4)
+    bs, T, n = 1, 1, 64 * 512 * 3 - 37
+    tracks = 0.1 * torch.randn(bs, T, n)
+    tp, fp, mp = torch.rand(bs, T, 27), torch.rand(bs, 25), torch.rand(bs, 26)
+    gmix = torch.randn(bs, 2, n)
+    a = harness.console(ranges, tracks, tp, fp, mp, FULL, grad_mix=gmix, want_mixed=False, want_grad_tracks=True)
+    b = harness.console(ranges, tracks, tp, fp, mp, FULL, grad_mix=gmix, want_mixed=False, want_grad_tracks=True,
+                        multipass_eq=True)
+    assert rel(a["mix"], b["mix"]) < 2e-5 and rel(a["grad_tracks"], b["grad_tracks"]) < 5e-5
+    x, y = tp.double().requires_grad_(True), mp.double().requires_grad_(True)
+    _, mix, *_ = oc.console_forward(tracks.double(), x, fp.double(), y, **FULL)
+    (mix * gmix.double()).sum().backward()
+    assert rel(b["mix"], mix) < 1e-4
+    assert rel(b["grad_tp"], x.grad) < 2e-2 and rel(b["grad_mp"], y.grad) < 2e-2
+
+
 def test_console_status_flag(ranges):
     tp, fp, mp = torch.rand(1, 1, 27), torch.rand(1, 25), torch.rand(1, 26)
     mp[0, 24] = 1.5
