@@ -20,7 +20,6 @@ constexpr int kAfHop = kAfFft / 4;  // reference hop_length = fft_size // 4 (mst
 constexpr int kAfBins = kAfM + 1;
 constexpr int kAfBands = 24;
 constexpr int kAfThreads = 1024;
-constexpr int kAfFramesPerWG = 4;
 
 // tables (floats): twM: kAfM float2 (W_M^t) | twN: (kAfM + 1) float2 (W_N^k) | win: kAfFft floats
 constexpr int64_t kAfTwM = 0, kAfTwN = 2 * kAfM, kAfWin = kAfTwN + 2 * (kAfM + 1), kAfTablesFloats = kAfWin + kAfFft;
@@ -115,8 +114,9 @@ struct AfArgs {
     float* magpart;       // (4*bs, n_groups, kAfBins) partial sums of |X| over a strip of frames
     float* meanmag;       // (4*bs, kAfBins)
     float* bark;          // (4*bs, 24) log band energies; (4*bs, 24) linear band energies follow
-    float* stats;         // (2*bs, 2, 8) per (signal set, b, channel) reductions, see k_af_stats
+    double* stats;        // (2*bs, 8) reduced statistics per (signal set, b), see k_af_stats / k_af_stats_reduce
     float* statpart;      // partials of the above
+    float* bandpart;      // (4*bs, kAfBinSlices, 24) partial band energies
     float* losses;        // 5 weighted loss scalars out
     float* coef;          // backward coefficients
     const float* grad_losses;  // (5) upstream dL/d(loss_k)
@@ -139,6 +139,21 @@ __device__ __forceinline__ void af_signal(const AfArgs& a, int s, const float*& 
 __device__ __forceinline__ void af_load_frame(float2* buf, const float* l, const float* r, float sign, const float* win, int f,
                                               int64_t n, int tid) {
     const int64_t start = (int64_t)f * kAfHop - kAfFft / 2;
+    // interior frames of 16-byte aligned rows (all but the two reflected ends): eight samples per lane and step
+    if (start >= 0 && start + kAfFft <= n && !(((uintptr_t)l | (uintptr_t)r) & 15) && !(n & 3)) {
+        for (int q = tid; q < kAfM / 4; q += kAfThreads) {
+            const int m = 4 * q;
+            const float4 l0 = *reinterpret_cast<const float4*>(l + start + 2 * m), l1 = *reinterpret_cast<const float4*>(l + start + 2 * m + 4);
+            const float4 r0 = *reinterpret_cast<const float4*>(r + start + 2 * m), r1 = *reinterpret_cast<const float4*>(r + start + 2 * m + 4);
+            const float2* w2 = reinterpret_cast<const float2*>(win + 2 * m);  // the window table is 8-byte aligned
+            const float2 wa = w2[0], wb = w2[1], wc = w2[2], wd = w2[3];
+            buf[swz(m)] = make_float2(wa.x * (l0.x + sign * r0.x), wa.y * (l0.y + sign * r0.y));
+            buf[swz(m + 1)] = make_float2(wb.x * (l0.z + sign * r0.z), wb.y * (l0.w + sign * r0.w));
+            buf[swz(m + 2)] = make_float2(wc.x * (l1.x + sign * r1.x), wc.y * (l1.y + sign * r1.y));
+            buf[swz(m + 3)] = make_float2(wd.x * (l1.z + sign * r1.z), wd.y * (l1.w + sign * r1.w));
+        }
+        return;
+    }
     for (int m = tid; m < kAfM; m += kAfThreads) {
         const int64_t i0 = af_reflect(start + 2 * m, n), i1 = af_reflect(start + 2 * m + 1, n);
         const float x0 = l[i0] + sign * r[i0], x1 = l[i1] + sign * r[i1];
@@ -172,8 +187,9 @@ __global__ __launch_bounds__(kAfThreads) void k_af_bark_fwd(AfArgs a) {
     float acc_lo[8], acc_hi[8], acc_mid = 0.0f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc_lo[j] = acc_hi[j] = 0.0f;
-    const int f0 = grp * kAfFramesPerWG;
-    for (int f = f0; f < f0 + kAfFramesPerWG && f < a.n_frames; ++f) {
+    // strips of near-equal length: frames [grp F / G, (grp+1) F / G)
+    const int f0 = (int)(((int64_t)grp * a.n_frames) / a.n_groups), f1 = (int)(((int64_t)(grp + 1) * a.n_frames) / a.n_groups);
+    for (int f = f0; f < f1; ++f) {
         __syncthreads();
         af_load_frame(buf, l, r, sign, win, f, a.n, tid);
         __syncthreads();
@@ -202,15 +218,19 @@ __global__ __launch_bounds__(kAfThreads) void k_af_bark_fwd(AfArgs a) {
     if (tid == 0) out[kAfM / 2] = acc_mid;
 }
 
-// mean over frames + filterbank + log.  grid (4*bs), 256 lanes.
+// mean over frames + filterbank, one slice of the bins per workgroup.  grid (kAfBinSlices, 4*bs), 256 lanes.
+constexpr int kAfStatSpan = 256 * 16;  // samples per k_af_stats workgroup
+constexpr int kAfBinSlices = 16;
+constexpr int kAfSliceBins = (kAfBins + kAfBinSlices - 1) / kAfBinSlices;
 __global__ __launch_bounds__(256) void k_af_bark_reduce(AfArgs a) {
     __shared__ float red[4][kAfBands];
-    const int tid = threadIdx.x, s = blockIdx.x;
+    const int tid = threadIdx.x, s = blockIdx.y, sl = blockIdx.x;
     float band[kAfBands];
 #pragma unroll
     for (int j = 0; j < kAfBands; ++j) band[j] = 0.0f;
     const float invF = 1.0f / (float)a.n_frames;
-    for (int k = tid; k < kAfBins; k += 256) {
+    const int k1 = (sl + 1) * kAfSliceBins < kAfBins ? (sl + 1) * kAfSliceBins : kAfBins;
+    for (int k = sl * kAfSliceBins + tid; k < k1; k += 256) {
         float m = 0.0f;
         for (int g = 0; g < a.n_groups; ++g) m += a.magpart[((int64_t)s * a.n_groups + g) * kAfBins + k];
         m *= invF;
@@ -225,16 +245,53 @@ __global__ __launch_bounds__(256) void k_af_bark_reduce(AfArgs a) {
         if ((tid & 63) == 0) red[tid >> 6][j] = v;
     }
     __syncthreads();
+    if (tid < kAfBands)
+        a.bandpart[((int64_t)s * kAfBinSlices + sl) * kAfBands + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+}
+// slices -> band energies (log and linear) of signal s, and the statistics of (set, b) = blockIdx.x < 2*bs.
+// grid (4*bs), 64 lanes: fixed-order sums.
+__global__ __launch_bounds__(64) void k_af_finish(AfArgs a) {
+    const int tid = threadIdx.x, s = blockIdx.x;
     if (tid < kAfBands) {
-        const float lin = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+        float lin = 0.0f;
+        for (int sl = 0; sl < kAfBinSlices; ++sl) lin += a.bandpart[((int64_t)s * kAfBinSlices + sl) * kAfBands + tid];
         a.bark[(int64_t)s * kAfBands + tid] = logf(lin + 1e-8f);
         a.bark[(int64_t)(4 * a.bs + s) * kAfBands + tid] = lin;
+    }
+    if (s < 2 * a.bs) {  // statistics of signal set / batch item sb = s: lanes stride over the time blocks
+        double sum[4] = {0, 0, 0, 0};
+        float ml = -1.f, mr = -1.f;
+        int64_t il = 0x7fffffffffffLL, ir = 0x7fffffffffffLL;
+        for (int k = tid; k < a.n_statblk; k += 64) {
+            const float* p = a.statpart + ((int64_t)s * a.n_statblk + k) * 8;
+            const float4 v0 = *reinterpret_cast<const float4*>(p), v1 = *reinterpret_cast<const float4*>(p + 4);
+            sum[0] += (double)v0.x; sum[1] += (double)v0.y; sum[2] += (double)v0.z; sum[3] += (double)v0.w;
+            // first maximum in time order: ascending k inside a lane, ties across lanes broken by the index below
+            if (v1.x > ml) { ml = v1.x; il = (int64_t)k * kAfStatSpan + __float_as_int(v1.y); }
+            if (v1.z > mr) { mr = v1.z; ir = (int64_t)k * kAfStatSpan + __float_as_int(v1.w); }
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sum[q] += __shfl_xor(sum[q], m);
+            float ov = __shfl_xor(ml, m);
+            int64_t oi = __shfl_xor(il, m);
+            if (ov > ml || (ov == ml && oi < il)) { ml = ov; il = oi; }
+            ov = __shfl_xor(mr, m);
+            oi = __shfl_xor(ir, m);
+            if (ov > mr || (ov == mr && oi < ir)) { mr = ov; ir = oi; }
+        }
+        if (tid == 0) {
+            double* o = a.stats + (int64_t)s * 8;
+            const double N = (double)a.n;
+            o[0] = sum[0] / N; o[1] = sum[1] / N; o[2] = sum[2] / N; o[3] = sum[3] / N;  // mean L^2, R^2, (L+R)^2, (L-R)^2
+            o[4] = ml; o[5] = (double)il; o[6] = mr; o[7] = (double)ir;
+        }
     }
 }
 
 // ---- closed-form features: per (set in {pred,target}, b) partial reductions over a slice of time
 // stat slots: 0 sum L^2, 1 sum R^2, 2 sum (L+R)^2, 3 sum (L-R)^2, 4 max|L|, 5 argmax L, 6 max|R|, 7 argmax R
-constexpr int kAfStatSpan = 256 * 16;
 __global__ __launch_bounds__(256) void k_af_stats(AfArgs a) {
     __shared__ float sv[4][8];
     const int tid = threadIdx.x, sb = blockIdx.y;  // sb = set * bs + b
@@ -300,19 +357,8 @@ __device__ void af_features(const AfArgs& a, int b, const float* g, double* part
     const double N = (double)a.n;
     const double c20 = 8.685889638065035;  // 20 / ln 10
     double st[2][8];
-    for (int set = 0; set < 2; ++set) {
-        double s[4] = {0, 0, 0, 0};
-        float ml = -1.f, mr = -1.f;
-        int64_t il = 0, ir = 0;
-        for (int k = 0; k < a.n_statblk; ++k) {
-            const float* p = a.statpart + ((int64_t)(set * a.bs + b) * a.n_statblk + k) * 8;
-            for (int q = 0; q < 4; ++q) s[q] += (double)p[q];
-            if (p[4] > ml) { ml = p[4]; il = (int64_t)k * kAfStatSpan + __float_as_int(p[5]); }
-            if (p[6] > mr) { mr = p[6]; ir = (int64_t)k * kAfStatSpan + __float_as_int(p[7]); }
-        }
-        for (int q = 0; q < 4; ++q) st[set][q] = s[q] / N;  // mean L^2, R^2, (L+R)^2, (L-R)^2
-        st[set][4] = ml; st[set][5] = (double)il; st[set][6] = mr; st[set][7] = (double)ir;
-    }
+    for (int set = 0; set < 2; ++set)
+        for (int q = 0; q < 8; ++q) st[set][q] = a.stats[((int64_t)set * a.bs + b) * 8 + q];  // k_af_finish
     const double g0 = g ? g[0] : 0.0, g1 = g ? g[1] : 0.0, g2 = g ? g[2] : 0.0, g3 = g ? g[3] : 0.0;
     double cLL = 0, cLR = 0, cRL = 0, cRR = 0, dl = 0, dr = 0;
     for (int ch = 0; ch < 2; ++ch) {  // rms + crest factor
@@ -526,15 +572,27 @@ __global__ void k_af_tables(float* tables) {
 
 struct AfPlan {
     int n_frames, n_groups, n_statblk;
-    int64_t magpart, meanmag, bark, statpart, coef, total;
+    int64_t magpart, meanmag, bark, statpart, bandpart, stats, coef, total;
     bool ok;
 };
+// frames of a signal are cut into G strips (one workgroup each, one 128 KiB workgroup per CU, 256 CUs): choose G to
+// minimise  rounds x longest strip  = ceil(G S / 256) x ceil(F / G);  e.g. F = 33, S = 32: G = 8 -> 1 x 5 (G = 9: 2 x 4)
+static int af_groups(int n_frames, int n_signals) {
+    int best = 1;
+    int64_t best_cost = INT64_MAX;
+    for (int g = 1; g <= n_frames; ++g) {
+        const int64_t rounds = ((int64_t)g * n_signals + 255) / 256, len = (n_frames + g - 1) / g;
+        const int64_t cost = rounds * len * 1024 + g;  // ties: fewer partial-sum rows
+        if (cost < best_cost) { best_cost = cost; best = g; }
+    }
+    return best;
+}
 static AfPlan af_plan(int bs, int64_t n) {
     AfPlan p{};
     p.ok = bs > 0 && n > kAfFft / 2;
     if (!p.ok) return p;
     p.n_frames = 1 + (int)(n / kAfHop);
-    p.n_groups = (p.n_frames + kAfFramesPerWG - 1) / kAfFramesPerWG;
+    p.n_groups = af_groups(p.n_frames, 4 * bs);
     p.n_statblk = (int)((n + kAfStatSpan - 1) / kAfStatSpan);
     int64_t o = 0;
     auto take = [&](int64_t k) { int64_t at = o; o += round_up(k, 64); return at; };
@@ -542,6 +600,8 @@ static AfPlan af_plan(int bs, int64_t n) {
     p.meanmag = take((int64_t)6 * bs * kAfBins);  // 4*bs mean magnitudes + 2*bs bark cotangents
     p.bark = take((int64_t)8 * bs * kAfBands);    // log energies, then linear energies
     p.statpart = take((int64_t)2 * bs * p.n_statblk * 8);
+    p.bandpart = take((int64_t)4 * bs * kAfBinSlices * kAfBands);
+    p.stats = take((int64_t)2 * bs * 8 * 2);  // doubles
     p.coef = take((int64_t)bs * 16);
     p.total = o;
     return p;
@@ -552,6 +612,7 @@ static AfArgs af_args(const AfPlan& p, int bs, int64_t n, const float* pred, con
     a.pred = pred; a.target = target; a.tables = tables; a.fb = fb;
     a.magpart = ws + p.magpart; a.meanmag = ws + p.meanmag; a.bark = ws + p.bark;
     a.statpart = ws + p.statpart; a.coef = ws + p.coef;
+    a.bandpart = ws + p.bandpart; a.stats = reinterpret_cast<double*>(ws + p.stats);
     for (int i = 0; i < 5; ++i) a.weights[i] = weights[i];
     a.bs = bs; a.n_frames = p.n_frames; a.n_groups = p.n_groups; a.n_statblk = p.n_statblk; a.n = n;
     return a;
@@ -581,7 +642,8 @@ extern "C" int mst_afloss_forward(const float* pred, const float* target, int32_
     a.losses = losses5;
     hipLaunchKernelGGL(k_af_stats, dim3(p.n_statblk, 2 * bs), dim3(256), 0, stream, a);
     hipLaunchKernelGGL(k_af_bark_fwd, dim3(p.n_groups, 4 * bs), dim3(kAfThreads), 0, stream, a);
-    hipLaunchKernelGGL(k_af_bark_reduce, dim3(4 * bs), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(k_af_bark_reduce, dim3(kAfBinSlices, 4 * bs), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(k_af_finish, dim3(4 * bs), dim3(64), 0, stream, a);
     hipLaunchKernelGGL(k_af_final, dim3(1), dim3(64), 0, stream, a);
     return (int)hipGetLastError();
 }

@@ -179,15 +179,17 @@ class _AudioFeatureFunction(torch.autograd.Function):
                        "mst_afloss_forward")
         ctx.meta = (bs, n, w, nbytes, pred.shape)
         ctx.save_for_backward(x, y, tables, fb, ws)
-        return losses
+        # five 0-dim outputs (views of one buffer) instead of one (5,) tensor the caller would index: indexing costs
+        # ~3 tiny kernels per key in forward + backward, 5 x that is more than the closed-form features themselves
+        return tuple(losses.unbind(0))
 
     @staticmethod
-    def backward(ctx, grad_losses):
+    def backward(ctx, *grad_each):
         x, y, tables, fb, ws = ctx.saved_tensors
         bs, n, w, nbytes, shape = ctx.meta
         lib = _hip.lib()
         dev = x.device
-        g = grad_losses.float().contiguous()
+        g = torch.stack([gi.float().reshape(()) for gi in grad_each]).contiguous()
         gx = torch.empty_like(x)
         with torch.cuda.device(dev):
             _hip.check(lib.mst_afloss_backward(_cabi.ptr(x), _cabi.ptr(y), bs, n, w, _cabi.ptr(tables), _cabi.ptr(fb), _cabi.ptr(g),
@@ -217,4 +219,4 @@ class AudioFeatureLoss(torch.nn.Module):
 
     def forward(self, input: torch.Tensor, target: torch.Tensor):
         losses = _AudioFeatureFunction.apply(input, target, tuple(self.weights), self.sample_rate)
-        return {key: losses[i] for i, key in enumerate(AF_KEYS)}
+        return dict(zip(AF_KEYS, losses))
