@@ -14,6 +14,9 @@
 // (incl. the reflect-padding fold-back) uses hardware float atomics into grad_pred.
 #include "mst_kernels.h"
 #include <cstdlib>
+#ifndef MST_STFT_UNROLL_STAGES
+#define MST_STFT_UNROLL_STAGES 1  // stage loops of the transforms unrolled so that the stage constants fold (386 -> 368 us; 0 = rolled, for A/B)
+#endif
 
 namespace mst {
 
@@ -62,7 +65,11 @@ __device__ __forceinline__ float2* lds_fft(float2* a, float2* b, const Twiddles<
         __syncthreads();
     }
     constexpr int q = NFFT >> 2;
+#if MST_STFT_UNROLL_STAGES
+#pragma unroll
+#else
 #pragma unroll 1
+#endif
     for (; Ns < NFFT; Ns <<= 2) {
         const int tstep = NFFT / (4 * Ns);
 #pragma unroll
@@ -139,7 +146,11 @@ __device__ __forceinline__ void fft_dif(float2* buf, const Twiddles<N>& T, int t
         }
         __syncthreads();
     }
+#if MST_STFT_UNROLL_STAGES
+#pragma unroll
+#else
 #pragma unroll 1
+#endif
     for (int L = M / 4; L >= 1; L >>= 2) {
         const int tstep = N / (4 * L);
 #pragma unroll
@@ -174,7 +185,11 @@ __device__ __forceinline__ void fft_dit(float2* buf, const Twiddles<N>& T, int t
     constexpr int LG = ilog2(N);
     constexpr bool ODD = LG & 1;
     constexpr int M = ODD ? N / 2 : N;
+#if MST_STFT_UNROLL_STAGES
+#pragma unroll
+#else
 #pragma unroll 1
+#endif
     for (int L = 1; L < M; L <<= 2) {
         const int tstep = N / (4 * L);
 #pragma unroll
