@@ -168,6 +168,23 @@ __device__ __forceinline__ void af_load_frame(float2* buf, const float* l, const
 }
 
 // X[k] and X[M-k] of the real frame from the digit-reversed half-size spectrum
+__device__ __forceinline__ int rev4_6(int k) {  // reverse the 6 base-4 digits of a 12-bit index
+    int r = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        r = (r << 2) | (k & 3);
+        k >>= 2;
+    }
+    return r;
+}
+// X[k], X[M-k] from the half-size spectrum values z[k], z[M-k] and w = W_N^k
+__device__ __forceinline__ void af_untangle_core(float2 zk, float2 zm, float2 w, float2& Xk, float2& Xm) {
+    const float2 E = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
+    const float2 O = make_float2(0.5f * (zk.y + zm.y), -0.5f * (zk.x - zm.x));
+    const float2 wo = cmulf(w, O);
+    Xk = make_float2(E.x + wo.x, E.y + wo.y);
+    Xm = make_float2(E.x - wo.x, -(E.y - wo.y));
+}
 template <bool SWZ>
 __device__ __forceinline__ void af_untangle(const float2* buf, const float2* twN, int k, float2& Xk, float2& Xm) {
     const float2 zk = buf[swzT<SWZ>(rev4_7(k))], zm = buf[swzT<SWZ>(rev4_7((kAfM - k) & (kAfM - 1)))];
@@ -190,8 +207,21 @@ __global__ __launch_bounds__(kAfThreads) void k_af_bark_fwd(AfArgs a) {
     const float *l, *r;
     float sign;
     af_signal(a, s, l, r, sign);
-    // each lane owns bins k = tid + 1024 j (j < 8) and their mirrors M - k; lane 0 also owns bin M/2
-    float acc_lo[8], acc_hi[8], acc_mid = 0.0f;
+    // The spectrum sits digit-reversed in plain (unswizzled) slots.  Lane tid owns the slot groups m = tid + 1024 j
+    // (j < 4): slots 4m, 4m+1 hold bins k = d 4096 + r (d = 0, 1; r = rev4_6(m)) and their mirrors M - k sit in slots
+    // 4m'+3, 4m'+2 with m' = rev4_6(4096 - r) - two 16-byte LDS reads per group, consecutive lanes on consecutive
+    // groups.  (m = 0 pairs bins 0 / M and 4096 / 12288 in slots 0, 1, 3; lane 0 also owns bin M/2.)
+    int rr[4], mp[4];
+    float2 w0[4], w1[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = tid + kAfThreads * j;
+        rr[j] = rev4_6(m);
+        mp[j] = rev4_6((4096 - rr[j]) & 4095);
+        w0[j] = twN[rr[j]];
+        w1[j] = twN[4096 + rr[j]];
+    }
+    float acc_lo[8], acc_hi[8], acc_mid = 0.0f;  // [2 j + d]: bin k = d 4096 + rr[j]  and its mirror
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc_lo[j] = acc_hi[j] = 0.0f;
     // strips of near-equal length: frames [grp F / G, (grp+1) F / G)
@@ -202,12 +232,18 @@ __global__ __launch_bounds__(kAfThreads) void k_af_bark_fwd(AfArgs a) {
         __syncthreads();
         fft16k_dif<false>(buf, T, tid);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int k = tid + kAfThreads * j;  // 0 .. M/2 - 1  (8 * 1024 = M/2)
+        for (int j = 0; j < 4; ++j) {
+            const int m = tid + kAfThreads * j;
+            const float4 zk2 = *reinterpret_cast<const float4*>(&buf[4 * m]);
+            float4 zm2 = *reinterpret_cast<const float4*>(&buf[4 * mp[j] + 2]);
+            if (m == 0) zm2 = make_float4(buf[3].x, buf[3].y, buf[0].x, buf[0].y);  // mirrors of bins 4096 and 0
             float2 Xk, Xm;
-            af_untangle<false>(buf, twN, k, Xk, Xm);
-            acc_lo[j] += sqrtf(Xk.x * Xk.x + Xk.y * Xk.y);
-            acc_hi[j] += sqrtf(Xm.x * Xm.x + Xm.y * Xm.y);  // k = 0 -> bin M (Nyquist)
+            af_untangle_core(make_float2(zk2.x, zk2.y), make_float2(zm2.z, zm2.w), w0[j], Xk, Xm);
+            acc_lo[2 * j] += sqrtf(Xk.x * Xk.x + Xk.y * Xk.y);
+            acc_hi[2 * j] += sqrtf(Xm.x * Xm.x + Xm.y * Xm.y);  // k = 0 -> bin M (Nyquist)
+            af_untangle_core(make_float2(zk2.z, zk2.w), make_float2(zm2.x, zm2.y), w1[j], Xk, Xm);
+            acc_lo[2 * j + 1] += sqrtf(Xk.x * Xk.x + Xk.y * Xk.y);
+            acc_hi[2 * j + 1] += sqrtf(Xm.x * Xm.x + Xm.y * Xm.y);
         }
         if (tid == 0) {
             float2 Xk, Xm;
@@ -217,10 +253,13 @@ __global__ __launch_bounds__(kAfThreads) void k_af_bark_fwd(AfArgs a) {
     }
     float* out = a.magpart + ((int64_t)s * a.n_groups + grp) * kAfBins;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int k = tid + kAfThreads * j;
-        out[k] = acc_lo[j];
-        out[kAfM - k] = acc_hi[j];  // k = 0 writes bin M
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            const int k = d * 4096 + rr[j];
+            out[k] = acc_lo[2 * j + d];
+            out[kAfM - k] = acc_hi[2 * j + d];  // k = 0 writes bin M
+        }
     }
     if (tid == 0) out[kAfM / 2] = acc_mid;
 }
