@@ -40,13 +40,18 @@ constexpr int kFetch = kEqWG * kSlabVec / kEqWG;     // float4 each thread moves
 struct SlabRegs {
     float4 v[kFetch];
 };
+// FAST (whole tile inside the row, row base 16-byte aligned - every tile but a ragged last one): plain 16-byte
+// accesses; otherwise the guarded load4 / store4, whose bounds + alignment tests cost ~10 scalar/branch
+// instructions per access.
+template <bool FAST>
 __device__ __forceinline__ void slab_fetch(SlabRegs& r, const float* __restrict__ row, int64_t tile_base, int j, int64_t n, int tid) {
 #pragma unroll
     for (int q0 = 0; q0 < kFetch; ++q0) {
         const int q = tid + kEqWG * q0;      // float4 index inside the slab image
         const int lane = q / kSlabVec;     // owning lane
         const int i = (q % kSlabVec) * 4;
-        r.v[q0] = load4(row, tile_base + (int64_t)lane * kEqChunk + j * kSlab + i, n);
+        const int64_t at = tile_base + (int64_t)lane * kEqChunk + j * kSlab + i;
+        r.v[q0] = FAST ? *reinterpret_cast<const float4*>(row + at) : load4(row, at, n);
     }
 }
 __device__ __forceinline__ void slab_stash(const SlabRegs& r, float* __restrict__ tile, int tid) {
@@ -56,6 +61,7 @@ __device__ __forceinline__ void slab_stash(const SlabRegs& r, float* __restrict_
         *reinterpret_cast<float4*>(&tile[(q / kSlabVec) * kLdw + (q % kSlabVec) * 4]) = r.v[q0];
     }
 }
+template <bool FAST>
 __device__ __forceinline__ void slab_store(const float* __restrict__ tile, float* __restrict__ row, int64_t tile_base,
                                            int j, int64_t n, int tid) {
 #pragma unroll
@@ -63,8 +69,10 @@ __device__ __forceinline__ void slab_store(const float* __restrict__ tile, float
         const int q = tid + kEqWG * q0;
         const int lane = q / kSlabVec;
         const int i = (q % kSlabVec) * 4;
-        store4(row, tile_base + (int64_t)lane * kEqChunk + j * kSlab + i, n,
-               *reinterpret_cast<const float4*>(&tile[lane * kLdw + i]));
+        const int64_t at = tile_base + (int64_t)lane * kEqChunk + j * kSlab + i;
+        const float4 v = *reinterpret_cast<const float4*>(&tile[lane * kLdw + i]);
+        if (FAST) *reinterpret_cast<float4*>(row + at) = v;
+        else store4(row, at, n, v);
     }
 }
 
@@ -79,14 +87,21 @@ __device__ __forceinline__ void slab_store(const float* __restrict__ tile, float
 #ifndef MST_EQ_SCHEDBAR
 #define MST_EQ_SCHEDBAR 0
 #endif
+template <bool FAST>
 __device__ __forceinline__ void slab_first(SlabRegs& r, const float* __restrict__ row, int64_t tile_base, int j, int64_t n, int tid) {
-    if (MST_EQ_PREFETCH) slab_fetch(r, row, tile_base, j, n, tid);
+    if (MST_EQ_PREFETCH) slab_fetch<FAST>(r, row, tile_base, j, n, tid);
 }
+template <bool FAST>
 __device__ __forceinline__ void slab_enter(SlabRegs& r, const float* __restrict__ row, int64_t tile_base, int j, int64_t n, int tid) {
-    if (!MST_EQ_PREFETCH) slab_fetch(r, row, tile_base, j, n, tid);
+    if (!MST_EQ_PREFETCH) slab_fetch<FAST>(r, row, tile_base, j, n, tid);
 }
+template <bool FAST>
 __device__ __forceinline__ void slab_next(SlabRegs& r, const float* __restrict__ row, int64_t tile_base, int j, bool valid, int64_t n, int tid) {
-    if (MST_EQ_PREFETCH && valid) slab_fetch(r, row, tile_base, j, n, tid);
+    if (MST_EQ_PREFETCH && valid) slab_fetch<FAST>(r, row, tile_base, j, n, tid);
+}
+// whole-workgroup decision: the tile lies inside the row and the row base allows 16-byte accesses
+__device__ __forceinline__ bool tile_fast(const float* row, int64_t tile_base, int64_t n) {
+    return tile_base + kTile <= n && !((uintptr_t)row & 15);
 }
 __device__ __forceinline__ void slab_fence() {
 #if MST_EQ_SCHEDBAR
@@ -99,15 +114,14 @@ __device__ __forceinline__ void slab_fence() {
 // FUSE_GC (forward run of mono rows only): the compressor's static curve is evaluated on the fresh EQ
 // output and the zero-state envelope end value of every 2048-sample compressor block (= 32 lanes) is
 // written to zs_comp[sig][block] - this replaces the separate k_comp_zs pass over the EQ output.
-template <int DIR, bool MODE_RUN, bool FUSE_GC = false, bool SCAN1 = false>
-__global__ __launch_bounds__(kEqWG) void k_cascade(const float* __restrict__ in, int64_t in_stride,
+template <int DIR, bool MODE_RUN, bool FUSE_GC, bool SCAN1, bool FAST>
+__device__ __forceinline__ void cascade_body(const float* __restrict__ in, int64_t in_stride,
                                                  float* __restrict__ out, int64_t out_stride,
                                                  const float* __restrict__ rc, int split,
                                                  const float* __restrict__ s0, float* __restrict__ z,
-                                                 int nc_pad, int64_t n, float* __restrict__ zs_comp = nullptr,
-                                                 int nblk_comp = 0, const float* __restrict__ pw1 = nullptr, int ntiles = 0,
-                                                 float* __restrict__ agg = nullptr) {
-    __shared__ __attribute__((aligned(16))) float tile[kEqWG * kLdw];
+                                                 int nc_pad, int64_t n, float* __restrict__ zs_comp,
+                                                 int nblk_comp, const float* __restrict__ pw1, int ntiles,
+                                                 float* __restrict__ agg, float* __restrict__ tile) {
     const int tid = threadIdx.x, sig = blockIdx.y;
     const int64_t tile_base = (int64_t)blockIdx.x * kEqWG * kEqChunk;
     const int chunk = blockIdx.x * kEqWG + tid;
@@ -115,7 +129,7 @@ __global__ __launch_bounds__(kEqWG) void k_cascade(const float* __restrict__ in,
     float* outrow = MODE_RUN ? out + (int64_t)sig * out_stride : nullptr;
     auto order = [](int jj) { return (DIR == EQ_FWD) ? jj : kNSlab - 1 - jj; };
     SlabRegs pre;
-    slab_first(pre, inrow, tile_base, order(0), n, tid);  // first slab in flight while constants load
+    slab_first<FAST>(pre, inrow, tile_base, order(0), n, tid);  // first slab in flight while constants load
 
     const float* coef = rc + (int64_t)filter_row(sig, split) * RC_STRIDE + RC_SOS;
     float c[5 * kSections];
@@ -165,10 +179,10 @@ __global__ __launch_bounds__(kEqWG) void k_cascade(const float* __restrict__ in,
 
     for (int jj = 0; jj < kNSlab; ++jj) {
         const int j = order(jj);
-        slab_enter(pre, inrow, tile_base, j, n, tid);
+        slab_enter<FAST>(pre, inrow, tile_base, j, n, tid);
         slab_stash(pre, tile, tid);
         __syncthreads();
-        slab_next(pre, inrow, tile_base, order(jj + 1 < kNSlab ? jj + 1 : jj), jj + 1 < kNSlab, n, tid);
+        slab_next<FAST>(pre, inrow, tile_base, order(jj + 1 < kNSlab ? jj + 1 : jj), jj + 1 < kNSlab, n, tid);
         if (DIR == EQ_FWD) {
 #pragma unroll
             for (int i4 = 0; i4 < kSlab; i4 += 4) {
@@ -199,7 +213,7 @@ __global__ __launch_bounds__(kEqWG) void k_cascade(const float* __restrict__ in,
         }
         __syncthreads();
         if (MODE_RUN) {
-            slab_store(tile, outrow, tile_base, j, n, tid);
+            slab_store<FAST>(tile, outrow, tile_base, j, n, tid);
             __syncthreads();  // the image is read by other lanes' stores before the next stash overwrites it
         }
         slab_fence();
@@ -234,6 +248,22 @@ __global__ __launch_bounds__(kEqWG) void k_cascade(const float* __restrict__ in,
     }
 }
 
+template <int DIR, bool MODE_RUN, bool FUSE_GC = false, bool SCAN1 = false>
+__global__ __launch_bounds__(kEqWG) void k_cascade(const float* __restrict__ in, int64_t in_stride,
+                                                 float* __restrict__ out, int64_t out_stride,
+                                                 const float* __restrict__ rc, int split,
+                                                 const float* __restrict__ s0, float* __restrict__ z,
+                                                 int nc_pad, int64_t n, float* __restrict__ zs_comp = nullptr,
+                                                 int nblk_comp = 0, const float* __restrict__ pw1 = nullptr, int ntiles = 0,
+                                                 float* __restrict__ agg = nullptr) {
+    __shared__ __attribute__((aligned(16))) float tile[kEqWG * kLdw];
+    const int64_t tile_base = (int64_t)blockIdx.x * kTile;
+    const bool fast = tile_fast(in + (int64_t)blockIdx.y * in_stride, tile_base, n) &&
+                      (!MODE_RUN || !((uintptr_t)(out + (int64_t)blockIdx.y * out_stride) & 15));
+    if (fast) cascade_body<DIR, MODE_RUN, FUSE_GC, SCAN1, true>(in, in_stride, out, out_stride, rc, split, s0, z, nc_pad, n, zs_comp, nblk_comp, pw1, ntiles, agg, tile);
+    else cascade_body<DIR, MODE_RUN, FUSE_GC, SCAN1, false>(in, in_stride, out, out_stride, rc, split, s0, z, nc_pad, n, zs_comp, nblk_comp, pw1, ntiles, agg, tile);
+}
+
 // ---- all-pole bank for the coefficient gradients ------------------------------------------------
 // filter f = 2k : w = u - a1 w1 - a2 w2 (1/A_k);  f = 2k+1 : w = u/b0 - (b1/b0) w1 - (b2/b0) w2 (1/B_k)
 struct ApCoef {
@@ -252,10 +282,10 @@ __device__ __forceinline__ void load_ap(const float* coef, ApCoef& k) {
 }
 
 // zero-state end states of the 12 all-pole filters per lane chunk: z[sig][24][nc_pad]
-__global__ __launch_bounds__(kEqWG) void k_allpole_zs(const float* __restrict__ u, int64_t u_stride,
-                                                    const float* __restrict__ rc, int split, float* __restrict__ z,
-                                                    int nc_pad, int64_t n) {
-    __shared__ __attribute__((aligned(16))) float tile[kEqWG * kLdw];
+template <bool FAST>
+__device__ __forceinline__ void allpole_zs_body(const float* __restrict__ u, int64_t u_stride,
+                                                const float* __restrict__ rc, int split, float* __restrict__ z,
+                                                int nc_pad, int64_t n, float* __restrict__ tile) {
     const int tid = threadIdx.x, sig = blockIdx.y;
     const int64_t tile_base = (int64_t)blockIdx.x * kEqWG * kEqChunk;
     const int chunk = blockIdx.x * kEqWG + tid;
@@ -267,12 +297,12 @@ __global__ __launch_bounds__(kEqWG) void k_allpole_zs(const float* __restrict__ 
     const float* urow = u + (int64_t)sig * u_stride;
     float* mine = &tile[tid * kLdw];
     SlabRegs pre;
-    slab_first(pre, urow, tile_base, 0, n, tid);
+    slab_first<FAST>(pre, urow, tile_base, 0, n, tid);
     for (int j = 0; j < kNSlab; ++j) {
-        slab_enter(pre, urow, tile_base, j, n, tid);
+        slab_enter<FAST>(pre, urow, tile_base, j, n, tid);
         slab_stash(pre, tile, tid);
         __syncthreads();
-        slab_next(pre, urow, tile_base, j + 1, j + 1 < kNSlab, n, tid);
+        slab_next<FAST>(pre, urow, tile_base, j + 1, j + 1 < kNSlab, n, tid);
 #pragma unroll 4
         for (int i = 0; i < kSlab; ++i) {
             const float x = mine[i];
@@ -299,15 +329,22 @@ __global__ __launch_bounds__(kEqWG) void k_allpole_zs(const float* __restrict__ 
     }
 }
 
+__global__ __launch_bounds__(kEqWG) void k_allpole_zs(const float* __restrict__ u, int64_t u_stride,
+                                                    const float* __restrict__ rc, int split, float* __restrict__ z,
+                                                    int nc_pad, int64_t n) {
+    __shared__ __attribute__((aligned(16))) float tile[kEqWG * kLdw];
+    if (tile_fast(u + (int64_t)blockIdx.y * u_stride, (int64_t)blockIdx.x * kTile, n)) allpole_zs_body<true>(u, u_stride, rc, split, z, nc_pad, n, tile);
+    else allpole_zs_body<false>(u, u_stride, rc, split, z, nc_pad, n, tile);
+}
+
 // coefficient-gradient partial sums: part[sig][block][30] = {db0 db1 db2 da1 da2} x 6 sections
-__global__ __launch_bounds__(kEqWG) void k_coefgrad(const float* __restrict__ u, int64_t u_stride,
-                                                  const float* __restrict__ g, int64_t g_stride,
-                                                  const float* __restrict__ rc, int split,
-                                                  const float* __restrict__ s0, int nc_pad,
-                                                  float* __restrict__ part, int64_t n) {
-    __shared__ __attribute__((aligned(16))) float tile_u[kEqWG * kLdw];
-    __shared__ __attribute__((aligned(16))) float tile_g[kEqWG * kLdw];
-    __shared__ float red[kEqWG / 64][EP_COUNT];
+template <bool FAST>
+__device__ __forceinline__ void coefgrad_body(const float* __restrict__ u, int64_t u_stride,
+                                              const float* __restrict__ g, int64_t g_stride,
+                                              const float* __restrict__ rc, int split,
+                                              const float* __restrict__ s0, int nc_pad,
+                                              float* __restrict__ part, int64_t n, float* __restrict__ tile_u,
+                                              float* __restrict__ tile_g, float (*red)[EP_COUNT]) {
     const int tid = threadIdx.x, sig = blockIdx.y;
     const int64_t tile_base = (int64_t)blockIdx.x * kEqWG * kEqChunk;
     const int chunk = blockIdx.x * kEqWG + tid;
@@ -338,16 +375,16 @@ __global__ __launch_bounds__(kEqWG) void k_coefgrad(const float* __restrict__ u,
     float* mu = &tile_u[tid * kLdw];
     float* mg = &tile_g[tid * kLdw];
     SlabRegs pu, pg;
-    slab_first(pu, urow, tile_base, 0, n, tid);
-    slab_first(pg, grow, tile_base, 0, n, tid);
+    slab_first<FAST>(pu, urow, tile_base, 0, n, tid);
+    slab_first<FAST>(pg, grow, tile_base, 0, n, tid);
     for (int j = 0; j < kNSlab; ++j) {
-        slab_enter(pu, urow, tile_base, j, n, tid);
-        slab_enter(pg, grow, tile_base, j, n, tid);
+        slab_enter<FAST>(pu, urow, tile_base, j, n, tid);
+        slab_enter<FAST>(pg, grow, tile_base, j, n, tid);
         slab_stash(pu, tile_u, tid);
         slab_stash(pg, tile_g, tid);
         __syncthreads();
-        slab_next(pu, urow, tile_base, j + 1, j + 1 < kNSlab, n, tid);
-        slab_next(pg, grow, tile_base, j + 1, j + 1 < kNSlab, n, tid);
+        slab_next<FAST>(pu, urow, tile_base, j + 1, j + 1 < kNSlab, n, tid);
+        slab_next<FAST>(pg, grow, tile_base, j + 1, j + 1 < kNSlab, n, tid);
 #pragma unroll 1
         for (int i4 = 0; i4 < kSlab; i4 += 4) {
             const float4 xv = *reinterpret_cast<const float4*>(&mu[i4]);
@@ -392,6 +429,21 @@ __global__ __launch_bounds__(kEqWG) void k_coefgrad(const float* __restrict__ u,
         for (int w = 1; w < kEqWG / 64; ++w) v += red[w][tid];
         part[((int64_t)sig * gridDim.x + blockIdx.x) * EP_COUNT + tid] = v;
     }
+}
+
+__global__ __launch_bounds__(kEqWG) void k_coefgrad(const float* __restrict__ u, int64_t u_stride,
+                                                  const float* __restrict__ g, int64_t g_stride,
+                                                  const float* __restrict__ rc, int split,
+                                                  const float* __restrict__ s0, int nc_pad,
+                                                  float* __restrict__ part, int64_t n) {
+    __shared__ __attribute__((aligned(16))) float tile_u[kEqWG * kLdw];
+    __shared__ __attribute__((aligned(16))) float tile_g[kEqWG * kLdw];
+    __shared__ float red[kEqWG / 64][EP_COUNT];
+    const int64_t tile_base = (int64_t)blockIdx.x * kTile;
+    if (tile_fast(u + (int64_t)blockIdx.y * u_stride, tile_base, n) && !((uintptr_t)(g + (int64_t)blockIdx.y * g_stride) & 15))
+        coefgrad_body<true>(u, u_stride, g, g_stride, rc, split, s0, nc_pad, part, n, tile_u, tile_g, red);
+    else
+        coefgrad_body<false>(u, u_stride, g, g_stride, rc, split, s0, nc_pad, part, n, tile_u, tile_g, red);
 }
 
 // ---- host-side launch helpers (called from mst_console.hip) --------------------------------------
