@@ -65,7 +65,7 @@ def test_console_generic_scan_width(ranges):
     """A row length for which a carry-scan lane owns K = 3 chunks (not one of the unrolled widths 1/2/4/8): the
     sub-span path of k_scan, for the 12-state cascades (three-kernel EQ) and for the all-pole bank (both runs)."""
     torch.manual_seed(4)
-    bs, T, n = 1, 1, 64 * 512 * 3 - 37
+    bs, T, n = 1, 1, 64 * 1025 + 11  # 1026 chunks of 64 samples -> K = ceil(1026 / 512) = 3
     tracks = 0.1 * torch.randn(bs, T, n)
     tp, fp, mp = torch.rand(bs, T, 27), torch.rand(bs, 25), torch.rand(bs, 26)
     gmix = torch.randn(bs, 2, n)
