@@ -50,6 +50,12 @@ void aux_join(AuxPool* p, hipStream_t main, int k) {
 
 using namespace mst;
 
+// developer switch (A/B): MST_ALLPOLE_SEPARATE=1 keeps the all-pole zero-state pass as its own backward kernel
+static bool fuse_allpole() {
+    static const bool on = getenv("MST_ALLPOLE_SEPARATE") == nullptr;
+    return on;
+}
+
 extern "C" int mst_abi_version(void) { return 1; }
 
 extern "C" size_t mst_console_workspace_bytes(const mst_console_desc* d) {
@@ -85,13 +91,16 @@ extern "C" int mst_console_forward(const mst_console_desc* d, const float* track
     const float* p1F_m = L.eq1 ? ws + L.pow1F_m : nullptr;
     const float* sE_t = L.eq1 ? ws + L.zE_t : ws + L.sE_t;
     const float* sE_m = L.eq1 ? ws + L.zE_m : ws + L.sE_m;
+    // a call that saves for backward also leaves the all-pole zero-state ends of the coefficient-gradient pass
+    float* zP_t = (save && fuse_allpole()) ? ws + L.zP_t : nullptr;
+    float* zP_m = (save && fuse_allpole()) ? ws + L.zP_m : nullptr;
     launch_cascade(EQ_FWD, false, tracks, d->track_row_stride, nullptr, 0, ws + L.rc_t, L.R, nullptr, ws + L.zE_t, L.ncE_pad, n, L.R, stream, p1F_t, L.ntE, ws + L.aggF_t);
     if (!L.eq1) launch_scan12(false, ws + L.zE_t, ws + L.sE_t, ws + L.powF_t, L.R, L.ncE, L.ncE_pad, L.KE, L.R, stream);
     if (t_comp)  // EQ run fused with the gain computer + per-block envelope aggregates
         launch_cascade_run_gc(tracks, d->track_row_stride, ws + L.u_t, Ns, ws + L.rc_t, L.R, sE_t, L.ncE_pad, n, L.R,
-                              ws + L.zS_t, L.nblkC, stream, p1F_t, L.ntE, ws + L.aggF_t);
+                              ws + L.zS_t, L.nblkC, stream, p1F_t, L.ntE, ws + L.aggF_t, zP_t);
     else
-        launch_cascade(EQ_FWD, true, tracks, d->track_row_stride, ws + L.u_t, Ns, ws + L.rc_t, L.R, sE_t, nullptr, L.ncE_pad, n, L.R, stream, p1F_t, L.ntE, ws + L.aggF_t);
+        launch_cascade(EQ_FWD, true, tracks, d->track_row_stride, ws + L.u_t, Ns, ws + L.rc_t, L.R, sE_t, nullptr, L.ncE_pad, n, L.R, stream, p1F_t, L.ntE, ws + L.aggF_t, zP_t);
     const bool bus_is_mix = !m_on && !o_on;
     TrackApplyArgs ta{ws + L.u_t, Ns, ws + L.rc_t, ws + L.zS_t, (save && t_comp) ? ws + L.gs_t : nullptr,
                       bus_is_mix ? mix : ws + L.bus, bus_is_mix ? n : Ns, mixed_tracks,
@@ -102,7 +111,7 @@ extern "C" int mst_console_forward(const mst_console_desc* d, const float* track
     if (m_on) {
         launch_cascade(EQ_FWD, false, ws + L.bus, Ns, nullptr, 0, ws + L.rc_m, 0, nullptr, ws + L.zE_m, L.ncE_pad, n, 2 * L.bs, stream, p1F_m, L.ntE, ws + L.aggF_m);
         if (!L.eq1) launch_scan12(false, ws + L.zE_m, ws + L.sE_m, ws + L.powF_m, 0, L.ncE, L.ncE_pad, L.KE, 2 * L.bs, stream);
-        launch_cascade(EQ_FWD, true, ws + L.bus, Ns, ws + L.v_m, Ns, ws + L.rc_m, 0, sE_m, nullptr, L.ncE_pad, n, 2 * L.bs, stream, p1F_m, L.ntE, ws + L.aggF_m);
+        launch_cascade(EQ_FWD, true, ws + L.bus, Ns, ws + L.v_m, Ns, ws + L.rc_m, 0, sE_m, nullptr, L.ncE_pad, n, 2 * L.bs, stream, p1F_m, L.ntE, ws + L.aggF_m, zP_m);
         launch_comp_zs(2, ws + L.v_m, Ns, ws + L.rc_m, ws + L.zS_m, L.ncC_pad, n, L.bs, stream);
         MasterApplyArgs ma{ws + L.v_m, Ns, ws + L.rc_m, ws + L.zS_m, save ? ws + L.gs_m : nullptr, mix, n,
                            L.ncC_pad, d->master_lookahead, 1, n, aligned};
@@ -143,7 +152,7 @@ extern "C" int mst_console_backward(const mst_console_desc* d, const float* trac
         aux_fork(aux, stream, 0);
         side = aux->s[0];
     }
-    launch_allpole_zs(ws + L.u_t, Ns, ws + L.rc_t, L.R, ws + L.zP_t, L.ncE_pad, n, nsig_all, side);
+    if (!fuse_allpole()) launch_allpole_zs(ws + L.u_t, Ns, ws + L.rc_t, L.R, ws + L.zP_t, L.ncE_pad, n, nsig_all, side);
     launch_scan2(ws + L.zP_t, ws + L.sP_t, ws + L.powP_t, L.R, L.ncE, L.ncE_pad, L.KE, nsig_all, side);
 
     // ---- master bus: compressor adjoint, EQ adjoint (-> grad of the stereo bus)

@@ -114,14 +114,17 @@ __device__ __forceinline__ void slab_fence() {
 // FUSE_GC (forward run of mono rows only): the compressor's static curve is evaluated on the fresh EQ
 // output and the zero-state envelope end value of every 2048-sample compressor block (= 32 lanes) is
 // written to zs_comp[sig][block] - this replaces the separate k_comp_zs pass over the EQ output.
-template <int DIR, bool MODE_RUN, bool FUSE_GC, bool SCAN1, bool FAST>
+// FUSE_AP (forward run, when the call saves for backward): the all-pole bank of the coefficient-gradient pass
+// (k_allpole_zs) advances on the fresh EQ output too and its zero-state chunk end states go to zp - the backward then
+// starts at the all-pole carry scan, one pass over u less.
+template <int DIR, bool MODE_RUN, bool FUSE_GC, bool SCAN1, bool FAST, bool FUSE_AP>
 __device__ __forceinline__ void cascade_body(const float* __restrict__ in, int64_t in_stride,
                                                  float* __restrict__ out, int64_t out_stride,
                                                  const float* __restrict__ rc, int split,
                                                  const float* __restrict__ s0, float* __restrict__ z,
                                                  int nc_pad, int64_t n, float* __restrict__ zs_comp,
                                                  int nblk_comp, const float* __restrict__ pw1, int ntiles,
-                                                 float* __restrict__ agg, float* __restrict__ tile) {
+                                                 float* __restrict__ agg, float* __restrict__ tile, float* __restrict__ zp) {
     const int tid = threadIdx.x, sig = blockIdx.y;
     const int64_t tile_base = (int64_t)blockIdx.x * kEqWG * kEqChunk;
     const int chunk = blockIdx.x * kEqWG + tid;
@@ -176,6 +179,17 @@ __device__ __forceinline__ void cascade_body(const float* __restrict__ in, int64
     CompK ck{};
     float zacc = 0.0f;
     if (FUSE_GC) ck = load_comp(rc + (int64_t)filter_row(sig, split) * RC_STRIDE);
+    f2 ak1[kSections], ak2[kSections], akin[kSections], aw1[kSections], aw2[kSections];  // see k_coefgrad
+    if (FUSE_AP) {
+#pragma unroll
+        for (int s = 0; s < kSections; ++s) {
+            const float ib0 = 1.0f / c[5 * s];
+            ak1[s] = f2{-c[5 * s + 3], -(c[5 * s + 1] / c[5 * s])};
+            ak2[s] = f2{-c[5 * s + 4], -(c[5 * s + 2] / c[5 * s])};
+            akin[s] = f2{1.0f, ib0};
+            aw1[s] = aw2[s] = f2{0.0f, 0.0f};
+        }
+    }
 
     for (int jj = 0; jj < kNSlab; ++jj) {
         const int j = order(jj);
@@ -192,6 +206,19 @@ __device__ __forceinline__ void cascade_body(const float* __restrict__ in, int64
                 v.z = cascade_step<float>(v.z, c, st);
                 v.w = cascade_step<float>(v.w, c, st);
                 if (MODE_RUN) *reinterpret_cast<float4*>(&mine[i4]) = v;
+                if (FUSE_AP) {
+                    const float ys[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const f2 xx = {ys[t], ys[t]};
+#pragma unroll
+                        for (int s = 0; s < kSections; ++s) {
+                            const f2 w = ak2[s] * aw2[s] + (ak1[s] * aw1[s] + xx * akin[s]);
+                            aw2[s] = aw1[s];
+                            aw1[s] = w;
+                        }
+                    }
+                }
                 if (FUSE_GC) {
                     float dd;
                     zacc = fmaf(ck.alpha, zacc, ck.oma * gain_computer(v.x, ck, dd));
@@ -232,6 +259,16 @@ __device__ __forceinline__ void cascade_body(const float* __restrict__ in, int64
 #pragma unroll
         for (int i = 0; i < kStates; ++i) z[((int64_t)sig * kStates + i) * nc_pad + chunk] = st[i];
     }
+    if (FUSE_AP) {
+#pragma unroll
+        for (int s = 0; s < kSections; ++s) {
+            const int64_t base = ((int64_t)sig * 24 + 4 * s) * nc_pad + chunk;
+            zp[base] = aw1[s][0];
+            zp[base + nc_pad] = aw2[s][0];
+            zp[base + 2 * (int64_t)nc_pad] = aw1[s][1];
+            zp[base + 3 * (int64_t)nc_pad] = aw2[s][1];
+        }
+    }
     if (FUSE_GC) {
         // fold the 32 lane values of each 2048-sample block: v_l += a64^d v_(l-d) inside 32-lane segments
         const float l2a64 = 8.0f * rc[(int64_t)filter_row(sig, split) * RC_STRIDE + RC_LOG2A_C];  // log2(alpha^64)
@@ -248,20 +285,21 @@ __device__ __forceinline__ void cascade_body(const float* __restrict__ in, int64
     }
 }
 
-template <int DIR, bool MODE_RUN, bool FUSE_GC = false, bool SCAN1 = false>
+template <int DIR, bool MODE_RUN, bool FUSE_GC = false, bool SCAN1 = false, bool FUSE_AP = false>
 __global__ __launch_bounds__(kEqWG) void k_cascade(const float* __restrict__ in, int64_t in_stride,
                                                  float* __restrict__ out, int64_t out_stride,
                                                  const float* __restrict__ rc, int split,
                                                  const float* __restrict__ s0, float* __restrict__ z,
                                                  int nc_pad, int64_t n, float* __restrict__ zs_comp = nullptr,
                                                  int nblk_comp = 0, const float* __restrict__ pw1 = nullptr, int ntiles = 0,
-                                                 float* __restrict__ agg = nullptr) {
+                                                 float* __restrict__ agg = nullptr, float* __restrict__ zp = nullptr) {
+    static_assert(!FUSE_AP || (MODE_RUN && DIR == EQ_FWD), "the all-pole bank rides on the forward run only");
     __shared__ __attribute__((aligned(16))) float tile[kEqWG * kLdw];
     const int64_t tile_base = (int64_t)blockIdx.x * kTile;
     const bool fast = tile_fast(in + (int64_t)blockIdx.y * in_stride, tile_base, n) &&
                       (!MODE_RUN || !((uintptr_t)(out + (int64_t)blockIdx.y * out_stride) & 15));
-    if (fast) cascade_body<DIR, MODE_RUN, FUSE_GC, SCAN1, true>(in, in_stride, out, out_stride, rc, split, s0, z, nc_pad, n, zs_comp, nblk_comp, pw1, ntiles, agg, tile);
-    else cascade_body<DIR, MODE_RUN, FUSE_GC, SCAN1, false>(in, in_stride, out, out_stride, rc, split, s0, z, nc_pad, n, zs_comp, nblk_comp, pw1, ntiles, agg, tile);
+    if (fast) cascade_body<DIR, MODE_RUN, FUSE_GC, SCAN1, true, FUSE_AP>(in, in_stride, out, out_stride, rc, split, s0, z, nc_pad, n, zs_comp, nblk_comp, pw1, ntiles, agg, tile, zp);
+    else cascade_body<DIR, MODE_RUN, FUSE_GC, SCAN1, false, FUSE_AP>(in, in_stride, out, out_stride, rc, split, s0, z, nc_pad, n, zs_comp, nblk_comp, pw1, ntiles, agg, tile, zp);
 }
 
 // ---- all-pole bank for the coefficient gradients ------------------------------------------------
@@ -451,12 +489,21 @@ __global__ __launch_bounds__(kEqWG) void k_coefgrad(const float* __restrict__ u,
 // the zs launch's in-tile end states, and no carry-scan launch goes in between.
 void launch_cascade(int dir, bool run, const float* in, int64_t in_stride, float* out, int64_t out_stride, const float* rc,
                     int split, const float* s0, float* z, int nc_pad, int64_t n, int nsig, hipStream_t stream, const float* pw1,
-                    int ntiles, float* agg) {
+                    int ntiles, float* agg, float* zp) {
     const dim3 grid(pw1 ? ntiles : nc_pad / kEqWG, nsig), block(kEqWG);
     float* const nozs = nullptr;
+    if (zp && dir == EQ_FWD && run) {  // forward run + all-pole bank
+        if (pw1)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cascade<EQ_FWD, true, false, true, true>), grid, block, 0, stream, in, in_stride, out,
+                               out_stride, rc, split, s0, z, nc_pad, n, nozs, 0, pw1, ntiles, agg, zp);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cascade<EQ_FWD, true, false, false, true>), grid, block, 0, stream, in, in_stride, out,
+                               out_stride, rc, split, s0, z, nc_pad, n, nozs, 0, pw1, ntiles, agg, zp);
+        return;
+    }
 #define MST_LAUNCH_CASCADE(D, R, S) \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cascade<D, R, false, S>), grid, block, 0, stream, in, in_stride, out, out_stride, rc, \
-                       split, s0, z, nc_pad, n, nozs, 0, pw1, ntiles, agg)
+                       split, s0, z, nc_pad, n, nozs, 0, pw1, ntiles, agg, nozs)
     if (pw1) {
         if (dir == EQ_FWD && !run) MST_LAUNCH_CASCADE(EQ_FWD, false, true);
         else if (dir == EQ_FWD) MST_LAUNCH_CASCADE(EQ_FWD, true, true);
@@ -473,15 +520,24 @@ void launch_cascade(int dir, bool run, const float* in, int64_t in_stride, float
 
 void launch_cascade_run_gc(const float* in, int64_t in_stride, float* out, int64_t out_stride, const float* rc, int split,
                            const float* s0, int nc_pad, int64_t n, int nsig, float* zs_comp, int nblk_comp, hipStream_t stream,
-                           const float* pw1, int ntiles, float* agg) {
+                           const float* pw1, int ntiles, float* agg, float* zp) {
     static_assert(kEqChunk * 32 == kWG * kCompChunk, "a compressor block must be 32 EQ lanes");
     const dim3 grid(pw1 ? ntiles : nc_pad / kEqWG, nsig), block(kEqWG);
+    if (zp) {
+        if (pw1)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cascade<EQ_FWD, true, true, true, true>), grid, block, 0, stream, in, in_stride, out, out_stride,
+                               rc, split, s0, (float*)nullptr, nc_pad, n, zs_comp, nblk_comp, pw1, ntiles, agg, zp);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cascade<EQ_FWD, true, true, false, true>), grid, block, 0, stream, in, in_stride, out, out_stride,
+                               rc, split, s0, (float*)nullptr, nc_pad, n, zs_comp, nblk_comp, pw1, ntiles, agg, zp);
+        return;
+    }
     if (pw1)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cascade<EQ_FWD, true, true, true>), grid, block, 0, stream, in, in_stride, out, out_stride,
-                           rc, split, s0, (float*)nullptr, nc_pad, n, zs_comp, nblk_comp, pw1, ntiles, agg);
+                           rc, split, s0, (float*)nullptr, nc_pad, n, zs_comp, nblk_comp, pw1, ntiles, agg, (float*)nullptr);
     else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cascade<EQ_FWD, true, true, false>), grid, block, 0, stream, in, in_stride, out, out_stride,
-                           rc, split, s0, (float*)nullptr, nc_pad, n, zs_comp, nblk_comp, pw1, ntiles, agg);
+                           rc, split, s0, (float*)nullptr, nc_pad, n, zs_comp, nblk_comp, pw1, ntiles, agg, (float*)nullptr);
 }
 
 void launch_allpole_zs(const float* u, int64_t u_stride, const float* rc, int split, float* z, int nc_pad, int64_t n,

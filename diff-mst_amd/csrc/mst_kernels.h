@@ -43,15 +43,17 @@ void launch_prep(const PrepArgs& a, hipStream_t stream);
 void launch_prep_bwd(const PrepBwdArgs& a, hipStream_t stream);
 
 // ---- mst_eq.hip
+// zp != nullptr (forward run only): the all-pole bank of the coefficient-gradient pass rides along, its zero-state chunk
+// end states are written to zp (nsig x 24 x nc_pad) and the backward needs no k_allpole_zs launch.
 // pw1 (in-wave scan tables of these rows) != nullptr: SCAN1 kernels, no carry-scan launch between zs and run (mst_eq.hip);
 // agg (nsig x 12 x kMaxTiles1) carries the tile aggregates from the zs launch to the run launch
 void launch_cascade(int dir, bool run, const float* in, int64_t in_stride, float* out, int64_t out_stride, const float* rc,
                     int split, const float* s0, float* z, int nc_pad, int64_t n, int nsig, hipStream_t stream,
-                    const float* pw1 = nullptr, int ntiles = 0, float* agg = nullptr);
+                    const float* pw1 = nullptr, int ntiles = 0, float* agg = nullptr, float* zp = nullptr);
 // forward run of mono rows fused with the compressor's zero-state block aggregates (replaces k_comp_zs<1>)
 void launch_cascade_run_gc(const float* in, int64_t in_stride, float* out, int64_t out_stride, const float* rc, int split,
                            const float* s0, int nc_pad, int64_t n, int nsig, float* zs_comp, int nblk_comp, hipStream_t stream,
-                           const float* pw1 = nullptr, int ntiles = 0, float* agg = nullptr);
+                           const float* pw1 = nullptr, int ntiles = 0, float* agg = nullptr, float* zp = nullptr);
 void launch_allpole_zs(const float* u, int64_t u_stride, const float* rc, int split, float* z, int nc_pad, int64_t n, int nsig,
                        hipStream_t stream);
 void launch_coefgrad(const float* u, int64_t u_stride, const float* g, int64_t g_stride, const float* rc, int split,
