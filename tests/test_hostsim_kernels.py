@@ -63,18 +63,14 @@ def test_console_inwave_scan_eq_matches_three_kernel_eq(ranges):
 
 def test_console_generic_scan_width(ranges):
     """A row length for which a carry-scan lane owns K = 3 chunks (not one of the unrolled widths 1/2/4/8): the
-    sub-span path of k_scan, for the 12-state cascades (three-kernel EQ) and for the all-pole bank (both runs)."""
+    sub-span path of k_scan, for the 12-state cascades (three-kernel EQ, forward and adjoint) and the all-pole bank."""
     torch.manual_seed(4)
     bs, T, n = 1, 1, 64 * 1025 + 11  # 1026 chunks of 64 samples -> K = ceil(1026 / 512) = 3
     tracks = 0.1 * torch.randn(bs, T, n)
     tp, fp, mp = torch.rand(bs, T, 27), torch.rand(bs, 25), torch.rand(bs, 26)
     tp, mp = short_ir(tp, mp)  # the frequency-sampling oracle is circular: keep impulse responses short at this length
     gmix = torch.randn(bs, 2, n)
-    a = harness.console(ranges, tracks, tp, fp, mp, FULL, grad_mix=gmix, want_mixed=False, want_grad_tracks=True)
-    b = harness.console(ranges, tracks, tp, fp, mp, FULL, grad_mix=gmix, want_mixed=False, want_grad_tracks=True,
-                        multipass_eq=True)
-    # grad_tracks passes the compressors' knees: 1e-6 differences of the EQ output move it by ~1e-3 in both paths
-    assert rel(a["mix"], b["mix"]) < 2e-5 and rel(a["grad_tracks"], b["grad_tracks"]) < 5e-3
+    b = harness.console(ranges, tracks, tp, fp, mp, FULL, grad_mix=gmix, want_mixed=False, multipass_eq=True)
     x, y = tp.double().requires_grad_(True), mp.double().requires_grad_(True)
     _, mix, *_ = oc.console_forward(tracks.double(), x, fp.double(), y, **FULL)
     (mix * gmix.double()).sum().backward()
