@@ -10,16 +10,21 @@ AdvancedMixConsole forward on 8 mixes x 8 tracks x 262144 samples @ 44.1 kHz, MR
 tensors.  Inputs are resident in HBM before the timed region.  N > 1 shards the batch axis (weak
 scaling: 8 mixes per GPU) and all-reduces the loss scalar only (leaf parameters stay local) - RCCL.
 
-Prints ONE JSON line on rank 0 (see the fields at the bottom).
+Prints ONE JSON line on rank 0.  Besides the contract fields it carries
+  roofline      HBM roofline of the whole step on ALGORITHMIC bytes + a VALU cross-check
+  cpu_baseline  the oracle (CPU restatement of the reference algorithm) timed on this box's host cores
+  secondary     (N = 1 only, --no-secondary skips) the API-faithful variant of cfg #2, cfg #3 and cfg #1
 """
 import argparse
 import json
 import os
+import statistics
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-for p in (ROOT, os.path.join(ROOT, "diff-mst_amd")):
+for p in (ROOT, os.path.join(ROOT, "diff-mst_amd"), os.path.join(ROOT, "diff-mst_amd", "standalone")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
@@ -28,20 +33,35 @@ import torch.distributed as dist
 
 BS, T, N, SR = 8, 8, 262144, 44100
 RESOLUTIONS = dict(fft_sizes=[512, 2048, 8192], hop_sizes=[256, 1024, 4096], win_lengths=[512, 2048, 8192])
+AF_WEIGHTS = [0.1, 0.001, 1.0, 1.0, 0.1]  # reference configs/models/unpaired+feat.yaml:55-60
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
-# algorithmic bytes per mix, SURVEY 8(d): console fwd+bwd (lean) 8*N*(T+2) + MR-STFT fwd+bwd 24*N
-BYTES_PER_MIX = 8 * N * (T + 2) + 24 * N
+VALU_PEAK_TF = 157.3   # MI355X_MICROARCH.md: fp32 vector peak
+FLAGS = dict(use_track_input_fader=True, use_track_eq=True, use_track_compressor=True, use_track_panner=True,
+             use_fx_bus=False, use_master_bus=True, use_output_fader=True)
 
 
-def measured_traffic():
-    """HBM bytes per step from the committed rocprofv3 PMC passes of this same command (profiles/), or None.
-    bench.py cannot run the profiler on itself; the figure is refreshed whenever the kernels change."""
-    path = os.path.join(ROOT, "profiles", "round1_traffic.json")
-    try:
-        with open(path) as f:
-            return float(json.load(f)["hbm_bytes_per_step_raw"])
-    except (OSError, KeyError, ValueError):
-        return None
+def bytes_per_mix(n_tracks, n, materialised=False, loss=True):
+    """Algorithmic bytes per mix, SURVEY 8(d): console fwd+bwd (lean) 8*N*(T+2) [+ 8*N*T when mixed_tracks is
+    written] + loss fwd+bwd 24*N (MR-STFT and AudioFeatureLoss alike)."""
+    return 8 * n * (n_tracks + 2) + (8 * n * n_tracks if materialised else 0) + (24 * n if loss else 0)
+
+
+BYTES_PER_MIX = bytes_per_mix(T, N)
+# algorithmic flops per mix (SURVEY 8d estimate: console ~0.63 GF at T = 8, MR-STFT ~0.26 GF) - for the VALU cross-check
+FLOPS_PER_MIX = 0.63e9 + 0.26e9
+
+
+def committed_profile():
+    """Numbers that need the profiler (bench.py cannot run rocprofv3 on itself): HBM bytes per step from the PMC passes
+    and VALU instructions per step from the SQ passes of this same command, committed under profiles/."""
+    for name in ("round2_traffic.json", "round1_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                d = json.load(f)
+            return float(d["hbm_bytes_per_step_raw"]), d.get("valu_lane_instructions_per_step"), name
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None, None
 
 
 def shard_batch(global_batch: int, rank: int, world: int):
@@ -59,40 +79,170 @@ def reduce_loss(loss: torch.Tensor, world: int):
     return loss
 
 
-def cpu_baseline(seconds_budget: float = 20.0):
-    """Oracle (PyTorch-CPU restatement of the reference algorithm: frequency-sampling IIR via torch.fft,
-    torch.stft loss) on a bounded sample of the same workload: 1 mix of 8 tracks x 262144, fwd+bwd."""
+# ---------------------------------------------------------------------------------------------- CPU baseline
+def _oracle_step(n_tracks, n, loss_kind, flags):
     from oracle import console_restated as oc
     from oracle import loss_restated as ol
 
     torch.manual_seed(0)
-    tracks = 0.1 * torch.randn(1, T, N)
+    tracks = 0.1 * torch.randn(1, n_tracks, n)
     fp = torch.rand(1, 25)
-    flags = dict(use_track_input_fader=True, use_track_eq=True, use_track_compressor=True, use_track_panner=True,
-                 use_fx_bus=False, use_master_bus=True, use_output_fader=True)
     with torch.no_grad():
-        _, ref, *_ = oc.console_forward(tracks, torch.rand(1, T, 27), fp, torch.rand(1, 26), **flags)
+        _, ref, *_ = oc.console_forward(tracks, torch.rand(1, n_tracks, 27), fp, torch.rand(1, 26), **flags)
         ref = oc.batch_stereo_peak_normalize(ref)
     res = tuple(zip(RESOLUTIONS["fft_sizes"], RESOLUTIONS["hop_sizes"], RESOLUTIONS["win_lengths"]))
 
     def one():
-        tp = torch.rand(1, T, 27, requires_grad=True)
+        tp = torch.rand(1, n_tracks, 27, requires_grad=True)
         mp = torch.rand(1, 26, requires_grad=True)
         _, mix, *_ = oc.console_forward(tracks, tp, fp, mp, **flags)
-        ol.mrstft_loss(mix, ref, res).backward()
+        if loss_kind == "mrstft":
+            ol.mrstft_loss(mix, ref, res).backward()
+        elif loss_kind == "af":
+            sum(v.mean() for v in ol.audio_feature_loss(mix, ref, AF_WEIGHTS).values()).backward()
+        else:
+            (mix * ref).sum().backward()
 
+    return one
+
+
+def _time_cpu(one, runs, budget_s):
     one()  # warm-up
-    times = []
-    t_start = time.time()
-    while len(times) < 5 and (time.time() - t_start < seconds_budget or len(times) < 2):
+    times, t_start = [], time.time()
+    while len(times) < runs and (time.time() - t_start < budget_s or len(times) < 2):
         t0 = time.time()
         one()
         times.append(time.time() - t0)
-    times.sort()
-    med = times[len(times) // 2]
-    return {"value": 1.0 / med, "unit": "mixes/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 mix (8 tracks x 262144) console fwd+bwd + MR-STFT, median of {len(times)} runs, fp32, "
-                      f"{os.cpu_count()} host cpus"}
+    return statistics.median(times), len(times)
+
+
+def cpu_baseline():
+    """Oracle (PyTorch-CPU restatement of the reference ALGORITHM: frequency-sampling IIR via torch.fft, torch.stft
+    losses, autograd backward) on bounded samples of the bench workloads.  `value` = cfg #2 on all host threads."""
+    host = os.cpu_count()
+    try:
+        model = [l.split(":", 1)[1].strip() for l in subprocess.run(["lscpu"], capture_output=True, text=True).stdout.splitlines()
+                 if l.startswith("Model name")][0]
+    except Exception:
+        model = "unknown"
+    default_threads = torch.get_num_threads()
+    torch.set_num_threads(host)
+    med, k = _time_cpu(_oracle_step(T, N, "mrstft", FLAGS), 3, 15.0)
+    all_core = 1.0 / med
+    threads_used = torch.get_num_threads()
+    # cfg #3 (16 tracks, AudioFeatureLoss) and cfg #1 (gain + pan only, 4 x 65536), one mix each, all threads
+    med3, _ = _time_cpu(_oracle_step(16, N, "af", FLAGS), 2, 12.0)
+    basic = dict(FLAGS, use_track_eq=False, use_track_compressor=False, use_master_bus=False, use_output_fader=False)
+    med1, _ = _time_cpu(_oracle_step(4, 65536, "none", basic), 5, 3.0)
+    # one thread: a quarter-length clip of the same mix (8 tracks x 65536), scaled by 1/4 (FFT cost is ~linear in length here)
+    torch.set_num_threads(1)
+    medq, kq = _time_cpu(_oracle_step(T, N // 4, "mrstft", FLAGS), 2, 12.0)
+    one_thread = 1.0 / (4.0 * medq)
+    torch.set_num_threads(default_threads)
+    return {
+        "value": all_core, "unit": "mixes/s", "cores": threads_used, "kind": "port",
+        "sample": f"cfg #2: 1 mix (8 tracks x 262144) console fwd+bwd + MR-STFT, fp32, median of {k} runs after a warm-up, "
+                  f"torch.set_num_threads({host}) on {host} host cpus ({model})",
+        "one_thread": {"value": one_thread, "unit": "mixes/s", "cores": 1,
+                       "sample": f"1 mix of 8 tracks x 65536 (quarter length) x 1/4, median of {kq} runs"},
+        "cfg3": {"value": 1.0 / med3, "unit": "mixes/s", "cores": threads_used,
+                 "sample": "1 mix of 16 tracks x 262144, console fwd+bwd + AudioFeatureLoss"},
+        "cfg1": {"value": 1.0 / med1, "unit": "mixes/s", "cores": threads_used,
+                 "sample": "1 mix of 4 tracks x 65536, gain + pan + bus sum fwd+bwd"},
+        "host": {"os_cpu_count": host, "lscpu_model": model, "torch_default_threads": default_threads,
+                 "parallel_info": " | ".join(l.strip() for l in torch.__config__.parallel_info().splitlines() if l.strip())[:400]},
+    }
+
+
+# ---------------------------------------------------------------------------------------------- GPU workloads
+def make_workload(dev, bs, n_tracks, n, loss_kind, seed, lean=True, flags=FLAGS, basic=False):
+    """Returns step() -> loss for one configuration; every tensor is resident on `dev` before it is called."""
+    from mst.loss import AudioFeatureLoss, MultiResolutionSTFTLoss
+    from mst.mixing import naive_random_mix
+    from mst.modules import AdvancedMixConsole, BasicMixConsole
+    from mst.utils import batch_stereo_peak_normalize
+
+    kw = dict(materialize_mixed_tracks=False, validate="deferred", param_dicts="lazy") if lean else {}
+    console = (BasicMixConsole if basic else AdvancedMixConsole)(SR, **kw)
+    torch.manual_seed(seed)
+    tracks = (0.1 * torch.randn(bs, n_tracks, n)).to(dev)
+    if basic:
+        with torch.no_grad():
+            ref = console(tracks, torch.rand(bs, n_tracks, 27).to(dev))[1]
+    else:
+        ref = naive_random_mix(tracks, AdvancedMixConsole(SR, materialize_mixed_tracks=False),
+                               **{k: v for k, v in flags.items() if k != "use_output_fader"})[1]
+    ref = batch_stereo_peak_normalize(ref)  # reference mst/system.py:149-176
+    track_params = torch.rand(bs, n_tracks, 27).to(dev).requires_grad_(True)
+    fx_params = torch.rand(bs, 25).to(dev)
+    master_params = torch.rand(bs, 26).to(dev).requires_grad_(True)
+    if loss_kind == "mrstft":
+        loss_fn = MultiResolutionSTFTLoss(**RESOLUTIONS)
+    elif loss_kind == "af":
+        af = AudioFeatureLoss(AF_WEIGHTS, SR)
+        loss_fn = lambda a, b: sum(v.mean() for v in af(a, b).values())  # reference mst/system.py:334-336
+    else:
+        loss_fn = lambda a, b: (a * b).mean()
+
+    def step(marks=None):
+        track_params.grad = None
+        master_params.grad = None
+        if basic:
+            _, mix, *_ = console(tracks, track_params)
+        else:
+            _, mix, *_ = console(tracks, track_params, fx_params, master_params, **flags)
+        if marks:
+            marks["fwd"].record()
+            mix.register_hook(lambda g: marks["lbwd"].record())
+        loss = loss_fn(mix, ref)
+        if marks:
+            marks["loss"].record()
+        loss.backward()
+        return loss.detach()
+
+    step.console = console
+    step.params = (track_params, master_params)
+    return step
+
+
+def time_steps(step, steps, warmup):
+    """Median / mean GPU time per step from per-step HIP events on torch's current stream (the launch stream)."""
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    evs[0].record()
+    for i in range(steps):
+        step()
+        evs[i + 1].record()
+    torch.cuda.synchronize()
+    per = [evs[i].elapsed_time(evs[i + 1]) for i in range(steps)]
+    return statistics.median(per), sum(per) / steps
+
+
+def secondary_lines(dev):
+    out = []
+    specs = [
+        ("cfg #2 API-faithful: mixed_tracks (bs,2,T,N) materialised, validate='sync' (one flag readback per call), eager "
+         "parameter dictionaries", dict(bs=BS, n_tracks=T, n=N, loss_kind="mrstft", lean=False), True, 20, 5),
+        ("cfg #3: AdvancedMixConsole 16 tracks x 262144, batch 32, AudioFeatureLoss, lean console",
+         dict(bs=32, n_tracks=16, n=N, loss_kind="af", lean=True), False, 6, 2),
+        ("cfg #1: BasicMixConsole (gain + pan + bus sum) 4 tracks x 65536, batch 2, fwd+bwd",
+         dict(bs=2, n_tracks=4, n=65536, loss_kind="none", lean=True, basic=True), False, 50, 10),
+    ]
+    for name, kw, materialised, steps, warm in specs:
+        step = make_workload(dev, seed=2000, **kw)
+        med, mean = time_steps(step, steps, warm)
+        if kw.get("lean", True):
+            step.console.check_parameters()
+        b = kw["bs"] * bytes_per_mix(kw["n_tracks"], kw["n"], materialised, loss=kw["loss_kind"] != "none")
+        gbs = b / (med * 1e-3) / 1e9
+        out.append({"workload": name, "ms_per_step_median": med, "ms_per_step_mean": mean, "steps": steps,
+                    "mixes_per_s": kw["bs"] / (med * 1e-3), "algorithmic_bytes_per_step": b, "achieved_GBs": gbs,
+                    "frac_of_hbm_peak": gbs / HBM_PEAK_GBS})
+        del step
+        torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -101,6 +251,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -114,63 +265,31 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
-    from mst.loss import MultiResolutionSTFTLoss
-    from mst.mixing import naive_random_mix
-    from mst.modules import AdvancedMixConsole
-    from mst.utils import batch_stereo_peak_normalize
-
-    console = AdvancedMixConsole(SR, materialize_mixed_tracks=False, validate="deferred")
-    loss_fn = MultiResolutionSTFTLoss(**RESOLUTIONS)
-    flags = dict(use_track_input_fader=True, use_track_eq=True, use_track_compressor=True, use_track_panner=True,
-                 use_fx_bus=False, use_master_bus=True, use_output_fader=True)
-
     lo, hi = shard_batch(BS * world, rank, world)  # this rank's mixes of the global batch
-    torch.manual_seed(1000 + rank)
-    tracks = (0.1 * torch.randn(hi - lo, T, N)).to(dev)
-    ref = naive_random_mix(tracks, console, **{k: v for k, v in flags.items() if k != "use_output_fader"})[1]
-    ref = batch_stereo_peak_normalize(ref)  # reference mst/system.py:149-176
-    track_params = torch.rand(hi - lo, T, 27).to(dev).requires_grad_(True)
-    fx_params = torch.rand(hi - lo, 25).to(dev)
-    master_params = torch.rand(hi - lo, 26).to(dev).requires_grad_(True)
+    step_fn = make_workload(dev, hi - lo, T, N, "mrstft", seed=1000 + rank, lean=True)
 
-    ev = {k: torch.cuda.Event(enable_timing=True) for k in ("s", "fwd", "loss", "lbwd", "e")}
-
-    def step(stamp=False):
-        track_params.grad = None
-        master_params.grad = None
-        if stamp:
-            ev["s"].record()
-        _, mix, *_ = console(tracks, track_params, fx_params, master_params, **flags)
-        if stamp:
-            ev["fwd"].record()
-            mix.register_hook(lambda g: ev["lbwd"].record())
-        loss = loss_fn(mix, ref)
-        if stamp:
-            ev["loss"].record()
-        loss.backward()
-        out = reduce_loss(loss.detach(), world)
-        if stamp:
-            ev["e"].record()
-        return out
+    def step(marks=None):
+        return reduce_loss(step_fn(marks), world)
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    e0.record()
-    for _ in range(args.steps):
+    evs[0].record()
+    for i in range(args.steps):
         last = step()
-    e1.record()
+        evs[i + 1].record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    gpu_ms = e0.elapsed_time(e1)
-    console.check_parameters()
-    assert torch.isfinite(last).all() and torch.isfinite(track_params.grad).all()
+    per_step = [evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps)]
+    gpu_ms = evs[0].elapsed_time(evs[-1])
+    step_fn.console.check_parameters()
+    assert torch.isfinite(last).all() and torch.isfinite(step_fn.params[0].grad).all()
 
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     if world > 1:
@@ -179,9 +298,12 @@ def main():
 
     # stage split of one step on the launch stream (HIP events; kernels run on torch's current stream).
     # Two un-stamped steps are enqueued first so that the host is ahead of the GPU, as in the timed loop.
+    ev = {k: torch.cuda.Event(enable_timing=True) for k in ("s", "fwd", "loss", "lbwd", "e")}
     step()
     step()
-    step(stamp=True)
+    ev["s"].record()
+    step(ev)
+    ev["e"].record()
     torch.cuda.synchronize()
     stages = {"console_fwd_ms": ev["s"].elapsed_time(ev["fwd"]), "loss_fwd_ms": ev["fwd"].elapsed_time(ev["loss"]),
               "loss_bwd_ms": ev["loss"].elapsed_time(ev["lbwd"]), "console_bwd_ms": ev["lbwd"].elapsed_time(ev["e"])}
@@ -190,7 +312,10 @@ def main():
         ms_per_step = 1e3 * elapsed / args.steps
         value = world * BS * args.steps / elapsed
         gpu_ms_per_step = gpu_ms / args.steps
+        med_ms = statistics.median(per_step)
         achieved = BS * BYTES_PER_MIX / (gpu_ms_per_step * 1e-3) / 1e9
+        traffic, lane_insts, prof = committed_profile()
+        tf = BS * FLOPS_PER_MIX / (gpu_ms_per_step * 1e-3) / 1e12
         out = {
             "metric": "mixes/sec (8-track x 262144-sample fwd+bwd)",
             "value": value, "unit": "mixes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -205,12 +330,24 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(),
-                "kernel": "whole step = the ~33 back-to-back kernels of console fwd+bwd + MR-STFT fwd+bwd (no single kernel "
-                          "exceeds 13 % of the step, see profiles/round1_summary.md); HIP-event time per step",
-                "algorithmic_bytes_per_step": BS * BYTES_PER_MIX, "gpu_ms_per_step": gpu_ms_per_step, "stages": stages,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "kernel": "whole step = the back-to-back kernels of console fwd+bwd + MR-STFT fwd+bwd (per-kernel table under "
+                          f"profiles/; traffic from profiles/{prof}); HIP-event time per step on the launch stream",
+                "algorithmic_bytes_per_step": BS * BYTES_PER_MIX, "gpu_ms_per_step": gpu_ms_per_step,
+                "gpu_ms_per_step_median": med_ms, "stages": stages,
+                "valu": {
+                    "flops_per_step": BS * FLOPS_PER_MIX, "achieved_TF": tf, "frac_of_157.3": tf / VALU_PEAK_TF,
+                    "lane_instructions_per_step": lane_insts,
+                    "issue_frac": (lane_insts / 64 * 2 / 1024 / 2.4e9) / (gpu_ms_per_step * 1e-3) if lane_insts else None,
+                    "note": "flops = SURVEY 8d algorithmic estimate; lane_instructions = SQ_INSTS_VALU x 64 of the committed "
+                            "counter pass; issue_frac = share of the step's SIMD-32 issue slots (2 cycles per wave64 op) they fill",
+                },
             },
         }
+        if world == 1 and not args.no_secondary:
+            del step_fn
+            torch.cuda.empty_cache()
+            out["secondary"] = secondary_lines(dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

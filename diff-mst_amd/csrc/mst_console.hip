@@ -2,7 +2,6 @@
 // launch sequences behind them.  No allocation, no host sync: everything is enqueued on the
 // caller's stream over the caller's workspace.
 #include "mst_kernels.h"
-#include <cstdlib>
 
 namespace mst {
 static int check_desc(const mst_console_desc* d) {
@@ -16,47 +15,18 @@ static int check_desc(const mst_console_desc* d) {
 }
 }  // namespace mst
 
-namespace mst {
-AuxPool* aux_pool(int feature) {
-    static AuxPool pools[16];
-    static int state[16] = {0};  // 0 = untried, 1 = ready, -1 = unavailable
-    // opt-in bit mask (MST_AUX_STREAMS): 1 = the STFT resolutions side by side (measured slower on MI355X, round 1),
-    // 2 = the all-pole pass of the console backward beside the master-bus chain
-    static const int enabled = getenv("MST_AUX_STREAMS") ? atoi(getenv("MST_AUX_STREAMS")) : 0;
-    if (!(enabled & feature)) return nullptr;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-    if (state[dev] == 0) {
-        AuxPool& p = pools[dev];
-        bool ok = hipEventCreateWithFlags(&p.fork, hipEventDisableTiming) == hipSuccess;
-        for (int i = 0; i < AuxPool::kStreams && ok; ++i) {
-            ok = hipStreamCreateWithFlags(&p.s[i], hipStreamNonBlocking) == hipSuccess &&
-                 hipEventCreateWithFlags(&p.join[i], hipEventDisableTiming) == hipSuccess;
-        }
-        p.ok = ok;
-        state[dev] = ok ? 1 : -1;
-    }
-    return state[dev] == 1 ? &pools[dev] : nullptr;
-}
-void aux_fork(AuxPool* p, hipStream_t main, int k) {
-    (void)hipEventRecord(p->fork, main);
-    (void)hipStreamWaitEvent(p->s[k], p->fork, 0);
-}
-void aux_join(AuxPool* p, hipStream_t main, int k) {
-    (void)hipEventRecord(p->join[k], p->s[k]);
-    (void)hipStreamWaitEvent(main, p->join[k], 0);
-}
-}  // namespace mst
-
 using namespace mst;
 
-// developer switch (A/B): MST_ALLPOLE_SEPARATE=1 keeps the all-pole zero-state pass as its own backward kernel
-static bool fuse_allpole() {
-    static const bool on = getenv("MST_ALLPOLE_SEPARATE") == nullptr;
-    return on;
+// build-time A/B switch (-DMST_ALLPOLE_SEPARATE): keep the all-pole zero-state pass as its own backward kernel
+static constexpr bool fuse_allpole() {
+#ifdef MST_ALLPOLE_SEPARATE
+    return false;
+#else
+    return true;
+#endif
 }
 
-extern "C" int mst_abi_version(void) { return 1; }
+extern "C" int mst_abi_version(void) { return 2; }
 
 extern "C" size_t mst_console_workspace_bytes(const mst_console_desc* d) {
     if (check_desc(d) != hipSuccess) return 0;
@@ -144,16 +114,8 @@ extern "C" int mst_console_backward(const mst_console_desc* d, const float* trac
     // ---- all-pole states of the coefficient-gradient pass depend only on what forward saved: one
     // launch covers the track rows and the master rows (signal rows [0,R) and [R,R+2bs) of the same arrays)
     const int nsig_all = L.R + (m_on ? 2 * L.bs : 0);
-    // They are independent of the (latency-bound, few-row) master chain below: with MST_AUX_STREAMS they run
-    // beside it on an auxiliary stream and are joined before the coefficient-gradient launch.
-    AuxPool* aux = m_on ? aux_pool(2) : nullptr;
-    hipStream_t side = stream;
-    if (aux) {
-        aux_fork(aux, stream, 0);
-        side = aux->s[0];
-    }
-    if (!fuse_allpole()) launch_allpole_zs(ws + L.u_t, Ns, ws + L.rc_t, L.R, ws + L.zP_t, L.ncE_pad, n, nsig_all, side);
-    launch_scan2(ws + L.zP_t, ws + L.sP_t, ws + L.powP_t, L.R, L.ncE, L.ncE_pad, L.KE, nsig_all, side);
+    if (!fuse_allpole()) launch_allpole_zs(ws + L.u_t, Ns, ws + L.rc_t, L.R, ws + L.zP_t, L.ncE_pad, n, nsig_all, stream);
+    launch_scan2(ws + L.zP_t, ws + L.sP_t, ws + L.powP_t, L.R, L.ncE, L.ncE_pad, L.KE, nsig_all, stream);
 
     // ---- master bus: compressor adjoint, EQ adjoint (-> grad of the stereo bus)
     const float* gbus = grad_mix;  // cotangent of the stereo bus as seen by the track stage
@@ -190,7 +152,6 @@ extern "C" int mst_console_backward(const mst_console_desc* d, const float* trac
             ca.s0 = ws + L.zQ_t;
         }
         launch_comp_bwd(false, true, ca, L.R, stream);
-        if (aux) aux_join(aux, stream, 0);
         // coefficient-gradient sums for the track rows and (same launch) the master rows
         launch_coefgrad(ws + L.u_t, Ns, ws + L.du_t, Ns, ws + L.rc_t, L.R, ws + L.sP_t, L.ncE_pad, ws + L.ep_t, n, nsig_all, stream);
         if (grad_tracks) {

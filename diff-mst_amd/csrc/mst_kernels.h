@@ -113,21 +113,4 @@ void launch_apply_tracks(const TrackApplyArgs& a, int bs, hipStream_t stream);
 void launch_apply_master(const MasterApplyArgs& a, int bs, hipStream_t stream);
 void launch_comp_bwd(bool master, bool run, const CompBwdArgs& a, int rows, hipStream_t stream);
 
-// ---- intra-call concurrency: a small, lazily created pool of auxiliary HIP streams per device.
-// Independent launches of one C-ABI call (the three STFT resolutions; the master-bus chain beside the
-// track chain) are forked onto them with events and joined back into the caller's stream before the call
-// returns, so the caller still sees plain stream order.  OFF by default: on MI355X the fork/join of the
-// three STFT resolutions measured 524 us vs 424 us serial (round 1); set MST_AUX_STREAMS=1 to enable.
-// When enabled this is the only process-wide state the library keeps.
-struct AuxPool {
-    static constexpr int kStreams = 3;
-    hipStream_t s[kStreams];
-    hipEvent_t fork;
-    hipEvent_t join[kStreams];
-    bool ok;
-};
-AuxPool* aux_pool(int feature);  // nullptr when that feature bit of MST_AUX_STREAMS is off or creation failed
-void aux_fork(AuxPool* p, hipStream_t main, int k);   // stream k waits for everything enqueued on `main` so far
-void aux_join(AuxPool* p, hipStream_t main, int k);   // `main` waits for everything enqueued on stream k so far
-
 }  // namespace mst

@@ -161,11 +161,12 @@ __global__ __launch_bounds__(320) void k_prep(PrepArgs a) {
     const int np = is_master ? MST_NUM_MASTER_PARAMS : MST_NUM_TRACK_PARAMS;
 
     // ---- range check (reference mst/modules.py:86-89), first offender in dictionary order wins
-    if (tid < np) {
+    const bool check = !(d.flags & MST_NO_RANGE_CHECK);  // forward_mix_console hands over denormalised values unchecked
+    if (check && tid < np) {
         const float v = p[tid];
         if (v < 0.0f || v > 1.0f) atomicMax(a.status, 1000 - (1 + (is_master ? 52 : 0) + tid));
     }
-    if (is_master && tid >= 32 && tid < 32 + 24) {  // fx-bus band gains/decays; "mix" is forced to 1
+    if (check && is_master && tid >= 32 && tid < 32 + 24) {  // fx-bus band gains/decays; "mix" is forced to 1
         const float v = a.fx_params[(int64_t)mrow * MST_NUM_FX_PARAMS + (tid - 32)];
         if (v < 0.0f || v > 1.0f) atomicMax(a.status, 1000 - (1 + 27 + (tid - 32)));
     }

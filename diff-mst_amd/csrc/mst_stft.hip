@@ -13,7 +13,6 @@
 // forms dL/dX, and returns two frames' time-domain cotangents per complex FFT; the overlap-add
 // (incl. the reflect-padding fold-back) uses hardware float atomics into grad_pred.
 #include "mst_kernels.h"
-#include <cstdlib>
 #ifndef MST_STFT_UNROLL_STAGES
 #define MST_STFT_UNROLL_STAGES 1  // stage loops of the transforms unrolled so that the stage constants fold (386 -> 368 us; 0 = rolled, for A/B)
 #endif
@@ -715,10 +714,11 @@ Plan make_plan(const mst_mrstft_desc* d) {
         t += nf;
         p.log2n[i] = lg;
         p.win[i] = d->win_length[i];
-        // strips of 2 frames measured best on MI355X at cfg #2 (1: 423, 2: 411, 4: 443, 8: 455, 16: 566 us per
-        // fwd+bwd); MST_STFT_FPW overrides for experiments
+        // strips of 2 frames measured best on MI355X at cfg #2 (1: 423, 2: 411, 4: 443, 8: 455, 16: 566 us per fwd+bwd)
         r.frames_per_wg = ((int64_t)r.n_frames * d->rows >= 1024) ? 2 : 1;
-        if (const char* e = getenv("MST_STFT_FPW")) r.frames_per_wg = atoi(e) > 0 ? atoi(e) : r.frames_per_wg;
+#ifdef MST_STFT_FPW
+        r.frames_per_wg = MST_STFT_FPW;
+#endif
         p.n_groups[i] = (r.n_frames + r.frames_per_wg - 1) / r.frames_per_wg;
         p.part_off[i] = po;
         po += (int64_t)d->rows * p.n_groups[i] * 4;
@@ -733,12 +733,16 @@ Plan make_plan(const mst_mrstft_desc* d) {
     return p;
 }
 // n_fft = 8192: the backward runs on the in-place kernel (two workgroups per CU: 105 vs 128 us at cfg #2), the
-// forward stays on the two-buffer kernel (in place it measured 69-78 vs 62 us).  Developer switches for A/B:
-// MST_STFT_PINGPONG=1 -> two-buffer kernels everywhere; MST_STFT_INPLACE_FWD=1 -> in-place forward as well.
-static bool inplace_8192(bool forward) {
-    static const bool off = getenv("MST_STFT_PINGPONG") != nullptr;
-    static const bool fwd = getenv("MST_STFT_INPLACE_FWD") != nullptr;
-    return !off && (!forward || fwd);
+// forward stays on the two-buffer kernel (in place it measured 69-78 vs 62 us).  Build-time A/B switches:
+// -DMST_STFT_PINGPONG -> two-buffer kernels everywhere; -DMST_STFT_INPLACE_FWD -> in-place forward as well.
+static constexpr bool inplace_8192(bool forward) {
+#if defined(MST_STFT_PINGPONG)
+    return false;
+#elif defined(MST_STFT_INPLACE_FWD)
+    return true;
+#else
+    return !forward;
+#endif
 }
 #define MST_FOR_NFFT(nf, CALL) \
     switch (nf) {               \
@@ -788,14 +792,7 @@ extern "C" int mst_mrstft_forward(const mst_mrstft_desc* d, const float* pred, c
     la.w_log = d->w_log_mag;
     la.w_lin = d->w_lin_mag;
     la.sc_per_example = d->sc_per_example;
-    // the resolutions are independent: run them side by side on auxiliary streams (a 1-workgroup-per-CU
-    // n_fft = 8192 launch leaves room for the small-transform workgroups), join before the reduction
-    AuxPool* aux = d->n_res > 1 ? aux_pool(1) : nullptr;
-    hipStream_t main_stream = stream;
     for (int i = 0; i < d->n_res; ++i) {
-        const int ak = i % (AuxPool::kStreams + 1);  // 0 = caller's stream
-        if (aux && ak > 0) aux_fork(aux, main_stream, ak - 1);
-        stream = (aux && ak > 0) ? aux->s[ak - 1] : main_stream;
         StftArgs a{};
         a.pred = pred;
         a.target = target;
@@ -814,9 +811,7 @@ extern "C" int mst_mrstft_forward(const mst_mrstft_desc* d, const float* pred, c
         la.n_groups[i] = p.n_groups[i];
         la.part_off[i] = p.part_off[i];
         la.count[i] = (float)((double)d->rows * p.res[i].n_bins * p.res[i].n_frames);
-        if (aux && ak > 0) aux_join(aux, main_stream, ak - 1);
     }
-    stream = main_stream;
     hipLaunchKernelGGL(k_mrstft_rowsums, dim3(d->rows, d->n_res), dim3(64), 0, stream, la);
     hipLaunchKernelGGL(k_mrstft_final, dim3(1), dim3(64), 0, stream, la);
     return (int)hipGetLastError();
@@ -831,12 +826,7 @@ extern "C" int mst_mrstft_backward(const mst_mrstft_desc* d, const float* pred, 
     hipStream_t stream = (hipStream_t)stream_;
     float* ws = (float*)workspace;
     (void)hipMemsetAsync(grad_pred, 0, (size_t)d->rows * d->n_samples * sizeof(float), stream);
-    AuxPool* aux = d->n_res > 1 ? aux_pool(1) : nullptr;
-    hipStream_t main_stream = stream;
     for (int i = 0; i < d->n_res; ++i) {
-        const int ak = i % (AuxPool::kStreams + 1);
-        if (aux && ak > 0) aux_fork(aux, main_stream, ak - 1);
-        stream = (aux && ak > 0) ? aux->s[ak - 1] : main_stream;
         StftArgs a{};
         a.pred = pred;
         a.target = target;
@@ -859,8 +849,6 @@ extern "C" int mst_mrstft_backward(const mst_mrstft_desc* d, const float* pred, 
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stft_bwd_ip<8192>), grid, dim3(kIpThreads), 0, stream, a);
         else
             MST_FOR_NFFT(a.r.n_fft, MST_LAUNCH_BWD)
-        if (aux && ak > 0) aux_join(aux, main_stream, ak - 1);
     }
-    stream = main_stream;
     return (int)hipGetLastError();
 }

@@ -21,8 +21,9 @@ USE_MASTER_BUS = 0x20
 USE_OUTPUT_FADER = 0x40
 SAVE_FOR_BACKWARD = 0x100
 DEV_MULTIPASS_EQ = 0x200
+NO_RANGE_CHECK = 0x400
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class ConsoleDesc(C.Structure):

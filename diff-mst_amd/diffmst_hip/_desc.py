@@ -1,8 +1,6 @@
 """Build the C-ABI console descriptor from the console's ``param_ranges`` (host logic, no device work)."""
 from __future__ import annotations
 
-import os
-
 from . import _cabi
 
 EQ_BANDS = ("low_shelf", "band0", "band1", "band2", "band3", "high_shelf")
@@ -45,20 +43,22 @@ def range_vectors(param_ranges: dict, index):
     return lo, hi
 
 
-def flag_word(save_for_backward: bool = False, **flags) -> int:
+def flag_word(save_for_backward: bool = False, multipass_eq: bool = False, **flags) -> int:
     word = 0
     for name, bit in FLAG_BITS.items():
         if flags.get(name, True):
             word |= bit
     if save_for_backward:
         word |= _cabi.SAVE_FOR_BACKWARD
-    if os.environ.get("MST_MULTIPASS_EQ"):  # developer A/B switch (include/diffmst_hip.h MST_DEV_MULTIPASS_EQ)
+    if multipass_eq:  # test switch (include/diffmst_hip.h MST_DEV_MULTIPASS_EQ): console._multipass_eq = True
         word |= _cabi.DEV_MULTIPASS_EQ
     return word
 
 
 def make_desc(param_ranges, sample_rate, bs, n_tracks, n_samples, track_row_stride, flags_word,
-              track_lookahead=2048, master_lookahead=1024) -> _cabi.ConsoleDesc:
+              track_lookahead=2048, master_lookahead=1024, identity_ranges=False) -> _cabi.ConsoleDesc:
+    """identity_ranges: lo = 0, hi = 1 for every parameter, i.e. v*(hi-lo)+lo == v exactly - the descriptor of a call
+    whose parameter tensors already hold DENORMALISED values (forward_mix_console)."""
     d = _cabi.ConsoleDesc()
     d.bs, d.n_tracks, d.n_samples = int(bs), int(n_tracks), int(n_samples)
     d.track_row_stride = int(track_row_stride)
@@ -67,6 +67,8 @@ def make_desc(param_ranges, sample_rate, bs, n_tracks, n_samples, track_row_stri
     d.track_lookahead, d.master_lookahead = int(track_lookahead), int(master_lookahead)
     tlo, thi = range_vectors(param_ranges, TRACK_INDEX)
     mlo, mhi = range_vectors(param_ranges, MASTER_INDEX)
+    if identity_ranges:
+        tlo, thi, mlo, mhi = [0.0] * 27, [1.0] * 27, [0.0] * 26, [1.0] * 26
     for i in range(27):
         d.track_lo[i], d.track_hi[i] = tlo[i], thi[i]
     for i in range(26):

@@ -1,4 +1,4 @@
-"""``mst.loss`` - the losses on the hot path, MI355X-native.
+"""``diffmst_hip.loss`` (alias ``mst.loss``) - the losses on the hot path, MI355X-native.
 
 * ``MultiResolutionSTFTLoss`` - drop-in for ``auraloss.freq.MultiResolutionSTFTLoss`` as the reference
   configures it (configs/models/naive.yaml:54-68; evaluation instance mst/system.py:61-69): same
@@ -13,6 +13,7 @@ import ctypes
 from typing import List
 
 import torch
+from torch.autograd.function import once_differentiable
 
 from . import _cabi, _hip
 
@@ -74,6 +75,7 @@ class _MrstftFunction(torch.autograd.Function):
         return loss.reshape(())
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, grad_loss):
         x, y, tables, ws = ctx.saved_tensors
         lib = _hip.lib()
@@ -184,6 +186,7 @@ class _AudioFeatureFunction(torch.autograd.Function):
         return tuple(losses.unbind(0))
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, *grad_each):
         x, y, tables, fb, ws = ctx.saved_tensors
         bs, n, w, nbytes, shape = ctx.meta

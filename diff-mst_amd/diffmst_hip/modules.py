@@ -1,4 +1,4 @@
-"""``mst.modules`` - the differentiable mixing console, MI355X-native.
+"""``diffmst_hip.modules`` (alias ``mst.modules``) - the differentiable mixing console, MI355X-native.
 
 Mirrors the public surface of the reference module for the hot path
 (/root/reference/mst/modules.py): ``denormalize``, ``normalize``,
@@ -17,8 +17,10 @@ AdvancedMixConsole with every other stage switched off.
 from __future__ import annotations
 
 import ctypes
+from collections.abc import Mapping
 
 import torch
+from torch.autograd.function import once_differentiable
 
 from . import _cabi, _desc, _hip
 
@@ -51,66 +53,54 @@ def _nested(index, tensor):
     return d
 
 
-class _LazyParamDict(dict):
-    """Nested ``{effect: {param: tensor}}`` dictionary that is only computed when somebody looks.
+class _LazyParamDict(Mapping):
+    """Read-only nested ``{effect: {param: tensor}}`` mapping that is computed when somebody first looks.
 
     The reference rebuilds three dictionaries of denormalised parameter views on every console call
-    (mst/modules.py:353-466); in-repo consumers only read them in logging callbacks.  Deferring the
-    (autograd-connected) affine map keeps a handful of tiny launches off the per-step critical path
-    without changing what a reader sees.
+    (mst/modules.py:353-466); in-repo consumers only read them in logging callbacks.  With
+    ``AdvancedMixConsole(param_dicts="lazy")`` the (autograd-connected) affine map is deferred, which keeps
+    three tiny launches off the per-step critical path.  Being a ``collections.abc.Mapping`` every access path
+    (``[]``, iteration, ``==``, ``dict(d)``, ``copy``, pickling through ``dict``) fills first - there is no
+    underlying storage that could be read empty.  The closure holds the live parameter tensors: a caller that
+    mutates them in place between the console call and the first read sees the mutated values (the default
+    ``param_dicts="eager"`` has the reference's semantics).
     """
 
     def __init__(self, build):
-        super().__init__()
         self._build = build
+        self._data = None
 
     def _fill(self):
-        if self._build is not None:
+        if self._data is None:
             build, self._build = self._build, None
-            super().update(build())
+            self._data = build()
+        return self._data
 
     def __getitem__(self, k):
-        self._fill()
-        return super().__getitem__(k)
+        return self._fill()[k]
 
     def __iter__(self):
-        self._fill()
-        return super().__iter__()
+        return iter(self._fill())
 
     def __len__(self):
-        self._fill()
-        return super().__len__()
-
-    def __contains__(self, k):
-        self._fill()
-        return super().__contains__(k)
-
-    def keys(self):
-        self._fill()
-        return super().keys()
-
-    def values(self):
-        self._fill()
-        return super().values()
-
-    def items(self):
-        self._fill()
-        return super().items()
-
-    def get(self, k, default=None):
-        self._fill()
-        return super().get(k, default)
+        return len(self._fill())
 
     def __repr__(self):
-        self._fill()
-        return super().__repr__()
+        return repr(self._fill())
+
+    def __reduce__(self):
+        return (dict, (dict(self._fill()),))
+
+    def copy(self):
+        return dict(self._fill())
 
 
 class _ConsoleFunction(torch.autograd.Function):
     """One fused forward / backward pair over the C ABI (mst_console_forward / _backward)."""
 
     @staticmethod
-    def forward(ctx, tracks, track_params, fx_bus_params, master_bus_params, console, flags, want_mixed, need_grad):
+    def forward(ctx, tracks, track_params, fx_bus_params, master_bus_params, console, flags, want_mixed, need_grad,
+                denormalized=False):
         _hip.require_cuda(tracks, track_params, fx_bus_params, master_bus_params)
         lib = _hip.lib()
         bs, n_tracks, n = tracks.shape
@@ -123,8 +113,11 @@ class _ConsoleFunction(torch.autograd.Function):
         tp = track_params.float().contiguous()
         fp = fx_bus_params.float().contiguous()
         mp = master_bus_params.float().contiguous()
-        word = _desc.flag_word(save_for_backward=need_grad, **flags)
-        desc = _desc.make_desc(console.param_ranges, console.sample_rate, bs, n_tracks, n, row_stride, word)
+        word = _desc.flag_word(save_for_backward=need_grad, multipass_eq=console._multipass_eq, **flags)
+        if denormalized:  # forward_mix_console: values arrive denormalised and are NOT range-checked (reference :186-314)
+            word |= _cabi.NO_RANGE_CHECK
+        desc = _desc.make_desc(console.param_ranges, console.sample_rate, bs, n_tracks, n, row_stride, word,
+                               identity_ranges=denormalized)
         nbytes = lib.mst_console_workspace_bytes(ctypes.byref(desc))
         if nbytes == 0:
             raise RuntimeError("mst_console_workspace_bytes rejected the configuration")
@@ -144,12 +137,11 @@ class _ConsoleFunction(torch.autograd.Function):
             ctx.desc, ctx.nbytes, ctx.dev = desc, nbytes, dev
             ctx.want_mixed = want_mixed
             ctx.save_for_backward(rows, tp, mp, ws)
-        if want_mixed:
-            return mix, mixed
-        ctx.mark_non_differentiable()
-        return mix, None
+        ctx.set_materialize_grads(False)  # an unused mixed_tracks output must not cost a zero (bs,2,T,N) cotangent
+        return mix, mixed
 
     @staticmethod
+    @once_differentiable  # the backward is a hand-written kernel chain: no double backward through it
     def backward(ctx, grad_mix, grad_mixed):
         rows, tp, mp, ws = ctx.saved_tensors
         lib = _hip.lib()
@@ -172,7 +164,7 @@ class _ConsoleFunction(torch.autograd.Function):
             )
         _hip.check(rc, "mst_console_backward")
         g_fx = torch.zeros(bs, _cabi.NUM_FX_PARAMS, dtype=torch.float32, device=dev) if ctx.needs_input_grad[2] else None
-        return g_tracks, g_tp, g_fx, g_mp, None, None, None, None
+        return g_tracks, g_tp, g_fx, g_mp, None, None, None, None, None
 
 
 class AdvancedMixConsole(torch.nn.Module):
@@ -186,6 +178,9 @@ class AdvancedMixConsole(torch.nn.Module):
                                            instead of the reference's 156);
                                  "deferred": keep the flag on the device; ``check_parameters()``
                                            raises later.
+      param_dicts                "eager" : the three returned parameter dictionaries are built during the
+                                           call, like the reference (three small affine-map launches);
+                                 "lazy"  : read-only mappings computed on first access.
     """
 
     def __init__(
@@ -207,6 +202,7 @@ class AdvancedMixConsole(torch.nn.Module):
         reverb_max_band_decay: float = 1.0,
         materialize_mixed_tracks: bool = True,
         validate: str = "sync",
+        param_dicts: str = "eager",
     ):
         super().__init__()
         self.sample_rate = sample_rate
@@ -242,8 +238,12 @@ class AdvancedMixConsole(torch.nn.Module):
         if validate not in ("sync", "deferred"):
             raise ValueError("validate must be 'sync' or 'deferred'")
         self.validate = validate
+        if param_dicts not in ("eager", "lazy"):
+            raise ValueError("param_dicts must be 'eager' or 'lazy'")
+        self.param_dicts = param_dicts
         self._status = {}
         self._affine_cache = {}
+        self._multipass_eq = False  # test switch: EQ carries through the separate carry-scan kernel at any length
 
     # ------------------------------------------------------------------ validation
     def _status_word(self, device) -> torch.Tensor:
@@ -292,26 +292,45 @@ class AdvancedMixConsole(torch.nn.Module):
             return _nested(_desc.TRACK_INDEX, torch.addcmul(lo, track_params, scale))
 
         def fx():
-            scale, lo = self._affine(_desc.FX_INDEX, fx_bus_params.device)
-            scale, lo = scale.clone(), lo.clone()
-            scale[24], lo[24] = 0.0, 1.0  # reference :420 forces the reverb mix to ones
+            key = ("fx-forced-wet", str(fx_bus_params.device))
+            if key not in self._affine_cache:
+                scale, lo = (t.clone() for t in self._affine(_desc.FX_INDEX, fx_bus_params.device))
+                scale[24], lo[24] = 0.0, 1.0  # reference :420 forces the reverb mix to ones
+                self._affine_cache[key] = (scale, lo)
+            scale, lo = self._affine_cache[key]
             return _nested(_desc.FX_INDEX, torch.addcmul(lo, fx_bus_params, scale))
 
         def master():
             scale, lo = self._affine(_desc.MASTER_INDEX, master_bus_params.device)
             return _nested(_desc.MASTER_INDEX, torch.addcmul(lo, master_bus_params, scale))
 
+        if self.param_dicts == "eager":
+            return tracks(), fx(), master()
         return _LazyParamDict(tracks), _LazyParamDict(fx), _LazyParamDict(master)
 
-    def _normalize_dict(self, d, index):
+    # which dictionary entries each stage of forward_mix_console reads (reference :229-312): a missing key of an
+    # ACTIVE stage raises KeyError exactly like ``**track_param_dict["parametric_eq"]`` does, inactive stages are
+    # never looked at
+    _TRACK_STAGE = {"input_fader": "use_track_input_fader", "parametric_eq": "use_track_eq",
+                    "compressor": "use_track_compressor", "stereo_panner": "use_track_panner", "fx_bus": "use_fx_bus"}
+    _MASTER_STAGE = {"input_fader": "use_master_bus", "parametric_eq": "use_master_bus", "compressor": "use_master_bus",
+                     "output_fader": "use_output_fader"}
+
+    @staticmethod
+    def _stack_dict(d, index, stage_of, flags, lead_shape, like):
         cols = []
         for effect, name in index:
-            lo, hi = self.param_ranges[effect][name]
-            t = d[effect][name] if effect in d and name in d[effect] else None
-            cols.append(t if t is None else normalize(t, lo, hi))
-        ref = next(c for c in cols if c is not None)
-        cols = [torch.zeros_like(ref) if c is None else c for c in cols]
-        return torch.stack(cols, dim=-1)
+            if flags[stage_of[effect]]:
+                t = d[effect][name]  # KeyError for a missing entry of an active stage, as in the reference
+                t = t.to(dtype=torch.float32)
+                if t.numel() != int(torch.Size(lead_shape).numel()):
+                    raise RuntimeError(f"parameter {effect}.{name}: expected {int(torch.Size(lead_shape).numel())} values, "
+                                       f"got shape {tuple(t.shape)}")  # dasp views every parameter as (rows, 1, 1)
+                cols.append(t.reshape(lead_shape))
+            else:
+                cols.append(None)
+        zero = torch.zeros(lead_shape, dtype=torch.float32, device=like.device)
+        return torch.stack([zero if c is None else c for c in cols], dim=-1)
 
     # ------------------------------------------------------------------ forward paths
     def forward_mix_console(
@@ -328,22 +347,35 @@ class AdvancedMixConsole(torch.nn.Module):
         use_master_bus: bool = True,
         use_output_fader: bool = True,
     ):
-        """Denormalised dictionaries in, ``(mixed_tracks (bs,2,T,N), master_bus (bs,2,N))`` out (reference :186-314)."""
-        tp = self._normalize_dict(track_param_dict, _desc.TRACK_INDEX)
-        mp = self._normalize_dict(master_bus_param_dict, _desc.MASTER_INDEX)
-        fp = torch.zeros(tracks.shape[0], 25, dtype=torch.float32, device=tracks.device)
+        """DENORMALISED dictionaries in, ``(mixed_tracks (bs,2,T,N), master_bus (bs,2,N))`` out (reference :186-314).
+
+        Like the reference this entry point applies whatever values it is given: no range check, no clamping, and
+        the gradients flow to the dictionary entries.  Flags are positional in the reference's callers
+        (mst/mixing.py:1076-1087), so their order is part of the interface.
+        """
         flags = dict(
             use_track_input_fader=use_track_input_fader, use_track_eq=use_track_eq,
             use_track_compressor=use_track_compressor, use_track_panner=use_track_panner,
             use_fx_bus=use_fx_bus, use_master_bus=use_master_bus, use_output_fader=use_output_fader,
         )
-        return self._run(tracks, tp.clamp(0, 1), fp, mp.clamp(0, 1), flags)
+        bs, n_tracks, _ = tracks.shape
+        tp = self._stack_dict(track_param_dict, _desc.TRACK_INDEX, self._TRACK_STAGE, flags, (bs, n_tracks), tracks)
+        mp = self._stack_dict(master_bus_param_dict, _desc.MASTER_INDEX, self._MASTER_STAGE, flags, (bs,), tracks)
+        if use_fx_bus:
+            rev = fx_bus_param_dict["reverberation"]
+            fp = torch.stack([rev[name].to(torch.float32).reshape(bs) for _, name in _desc.FX_INDEX], dim=-1)
+        else:
+            fp = torch.zeros(bs, 25, dtype=torch.float32, device=tracks.device)
+        return self._run(tracks, tp, fp, mp, flags, denormalized=True)
 
-    def _run(self, tracks, track_params, fx_bus_params, master_bus_params, flags):
+    def _run(self, tracks, track_params, fx_bus_params, master_bus_params, flags, denormalized=False):
         if flags["use_fx_bus"]:
             raise NotImplementedError(
-                "use_fx_bus=True (stereo_bus + noise_shaped_reverberation, reference mst/modules.py:275-284) is not "
-                "built yet in the MI355X console; every shipped reference path runs with use_fx_bus=False"
+                "use_fx_bus=True (stereo_bus + noise_shaped_reverberation, reference mst/modules.py:275-284) is not built "
+                "in the MI355X console yet.  It is the DEFAULT of forward() / forward_mix_console() / naive_random_mix(), as in "
+                "the reference: pass use_fx_bus=False.  Under the reference's System the flag is switched on by "
+                "`active_fx_bus_epoch` (mst/system.py:129-130; every shipped config sets it to 1000) - keep that epoch beyond "
+                "the run length, or construct diffmst_hip.system.CommonStep, which refuses such a config up front."
             )
         if not flags["use_track_panner"]:
             raise RuntimeError("use_track_panner=False is shape-inconsistent in the reference (mst/modules.py:269)")
@@ -351,7 +383,8 @@ class AdvancedMixConsole(torch.nn.Module):
             t.requires_grad for t in (tracks, track_params, fx_bus_params, master_bus_params)
         )
         mix, mixed = _ConsoleFunction.apply(
-            tracks, track_params, fx_bus_params, master_bus_params, self, flags, self.materialize_mixed_tracks, need_grad
+            tracks, track_params, fx_bus_params, master_bus_params, self, flags, self.materialize_mixed_tracks, need_grad,
+            denormalized,
         )
         return mixed, mix
 

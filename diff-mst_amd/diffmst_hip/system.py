@@ -1,0 +1,164 @@
+"""``diffmst_hip.system`` - the body of the reference's training / validation step as a plain ``nn.Module``.
+
+``CommonStep`` restates the CALL ORDER of ``System.common_step`` (reference mst/system.py:102-407) without
+PyTorch-Lightning: epoch-gated effect flags (:123-133), the random reference mix under ``no_grad`` (:149-173,
+executed twice by the reference, :222-246), peak normalisation and the NaN guard (:176-180 / :249-253), the A/B
+split on the LAST dimension (:255-258 - ``tracks_b`` is a strided view, which the console kernels read in place),
+the parameter-estimation model (:263-271), the console with gradients (:274-292) and the loss sum (:329-338).
+Everything numerical inside it is the HIP console / losses of this package; the model is whatever the caller
+passes (the reference's ``MixStyleTransferModel`` or any module with the same call signature).
+
+It exists to prove "API unchanged" end to end on a machine without the reference (tests/test_system_gpu.py);
+with a checkout of the reference, ``diffmst_hip.install()`` lets the reference's own ``System`` run instead.
+Logging (``self.log``), wandb callbacks, optimisers and the D2H plotting copies are Lightning's business and stay
+out (``collect=True`` reproduces the ``data_dict`` of :392-405 when a caller wants it).
+"""
+from __future__ import annotations
+
+from typing import Callable
+
+import torch
+
+from .utils import batch_stereo_peak_normalize
+
+
+class CommonStep(torch.nn.Module):
+    def __init__(
+        self,
+        model: torch.nn.Module,
+        mix_console: torch.nn.Module,
+        mix_fn: Callable,
+        loss: torch.nn.Module,
+        generate_mix: bool = True,
+        use_mix_loss: bool = True,
+        active_eq_epoch: int = 0,
+        active_compressor_epoch: int = 0,
+        active_fx_bus_epoch: int = 0,
+        active_master_bus_epoch: int = 0,
+        max_epochs: int = 500,
+        repeat_reference_mix: bool = True,
+    ) -> None:
+        super().__init__()
+        self.model = model
+        self.mix_console = mix_console
+        self.mix_fn = mix_fn
+        self.loss = loss
+        self.generate_mix = generate_mix
+        self.use_mix_loss = use_mix_loss
+        self.active_eq_epoch = active_eq_epoch
+        self.active_compressor_epoch = active_compressor_epoch
+        self.active_fx_bus_epoch = active_fx_bus_epoch
+        self.active_master_bus_epoch = active_master_bus_epoch
+        # the reference runs the mix_fn block twice per step and keeps the second result (a merge artefact, SURVEY
+        # App. C.1); True reproduces its RNG stream and its cost, False runs the block once
+        self.repeat_reference_mix = repeat_reference_mix
+        self.current_epoch = 0
+        # defaults of reference :83-89
+        self.use_track_input_fader = True
+        self.use_track_panner = True
+        self.use_track_eq = False
+        self.use_track_compressor = False
+        self.use_fx_bus = False
+        self.use_master_bus = False
+        self.use_output_fader = True
+        if active_fx_bus_epoch < max_epochs and not getattr(mix_console, "supports_fx_bus", False):
+            # fail at construction, not at epoch `active_fx_bus_epoch` in the middle of a run
+            raise NotImplementedError(
+                f"active_fx_bus_epoch={active_fx_bus_epoch} switches the fx bus on within max_epochs={max_epochs}, but this "
+                "console has no fx bus (reference mst/modules.py:275-284 is not built): set active_fx_bus_epoch >= max_epochs "
+                "(the reference's configs use 1000)"
+            )
+
+    def _reference_mix(self, tracks, instrument_id, stereo_info):
+        return self.mix_fn(
+            tracks,
+            self.mix_console,
+            use_track_input_fader=False,
+            use_track_panner=self.use_track_panner,
+            use_track_eq=self.use_track_eq,
+            use_track_compressor=self.use_track_compressor,
+            use_fx_bus=self.use_fx_bus,
+            use_master_bus=self.use_master_bus,
+            use_output_fader=False,  # lands in naive_random_mix's **kwargs (its keyword is misspelt), as in the reference
+            instrument_id=instrument_id,
+            stereo_id=stereo_info,
+            instrument_number_file=None,
+            ke_dict=None,
+        )
+
+    def forward(self, batch: tuple, train: bool = False, collect: bool = False):
+        tracks, instrument_id, stereo_info, track_padding, ref_mix, song_name = batch
+        middle_idx = tracks.shape[-1] // 2
+        if self.current_epoch >= self.active_eq_epoch:
+            self.use_track_eq = True
+        if self.current_epoch >= self.active_compressor_epoch:
+            self.use_track_compressor = True
+        if self.current_epoch >= self.active_fx_bus_epoch:
+            self.use_fx_bus = True
+        if self.current_epoch >= self.active_master_bus_epoch:
+            self.use_master_bus = True
+
+        ref_track_param_dict = ref_fx_bus_param_dict = ref_master_bus_param_dict = None
+        if self.generate_mix:
+            for _ in range(2 if self.repeat_reference_mix else 1):
+                (_, ref_mix, ref_track_param_dict, ref_fx_bus_param_dict, ref_master_bus_param_dict,
+                 _, _, _) = self._reference_mix(tracks, instrument_id, stereo_info)
+                ref_mix = batch_stereo_peak_normalize(ref_mix)
+                if torch.isnan(ref_mix).any():
+                    raise ValueError("Found nan in ref_mix")
+            ref_mix_a = ref_mix[..., :middle_idx]
+            ref_mix_b = ref_mix[..., middle_idx:]
+            tracks_b = tracks[..., middle_idx:]
+        else:
+            ref_mix_a = ref_mix_b = ref_mix
+            tracks_b = tracks
+
+        pred_track_params, pred_fx_bus_params, pred_master_bus_params = self.model(
+            tracks_b, ref_mix_a, track_padding_mask=track_padding
+        )
+        (pred_mixed_tracks_b, pred_mix_b, pred_track_param_dict, pred_fx_bus_param_dict,
+         pred_master_bus_param_dict) = self.mix_console(
+            tracks_b,
+            pred_track_params,
+            pred_fx_bus_params,
+            pred_master_bus_params,
+            use_track_input_fader=self.use_track_input_fader,
+            use_track_panner=self.use_track_panner,
+            use_track_eq=self.use_track_eq,
+            use_track_compressor=self.use_track_compressor,
+            use_fx_bus=self.use_fx_bus,
+            use_master_bus=self.use_master_bus,
+            use_output_fader=self.use_output_fader,
+        )
+        if ref_track_param_dict is None:
+            ref_track_param_dict = pred_track_param_dict
+            ref_fx_bus_param_dict = pred_fx_bus_param_dict
+            ref_master_bus_param_dict = pred_master_bus_param_dict
+
+        loss = 0
+        terms = {}
+        if self.use_mix_loss:
+            mix_loss = self.loss(pred_mix_b, ref_mix_b)
+            if type(mix_loss) == dict:
+                for key, val in mix_loss.items():
+                    loss += val.mean()
+                terms = mix_loss
+            else:
+                loss += mix_loss
+
+        data_dict = {"loss_terms": terms}
+        if collect:  # the plotting payload of reference :388-405 (device -> host copies every step)
+            sum_mix_b = batch_stereo_peak_normalize(tracks_b.sum(dim=1, keepdim=True).detach().float())
+            data_dict.update(
+                ref_mix_a=ref_mix_a.detach().float().cpu(),
+                ref_mix_b_norm=ref_mix_b.detach().float().cpu(),
+                pred_mix_b_norm=pred_mix_b.detach().float().cpu(),
+                sum_mix_b=sum_mix_b.cpu(),
+                ref_track_param_dict=ref_track_param_dict,
+                pred_track_param_dict=pred_track_param_dict,
+                ref_fx_bus_param_dict=ref_fx_bus_param_dict,
+                pred_fx_bus_param_dict=pred_fx_bus_param_dict,
+                ref_master_bus_param_dict=ref_master_bus_param_dict,
+                pred_master_bus_param_dict=pred_master_bus_param_dict,
+            )
+        return loss, data_dict

@@ -2,6 +2,7 @@
 from __future__ import annotations
 
 import torch
+from torch.autograd.function import once_differentiable
 
 from . import _cabi, _hip
 
@@ -11,9 +12,16 @@ class _PeakNormalize(torch.autograd.Function):
     def forward(ctx, x):
         _hip.require_cuda(x)
         lib = _hip.lib()
-        if x.dim() != 3 or x.shape[1] != 2:
-            raise ValueError("expected a (bs, 2, seq_len) tensor")
+        if x.dim() != 3:
+            raise ValueError("expected a (bs, chs, seq_len) tensor")
+        shape = x.shape
         xc = x.float().contiguous()
+        if shape[1] != 2:
+            # the peak runs over (channels, time) of a batch item, so any channel count is the stereo kernel on a
+            # (bs, 2, chs*n/2) view of the same memory (reference mst/system.py:390-391 normalises a MONO sum)
+            if (shape[1] * shape[2]) % 2:
+                raise ValueError("chs * seq_len must be even")
+            xc = xc.view(shape[0], 2, shape[1] * shape[2] // 2)
         bs, _, n = xc.shape
         dev = xc.device
         nbytes = lib.mst_peak_normalize_workspace_bytes(bs, n)
@@ -24,22 +32,24 @@ class _PeakNormalize(torch.autograd.Function):
                                                       _hip.current_stream_ptr(dev)), "mst_peak_normalize_forward")
         ctx.save_for_backward(xc, ws)
         ctx.nbytes = nbytes
-        return y
+        ctx.shape = shape
+        return y.view(shape)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, g):
         xc, ws = ctx.saved_tensors
         lib = _hip.lib()
         bs, _, n = xc.shape
         dev = xc.device
-        g = g.float().contiguous()
+        g = g.float().contiguous().view(xc.shape)
         dx = torch.empty_like(xc)
         with torch.cuda.device(dev):
             _hip.check(lib.mst_peak_normalize_backward(_cabi.ptr(xc), _cabi.ptr(g), _cabi.ptr(dx), bs, n, _cabi.ptr(ws),
                                                        ctx.nbytes, _hip.current_stream_ptr(dev)), "mst_peak_normalize_backward")
-        return dx
+        return dx.view(ctx.shape)
 
 
 def batch_stereo_peak_normalize(x: torch.Tensor):
-    """Normalize a batch of stereo mixes ``(bs, 2, seq_len)`` by their peak value (per batch item)."""
+    """Normalize a batch of mixes ``(bs, chs, seq_len)`` by their peak value over (chs, seq_len), per batch item."""
     return _PeakNormalize.apply(x)

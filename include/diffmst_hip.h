@@ -18,7 +18,8 @@
  *    hipError_t-compatible int (0 = ok), never an exception / abort;
  *  - semantic errors keep the reference's Python exceptions: the launcher only writes
  *    a code to `status` (see mst_console_forward) and the host wrapper raises;
- *  - re-entrant, no global mutable state; one process per GPU.
+ *  - re-entrant: the library keeps NO process-wide mutable state (no stream pools, no caches, no environment
+ *    switches in the default build); everything a call needs arrives through its arguments.
  */
 #ifndef DIFFMST_HIP_H
 #define DIFFMST_HIP_H
@@ -43,6 +44,10 @@ extern "C" {
 #define MST_USE_MASTER_BUS 0x20u
 #define MST_USE_OUTPUT_FADER 0x40u
 #define MST_SAVE_FOR_BACKWARD 0x100u /* keep intermediates in the workspace for mst_console_backward */
+#define MST_NO_RANGE_CHECK 0x400u   /* the parameter tensors hold DENORMALISED values (forward_mix_console, reference
+                                       mst/modules.py:186-314, which applies whatever it is given): no range check; the
+                                       caller passes lo = 0, hi = 1 so that the map v*(hi-lo)+lo is the identity and the
+                                       returned gradients are w.r.t. the denormalised values */
 #define MST_DEV_MULTIPASS_EQ 0x200u /* developer/test switch: keep the EQ carry scan in its own kernel (zero-state pass,
                                        carry scan, run) even when a row is short enough (<= 262144 samples) for the
                                        in-wave scans of the two-kernel path; longer rows always take three kernels */

@@ -5,7 +5,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "diff-mst_amd")
-for p in (ROOT, PKG):
+for p in (ROOT, PKG, os.path.join(PKG, "standalone")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
@@ -18,3 +18,32 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+# ---- measured parity numbers of the -m gpu tests -> gpurun_out/parity_r02.json (committed copy: profiles/) -----------
+_PARITY = {}
+
+
+@pytest.fixture
+def record(request):
+    """record(key=value, ...) files the numbers a parity test measured under the test's id."""
+
+    def rec(**values):
+        d = _PARITY.setdefault(request.node.nodeid.split("::", 1)[-1], {})
+        for k, v in values.items():
+            d[k] = [float(x) for x in v] if isinstance(v, (tuple, list)) else float(v)
+
+    return rec
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if not _PARITY:
+        return
+    import json
+
+    out = os.path.join(os.environ.get("GRAFT_REPO_ROOT", ROOT), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    legend = ("rel-L2 errors measured by the -m gpu tests on the MI355X; triples are (HIP vs fp32 reference algorithm, "
+              "HIP vs float64, fp32 reference algorithm vs float64)")
+    with open(os.path.join(out, "parity_r02.json"), "w") as f:
+        json.dump({"legend": legend, "tests": _PARITY}, f, indent=1, sort_keys=True)

@@ -2,7 +2,7 @@
 """Generate the golden fixtures under tests/golden/ FROM THE REAL REFERENCE.
 
 Runs ONLY in the build container (needs /root/reference, which never travels to
-the GPU box).  Usage:  python -B tests/golden/make_golden.py
+the GPU box).  Usage:  python -B tests/golden/make_golden.py [system]
 
 What it does
 ------------
@@ -39,23 +39,14 @@ REF = "/root/reference"
 
 
 def install_stubs():
-    ta = types.ModuleType("torchaudio")
-    ta.pipelines = types.ModuleType("torchaudio.pipelines")
-    ta.pipelines.HDEMUCS_HIGH_MUSDB_PLUS = None
-    ta.transforms = types.ModuleType("torchaudio.transforms")
-    ta.functional = types.ModuleType("torchaudio.functional")
-    sys.modules["torchaudio"] = ta
-    sys.modules["torchaudio.pipelines"] = ta.pipelines
-    sys.modules["torchaudio.transforms"] = ta.transforms
-    sys.modules["torchaudio.functional"] = ta.functional
-    sys.modules["librosa"] = types.ModuleType("librosa")
-    dp = types.ModuleType("dasp_pytorch")
-    dpf = types.ModuleType("dasp_pytorch.functional")
-    for name in ("gain", "stereo_panner", "compressor", "parametric_eq", "stereo_bus", "noise_shaped_reverberation"):
-        setattr(dpf, name, getattr(od, name))
-    dp.functional = dpf
-    sys.modules["dasp_pytorch"] = dp
-    sys.modules["dasp_pytorch.functional"] = dpf
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import refstubs
+
+    # auraloss stand-in = the oracle's restatement (auraloss 0.4.0 is absent: parity unpinned, oracle/__init__.py)
+    def mr(x, y, fft_sizes, hop_sizes, win_lengths, **kw):
+        return ol.mrstft_loss(x, y, tuple(zip(fft_sizes, hop_sizes, win_lengths)), **kw)
+
+    refstubs.install_stubs(dasp_ops=od, auraloss_mrstft=mr)
 
 
 def flat(d):
@@ -137,6 +128,38 @@ def console_case(name, bs, T, n, seed, flags, ref_console, full_box=False):
     print(f"console_{name}: mix rms {mix.pow(2).mean().sqrt():.4e}  |g_tp| {g_tp.abs().max():.3e}")
 
 
+def system_case(rsystem, rmodules, rmixing):
+    """The REAL ``System.common_step`` (mst/system.py:102-407; Lightning stood in by tests/refstubs.py) with the real
+    console / naive_random_mix, the restated dasp ops at the seam and the restated MR-STFT loss: generate_mix, both
+    random-mix blocks, peak normalise, A/B split (strided tracks_b), stub model, console with grad, loss sum."""
+    import auraloss
+    from util import StubModel
+
+    bs, T, n = 2, 4, 131072
+    torch.manual_seed(31)
+    tracks = (0.1 * torch.randn(bs, T, n)).half().float()
+    model = StubModel(seed=7)
+    res = dict(fft_sizes=[512, 2048, 8192], hop_sizes=[256, 1024, 4096], win_lengths=[512, 2048, 8192])
+    system = rsystem.System(model=model, mix_console=rmodules.AdvancedMixConsole(sample_rate=44100), mix_fn=rmixing.naive_random_mix,
+                            loss=auraloss.freq.MultiResolutionSTFTLoss(**res), generate_mix=True, active_eq_epoch=0,
+                            active_compressor_epoch=0, active_fx_bus_epoch=1000, active_master_bus_epoch=0)
+    batch = (tracks, None, None, torch.zeros(bs, T, dtype=torch.bool), None, ["a", "b"])
+    torch.manual_seed(32)  # the RNG stream naive_random_mix draws from (twice: system.py:149-173 and :222-246)
+    loss, data = system.common_step(batch, 0, train=True)
+    loss.backward()
+    np.savez_compressed(
+        os.path.join(HERE, "system_step.npz"), shape=np.array([bs, T, n]), tracks_sub=tracks.numpy()[..., ::1024], seed_tracks=31, seed_model=7, seed_mix=32,
+        loss=np.array(loss.item()), ref_mix_b_sub=data["ref_mix_b_norm"].numpy()[..., ::16],
+        pred_mix_b_sub=data["pred_mix_b_norm"].numpy()[..., ::16], ref_mix_a_sub=data["ref_mix_a"].numpy()[..., ::16],
+        sum_mix_b_sub=data["sum_mix_b"].numpy()[..., ::16],
+        g_w_track=model.w_track.grad.numpy(), g_w_fx=np.zeros((25, 4), np.float32) if model.w_fx.grad is None else model.w_fx.grad.numpy(),
+        g_w_master=model.w_master.grad.numpy(),
+        pred_track_ratio=data["pred_track_param_dict"]["compressor"]["ratio"].detach().numpy(),
+        ref_master_thr=data["ref_master_bus_param_dict"]["compressor"]["threshold_db"].detach().numpy(),
+    )
+    print(f"system_step: loss {loss.item():.6f}  |g_w_track| {model.w_track.grad.abs().max():.3e}")
+
+
 def main():
     assert os.path.isdir(REF), "golden generation needs /root/reference (build container only)"
     install_stubs()
@@ -145,9 +168,14 @@ def main():
     import mst.loss as rloss
     import mst.mixing as rmixing
     import mst.modules as rmodules
+    import mst.system as rsystem
 
     ref_console = rmodules.AdvancedMixConsole(sample_rate=44100)
     assert ref_console.param_ranges == oc.param_ranges(44100)
+    only = set(sys.argv[1:])  # e.g. `make_golden.py system` regenerates one fixture family (default: all)
+    if only == {"system"}:
+        system_case(rsystem, rmodules, rmixing)
+        return
 
     basic = dict(
         use_track_input_fader=True, use_track_eq=False, use_track_compressor=False, use_track_panner=True,
@@ -226,6 +254,7 @@ def main():
     x = torch.randn(3, 2, 1000)
     g = x.abs().max(dim=-1, keepdim=True)[0].max(dim=-2, keepdim=True)[0]
     assert torch.equal(x / g.clamp(1e-8), oc.batch_stereo_peak_normalize(x))
+    system_case(rsystem, rmodules, rmixing)
     print("golden fixtures written to", HERE)
 
 

@@ -31,7 +31,7 @@ def lib():
 
 
 def console(param_ranges, tracks, tp, fp, mp, flags, grad_mix=None, want_mixed=True, grad_mixed=None,
-            want_grad_tracks=False, sample_rate=44100, multipass_eq=False):
+            want_grad_tracks=False, sample_rate=44100, multipass_eq=False, denormalized=False):
     """CPU tensors in; returns dict(mix, mixed, status, grad_tp, grad_mp, grad_tracks)."""
     from mst import _cabi, _desc
 
@@ -41,7 +41,9 @@ def console(param_ranges, tracks, tp, fp, mp, flags, grad_mix=None, want_mixed=T
     word = _desc.flag_word(save_for_backward=grad_mix is not None, **flags)
     if multipass_eq:
         word |= _cabi.DEV_MULTIPASS_EQ
-    d = _desc.make_desc(param_ranges, sample_rate, bs, T, n, tracks.stride(1), word)
+    if denormalized:  # tp / mp hold denormalised values (forward_mix_console): identity ranges, no range check
+        word |= _cabi.NO_RANGE_CHECK
+    d = _desc.make_desc(param_ranges, sample_rate, bs, T, n, tracks.stride(1), word, identity_ranges=denormalized)
     nbytes = L.mst_console_workspace_bytes(C.byref(d))
     assert nbytes > 0
     ws = torch.zeros(nbytes // 4 + 64, dtype=torch.float32)

@@ -78,12 +78,15 @@ def assert_three_way(hip, r32, r64, key, tol32, slack=1e-4):
     assert h64 <= 2 * r + slack, (key, "hip-vs-ref32", h32, "hip-vs-f64", h64, "ref32-vs-f64", r)
 
 
+GOLDEN_GRAD_TOL = {"default": 1e-2, "console_fullbox_1x2x131072.npz": 1e-2}
+
+
 def parse_flags(arr):
     return {k: v == "True" for k, v in arr}
 
 
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "console_*.npz"))))
-def test_console_golden(path, console, dev):
+def test_console_golden(path, console, dev, record):
     """Fixtures produced by the REAL reference orchestration (tests/golden/make_golden.py)."""
     g = np.load(path, allow_pickle=True)
     flags = parse_flags(g["flags"])
@@ -91,13 +94,16 @@ def test_console_golden(path, console, dev):
     stride = int(g["mix_stride"])
     out = run_hip(console, dev, t("tracks"), t("track_params"), t("fx_bus_params"), t("master_bus_params"), flags,
                   gmix=t("grad_mix"))
-    assert rel(out["mix"][..., ::stride], t("mix")) < 1e-4
-    assert rel(out["mixed"][..., ::64], t("mixed_tracks_sub")) < 1e-4
-    if np.abs(g["grad_track_params"]).max() > 0:
-        assert rel(out["g_tp"], t("grad_track_params")) < 1e-2
-    if np.abs(g["grad_master_bus_params"]).max() > 0:
-        assert rel(out["g_mp"], t("grad_master_bus_params")) < 1e-2
-    else:
+    e_mix, e_mixed = rel(out["mix"][..., ::stride], t("mix")), rel(out["mixed"][..., ::64], t("mixed_tracks_sub"))
+    e_tp = rel(out["g_tp"], t("grad_track_params")) if np.abs(g["grad_track_params"]).max() > 0 else 0.0
+    e_mp = rel(out["g_mp"], t("grad_master_bus_params")) if np.abs(g["grad_master_bus_params"]).max() > 0 else 0.0
+    record(mix=e_mix, mixed_tracks=e_mixed, g_tp=e_tp, g_mp=e_mp)
+    assert e_mix < 1e-4 and e_mixed < 1e-4
+    # the fixture is the reference's fp32 autograd, itself ~1e-3 (short impulse responses) .. 5e-3 (full box) from float64
+    # (three-way tests); bounds = measured on the MI355X (profiles/parity_r02.json) plus margin
+    tol = GOLDEN_GRAD_TOL.get(os.path.basename(path), GOLDEN_GRAD_TOL["default"])
+    assert e_tp < tol and e_mp < tol, (e_tp, e_mp)
+    if np.abs(g["grad_master_bus_params"]).max() == 0:
         assert float(out["g_mp"].abs().max()) == 0.0
     # denormalised parameter dictionaries (reference mst/modules.py:462-466) - exact affine map
     for k in g.files:
@@ -110,7 +116,7 @@ def test_console_golden(path, console, dev):
 
 
 @pytest.mark.parametrize("bs,T,n,seed", [(2, 8, 262144, 0), (1, 4, 65536, 1), (2, 3, 131072, 2)])
-def test_console_three_way(bs, T, n, seed, console, dev):
+def test_console_three_way(bs, T, n, seed, console, dev, record):
     """HIP vs fp32 reference algorithm vs float64, forward and backward, BASELINE cfg #2 row shape."""
     torch.manual_seed(seed)
     tracks = 0.1 * torch.randn(bs, T, n)
@@ -123,6 +129,7 @@ def test_console_three_way(bs, T, n, seed, console, dev):
     for k in ("mix", "mixed", "g_tracks", "g_tp", "g_mp"):
         report[k] = (rel(hip[k], r32[k]), rel(hip[k], r64[k]), rel(r32[k], r64[k]))
     print("\n[three-way] key: (hip vs ref32, hip vs f64, ref32 vs f64)\n", report)
+    record(**report)
     for k in ("mix", "mixed"):
         assert report[k][0] < 1e-4, (k, report[k])
     for k in ("g_tracks", "g_tp", "g_mp"):
@@ -259,7 +266,7 @@ def test_linearity_and_determinism_full_size(console, dev):
     del flags
 
 
-def test_inwave_scan_equals_carry_scan_kernel_full_size(console, dev, monkeypatch):
+def test_inwave_scan_equals_carry_scan_kernel_full_size(console, dev):
     """The two EQ carry-resolution paths (in-wave scans, taken up to 262144 samples; separate carry-scan kernel,
     taken beyond) on the SAME cfg #2-sized input, forward and backward: fp32 round-off apart."""
     torch.manual_seed(21)
@@ -268,8 +275,9 @@ def test_inwave_scan_equals_carry_scan_kernel_full_size(console, dev, monkeypatc
     tp, fp, mp = torch.rand(bs, T, 27), torch.rand(bs, 25), torch.rand(bs, 26)
     gmix = torch.randn(bs, 2, n)
     a = run_hip(console, dev, tracks, tp, fp, mp, FULL, gmix=gmix, grad_tracks=True)
-    monkeypatch.setenv("MST_MULTIPASS_EQ", "1")
-    b = run_hip(console, dev, tracks, tp, fp, mp, FULL, gmix=gmix, grad_tracks=True)
+    multi = type(console)(44100)
+    multi._multipass_eq = True
+    b = run_hip(multi, dev, tracks, tp, fp, mp, FULL, gmix=gmix, grad_tracks=True)
     assert rel(a["mix"], b["mix"]) < 5e-6
     # the cotangents pass the compressors' knees / abs(): 1e-6 differences of u move them by ~1e-3 in BOTH paths
     # (each sits 3e-4 from float64, like the fp32 reference itself - tools/dbg_gtracks.py)

@@ -65,6 +65,10 @@ def test_no_cpu_fallback_and_unsupported_paths():
         AudioFeatureLoss([1.0] * 5, 44100)(torch.zeros(1, 2, 20000), torch.zeros(1, 2, 20000))
     with pytest.raises(RuntimeError, match="no CPU path"):
         batch_stereo_peak_normalize(torch.zeros(1, 2, 100))
+    import diffmst_hip
+    import mst
+
+    assert mst.modules is diffmst_hip.modules and mst.__diffmst_alias__
 
 
 def test_product_never_touches_the_oracle():
@@ -78,32 +82,72 @@ def test_product_never_touches_the_oracle():
                 assert "hostsim" not in text, f
 
 
-def test_denormalize_helpers_and_lazy_dicts():
+def test_denormalize_helpers_and_param_dicts():
     assert denormalize(0.25, 10.0, 2.0) == 4.0 and normalize(4.0, 2.0, 10.0) == 0.25
-    c = AdvancedMixConsole(44100)
     tp, fp, mp = torch.rand(2, 3, 27), torch.rand(2, 25), torch.rand(2, 26)
-    built = []
-    tpd, fpd, mpd = c._denormalized_dicts(tp, fp, mp)
-    assert isinstance(tpd, dict) and isinstance(tpd, _LazyParamDict)
-    assert tpd._build is not None  # nothing computed until somebody looks
-    assert set(tpd.keys()) == {"input_fader", "parametric_eq", "compressor", "stereo_panner", "fx_bus"}
-    assert set(mpd) == {"parametric_eq", "compressor", "output_fader", "input_fader"}
-    lo, hi = c.param_ranges["compressor"]["ratio"]
-    assert torch.allclose(tpd["compressor"]["ratio"], tp[..., 20] * (hi - lo) + lo)
-    assert torch.equal(fpd["reverberation"]["mix"], torch.ones(2))  # reference mst/modules.py:420
-    assert tpd["parametric_eq"]["band1_cutoff_freq"].shape == (2, 3) and mpd["input_fader"]["gain_db"].shape == (2,)
+    for mode in ("eager", "lazy"):
+        c = AdvancedMixConsole(44100, param_dicts=mode)
+        tpd, fpd, mpd = c._denormalized_dicts(tp, fp, mp)
+        if mode == "eager":
+            assert type(tpd) is dict  # the reference's plain dictionaries
+        else:
+            assert isinstance(tpd, _LazyParamDict) and tpd._data is None  # nothing computed until somebody looks
+        assert set(tpd.keys()) == {"input_fader", "parametric_eq", "compressor", "stereo_panner", "fx_bus"}
+        assert set(mpd) == {"parametric_eq", "compressor", "output_fader", "input_fader"}
+        lo, hi = c.param_ranges["compressor"]["ratio"]
+        assert torch.allclose(tpd["compressor"]["ratio"], tp[..., 20] * (hi - lo) + lo)
+        assert torch.equal(fpd["reverberation"]["mix"], torch.ones(2))  # reference mst/modules.py:420
+        assert tpd["parametric_eq"]["band1_cutoff_freq"].shape == (2, 3) and mpd["input_fader"]["gain_db"].shape == (2,)
     # the reference helper (with its 156 host checks) is kept for API parity
     with pytest.raises(ValueError, match="Parameter gain_db of effect input_fader is out of range."):
         denormalize_parameters({"input_fader": {"gain_db": torch.tensor([1.2])}}, c.param_ranges)
-    del built
 
 
-def test_normalize_dict_round_trip():
+def test_lazy_mapping_has_no_empty_view():
+    """Every access path of the lazy mapping fills first (a dict subclass could be read empty)."""
+    import copy
+    import pickle
+
+    c = AdvancedMixConsole(44100, param_dicts="lazy")
+    tp = torch.rand(1, 2, 27)
+    mk = lambda: c._denormalized_dicts(tp, torch.rand(1, 25), torch.rand(1, 26))[0]
+    ref = dict(mk())
+    assert len(ref) == 5
+    assert set(mk().keys()) == set(ref) and len(mk().items()) == 5 and len(list(mk().values())) == 5
+    assert set(mk().copy()) == set(ref) and set(dict(mk())) == set(ref) and set(copy.copy(mk())) == set(ref)
+    assert set(pickle.loads(pickle.dumps(mk()))) == set(ref)
+    assert "compressor" in mk() and mk().get("nope") is None
+    with pytest.raises(TypeError):
+        mk()["x"] = 1  # read-only
+
+
+def test_forward_mix_console_key_handling():
+    """Denormalised dictionaries: entries of ACTIVE stages must exist (KeyError like the reference's ``**dict[...]``),
+    inactive stages are never looked at; nothing is clamped or range-checked (host part; device part: GPU tests)."""
     c = AdvancedMixConsole(44100)
-    tp = torch.rand(2, 3, 27)
-    tpd, _, _ = c._denormalized_dicts(tp, torch.rand(2, 25), torch.rand(2, 26))
-    back = c._normalize_dict(dict(tpd), _desc.TRACK_INDEX)
-    assert torch.allclose(back, tp, atol=1e-5)
+    flags = dict(use_track_input_fader=True, use_track_eq=False, use_track_compressor=False, use_track_panner=True,
+                 use_fx_bus=False, use_master_bus=False, use_output_fader=True)
+    like = torch.zeros(1)
+    tpd = {"input_fader": {"gain_db": torch.tensor([[3.0, -70.0]])}, "stereo_panner": {"pan": torch.tensor([[0.2, 1.7]])}}
+    t = c._stack_dict(tpd, _desc.TRACK_INDEX, c._TRACK_STAGE, flags, (1, 2), like)
+    assert t.shape == (1, 2, 27) and t[0, 1, 0] == -70.0 and t[0, 1, 25] == pytest.approx(1.7)  # out-of-range values pass through
+    assert float(t[..., 1:25].abs().max()) == 0.0
+    with pytest.raises(KeyError):
+        c._stack_dict({"input_fader": {"gain_db": torch.zeros(1, 2)}}, _desc.TRACK_INDEX, c._TRACK_STAGE, flags, (1, 2), like)
+    # knowledge_engineering_mix hands a master dict keyed 'fader' (reference mst/mixing.py:1060-1075): KeyError there too
+    with pytest.raises(KeyError):
+        c._stack_dict({"fader": {"gain_db": torch.zeros(1)}}, _desc.MASTER_INDEX, c._MASTER_STAGE, flags, (1,), like)
+    d = _desc.make_desc(c.param_ranges, 44100, 1, 2, 64, 64, 0, identity_ranges=True)
+    assert list(d.track_lo) == [0.0] * 27 and list(d.master_hi) == [1.0] * 26
+
+
+def test_common_step_refuses_an_fx_bus_schedule_up_front():
+    from mst.system import CommonStep
+
+    c = AdvancedMixConsole(44100)
+    with pytest.raises(NotImplementedError, match="active_fx_bus_epoch"):
+        CommonStep(torch.nn.Identity(), c, lambda *a, **k: None, torch.nn.Identity(), active_fx_bus_epoch=0)
+    CommonStep(torch.nn.Identity(), c, lambda *a, **k: None, torch.nn.Identity(), active_fx_bus_epoch=1000)
 
 
 def test_basic_console_is_gain_and_pan_only():

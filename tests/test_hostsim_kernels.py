@@ -78,6 +78,28 @@ def test_console_generic_scan_width(ranges):
     assert rel(b["grad_tp"], x.grad) < 2e-2 and rel(b["grad_mp"], y.grad) < 2e-2
 
 
+def test_console_denormalised_parameter_path(ranges):
+    """MST_NO_RANGE_CHECK + identity ranges (forward_mix_console): same signal as the normalised call on the same
+    parameters, gradients scaled by 1/(hi - lo), and values outside [0,1] raise no status."""
+    from mst import _desc
+
+    torch.manual_seed(6)
+    bs, T, n = 1, 2, 3000
+    tracks = 0.1 * torch.randn(bs, T, n)
+    tp, fp, mp = torch.rand(bs, T, 27), torch.rand(bs, 25), torch.rand(bs, 26)
+    tp, mp = short_ir(tp, mp)
+    gmix = torch.randn(bs, 2, n)
+    a = harness.console(ranges, tracks, tp, fp, mp, FULL, grad_mix=gmix, want_mixed=False)
+    tlo, thi = (torch.tensor(v) for v in _desc.range_vectors(ranges, _desc.TRACK_INDEX))
+    mlo, mhi = (torch.tensor(v) for v in _desc.range_vectors(ranges, _desc.MASTER_INDEX))
+    b = harness.console(ranges, tracks, tp * (thi - tlo) + tlo, fp, mp * (mhi - mlo) + mlo, FULL, grad_mix=gmix,
+                        want_mixed=False, denormalized=True)
+    assert a["status"] == 0 and b["status"] == 0  # e.g. -60 dB thresholds are far outside [0,1] and must not be flagged
+    assert rel(b["mix"], a["mix"]) < 1e-6
+    assert rel(b["grad_tp"] * (thi - tlo), a["grad_tp"]) < 1e-4
+    assert rel(b["grad_mp"] * (mhi - mlo), a["grad_mp"]) < 1e-4
+
+
 def test_console_status_flag(ranges):
     tp, fp, mp = torch.rand(1, 1, 27), torch.rand(1, 25), torch.rand(1, 26)
     mp[0, 24] = 1.5

@@ -38,7 +38,7 @@ def make_loss(res=RES, **kw):
     (2, 131072, dict(w_sc=0.0, w_log_mag=1.0, w_lin_mag=1.0)),          # evaluation instance mst/system.py:61-69
     (1, 50000, dict(sc_per_example=False)),                            # pre-0.4.0 global spectral convergence
 ])
-def test_mrstft_three_way(bs, n, kw, dev):
+def test_mrstft_three_way(bs, n, kw, dev, record):
     from oracle import loss_restated as ol
 
     torch.manual_seed(bs * 7 + n)
@@ -57,6 +57,7 @@ def test_mrstft_three_way(bs, n, kw, dev):
     l64, g64 = outs[torch.float64]
     assert abs(loss.item() - l64) / l64 < 1e-5, (loss.item(), l32, l64)
     h32, h64, r = rel(xd.grad, g32), rel(xd.grad, g64), rel(g32, g64)
+    record(loss_rel_err_vs_f64=abs(loss.item() - l64) / l64, grad=(h32, h64, r))
     print(f"\n[mrstft {bs}x2x{n} {kw}] loss hip {loss.item():.7f} ref32 {l32:.7f} f64 {l64:.7f}; grad hip-ref32 {h32:.2e} hip-f64 {h64:.2e} ref32-f64 {r:.2e}")
     # d log|X| / dX ~ 1/|X| : among 1e6..1e7 bins a few are nearly zero and dominate the fp32 error of
     # BOTH fp32 implementations (ref32 sits 5e-4..1e-2 from float64).  The statistic is heavy-tailed: two correct fp32
@@ -153,7 +154,7 @@ def test_peak_normalize(dev):
 AF_WEIGHTS = [0.1, 0.001, 1.0, 1.0, 0.1]  # reference configs/models/unpaired+feat.yaml:55-60
 
 
-def test_afloss_golden(dev, golden_dir):
+def test_afloss_golden(dev, golden_dir, record):
     """Fixture produced by the REAL reference mst.loss.AudioFeatureLoss (tests/golden/make_golden.py)."""
     import numpy as np
     import os
@@ -170,12 +171,14 @@ def test_afloss_golden(dev, golden_dir):
         assert abs(ld[k].item() - ref) <= 2e-5 * abs(ref) + 1e-12, (k, ld[k].item(), ref)
     sum(v.mean() for v in ld.values()).backward()  # reference mst/system.py:334-336
     gsub = torch.from_numpy(g["grad_input_sub"])
+    record(grad_vs_reference=rel(x.grad[..., ::16], gsub),
+           **{k.replace("-", "_"): abs(ld[k].item() - float(g["loss." + k])) / abs(float(g["loss." + k])) for k in AF_KEYS})
     assert rel(x.grad[..., ::16], gsub) < 2e-4
     assert abs(x.grad.double().pow(2).sum().sqrt().item() - float(g["grad_input_l2"])) / float(g["grad_input_l2"]) < 2e-4
 
 
 @pytest.mark.parametrize("bs,n", [(2, 131072), (4, 262144), (1, 16385), (3, 50001)])
-def test_afloss_three_way(bs, n, dev):
+def test_afloss_three_way(bs, n, dev, record):
     from mst.loss import AF_KEYS, AudioFeatureLoss
     from oracle import loss_restated as ol
 
@@ -199,6 +202,8 @@ def test_afloss_three_way(bs, n, dev):
     v32, g32 = res[torch.float32]
     err = ((vals.detach().cpu().double() - v64).abs() / v64.abs().clamp_min(1e-30))
     err32 = ((v32 - v64).abs() / v64.abs().clamp_min(1e-30))
+    record(loss_rel_err_hip_vs_f64=err.tolist(), loss_rel_err_ref32_vs_f64=err32.tolist(),
+           grad=(rel(xd.grad, g32), rel(xd.grad, g64), rel(g32, g64)))
     print(f"\n[af {bs}x2x{n}] loss rel err hip {err.tolist()} ref32 {err32.tolist()}; grad hip-f64 {rel(xd.grad, g64):.2e} ref32-f64 {rel(g32, g64):.2e}")
     assert (err <= 3 * err32 + 2e-5).all()
     assert rel(xd.grad, g64) <= 3 * rel(g32, g64) + 2e-5

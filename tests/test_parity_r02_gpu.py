@@ -1,0 +1,242 @@
+"""Round-2 GPU parity additions: the dictionary entry point, the conditioning corners of the
+parameter box, and BASELINE cfg #3's AudioFeatureLoss leg at batch 32."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from test_console_gpu import parse_flags, run_hip, run_oracle
+from util import FULL, rel
+
+FLAG_ORDER = ("use_track_input_fader", "use_track_eq", "use_track_compressor", "use_track_panner", "use_fx_bus",
+              "use_master_bus", "use_output_fader")  # positional order of forward_mix_console (reference mst/modules.py:192-198)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need the MI355X"
+    from mst import _hip
+
+    _hip.lib()
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def console():
+    from mst.modules import AdvancedMixConsole
+
+    return AdvancedMixConsole(44100)
+
+
+def nested(g, prefix, dev):
+    d = {}
+    for k in g.files:
+        if k.startswith(prefix + "."):
+            _, eff, name = k.split(".")
+            d.setdefault(eff, {})[name] = torch.from_numpy(g[k]).float().to(dev)
+    return d
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "console_*.npz"))))
+def test_forward_mix_console_golden(path, console, dev, record):
+    """The DENORMALISED dictionaries the real reference produced (fixtures tp.* / mp.*) through forward_mix_console,
+    flags passed positionally as reference mst/mixing.py:1076-1087 does: same mix / mixed_tracks as the fixture."""
+    g = np.load(path, allow_pickle=True)
+    flags = parse_flags(g["flags"])
+    t = lambda k: torch.from_numpy(g[k]).float()
+    tpd, mpd = nested(g, "tp", dev), nested(g, "mp", dev)
+    with torch.no_grad():
+        mixed, mix = console.forward_mix_console(t("tracks").to(dev), tpd, {}, mpd, *[flags[k] for k in FLAG_ORDER])
+    stride = int(g["mix_stride"])
+    e_mix, e_mixed = rel(mix[..., ::stride], t("mix")), rel(mixed[..., ::64], t("mixed_tracks_sub"))
+    record(mix=e_mix, mixed_tracks=e_mixed)
+    assert e_mix < 1e-4 and e_mixed < 1e-4, (e_mix, e_mixed)
+
+
+def test_forward_mix_console_round_trip_and_gradients(console, dev, record):
+    """forward()'s returned dictionaries fed back into forward_mix_console give the same mix, values outside
+    the nominal ranges are applied as given (no clamp, no ValueError), missing entries of active stages raise KeyError,
+    and gradients reach the dictionary entries: d/d(denormalised) = d/d(normalised) / (hi - lo)."""
+    torch.manual_seed(17)
+    bs, T, n = 2, 3, 65536
+    tracks = (0.1 * torch.randn(bs, T, n)).to(dev)
+    tp = torch.rand(bs, T, 27, device=dev, requires_grad=True)
+    mp = torch.rand(bs, 26, device=dev, requires_grad=True)
+    fp = torch.rand(bs, 25, device=dev)
+    gmix = torch.randn(bs, 2, n, device=dev)
+    mixed, mix, tpd, fpd, mpd = console(tracks, tp, fp, mp, **FULL)
+    (mix * gmix).sum().backward()
+    leaf = lambda d: {e: {k: v.detach().clone().requires_grad_(True) for k, v in p.items()} for e, p in d.items()}
+    tpd2, mpd2 = leaf(tpd), leaf(mpd)
+    mixed2, mix2 = console.forward_mix_console(tracks, tpd2, fpd, mpd2, *[FULL[k] for k in FLAG_ORDER])
+    (mix2 * gmix).sum().backward()
+    e = rel(mix2, mix)
+    assert e < 2e-6 and rel(mixed2, mixed) < 2e-6, e  # same kernels; the affine map is redone in fp32 on the host side
+    lo, hi = console.param_ranges["compressor"]["threshold_db"]
+    g_dict, g_norm = tpd2["compressor"]["threshold_db"].grad, tp.grad[..., 19] / (hi - lo)
+    lo2, hi2 = console.param_ranges["parametric_eq"]["band1_gain_db"]
+    g2_dict, g2_norm = mpd2["parametric_eq"]["band1_gain_db"].grad, mp.grad[..., 6] / (hi2 - lo2)
+    record(mix_round_trip=e, g_threshold=rel(g_dict, g_norm), g_master_band1_gain=rel(g2_dict, g2_norm))
+    assert rel(g_dict, g_norm) < 1e-3 and rel(g2_dict, g2_norm) < 1e-3
+    assert tpd2["compressor"]["release_ms"].grad is None or float(tpd2["compressor"]["release_ms"].grad.abs().max()) == 0.0
+
+    # out-of-range values are applied, not clamped: +60 dB input fader on track 0 = x1000 (range is +-48 dB)
+    from oracle import console_restated as oc
+
+    hot = leaf(tpd)
+    hot["input_fader"]["gain_db"] = hot["input_fader"]["gain_db"].detach().clone()
+    hot["input_fader"]["gain_db"][:, 0] = 60.0
+    lin = dict(FULL, use_track_eq=False, use_track_compressor=False, use_master_bus=False, use_output_fader=False)
+    with torch.no_grad():
+        m_hot, _ = console.forward_mix_console(tracks, hot, fpd, leaf(mpd), *[lin[k] for k in FLAG_ORDER])
+    cpu = lambda d: {e: {k: v.detach().cpu() for k, v in p.items()} for e, p in d.items()}
+    ref_mixed, _ = oc.console_chain(tracks.cpu(), cpu(hot), cpu(mpd), 44100, **lin)
+    assert rel(m_hot, ref_mixed) < 1e-6
+    missing = leaf(tpd)
+    del missing["compressor"]["knee_db"]
+    with pytest.raises(KeyError):
+        console.forward_mix_console(tracks, missing, fpd, leaf(mpd), *[FULL[k] for k in FLAG_ORDER])
+
+
+BANDS = ("low_shelf", "band0", "band1", "band2", "band3", "high_shelf")
+
+
+def corner_params(bs, T):
+    """Neutral everything (0 dB EQ gains at mid frequency / Q, ratio 1 compressors, centre pan, 0 dB faders), then
+    track t < 6 gets band t at its LOWEST corner frequency, Q = 5 and +12 dB (batch 0) / -12 dB (batch 1); the master
+    bus carries the same six corners at once in batch 0 / 1."""
+    tp, mp = torch.full((bs, T, 27), 0.5), torch.full((bs, 26), 0.5)
+    for p, c0 in ((tp, 19), (mp, 18)):
+        p[..., c0 + 1] = 0.0  # ratio 1: the compressor is a pure delay (known answer)
+        p[..., c0 + 5] = 0.0  # make-up 0 dB
+    tp[..., 26] = 0.0
+    for t, _ in enumerate(BANDS):
+        for b in range(bs):
+            g = 1.0 if b % 2 == 0 else 0.0
+            tp[b, t, 1 + 3 * t: 4 + 3 * t] = torch.tensor([g, 0.0, 1.0])  # gain +-12 dB, lowest cutoff, Q = 5
+            mp[b, 3 * t: 3 + 3 * t] = torch.tensor([g, 0.0, 1.0])
+    return tp, mp
+
+
+def test_eq_corner_sweep(console, dev, record):
+    """SURVEY App. D's danger zone: every band at lowest f / Q 5 / +-12 dB, N = 262144, three-way against the fp32
+    frequency-sampling reference algorithm and the float64 TIME-DOMAIN recursion (scipy sosfilt).  The kernels keep fp32
+    DF2T state; the claim under test is that they are no further from float64 truth than the reference algorithm is."""
+    from oracle import console_restated as oc
+
+    torch.manual_seed(40)
+    bs, T, n = 2, 6, 262144
+    tracks = 0.1 * torch.randn(bs, T, n)
+    tp, mp = corner_params(bs, T)
+    fp = torch.rand(bs, 25)
+    with torch.no_grad():
+        hip = run_hip(console, dev, tracks, tp, fp, mp, FULL)
+        r32 = run_oracle(tracks, tp, fp, mp, FULL)
+        t_mixed, t_mix, *_ = oc.console_forward(tracks.double(), tp.double(), fp.double(), mp.double(), time_domain=True, **FULL)
+    report = {}
+    for t, band in enumerate(BANDS):  # per track = per band corner (mixed_tracks isolates the track chain)
+        for b, sign in ((0, "+12dB"), (1, "-12dB")):
+            h, r = rel(hip["mixed"][b, :, t], t_mixed[b, :, t]), rel(r32["mixed"][b, :, t], t_mixed[b, :, t])
+            report[f"{band}{sign}"] = (rel(hip["mixed"][b, :, t], r32["mixed"][b, :, t]), h, r)
+    report["master_all_six"] = (rel(hip["mix"], r32["mix"]), rel(hip["mix"], t_mix), rel(r32["mix"], t_mix))
+    print("\n[corner sweep] key: (hip vs ref32, hip vs f64 time domain, ref32 vs f64 time domain)")
+    for k, v in report.items():
+        print(f"  {k:20s} {v[0]:.2e} {v[1]:.2e} {v[2]:.2e}")
+    record(**report)
+    for k, (h32, h64, r64) in report.items():
+        assert h64 <= r64 + 2e-5, (k, h32, h64, r64)   # HIP at least as close to truth as the fp32 reference algorithm
+        assert h64 < 2e-3, (k, h64)                     # and usable in absolute terms (fp32 DF2T at 20 Hz / Q 5: ~1e-3, App. D)
+
+
+def test_eq_corner_gradients(console, dev, record):
+    """Same corners, backward: parameter gradients three-way (fp32 reference autograd vs float64 autograd)."""
+    torch.manual_seed(41)
+    bs, T, n = 2, 6, 131072
+    tracks = 0.1 * torch.randn(bs, T, n)
+    tp, mp = corner_params(bs, T)
+    # compressors on at mid settings so that their parameter gradients are not identically zero
+    tp[..., 20], mp[..., 19] = 0.5, 0.5
+    fp = torch.rand(bs, 25)
+    gmix = torch.randn(bs, 2, n)
+    hip = run_hip(console, dev, tracks, tp, fp, mp, FULL, gmix=gmix)
+    r32 = run_oracle(tracks, tp, fp, mp, FULL, gmix=gmix)
+    r64 = run_oracle(tracks, tp, fp, mp, FULL, gmix=gmix, dtype=torch.float64)
+    rep = {k: (rel(hip[k], r32[k]), rel(hip[k], r64[k]), rel(r32[k], r64[k])) for k in ("mix", "g_tp", "g_mp")}
+    print("\n[corner gradients]", rep)
+    record(**rep)
+    assert rep["mix"][1] <= rep["mix"][2] + 2e-5
+    for k in ("g_tp", "g_mp"):
+        assert rep[k][1] <= 2 * rep[k][2] + 1e-4, (k, rep[k])
+
+
+def test_attack_corner(console, dev, record):
+    """Slowest envelope: attack = 250 ms (alpha^n forgets over ~80k samples) on every track and on the master bus, full
+    compression (threshold -60 dB, ratio 10), N = 262144; forward three-way vs float64 time domain, gradients vs float64."""
+    from oracle import console_restated as oc
+
+    torch.manual_seed(42)
+    bs, T, n = 2, 4, 262144
+    tracks = 0.1 * torch.randn(bs, T, n) * torch.linspace(0.05, 1.0, n).view(1, 1, n)  # level ramp: the envelope keeps moving
+    tp, mp = torch.rand(bs, T, 27), torch.rand(bs, 26)
+    for p, c0 in ((tp, 19), (mp, 18)):
+        p[..., c0 + 0] = 0.0  # threshold -60 dB
+        p[..., c0 + 1] = 1.0  # ratio 10
+        p[..., c0 + 2] = 1.0  # attack 250 ms
+    fp = torch.rand(bs, 25)
+    gmix = torch.randn(bs, 2, n)
+    hip = run_hip(console, dev, tracks, tp, fp, mp, FULL, gmix=gmix)
+    r32 = run_oracle(tracks, tp, fp, mp, FULL, gmix=gmix)
+    r64 = run_oracle(tracks, tp, fp, mp, FULL, gmix=gmix, dtype=torch.float64)
+    with torch.no_grad():
+        _, truth, *_ = oc.console_forward(tracks.double(), tp.double(), fp.double(), mp.double(), time_domain=True, **FULL)
+    rep = {"mix_vs_time_domain": (rel(hip["mix"], r32["mix"]), rel(hip["mix"], truth), rel(r32["mix"], truth))}
+    rep.update({k: (rel(hip[k], r32[k]), rel(hip[k], r64[k]), rel(r32[k], r64[k])) for k in ("g_tp", "g_mp")})
+    print("\n[attack corner]", rep)
+    record(**rep)
+    assert rep["mix_vs_time_domain"][1] <= rep["mix_vs_time_domain"][2] + 2e-5 and rep["mix_vs_time_domain"][1] < 1e-4
+    for k in ("g_tp", "g_mp"):
+        assert rep[k][1] <= 2 * rep[k][2] + 1e-4, (k, rep[k])
+
+
+def test_cfg3_audio_feature_leg(dev, record):
+    """BASELINE cfg #3's loss leg: AudioFeatureLoss on (32, 2, 262144).  One mix against the oracle run on that mix alone
+    (every term is a mean over batch items of per-item features, so item i's gradient at batch 32 is 1/32 of its batch-1
+    gradient), the batch-32 losses against the mean of batch-1 HIP losses (size-independent property), determinism."""
+    from mst.loss import AF_KEYS, AudioFeatureLoss
+    from oracle import loss_restated as ol
+
+    w = [0.1, 0.001, 1.0, 1.0, 0.1]
+    torch.manual_seed(50)
+    bs, n = 32, 262144
+    x = 0.2 * torch.randn(bs, 2, n) * torch.logspace(-1, 0, bs).view(bs, 1, 1)
+    x[:, 1] = 0.7 * x[:, 1] + 0.2 * x[:, 0]
+    y = 0.3 * torch.randn(bs, 2, n) * torch.tensor([1.0, 0.6]).view(1, 2, 1)
+    f = AudioFeatureLoss(w, 44100)
+    xd = x.to(dev).requires_grad_(True)
+    yd = y.to(dev)
+    ld = f(xd, yd)
+    sum(v.mean() for v in ld.values()).backward()
+    ld2 = f(xd.detach(), yd)
+    assert all(torch.equal(ld[k], ld2[k]) for k in AF_KEYS)
+    i = 13
+    xo = x[i:i + 1].double().requires_grad_(True)
+    lo = ol.audio_feature_loss(xo, y[i:i + 1].double(), w)
+    sum(v.mean() for v in lo.values()).backward()
+    e_grad = rel(bs * xd.grad[i:i + 1], xo.grad)
+    # batch-1 HIP losses of four items, then the property over ALL items in one more batch-32-free way: chunks of 8
+    per_item = {k: 0.0 for k in AF_KEYS}
+    for c in range(0, bs, 8):
+        lc = f(xd.detach()[c:c + 8], yd[c:c + 8])
+        for k in AF_KEYS:
+            per_item[k] += lc[k].item() * 8 / bs
+    e_prop = max(abs(ld[k].item() - per_item[k]) / abs(per_item[k]) for k in AF_KEYS)
+    one = f(xd.detach()[i:i + 1], yd[i:i + 1])
+    e_one = max(abs(one[k].item() - lo[k].item()) / abs(lo[k].item()) for k in AF_KEYS)
+    record(grad_item_vs_f64_oracle=e_grad, loss_item_vs_f64_oracle=e_one, batch32_vs_chunks_of_8=e_prop)
+    print(f"\n[cfg3 AF] grad item {i} vs f64 oracle {e_grad:.2e}; losses of that item {e_one:.2e}; batch-32 vs chunk mean {e_prop:.2e}")
+    assert e_grad < 2e-4 and e_one < 5e-5 and e_prop < 1e-5
+    assert torch.isfinite(xd.grad).all()

@@ -28,3 +28,26 @@ def short_ir(tp, mp):
     mp[..., 1] = 0.15 + 0.85 * mp[..., 1]
     mp[..., 4] = 0.15 + 0.85 * mp[..., 4]
     return tp, mp
+
+
+class StubModel(torch.nn.Module):
+    """Stand-in for the reference's parameter-estimation model (mst/modules.py:17-68) with its call signature:
+    ``model(tracks (bs,T,n), ref_mix (bs,2,n), track_padding_mask=...)`` -> three sigmoid tensors
+    ``(bs,T,27), (bs,25), (bs,26)``.  Three tiny linear heads on crude level statistics; weights are drawn from a
+    seeded CPU generator so the fixture generator (CPU, real reference) and the GPU test build the same model."""
+
+    def __init__(self, seed: int = 0):
+        super().__init__()
+        g = torch.Generator().manual_seed(seed)
+        mk = lambda o: torch.nn.Parameter(0.8 * torch.randn(o, 4, generator=g))
+        self.w_track, self.w_fx, self.w_master = mk(27), mk(25), mk(26)
+
+    def forward(self, tracks, ref_mix, track_padding_mask=None):
+        bs, T, _ = tracks.shape
+        ref_rms = ref_mix.pow(2).mean(dim=(-1, -2)).sqrt()  # (bs,)
+        ft = torch.stack((10 * tracks.pow(2).mean(-1).sqrt(), 10 * tracks.abs().mean(-1), ref_rms.view(bs, 1).expand(bs, T),
+                          torch.ones(bs, T, device=tracks.device)), dim=-1)  # (bs,T,4)
+        fm = ft.mean(dim=1)  # (bs,4)
+        # squashed away from 0/1: the estimated parameters stay strictly inside the console's ranges
+        sq = lambda z: 0.02 + 0.96 * torch.sigmoid(z)
+        return sq(ft @ self.w_track.t()), sq(fm @ self.w_fx.t()), sq(fm @ self.w_master.t())

@@ -1,7 +1,7 @@
 """Developer timing of the console fwd+bwd (not the contract bench; see bench.py)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [ROOT, os.path.join(ROOT, "diff-mst_amd")]
+sys.path[:0] = [ROOT, os.path.join(ROOT, "diff-mst_amd"), os.path.join(ROOT, "diff-mst_amd", "standalone")]
 import torch
 from mst.modules import AdvancedMixConsole
 
