@@ -118,7 +118,9 @@ def _time_cpu(one, runs, budget_s):
 
 def cpu_baseline():
     """Oracle (PyTorch-CPU restatement of the reference ALGORITHM: frequency-sampling IIR via torch.fft, torch.stft
-    losses, autograd backward) on bounded samples of the bench workloads.  `value` = cfg #2 on all host threads."""
+    losses, autograd backward) on bounded samples of the bench workloads.  Three thread settings are timed on cfg #2 -
+    torch's default, 16 and 1 (more threads are NOT faster for these batched 2^19-point FFTs: the measured optimum on the
+    256-cpu EPYC box is a handful of threads) - and `value` is the best of them, with `cores` = the threads it used."""
     host = os.cpu_count()
     try:
         model = [l.split(":", 1)[1].strip() for l in subprocess.run(["lscpu"], capture_output=True, text=True).stdout.splitlines()
@@ -126,28 +128,28 @@ def cpu_baseline():
     except Exception:
         model = "unknown"
     default_threads = torch.get_num_threads()
-    torch.set_num_threads(host)
-    med, k = _time_cpu(_oracle_step(T, N, "mrstft", FLAGS), 3, 15.0)
-    all_core = 1.0 / med
-    threads_used = torch.get_num_threads()
-    # cfg #3 (16 tracks, AudioFeatureLoss) and cfg #1 (gain + pan only, 4 x 65536), one mix each, all threads
+    legs = {}
+    for threads in (default_threads, 16, 1):
+        if threads > host or threads in legs:
+            continue
+        torch.set_num_threads(threads)
+        med, k = _time_cpu(_oracle_step(T, N, "mrstft", FLAGS), 3, 12.0)
+        legs[threads] = (1.0 / med, k)
+    best = max(legs, key=lambda t: legs[t][0])
+    torch.set_num_threads(best)
+    # cfg #3 (16 tracks, AudioFeatureLoss) and cfg #1 (gain + pan only, 4 x 65536), one mix each, at the best thread count
     med3, _ = _time_cpu(_oracle_step(16, N, "af", FLAGS), 2, 12.0)
     basic = dict(FLAGS, use_track_eq=False, use_track_compressor=False, use_master_bus=False, use_output_fader=False)
     med1, _ = _time_cpu(_oracle_step(4, 65536, "none", basic), 5, 3.0)
-    # one thread: a quarter-length clip of the same mix (8 tracks x 65536), scaled by 1/4 (FFT cost is ~linear in length here)
-    torch.set_num_threads(1)
-    medq, kq = _time_cpu(_oracle_step(T, N // 4, "mrstft", FLAGS), 2, 12.0)
-    one_thread = 1.0 / (4.0 * medq)
     torch.set_num_threads(default_threads)
     return {
-        "value": all_core, "unit": "mixes/s", "cores": threads_used, "kind": "port",
-        "sample": f"cfg #2: 1 mix (8 tracks x 262144) console fwd+bwd + MR-STFT, fp32, median of {k} runs after a warm-up, "
-                  f"torch.set_num_threads({host}) on {host} host cpus ({model})",
-        "one_thread": {"value": one_thread, "unit": "mixes/s", "cores": 1,
-                       "sample": f"1 mix of 8 tracks x 65536 (quarter length) x 1/4, median of {kq} runs"},
-        "cfg3": {"value": 1.0 / med3, "unit": "mixes/s", "cores": threads_used,
+        "value": legs[best][0], "unit": "mixes/s", "cores": best, "kind": "port",
+        "sample": f"cfg #2: 1 mix (8 tracks x 262144) console fwd+bwd + MR-STFT, fp32, median of {legs[best][1]} runs after a warm-up, "
+                  f"best of the thread settings below on {host} host cpus ({model})",
+        "by_threads": {str(t): {"value": v, "unit": "mixes/s", "runs": k} for t, (v, k) in legs.items()},
+        "cfg3": {"value": 1.0 / med3, "unit": "mixes/s", "cores": best,
                  "sample": "1 mix of 16 tracks x 262144, console fwd+bwd + AudioFeatureLoss"},
-        "cfg1": {"value": 1.0 / med1, "unit": "mixes/s", "cores": threads_used,
+        "cfg1": {"value": 1.0 / med1, "unit": "mixes/s", "cores": best,
                  "sample": "1 mix of 4 tracks x 65536, gain + pan + bus sum fwd+bwd"},
         "host": {"os_cpu_count": host, "lscpu_model": model, "torch_default_threads": default_threads,
                  "parallel_info": " | ".join(l.strip() for l in torch.__config__.parallel_info().splitlines() if l.strip())[:400]},

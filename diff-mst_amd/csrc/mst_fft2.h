@@ -1,0 +1,218 @@
+// mst_fft2.h - the register-radix FFT engine of the spectrogram loss (round 2).
+//
+// One frame is transformed by a group of LG lanes that each hold 8 points per sequence IN REGISTERS and run radix-8
+// butterflies there; between passes the points are exchanged through ONE padded LDS buffer (Stockham autosort: natural
+// order in, natural order out).  Compared with the round-1 radix-4 LDS transform (4.5-6.5 LDS round trips per frame,
+// twiddles rebuilt from a two-level table inside every butterfly, 31-47 % of the LDS cycles lost to bank conflicts -
+// profiles/round2_counters.md) a frame makes 3-4 round trips, the inter-pass twiddles come from three per-lane constants
+// per pass fetched once per kernel from the exactly rounded table, and the layout below is conflict-free on the
+// (expensive) store side.
+//
+//   n_fft   lanes/frame  passes
+//   512     64           8 x 8 x 8
+//   2048    256          8 x 8 x 8 x 4      (the radix-4 pass: two butterflies per lane)
+//   8192    512          radix-2 decimation in frequency on the way in (x[i] +- x[i + 4096], the difference times
+//                        W_8192^i), then TWO independent 4096-point transforms 8 x 8 x 8 x 8: the even and the odd bins
+//   4096    512          8 x 8 x 8 x 8      (the half-size inverse of the 8192 backward)
+//
+// Pass p (radix R, Ns = product of the earlier radices) handles butterfly j: inputs j + t M/R, twiddles W_(Ns R)^(k t)
+// with k = j mod Ns, outputs (j - k) R + k + t Ns.  LDS slot of element i: i + i / 8 (one pad slot per 8 elements):
+//   pass-1 stores  lane j -> 9 j + t        ds_write_b64, 18 dwords between lanes: 16 lanes hit the 32 banks once
+//   Ns = 8 stores  8 consecutive lanes -> 8 consecutive slots of one padded row, the next 8 lanes 8 rows = 144 = 16 (mod 32)
+//                  dwords later: conflict-free as well
+//   Ns >= 64 stores and all loads: lane-consecutive elements; the pad slot every 8 elements makes two banks 2-way
+//                  (loads are 3x cheaper than stores on this LDS, MI355X_MICROARCH.md)
+#pragma once
+#include "mst_common.h"
+
+namespace mst {
+
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
+__device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }  // a * (-i)
+__device__ __forceinline__ float2 mul_pi(float2 a) { return make_float2(-a.y, a.x); }  // a * (+i)
+
+// ---- forward (e^{-i...}) butterflies, natural order in place ---------------------------------------
+__device__ __forceinline__ void fft4(float2& v0, float2& v1, float2& v2, float2& v3) {
+    const float2 s02 = cadd(v0, v2), d02 = csub(v0, v2), s13 = cadd(v1, v3), d13 = csub(v1, v3);
+    v0 = cadd(s02, s13);
+    v1 = cadd(d02, mul_mi(d13));
+    v2 = csub(s02, s13);
+    v3 = cadd(d02, mul_pi(d13));
+}
+template <int R>
+__device__ __forceinline__ void butterfly(float2* v);
+template <>
+__device__ __forceinline__ void butterfly<4>(float2* v) { fft4(v[0], v[1], v[2], v[3]); }
+template <>
+__device__ __forceinline__ void butterfly<8>(float2* v) {
+    constexpr float c = 0.70710678118654752f;
+    float2 e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6], o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7];
+    fft4(e0, e1, e2, e3);
+    fft4(o0, o1, o2, o3);
+    o1 = make_float2(c * (o1.x + o1.y), c * (o1.y - o1.x));    // * W8^1 = (c, -c)
+    o2 = mul_mi(o2);                                           // * W8^2 = -i
+    o3 = make_float2(c * (o3.y - o3.x), -c * (o3.x + o3.y));   // * W8^3 = (-c, -c)
+    v[0] = cadd(e0, o0); v[4] = csub(e0, o0);
+    v[1] = cadd(e1, o1); v[5] = csub(e1, o1);
+    v[2] = cadd(e2, o2); v[6] = csub(e2, o2);
+    v[3] = cadd(e3, o3); v[7] = csub(e3, o3);
+}
+
+constexpr int ilog2c(int n) { return n <= 1 ? 0 : 1 + ilog2c(n >> 1); }
+
+// M = length the passes run on, NSEQ sequences of it per frame, LG lanes per frame, NP passes of radix 8 (the last one
+// of radix RL <= 8)
+template <int N> struct FftPlan;
+template <> struct FftPlan<512>  { static constexpr int M = 512,  NSEQ = 1, LG = 64,  NP = 3, RL = 8; };
+template <> struct FftPlan<2048> { static constexpr int M = 2048, NSEQ = 1, LG = 256, NP = 4, RL = 4; };
+template <> struct FftPlan<4096> { static constexpr int M = 4096, NSEQ = 1, LG = 512, NP = 4, RL = 8; };
+template <> struct FftPlan<8192> { static constexpr int M = 4096, NSEQ = 2, LG = 512, NP = 4, RL = 8; };
+
+template <int N>
+struct FftShape {
+    using P = FftPlan<N>;
+    static constexpr int M = P::M, NSEQ = P::NSEQ, LG = P::LG, NP = P::NP, RL = P::RL;
+    static constexpr int NBL = (M / RL) / LG;      // butterflies per lane in the last pass (1, or 2 for the radix-4 pass)
+    static constexpr int SLOTS = M + M / 8;        // padded float2 slots per sequence
+    static constexpr int TWSCALE = N / M;          // W_M^e = W_N^(TWSCALE e)
+    static_assert(M / 8 == LG, "one radix-8 butterfly per lane and sequence in every pass but the last");
+    __device__ static __forceinline__ constexpr int slot(int i) { return i + (i >> 3); }
+};
+
+// ---- per-lane twiddle bases, held in registers for the lifetime of the kernel -----------------------------------
+// A butterfly with base exponent e multiplies input t by W^(e t), t = 1..R-1.  Only W^e, W^2e, W^4e are stored (exactly
+// rounded table entries); the other four are single products of two of them.
+template <int N>
+struct LaneTw {
+    using S = FftShape<N>;
+    float2 mid[S::NP - 2][3];                    // passes 2 .. NP-1 (radix 8, Ns = 8^(p-1))
+    float2 last[S::NBL][ilog2c(S::RL)];          // pass NP (radix RL, Ns = M / RL, k = j)
+    // tw = (cos, -sin)(2 pi t / N), t < N
+    __device__ __forceinline__ void init(const float2* __restrict__ tw, int lane) {
+        int Ns = 8;
+#pragma unroll
+        for (int p = 0; p < S::NP - 2; ++p) {
+            const int e = (lane & (Ns - 1)) * (S::M / (Ns * 8));  // W_(8 Ns)^(k t) = W_M^(k t M / (8 Ns))
+#pragma unroll
+            for (int b = 0; b < 3; ++b) mid[p][b] = tw[(S::TWSCALE * (e << b)) & (N - 1)];
+            Ns *= 8;
+        }
+#pragma unroll
+        for (int u = 0; u < S::NBL; ++u) {
+            const int j = lane + u * S::LG;
+#pragma unroll
+            for (int b = 0; b < ilog2c(S::RL); ++b) last[u][b] = tw[(S::TWSCALE * (j << b)) & (N - 1)];
+        }
+    }
+};
+template <int R>
+__device__ __forceinline__ void tw_apply(float2* v, const float2* base) {  // v[t] *= W^(e t)
+    v[1] = cmul(v[1], base[0]);
+    v[2] = cmul(v[2], base[1]);
+    v[3] = cmul(v[3], cmul(base[0], base[1]));
+    if (R == 8) {
+        v[4] = cmul(v[4], base[2]);
+        v[5] = cmul(v[5], cmul(base[0], base[2]));
+        v[6] = cmul(v[6], cmul(base[1], base[2]));
+        v[7] = cmul(v[7], cmul(cmul(base[0], base[1]), base[2]));
+    }
+}
+
+// ---- passes.  `buf` = one sequence's SLOTS float2 in LDS; every lane of the frame's group calls them; the group barrier
+// is __syncthreads() (one frame group per workgroup) and is placed by the caller.
+// pass 1: v[t] = input element lane + t LG; leaves its result in buf.
+template <int N>
+__device__ __forceinline__ void fft_first(float2* v, float2* __restrict__ buf, int lane) {
+    butterfly<8>(v);
+    float2* o = buf + lane * 9;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) o[t] = v[t];
+}
+template <int N>
+__device__ __forceinline__ void fft_load8(float2* v, const float2* __restrict__ buf, int lane) {
+    using S = FftShape<N>;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) v[t] = buf[S::slot(lane + t * (S::M / 8))];
+}
+// middle pass P (2 <= P < NP), Ns = 8^(P-1): twiddle + butterfly + store (after fft_load8 and a barrier)
+template <int N, int P>
+__device__ __forceinline__ void fft_mid_store(float2* v, float2* __restrict__ buf, const LaneTw<N>& tw, int lane) {
+    using S = FftShape<N>;
+    constexpr int Ns = P == 2 ? 8 : 64;
+    static_assert(P == 2 || P == 3, "middle passes");
+    tw_apply<8>(v, tw.mid[P - 2]);
+    butterfly<8>(v);
+    const int k = lane & (Ns - 1);
+    const int base = (lane - k) * 8 + k;  // element base + t Ns
+#pragma unroll
+    for (int t = 0; t < 8; ++t) buf[S::slot(base + t * Ns)] = v[t];
+}
+// last pass, butterfly u of this lane: afterwards v[t] = X[lane + u LG + t M / RL] (natural order, in registers)
+template <int N>
+__device__ __forceinline__ void fft_last(float2* v, const float2* __restrict__ buf, const LaneTw<N>& tw, int lane, int u) {
+    using S = FftShape<N>;
+    const int j = lane + u * S::LG;
+#pragma unroll
+    for (int t = 0; t < S::RL; ++t) v[t] = buf[S::slot(j + t * (S::M / S::RL))];
+    tw_apply<S::RL>(v, tw.last[u]);
+    butterfly<S::RL>(v);
+}
+
+// Whole transform of one sequence whose first-pass inputs are in v[8]: on return X[lane + u LG + t M / RL] = o[u][t].
+// Contains NP*2 - 2 barriers; buf may be overwritten by the caller after ONE more barrier.
+template <int N>
+__device__ __forceinline__ void fft_run(float2* v, float2 (*o)[FftShape<N>::RL], float2* __restrict__ buf, const LaneTw<N>& tw, int lane) {
+    using S = FftShape<N>;
+    fft_first<N>(v, buf, lane);
+    __syncthreads();
+#ifdef MST_FFT2_FIRST_PASS_ONLY
+    for (int u = 0; u < S::NBL; ++u) for (int t = 0; t < S::RL; ++t) o[u][t] = buf[S::slot(lane + t)];
+    return;
+#endif
+    fft_load8<N>(v, buf, lane);
+    __syncthreads();
+    fft_mid_store<N, 2>(v, buf, tw, lane);
+    __syncthreads();
+    if constexpr (S::NP == 4) {
+        fft_load8<N>(v, buf, lane);
+        __syncthreads();
+        fft_mid_store<N, 3>(v, buf, tw, lane);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int u = 0; u < S::NBL; ++u) fft_last<N>(o[u], buf, tw, lane, u);
+}
+
+// two sequences side by side (the even / odd halves of the 8192-point transform): same barriers as one
+template <int N>
+__device__ __forceinline__ void fft_run2(float2* va, float2* vb, float2 (*oa)[FftShape<N>::RL], float2 (*ob)[FftShape<N>::RL],
+                                         float2* __restrict__ bufa, float2* __restrict__ bufb, const LaneTw<N>& tw, int lane) {
+    using S = FftShape<N>;
+    fft_first<N>(va, bufa, lane);
+    fft_first<N>(vb, bufb, lane);
+    __syncthreads();
+    fft_load8<N>(va, bufa, lane);
+    fft_load8<N>(vb, bufb, lane);
+    __syncthreads();
+    fft_mid_store<N, 2>(va, bufa, tw, lane);
+    fft_mid_store<N, 2>(vb, bufb, tw, lane);
+    __syncthreads();
+    if constexpr (S::NP == 4) {
+        fft_load8<N>(va, bufa, lane);
+        fft_load8<N>(vb, bufb, lane);
+        __syncthreads();
+        fft_mid_store<N, 3>(va, bufa, tw, lane);
+        fft_mid_store<N, 3>(vb, bufb, tw, lane);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int u = 0; u < S::NBL; ++u) {
+        fft_last<N>(oa[u], bufa, tw, lane, u);
+        fft_last<N>(ob[u], bufb, tw, lane, u);
+    }
+}
+
+}  // namespace mst

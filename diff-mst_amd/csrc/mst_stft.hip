@@ -13,21 +13,16 @@
 // forms dL/dX, and returns two frames' time-domain cotangents per complex FFT; the overlap-add
 // (incl. the reflect-padding fold-back) uses hardware float atomics into grad_pred.
 #include "mst_kernels.h"
+#include "mst_stft.h"
 #ifndef MST_STFT_UNROLL_STAGES
 #define MST_STFT_UNROLL_STAGES 1  // stage loops of the transforms unrolled so that the stage constants fold (386 -> 368 us; 0 = rolled, for A/B)
 #endif
 
 namespace mst {
 
-constexpr int kMaxRes = 8;
-
-struct ResInfo {
-    int n_fft, hop, n_frames, n_bins;
-    int64_t tw_off, win_off;  // float offsets into the tables buffer (tw: n_fft float2, win: n_fft floats)
-    int frames_per_wg;                  // forward strip length
-};
-
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 
 // Forward DFT (e^{-i...}) of NFFT complex points held in LDS: Stockham autosort, radix-4 stages
 // (one radix-2 stage first when log2 NFFT is odd), natural order in AND out, ping-pong between
@@ -127,8 +122,6 @@ __device__ __forceinline__ int freq_pos(int k) {
     if (LG & 1) return (k & 1) * (N / 2) + rev4<LG / 2>(k >> 1);
     return rev4<LG / 2>(k);
 }
-__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 
 template <int N, int THREADS, bool R2_DONE = false>  // R2_DONE: the loader applied the leading radix-2 stage
 __device__ __forceinline__ void fft_dif(float2* buf, const Twiddles<N>& T, int tid) {
@@ -257,21 +250,6 @@ __device__ __forceinline__ void load_frame(float2* buf, const float* __restrict_
     }
 }
 
-struct StftArgs {
-    const float* pred;     // (rows, n)
-    const float* target;   // (rows, n)
-    const float* tables;
-    float* part;           // forward: (rows, n_groups, 4) partial sums {S1, S2, S3, S4}
-    const float* sums;     // backward: (rows, 4) reduced sums of this resolution
-    const float* coef;     // backward: (rows, 4) per-row gradient coefficients {c_sc, c_log, c_lin, -}
-    const float* grad_loss; // backward: upstream dL/dloss (one device float), folded into the coefficients
-    float* grad_pred;      // backward: (rows, n), accumulated with float atomics
-    ResInfo r;
-    int log2n;
-    int64_t n;
-    float eps;
-};
-
 // bin k of a transform result: natural order (ping-pong kernels) or the swizzled digit-reversed slots of fft_dif
 template <int N, bool INPLACE>
 __device__ __forceinline__ float2 bin_at(const float2* buf, int k) {
@@ -290,7 +268,6 @@ __device__ __forceinline__ void split_xy(const float2* buf, int k, float2& X, fl
 #endif
 constexpr int stft_threads(int n_fft) { return n_fft <= 512 ? 128 : (n_fft <= 2048 ? 512 : (n_fft <= 4096 ? 1024 : MST_STFT_T8192)); }
 
-constexpr float kLn2 = 0.6931471805599453f;
 
 template <int NFFT>
 __global__ __launch_bounds__(stft_threads(NFFT)) void k_stft_fwd(StftArgs a) {
@@ -593,6 +570,7 @@ __global__ __launch_bounds__(kIpThreads) void k_stft_bwd_ip(StftArgs a) {
     }
 }
 
+
 // ---- tables: twiddles (cos, -sin) and the (centre-padded) periodic Hann window -------------------
 __global__ void k_stft_tables(float* tables, ResInfo r, int win_length) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -685,6 +663,7 @@ namespace {
 struct Plan {
     ResInfo res[kMaxRes];
     int log2n[kMaxRes], n_groups[kMaxRes], win[kMaxRes];
+    bool engine2[kMaxRes];  // this resolution runs on the round-2 kernels (mst_fft2.h)
     int64_t part_off[kMaxRes];
     int64_t tables_floats;
     // workspace (floats): part | sums | coef | coef_scaled
@@ -720,6 +699,25 @@ Plan make_plan(const mst_mrstft_desc* d) {
         r.frames_per_wg = MST_STFT_FPW;
 #endif
         p.n_groups[i] = (r.n_frames + r.frames_per_wg - 1) / r.frames_per_wg;
+        // round-2 kernels: the reference's shape of resolution (hop = n_fft / 2, full-length window), rows long enough
+        // that no frame reflects at both ends, whole hops per row (the owner-computes overlap-add assumes it)
+        p.engine2[i] = (nf == 512 || nf == 2048 || nf == 8192) && r.hop * 2 == nf && d->win_length[i] == nf &&
+                       d->n_samples >= 2 * (int64_t)nf && d->n_samples % r.hop == 0;
+#ifdef MST_STFT_ROUND1
+        p.engine2[i] = false;
+#endif
+        if (p.engine2[i]) {
+            // balanced strips of ~8 / 4 / 2 frames (one workgroup each): consecutive frames share half their samples
+#ifndef MST_STFT2_STRIP_512
+#define MST_STFT2_STRIP_512 4
+#endif
+#ifndef MST_STFT2_STRIP_2048
+#define MST_STFT2_STRIP_2048 4
+#endif
+            // at cfg #2 (16 rows x 262144): 4100 one-wave / 1024 four-wave / 512 eight-wave workgroups = one resident round each
+            const int target = nf == 512 ? MST_STFT2_STRIP_512 : (nf == 2048 ? MST_STFT2_STRIP_2048 : 2);
+            p.n_groups[i] = r.n_frames / target > 0 ? r.n_frames / target : 1;
+        }
         p.part_off[i] = po;
         po += (int64_t)d->rows * p.n_groups[i] * 4;
     }
@@ -804,7 +802,9 @@ extern "C" int mst_mrstft_forward(const mst_mrstft_desc* d, const float* pred, c
         a.eps = d->eps;
         const dim3 grid(p.n_groups[i], d->rows);
 #define MST_LAUNCH_FWD(NF) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stft_fwd<NF>), grid, dim3(stft_threads(NF)), 0, stream, a)
-        if (a.r.n_fft == 8192 && inplace_8192(true))
+        if (p.engine2[i]) {
+            launch_stft2_fwd(a, p.n_groups[i], d->rows, stream);
+        } else if (a.r.n_fft == 8192 && inplace_8192(true))
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stft_fwd_ip<8192>), grid, dim3(kIpThreads), 0, stream, a);
         else
             MST_FOR_NFFT(a.r.n_fft, MST_LAUNCH_FWD)
@@ -825,6 +825,37 @@ extern "C" int mst_mrstft_backward(const mst_mrstft_desc* d, const float* pred, 
     if (workspace_bytes < (size_t)p.ws_floats * sizeof(float)) return hipErrorInvalidValue;
     hipStream_t stream = (hipStream_t)stream_;
     float* ws = (float*)workspace;
+    bool all2 = true;
+    for (int i = 0; i < d->n_res; ++i) all2 = all2 && p.engine2[i];
+    if (all2) {
+        // round-2 kernels: owner-computes overlap-add.  Seam-mode resolutions (8192) go first, onto a zeroed buffer; the
+        // halo-mode ones follow and add to it; with no seam-mode resolution the first launch owns the buffer (no memset).
+        bool zero = false;
+        for (int i = 0; i < d->n_res; ++i) zero = zero || stft2_bwd_needs_zero(p.res[i].n_fft);
+        if (zero) (void)hipMemsetAsync(grad_pred, 0, (size_t)d->rows * d->n_samples * sizeof(float), stream);
+        bool written = zero;
+        for (int pass = 0; pass < 2; ++pass) {
+            for (int i = 0; i < d->n_res; ++i) {
+                if (stft2_bwd_needs_zero(p.res[i].n_fft) != (pass == 0)) continue;
+                StftArgs a{};
+                a.pred = pred;
+                a.target = target;
+                a.tables = (const float*)tables;
+                a.sums = ws + p.sums_off + (int64_t)i * d->rows * 4;
+                a.coef = ws + p.coef_off + (int64_t)i * d->rows * 4;
+                a.grad_loss = grad_loss;
+                a.grad_pred = grad_pred;
+                a.r = p.res[i];
+                a.log2n = p.log2n[i];
+                a.n = d->n_samples;
+                a.eps = d->eps;
+                a.accumulate = (pass == 1 && written) ? 1 : 0;
+                launch_stft2_bwd(a, stft2_bwd_groups(a.r.n_fft, a.r.n_frames), d->rows, stream);
+                written = true;
+            }
+        }
+        return (int)hipGetLastError();
+    }
     (void)hipMemsetAsync(grad_pred, 0, (size_t)d->rows * d->n_samples * sizeof(float), stream);
     for (int i = 0; i < d->n_res; ++i) {
         StftArgs a{};

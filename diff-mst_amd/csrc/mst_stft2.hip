@@ -1,0 +1,480 @@
+// mst_stft2.hip - round-2 kernels of the multi-resolution STFT loss on the register-radix FFT engine (mst_fft2.h).
+// Same semantics as mst_stft.hip (auraloss 0.4.0; reference configs/models/naive.yaml:54-68); see mst_stft.h
+// for the split between the two files.
+#include "mst_stft.h"
+#include "mst_fft2.h"
+#ifndef MST_STFT2_ABLATE
+#define MST_STFT2_ABLATE 0  // timing diagnostics only (wrong results): 1 = no epilogue math, 2 = no global sample loads, 4 = first pass only
+#endif
+#ifndef MST_STFT2_W8192
+#define MST_STFT2_W8192 4  // min waves per SIMD asked of the 8192 FORWARD kernel: 2 workgroups of 512 lanes per CU (128 VGPRs, no spill)
+#endif
+#ifndef MST_STFT2_W8192_BWD
+#define MST_STFT2_W8192_BWD 2  // the backward kernel needs ~170 registers: at 128 it spills 71 (measured 102 us vs 77 us with one workgroup per CU)
+#endif
+
+namespace mst {
+
+__device__ __forceinline__ int reflect_i32(int i, int n) {
+    i = i < 0 ? -i : i;
+    return i >= n ? 2 * (n - 1) - i : i;
+}
+
+// W_16^t = (cos, -sin)(2 pi t / 16), t < 8 (the radix-2 split of the 8192-point transform: lane l owns i = l + 512 t)
+__device__ __forceinline__ float2 w16(int t) {
+    constexpr float c[8] = {1.0f, 0.92387953251128674f, 0.70710678118654752f, 0.38268343236508977f, 0.0f,
+                            -0.38268343236508977f, -0.70710678118654752f, -0.92387953251128674f};
+    constexpr float sn[8] = {0.0f, 0.38268343236508977f, 0.70710678118654752f, 0.92387953251128674f, 1.0f,
+                             0.92387953251128674f, 0.70710678118654752f, 0.38268343236508977f};
+    return make_float2(c[t], -sn[t]);
+}
+
+// Forward transform of ONE frame (pred + i target, windowed) by the LG lanes of a workgroup; afterwards the spectrum
+// Z sits in `buf` in natural order (padded slots): NSEQ = 1: Z[k] = buf[0][slot(k)]; NSEQ = 2 (n_fft = 8192):
+// Z[2m] = buf[0][slot(m)], Z[2m+1] = buf[1][slot(m)].  Ends with a barrier (the spectrum is readable by every lane).
+template <int N>
+struct FrameLoader {
+    using S = FftShape<N>;
+    static constexpr int LG = S::LG, PTS = N / LG, H = N / 2;
+    // raw(t) -> unwindowed (pred, target) sample pair of element lane + LG t; win[t] = its window value (NSEQ = 1);
+    // the 8192-point transform forms its window from the radix-2 twiddle it needs anyway:
+    //   W_N^i = wl W_16^t (i = lane + 512 t),  hann(i) = 0.5 - 0.5 Re W_N^i,  hann(i + N/2) = 0.5 + 0.5 Re W_N^i
+    template <typename F>
+    __device__ static __forceinline__ void transform(F&& raw, const float* win, float2 (*buf)[S::SLOTS],
+                                                     const LaneTw<N>& tw, float2 wl, int lane) {
+        if constexpr (S::NSEQ == 1) {
+            float2 v[8], o[S::NBL][S::RL];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const float2 z = raw(t);
+                v[t] = make_float2(win[t] * z.x, win[t] * z.y);
+            }
+            fft_run<N>(v, o, buf[0], tw, lane);
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < S::NBL; ++u)
+#pragma unroll
+                for (int t = 0; t < S::RL; ++t) buf[0][S::slot(lane + u * LG + t * (S::M / S::RL))] = o[u][t];
+        } else {
+            float2 e[8], d[8], oe[1][8], od[1][8];  // radix-2 decimation in frequency: even bins from z[i] + z[i + 4096], odd bins from the twiddled difference
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const float2 w = cmul(wl, w16(t));
+                const float h0 = 0.5f - 0.5f * w.x, h1 = 0.5f + 0.5f * w.x;
+                const float2 za = raw(t), zb = raw(t + 8);
+                const float2 a = make_float2(h0 * za.x, h0 * za.y), b = make_float2(h1 * zb.x, h1 * zb.y);
+                e[t] = cadd(a, b);
+                d[t] = cmul(csub(a, b), w);
+            }
+            fft_run2<N>(e, d, oe, od, buf[0], buf[1], tw, lane);
+            __syncthreads();
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                buf[0][S::slot(lane + t * (S::M / 8))] = oe[0][t];
+                buf[1][S::slot(lane + t * (S::M / 8))] = od[0][t];
+            }
+        }
+        __syncthreads();
+    }
+    // spectrum bin k of the frame transformed last
+    __device__ static __forceinline__ float2 bin(const float2 (*buf)[S::SLOTS], int k) {
+        if constexpr (S::NSEQ == 1) return buf[0][S::slot(k)];
+        else return buf[k & 1][S::slot(k >> 1)];
+    }
+    __device__ static __forceinline__ void split(const float2 (*buf)[S::SLOTS], int k, float2& X, float2& Y) {
+        const float2 zk = bin(buf, k), zn = bin(buf, (N - k) & (N - 1));
+        X = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
+        Y = make_float2(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
+    }
+};
+
+// periodic Hann window value of element lane + LG t.  n_fft <= 2048: from the table (same fp32 values as torch.hann_window);
+// 8192: 0.5 - 0.5 cos(2 pi i / N) with the cosine taken from the product W_N^lane W_32^t that the radix-2 split needs anyway
+template <int N>
+__device__ __forceinline__ void load_window(float* win, const float* __restrict__ wtab, int lane) {
+    constexpr int LG = FftShape<N>::LG;
+#pragma unroll
+    for (int t = 0; t < N / LG; ++t) win[t] = wtab[lane + LG * t];
+}
+
+// balanced strips: strip g of G covers frames [g F / G, (g + 1) F / G)
+__device__ __forceinline__ void strip_range(int g, int G, int F, int& f0, int& f1) {
+    f0 = (int)(((unsigned)g * (unsigned)F) / (unsigned)G);  // g F < 2^31: at most 2^20 frames per row in 2^11 strips
+    f1 = (int)(((unsigned)(g + 1) * (unsigned)F) / (unsigned)G);
+}
+
+template <int N>
+__global__ __launch_bounds__(FftPlan<N>::LG, (N == 8192 ? MST_STFT2_W8192 : 1)) void k_stft2_fwd(StftArgs a) {
+    using S = FftShape<N>;
+    using L = FrameLoader<N>;
+    constexpr int LG = S::LG, PTS = N / LG, H = N / 2;
+    __shared__ __attribute__((aligned(16))) float2 buf[S::NSEQ][S::SLOTS];
+    __shared__ float red[LG / 64][4];
+    const int lane = threadIdx.x, row = blockIdx.y;
+    const ResInfo r = a.r;
+    const float2* twg = reinterpret_cast<const float2*>(a.tables + r.tw_off);
+    LaneTw<N> tw;
+    tw.init(twg, lane);
+    const float2 wl = twg[lane];
+    float win[S::NSEQ == 1 ? PTS : 1];
+    if constexpr (S::NSEQ == 1) load_window<N>(win, a.tables + r.win_off, lane);
+    const float* x = a.pred + (int64_t)row * a.n;
+    const float* y = a.target + (int64_t)row * a.n;
+    int f0, f1;
+    strip_range(blockIdx.x, gridDim.x, r.n_frames, f0, f1);
+    float s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f;
+    const int nrow = (int)a.n;  // 32-bit sample indices: a row is < 2^31 samples
+    // Every frame is fetched whole (consecutive frames share half their samples: the re-read hits L2); the reflection costs
+    // three integer ops per sample and only ever acts in a row's first and last frame.  n_fft <= 2048: the NEXT frame's
+    // samples are requested before the current frame is transformed, so their latency hides behind ~700 instructions.
+    constexpr bool PREFETCH = S::NSEQ == 1;
+    float2 nxt[PREFETCH ? PTS : 1];
+    auto fetch = [&](int f, int t) {
+        const int i = reflect_i32(f * H - H + lane + LG * t, nrow);
+        if (MST_STFT2_ABLATE & 2) return make_float2((float)i, 1.0f);
+        return make_float2(x[i], y[i]);
+    };
+    if constexpr (PREFETCH) {
+#pragma unroll
+        for (int t = 0; t < PTS; ++t) nxt[t] = fetch(f0, t);
+    }
+    for (int f = f0; f < f1; ++f) {
+        if constexpr (PREFETCH) {
+            float2 cur[PTS];
+#pragma unroll
+            for (int t = 0; t < PTS; ++t) cur[t] = nxt[t];
+            if (f + 1 < f1) {
+#pragma unroll
+                for (int t = 0; t < PTS; ++t) nxt[t] = fetch(f + 1, t);
+            }
+            L::transform([&](int t) { return cur[t]; }, win, buf, tw, wl, lane);
+        } else {
+            // 8192: W_N^lane is re-fetched per frame (an L1 hit) instead of living in two registers across the epilogue - the
+            // kernel sits exactly at the 128-register edge that lets two 512-lane workgroups share a CU, and a spilled register
+            // means scratch memory for every wave of the launch
+            int li = lane;
+            asm volatile("" : "+v"(li));
+            const float2 wlf = twg[li];
+            L::transform([&](int t) { return fetch(f, t); }, win, buf, tw, wlf, lane);
+        }
+#pragma unroll 2
+        for (int k = lane; k <= ((MST_STFT2_ABLATE & 1) ? lane : N / 2); k += LG) {
+            float2 X, Y;
+            L::split(buf, k, X, Y);
+            const float xm = sqrtf(fmaxf(X.x * X.x + X.y * X.y, a.eps));
+            const float ym = sqrtf(fmaxf(Y.x * Y.x + Y.y * Y.y, a.eps));
+            const float d = ym - xm;
+            s1 = fmaf(d, d, s1);
+            s2 = fmaf(ym, ym, s2);
+            s3 += fabsf(__builtin_amdgcn_logf(xm) - __builtin_amdgcn_logf(ym));  // log2; scaled by ln2 below
+            s4 += fabsf(d);
+        }
+        __syncthreads();  // the next frame's first pass overwrites the spectrum
+    }
+    s3 *= kLn2;
+    const int wave = lane >> 6, wl_ = lane & 63;
+    s1 = wave_sum(s1); s2 = wave_sum(s2); s3 = wave_sum(s3); s4 = wave_sum(s4);
+    if (wl_ == 0) { red[wave][0] = s1; red[wave][1] = s2; red[wave][2] = s3; red[wave][3] = s4; }
+    __syncthreads();
+    if (lane < 4) {
+        float v = 0.f;
+        for (int w = 0; w < LG / 64; ++w) v += red[w][lane];
+        a.part[((int64_t)row * gridDim.x + blockIdx.x) * 4 + lane] = v;
+    }
+}
+
+
+// =====================================================================================================================
+// Backward.  Per frame: forward transform (recomputed), cotangent of the prediction's half spectrum, inverse transform of
+// its Hermitian extension, window, overlap-add.  The overlap-add is OWNER-COMPUTES - no float atomics on interior samples
+// and a fixed summation order everywhere, so the gradient is bitwise reproducible:
+//   hop = n_fft / 2: hop block b = samples [b h, (b+1) h) receives the second half of frame b and the first half of frame
+//   b + 1, and the lane that holds output element i of one frame holds element i of the next.  A workgroup walks
+//   consecutive frames keeping the previous frame's second half in registers (`carry`); a block is complete when the next
+//   frame's first half arrives and is written once.
+//   HALO mode (512 / 2048): a strip owns whole blocks [b0, b1) and transforms frames b0 .. b1, i.e. it recomputes the one
+//   frame it shares with the next strip (1 / strip-length extra work); every sample of grad_pred is written by exactly one
+//   lane of the launch (plain store, or read-modify-write when another resolution has already written: a.accumulate).
+//   SEAM mode (8192, where frames are few and a recomputed frame costs 1/3 more): every frame is transformed once; a
+//   strip's leading first half and trailing second half are seams, added with atomics onto a ZEROED buffer - exactly two
+//   contributions per seam sample, and x + y is commutative, so the result does not depend on their order.  Runs first.
+//   Row ends: frame 0's first half and the last frame's second half reflect back into the row (torch.stft centre
+//   padding); they are mirrored through LDS into the owning lanes' registers before the block is written.
+// IDFT(h) = conj(FFT(conj(h))).  512 / 2048: two frames share one complex inverse (He_a + i He_b, real part = frame a,
+// imaginary part = frame b).  8192: one frame per inverse of HALF size: y_even + i y_odd = IDFT_M(A + i Bq),
+// A[k] = H[k] + conj(H[M-k]), Bq[k] = (H[k] - conj(H[M-k])) conj(W_N^k), M = 4096 - the same 8 x 8 x 8 x 8 plan as the
+// even / odd halves of the forward transform.
+// =====================================================================================================================
+template <int N>
+__device__ __forceinline__ float2 cotangent(const float2 (*buf)[FftShape<N>::SLOTS], int k, float eps, const float* coef) {
+    float2 X, Y;
+    FrameLoader<N>::split(buf, k, X, Y);
+    const float p2 = X.x * X.x + X.y * X.y;
+    const float xm = sqrtf(fmaxf(p2, eps));
+    const float ym = sqrtf(fmaxf(Y.x * Y.x + Y.y * Y.y, eps));
+    float g = coef[0] * (xm - ym);
+    const float dl = __builtin_amdgcn_logf(xm) - __builtin_amdgcn_logf(ym);
+    g += coef[1] * ((dl > 0.f) - (dl < 0.f)) / xm;
+    g += coef[2] * ((xm > ym) - (xm < ym));
+    const float s = (p2 >= eps) ? g / xm : 0.0f;  // through sqrt(clamp(|X|^2, eps)): zero below the clamp
+    return make_float2(s * X.x, s * X.y);
+}
+
+#ifndef MST_STFT2_BWD_L512
+#define MST_STFT2_BWD_L512 5   // hop blocks per strip (halo mode): 6 frames per one-wave workgroup, 20 % recomputed
+#endif
+#ifndef MST_STFT2_BWD_L2048
+#define MST_STFT2_BWD_L2048 7  // 8 frames per 256-lane workgroup, 14 % recomputed
+#endif
+
+template <int N>
+__global__ __launch_bounds__(FftPlan<N>::LG, (N == 8192 ? MST_STFT2_W8192_BWD : 1)) void k_stft2_bwd(StftArgs a) {
+    using S = FftShape<N>;
+    using L = FrameLoader<N>;
+    constexpr int LG = S::LG, H = N / 2;
+    constexpr bool PAIR = S::NSEQ == 1, SEAMS = !PAIR;
+    constexpr int K = PAIR ? 4 : 8;  // floats of one half frame per lane
+    __shared__ __attribute__((aligned(16))) float2 buf[S::NSEQ][S::SLOTS];
+    __shared__ __attribute__((aligned(16))) float2 hb[PAIR ? S::SLOTS : 1];  // conj(He_a + i He_b)
+    const int lane = threadIdx.x, row = blockIdx.y;
+    const ResInfo r = a.r;
+    const float2* twg = reinterpret_cast<const float2*>(a.tables + r.tw_off);
+    LaneTw<N> tw;
+    tw.init(twg, lane);
+    const float2 wl = twg[lane];
+    float win[PAIR ? 8 : 1];
+    if constexpr (PAIR) load_window<N>(win, a.tables + r.win_off, lane);
+    const float* x = a.pred + (int64_t)row * a.n;
+    const float* y = a.target + (int64_t)row * a.n;
+    float* gx = a.grad_pred + (int64_t)row * a.n;
+    const float gl = a.grad_loss[0];
+    const float coef[3] = {a.coef[(int64_t)row * 4] * gl, a.coef[(int64_t)row * 4 + 1] * gl, a.coef[(int64_t)row * 4 + 2] * gl};
+    const int nrow = (int)a.n, B = nrow / H;  // hop blocks per row; frames 0 .. B
+    int F0, F1;  // frames [F0, F1) of this strip
+    if constexpr (SEAMS) {
+        strip_range(blockIdx.x, gridDim.x, B + 1, F0, F1);
+    } else {
+        int b0, b1;
+        strip_range(blockIdx.x, gridDim.x, B, b0, b1);
+        F0 = b0;
+        F1 = b1 + 1;
+    }
+    // offset, inside a hop block, of half-frame value q of this lane
+    auto pos = [&](int q) { return PAIR ? lane + LG * q : 2 * lane + 1024 * (q >> 1) + (q & 1); };
+    auto put = [&](int block, const float* v, bool rmw) {  // write one complete block
+        float* g = gx + block * H;
+        if constexpr (PAIR) {
+#pragma unroll
+            for (int q = 0; q < K; ++q) g[pos(q)] = rmw ? g[pos(q)] + v[q] : v[q];
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                float2* p = reinterpret_cast<float2*>(g + 2 * lane + 1024 * t);
+                const float2 o = rmw ? *p : make_float2(0.f, 0.f);
+                *p = make_float2(o.x + v[2 * t], o.y + v[2 * t + 1]);
+            }
+        }
+    };
+    auto seam = [&](int block, const float* v) {  // SEAM mode: one of the two contributions to a shared block
+        float* g = gx + block * H;
+#pragma unroll
+        for (int q = 0; q < K; ++q) unsafeAtomicAdd(&g[pos(q)], v[q]);
+    };
+    float* fold = reinterpret_cast<float*>(&buf[0][0]);  // H floats of scratch for the row-end mirrors (the transform buffer is idle then)
+    float carry[K];
+    bool have_carry = false;
+    // one finished frame: `first` -> block f - 1, `second` -> block f
+    auto emit = [&](int f, float* first, float* second) {
+        if (f == 0) {  // the first half lies before the row: sample -p reflects to +p, i.e. element i = H - p lands on block 0, offset p
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < K; ++q) fold[pos(q)] = first[q];
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < K; ++q)
+                if (pos(q) >= 1) second[q] += fold[H - pos(q)];
+            __syncthreads();
+        } else if (f == B) {  // the second half lies beyond the row: element H + i' reflects to sample n - 2 - i'
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < K; ++q) fold[pos(q)] = second[q];
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < K; ++q)
+                if (pos(q) <= H - 2) first[q] += fold[H - 2 - pos(q)];
+        }
+        if (f > 0) {
+            if (have_carry) {
+#pragma unroll
+                for (int q = 0; q < K; ++q) first[q] += carry[q];
+                put(f - 1, first, a.accumulate != 0);
+            } else if (SEAMS) {
+                seam(f - 1, first);
+            }
+        }
+        if (f == B) {
+            // i' = H - 1 reflects to sample n - H - 1 = the last sample of block B - 2, which this lane stored one frame ago
+            if (pos(K - 1) == H - 1) gx[nrow - H - 1] += fold[H - 1];
+            __syncthreads();
+            have_carry = false;
+        } else {
+#pragma unroll
+            for (int q = 0; q < K; ++q) carry[q] = second[q];
+            have_carry = true;
+        }
+    };
+    auto fetch = [&](int f, int t) {
+        const int i = reflect_i32(f * H - H + lane + LG * t, nrow);
+        return make_float2(x[i], y[i]);
+    };
+
+    if constexpr (PAIR) {
+        float2 nxt[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) nxt[t] = fetch(F0, t);
+        for (int fa = F0; fa < F1; fa += 2) {
+            const bool have_b = fa + 1 < F1;
+#pragma unroll 1
+            for (int which = 0; which < 2; ++which) {
+                if (which == 1 && !have_b) break;
+                const int f = fa + which;
+                float2 cur[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) cur[t] = nxt[t];
+                if (f + 1 < F1) {
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) nxt[t] = fetch(f + 1, t);
+                }
+                L::transform([&](int t) { return cur[t]; }, win, buf, tw, wl, lane);
+                for (int k = lane; k <= N / 2; k += LG) {
+                    const float2 G = cotangent<N>(buf, k, a.eps, coef);
+                    const bool edge = (k == 0) || (k == N / 2);
+                    const int sk = S::slot(k), sn = S::slot((N - k) & (N - 1));
+                    if (which == 0) {
+                        // conj(He): He[k] = G/2 -> (Gx/2, -Gy/2); He[N-k] = conj(G)/2 -> (Gx/2, +Gy/2)
+                        hb[sk] = edge ? make_float2(G.x, 0.f) : make_float2(0.5f * G.x, -0.5f * G.y);
+                        if (!edge) hb[sn] = make_float2(0.5f * G.x, 0.5f * G.y);
+                    } else if (edge) {
+                        hb[sk].y -= G.x;  // conj(i He_b[k]) = (0, -Gx) at the real bins
+                    } else {
+                        // conj(i He_b): i G/2 -> (-Gy/2, -Gx/2);  i conj(G)/2 -> (Gy/2, -Gx/2)
+                        const float2 h0 = hb[sk], h1 = hb[sn];
+                        hb[sk] = make_float2(h0.x - 0.5f * G.y, h0.y - 0.5f * G.x);
+                        hb[sn] = make_float2(h1.x + 0.5f * G.y, h1.y - 0.5f * G.x);
+                    }
+                }
+                __syncthreads();  // the spectrum has been consumed (the next transform overwrites it); hb is complete
+            }
+            // FFT(conj(h)) = conj(r_a + i r_b)  =>  r_a = Re, r_b = -Im
+            float2 v[8], o[S::NBL][S::RL];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) v[t] = hb[S::slot(lane + LG * t)];
+            fft_run<N>(v, o, buf[0], tw, lane);
+            float fa1[4], fa2[4], fb1[4], fb2[4];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float2 R = S::RL == 8 ? o[0][q] : o[q & 1][q >> 1];  // element lane + LG q
+                const float ra = win[q] * R.x, rb = -win[q] * R.y;
+                if (q < 4) { fa1[q] = ra; fb1[q] = rb; }
+                else { fa2[q - 4] = ra; fb2[q - 4] = rb; }
+            }
+            __syncthreads();  // the inverse has left buf[0]: emit() may use it as mirror scratch, the next transform as work space
+            emit(fa, fa1, fa2);
+            if (have_b) emit(fa + 1, fb1, fb2);
+        }
+    } else {
+        constexpr int M = S::M;                                    // 4096
+        constexpr int PER = (M / 2 + 1 + LG - 1) / LG;             // (k, M - k) pairs per lane
+        // window of samples 2m, 2m + 1 (m = lane + 512 t): 0.5 - 0.5 Re(W_N^(2 lane + c) W_8^t)
+        const float2 we = twg[2 * lane], wo = twg[2 * lane + 1];
+        for (int f = F0; f < F1; ++f) {
+            int li = lane;
+            asm volatile("" : "+v"(li));
+            const float2 wlf = twg[li];
+            L::transform([&](int t) { return fetch(f, t); }, win, buf, tw, wlf, lane);
+            float2 Vk[PER], Vm[PER];
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int k = lane + i * LG;
+                Vk[i] = Vm[i] = make_float2(0.f, 0.f);
+                if (k <= M / 2) {
+                    float2 Hk = cotangent<N>(buf, k, a.eps, coef), Hm = cotangent<N>(buf, M - k, a.eps, coef);
+                    if (k == 0) {
+                        Vk[i] = make_float2(Hk.x + Hm.x, -(Hk.x - Hm.x));  // V[0] = (H0 + HM) + i (H0 - HM), both real; conj
+                    } else {
+                        Hk = make_float2(0.5f * Hk.x, 0.5f * Hk.y);
+                        Hm = make_float2(0.5f * Hm.x, 0.5f * Hm.y);
+                        const float2 w = twg[k];  // W_N^k ; W_N^(M-k) = -conj(W_N^k)
+                        const float2 Ak = make_float2(Hk.x + Hm.x, Hk.y - Hm.y);
+                        const float2 Bk = cmul(make_float2(Hk.x - Hm.x, Hk.y + Hm.y), make_float2(w.x, -w.y));
+                        Vk[i] = make_float2(Ak.x - Bk.y, -(Ak.y + Bk.x));
+                        const float2 Am = make_float2(Hm.x + Hk.x, Hm.y - Hk.y);
+                        const float2 Bm = cmul(make_float2(Hm.x - Hk.x, Hm.y + Hk.y), make_float2(-w.x, -w.y));
+                        Vm[i] = make_float2(Am.x - Bm.y, -(Am.y + Bm.x));
+                    }
+                }
+            }
+            __syncthreads();  // every lane has read its bins
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int k = lane + i * LG;
+                if (k <= M / 2) {
+                    buf[0][S::slot(k)] = Vk[i];
+                    if (k != 0 && k != M / 2) buf[0][S::slot(M - k)] = Vm[i];
+                }
+            }
+            __syncthreads();
+            float2 v[8], o[1][8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) v[t] = buf[0][S::slot(lane + LG * t)];
+            __syncthreads();
+            fft_run<N>(v, o, buf[0], tw, lane);  // = conj(y_even + i y_odd) at m = lane + 512 t
+            float h1[8], h2[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const float2 w8 = t == 0 ? make_float2(1.f, 0.f) : (t == 1 ? make_float2(0.70710678118654752f, -0.70710678118654752f)
+                                : (t == 2 ? make_float2(0.f, -1.f) : (t == 3 ? make_float2(-0.70710678118654752f, -0.70710678118654752f)
+                                : (t == 4 ? make_float2(-1.f, 0.f) : (t == 5 ? make_float2(-0.70710678118654752f, 0.70710678118654752f)
+                                : (t == 6 ? make_float2(0.f, 1.f) : make_float2(0.70710678118654752f, 0.70710678118654752f)))))));
+                const float ce = we.x * w8.x - we.y * w8.y, co = wo.x * w8.x - wo.y * w8.y;  // cos(2 pi i / N), i = 2m, 2m + 1
+                const float ye = (0.5f - 0.5f * ce) * o[0][t].x, yo = -(0.5f - 0.5f * co) * o[0][t].y;
+                if (t < 4) { h1[2 * t] = ye; h1[2 * t + 1] = yo; }
+                else { h2[2 * (t - 4)] = ye; h2[2 * (t - 4) + 1] = yo; }
+            }
+            __syncthreads();
+            emit(f, h1, h2);
+        }
+    }
+    // trailing second half of a strip that does not end the row: the seam shared with the next strip (halo mode: the next
+    // strip recomputes this frame and owns the block)
+    if (SEAMS && have_carry) seam(F1 - 1, carry);
+}
+
+int stft2_bwd_groups(int n_fft, int n_frames) {
+    const int B = n_frames - 1;
+    if (n_fft == 8192) {  // seam mode: strips of >= 2 frames, the last one of >= 3 (it finishes block B - 2 itself)
+        int G = n_frames / 2;
+        while (G > 1 && n_frames - (int)(((int64_t)(G - 1) * n_frames) / G) < 3) --G;
+        return G > 0 ? G : 1;
+    }
+    const int L = n_fft == 512 ? MST_STFT2_BWD_L512 : MST_STFT2_BWD_L2048;  // halo mode: >= 2 blocks per strip
+    const int G = B / L;
+    return G > 0 ? G : 1;
+}
+bool stft2_bwd_needs_zero(int n_fft) { return n_fft == 8192; }
+
+void launch_stft2_bwd(const StftArgs& a, int n_groups, int rows, hipStream_t stream) {
+    const dim3 grid(n_groups, rows);
+    if (a.r.n_fft == 512) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stft2_bwd<512>), grid, dim3(FftPlan<512>::LG), 0, stream, a);
+    else if (a.r.n_fft == 2048) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stft2_bwd<2048>), grid, dim3(FftPlan<2048>::LG), 0, stream, a);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stft2_bwd<8192>), grid, dim3(FftPlan<8192>::LG), 0, stream, a);
+}
+
+void launch_stft2_fwd(const StftArgs& a, int n_groups, int rows, hipStream_t stream) {
+    const dim3 grid(n_groups, rows);
+    if (a.r.n_fft == 512) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stft2_fwd<512>), grid, dim3(FftPlan<512>::LG), 0, stream, a);
+    else if (a.r.n_fft == 2048) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stft2_fwd<2048>), grid, dim3(FftPlan<2048>::LG), 0, stream, a);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stft2_fwd<8192>), grid, dim3(FftPlan<8192>::LG), 0, stream, a);
+}
+
+}  // namespace mst

@@ -285,11 +285,12 @@ class AdvancedMixConsole(torch.nn.Module):
         return self._affine_cache[key]
 
     def _denormalized_dicts(self, track_params, fx_bus_params, master_bus_params):
-        """Same nested dicts as reference :353-466; one fused affine map per tensor, entries are views."""
+        """Same nested dicts as reference :353-466: one affine map per tensor (v * (hi - lo) + lo as a multiply and an add,
+        the reference's - and the device kernel's - two fp32 roundings, not a fused multiply-add), entries are views."""
 
         def tracks():
             scale, lo = self._affine(_desc.TRACK_INDEX, track_params.device)
-            return _nested(_desc.TRACK_INDEX, torch.addcmul(lo, track_params, scale))
+            return _nested(_desc.TRACK_INDEX, track_params * scale + lo)
 
         def fx():
             key = ("fx-forced-wet", str(fx_bus_params.device))
@@ -298,11 +299,11 @@ class AdvancedMixConsole(torch.nn.Module):
                 scale[24], lo[24] = 0.0, 1.0  # reference :420 forces the reverb mix to ones
                 self._affine_cache[key] = (scale, lo)
             scale, lo = self._affine_cache[key]
-            return _nested(_desc.FX_INDEX, torch.addcmul(lo, fx_bus_params, scale))
+            return _nested(_desc.FX_INDEX, fx_bus_params * scale + lo)
 
         def master():
             scale, lo = self._affine(_desc.MASTER_INDEX, master_bus_params.device)
-            return _nested(_desc.MASTER_INDEX, torch.addcmul(lo, master_bus_params, scale))
+            return _nested(_desc.MASTER_INDEX, master_bus_params * scale + lo)
 
         if self.param_dicts == "eager":
             return tracks(), fx(), master()

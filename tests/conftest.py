@@ -29,7 +29,10 @@ def record(request):
     """record(key=value, ...) files the numbers a parity test measured under the test's id."""
 
     def rec(**values):
-        d = _PARITY.setdefault(request.node.nodeid.split("::", 1)[-1], {})
+        import re
+
+        key = re.sub(r"\[/.*?/tests/golden/", "[", request.node.nodeid.split("::", 1)[-1])
+        d = _PARITY.setdefault(key, {})
         for k, v in values.items():
             d[k] = [float(x) for x in v] if isinstance(v, (tuple, list)) else float(v)
 

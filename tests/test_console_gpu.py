@@ -78,7 +78,11 @@ def assert_three_way(hip, r32, r64, key, tol32, slack=1e-4):
     assert h64 <= 2 * r + slack, (key, "hip-vs-ref32", h32, "hip-vs-f64", h64, "ref32-vs-f64", r)
 
 
-GOLDEN_GRAD_TOL = {"default": 1e-2, "console_fullbox_1x2x131072.npz": 1e-2}
+# measured r02 (profiles/parity_r02.json): basic 4e-7, refmix 3e-5, fullbox 6e-5, full_2x4x16384 5.4e-3, full_1x8x32768 6.0e-3
+# (the two short full-chain fixtures carry near-Nyquist high-Q bands whose fp32 design the reference's autograd itself misses by
+# ~5e-3 against float64, see test_flag_combinations)
+GOLDEN_GRAD_TOL = {"default": 5e-4, "console_basic_2x4x16384.npz": 1e-5, "console_full_2x4x16384.npz": 8e-3,
+                   "console_full_1x8x32768.npz": 8e-3}
 
 
 def parse_flags(arr):

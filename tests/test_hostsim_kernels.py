@@ -142,6 +142,41 @@ def test_mrstft_8192_inplace_transform():
     assert rel(out["grad_pred"], xo.grad) < 1e-5
 
 
+def test_mrstft_register_radix_engine():
+    """The round-2 kernels (mst_stft2.hip / mst_fft2.h): reference-shaped resolutions (hop = n_fft / 2, full window) on rows
+    that are whole hops long; 3 x 8192 samples = 7 frames of 8192, 25 of 2048, 97 of 512 per row, two rows."""
+    torch.manual_seed(8)
+    n = 3 * 8192
+    x = 0.3 * torch.randn(1, 2, n)
+    y = 0.6 * x + 0.2 * torch.randn(1, 2, n)
+    for res in (((512, 256, 512),), ((2048, 1024, 2048),), ((8192, 4096, 8192),)):
+        full = harness.mrstft(x, y, res, grad=False)
+        want = ol.mrstft_loss(x.double(), y.double(), res).item()
+        assert abs(full["loss"].item() - want) / want < 2e-6, (res, full["loss"].item(), want)
+    # backward: owner-computes overlap-add (halo strips for 512 / 2048, seam strips for 8192), row-end mirrors, each
+    # resolution alone (it owns the gradient buffer) and all three (8192 first onto zeros, the others add); the smooth
+    # spectral-convergence term pins the transforms and the overlap-add to fp32 round-off
+    for res in (((512, 256, 512),), ((2048, 1024, 2048),), ((8192, 4096, 8192),),
+                ((512, 256, 512), (2048, 1024, 2048), (8192, 4096, 8192)), ((2048, 1024, 2048), (512, 256, 512))):
+        out = harness.mrstft(x, y, res, w_sc=1.0, w_log_mag=0.0)
+        xo = x.double().requires_grad_(True)
+        lo = ol.mrstft_loss(xo, y.double(), res, w_sc=1.0, w_log_mag=0.0)
+        lo.backward()
+        assert abs(out["loss"].item() - lo.item()) / lo.item() < 1e-6
+        assert rel(out["grad_pred"], xo.grad) < 1e-5, res
+        again = harness.mrstft(x, y, res, w_sc=1.0, w_log_mag=0.0)
+        assert torch.equal(out["grad_pred"], again["grad_pred"])  # reproducible bit for bit
+    # the shortest row the round-2 kernels take (two 8192-frames deep) and the full loss (log-magnitude term included)
+    xs, ys = x[..., :16384].contiguous(), y[..., :16384].contiguous()
+    res = ((512, 256, 512), (2048, 1024, 2048), (8192, 4096, 8192))
+    out = harness.mrstft(xs, ys, res)
+    xo = xs.double().requires_grad_(True)
+    lo = ol.mrstft_loss(xo, ys.double(), res)
+    lo.backward()
+    assert abs(out["loss"].item() - lo.item()) / lo.item() < 2e-6
+    assert rel(out["grad_pred"], xo.grad) < 2e-3  # d log|X| / dX ~ 1/|X|: fp32-noise-limited (see the GPU tests)
+
+
 def test_afloss_small():
     torch.manual_seed(0)
     n = 17000  # just above the 16384-sample reflect pad: 3 frames

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Counter passes of one bench command on the GPU box (each --pmc set in its own run, kernel-trace only):
-#   tools/pmc_passes.sh <tag> [bench args...]
+#   tools/pmc_passes.sh <tag> [bench args...]          (PMC_SCRIPT=tools/loss_bench.py: another script of the repo)
 # writes gpurun_out/<tag>_{stats,sq1,sq2,fetch,write}/ and gpurun_out/<tag>_counters.txt (rocprofv3 -L excerpt)
 tag="$1"; shift
 args="${@:---steps 10 --warmup 2 --no-cpu-baseline --no-secondary}"
@@ -12,7 +12,7 @@ rocprofv3 -L 2>/dev/null | grep -oE "\b(SQ_[A-Z0-9_]+|GRBM_[A-Z0-9_]+|TCC_[A-Z0-
 run() {  # name, rocprof options...
   name="$1"; shift
   rm -rf "$O/${tag}_$name"
-  timeout 600 rocprofv3 "$@" -d "$O/${tag}_$name" -o r -- python "$R/bench.py" $args > "$O/${tag}_$name.log" 2>&1
+  timeout 600 rocprofv3 "$@" -d "$O/${tag}_$name" -o r -- python "$R/${PMC_SCRIPT:-bench.py}" $args > "$O/${tag}_$name.log" 2>&1
   echo "$name rc=$?"
 }
 run stats --kernel-trace --stats --output-format csv
