@@ -35,10 +35,11 @@ constexpr int RC_PANL = 36;    // tracks: left pan gain   | master: output-fader
 constexpr int RC_PANR = 37;    // tracks: right pan gain  | master: output-fader linear gain
 constexpr int RC_GIN = 38;     // input-fader linear gain (already folded into section 0)
 constexpr int RC_LOG2A_C = 39; // log2(alpha^kCompChunk), from fp64
-constexpr int RC_STRIDE = 40;
+constexpr int RC_SEND = 40;    // tracks: linear fx-bus send gain 10^(send_db/20)
+constexpr int RC_STRIDE = 44;
 
 // partial-sum slots of the compressor backward kernel
-constexpr int CP_THR = 0, CP_KAPPA = 1, CP_KNEE = 2, CP_ALPHA = 3, CP_MAKEUP = 4, CP_PANL = 5, CP_PANR = 6;
+constexpr int CP_THR = 0, CP_KAPPA = 1, CP_KNEE = 2, CP_ALPHA = 3, CP_MAKEUP = 4, CP_PANL = 5, CP_PANR = 6, CP_SEND = 7;
 constexpr int CP_COUNT = 8;
 constexpr int EP_COUNT = 30;  // coefficient-gradient partial sums: 6 x {b0 b1 b2 a1 a2}
 
@@ -165,6 +166,9 @@ struct Layout {
     int64_t cp_t, cp_m, ep_t, ep_m;      // partial sums
     int64_t pow1F_t, pow1F_m, pow1A_t, pow1A_m;  // in-wave scan tables rows x kPow1 x 144
     int64_t aggF_t, aggF_m, aggA_t, aggA_m;      // tile aggregates sigrows x 12 x kMaxTiles1 (forward / adjoint cascade)
+    // fx bus (only laid out when MST_USE_FX_BUS is set)
+    int fxS, fxTaps, fxK, fxBlk, fxBlkIr;         // impulse-response samples, band-pass taps, partitions, signal blocks, ir-bwd blocks
+    int64_t fx_rc, fx_in, fx_wnf, fx_ir, fx_Xs, fx_Hs, fx_Ys, fx_dXs, fx_dHs, fx_dir, fx_din, fx_part;
     int64_t total;                       // floats
 };
 
@@ -242,6 +246,25 @@ inline Layout make_layout(const mst_console_desc* d) {
     L.aggF_m = L.aggF_t + R * kStates * kMaxTiles1;
     L.aggA_t = take((R + 2 * B) * kStates * kMaxTiles1);
     L.aggA_m = L.aggA_t + R * kStates * kMaxTiles1;
+    if (d->flags & MST_USE_FX_BUS) {
+        L.fxS = d->fx_ir_samples;
+        L.fxTaps = d->fx_bandpass_taps;
+        L.fxK = L.fxS / 4096;
+        L.fxBlk = (int)((L.N + 4095) / 4096);
+        L.fxBlkIr = (L.fxS + 1023) / 1024;
+        L.fx_rc = take(B * 24);
+        L.fx_in = take(B * 2 * N);
+        L.fx_wnf = take(B * 2 * 12 * (int64_t)L.fxS);
+        L.fx_ir = take(B * 2 * (int64_t)L.fxS);
+        L.fx_Xs = take(B * (int64_t)L.fxBlk * 8192 * 2);
+        L.fx_Hs = take(B * (int64_t)L.fxK * 8192 * 2);
+        L.fx_Ys = take(B * (int64_t)L.fxBlk * 8192 * 2);
+        L.fx_dXs = take(B * (int64_t)L.fxBlk * 8192 * 2);
+        L.fx_dHs = take(B * (int64_t)L.fxK * 8192 * 2);
+        L.fx_dir = take(B * 2 * (int64_t)L.fxS);
+        L.fx_din = take(B * 2 * N);
+        L.fx_part = take(B * (int64_t)L.fxBlkIr * 24);
+    }
     L.total = o;
     return L;
 }

@@ -136,13 +136,14 @@ __device__ __forceinline__ void apply_tracks_body(const TrackApplyArgs& a) {
     __shared__ float lds[8];
     const int b = blockIdx.y, chunk = blockIdx.x * kWG + threadIdx.x;
     const int64_t i0 = (int64_t)chunk * CC;
-    float accL[CC], accR[CC];
+    float accL[CC], accR[CC], fxL[CC], fxR[CC];
 #pragma unroll
-    for (int i = 0; i < CC; ++i) accL[i] = accR[i] = 0.0f;
+    for (int i = 0; i < CC; ++i) accL[i] = accR[i] = fxL[i] = fxR[i] = 0.0f;
     for (int t = 0; t < a.T; ++t) {
         const int row = b * a.T + t;
         const float* rc = a.rc + (int64_t)row * RC_STRIDE;
         const float pl = rc[RC_PANL], pr = rc[RC_PANR];
+        const float sl = a.fx ? pl * rc[RC_SEND] : 0.0f, sr = a.fx ? pr * rc[RC_SEND] : 0.0f;  // fx send bus: sum_t send_t * panned track
         const float* urow = a.u + (int64_t)row * a.stride;
         float y[CC];
         if (a.comp_on) {
@@ -175,6 +176,13 @@ __device__ __forceinline__ void apply_tracks_body(const TrackApplyArgs& a) {
             accL[i] = fmaf(pl, y[i], accL[i]);
             accR[i] = fmaf(pr, y[i], accR[i]);
         }
+        if (a.fx) {
+#pragma unroll
+            for (int i = 0; i < CC; ++i) {
+                fxL[i] = fmaf(sl, y[i], fxL[i]);
+                fxR[i] = fmaf(sr, y[i], fxR[i]);
+            }
+        }
         if (a.mixed) {
             float ml[CC], mr[CC];
 #pragma unroll
@@ -188,6 +196,10 @@ __device__ __forceinline__ void apply_tracks_body(const TrackApplyArgs& a) {
     }
     ST8<FAST>(a.bus + ((int64_t)b * 2 + 0) * a.bus_stride, i0, a.n, accL);
     ST8<FAST>(a.bus + ((int64_t)b * 2 + 1) * a.bus_stride, i0, a.n, accR);
+    if (a.fx) {  // (bs, 2, stride) rows of the workspace: always 16-byte aligned
+        ST8<FAST>(a.fx + ((int64_t)b * 2 + 0) * a.stride, i0, a.n, fxL);
+        ST8<FAST>(a.fx + ((int64_t)b * 2 + 1) * a.stride, i0, a.n, fxR);
+    }
 }
 __device__ __forceinline__ bool block_interior(int64_t n, int lookahead, int aligned) {
     const int64_t lo = (int64_t)blockIdx.x * kWG * CC, hi = lo + (int64_t)kWG * CC;
@@ -272,6 +284,17 @@ __device__ __forceinline__ void load_gy(const CompBwdArgs& a, int row, const flo
             r[q] += mr[q];
         }
     }
+    if (!MASTER && a.gfx) {  // the panned track also feeds the fx send bus with gain `send`
+        const float send = rc[RC_SEND];
+        float fl[CC], fr[CC];
+        LD8S<FAST>(a.gfx + ((int64_t)b * 2 + 0) * a.gfx_stride, i, a.n, fl);
+        LD8S<FAST>(a.gfx + ((int64_t)b * 2 + 1) * a.gfx_stride, i, a.n, fr);
+#pragma unroll
+        for (int q = 0; q < CC; ++q) {
+            l[q] = fmaf(send, fl[q], l[q]);
+            r[q] = fmaf(send, fr[q], r[q]);
+        }
+    }
 #pragma unroll
     for (int q = 0; q < CC; ++q) {
         gl[q] = l[q];
@@ -327,6 +350,18 @@ __device__ __forceinline__ void comp_bwd_run_body(const CompBwdArgs& a) {
     float gl[CC], gr[CC], du0[CC], du1[CC];
     load_gy<MASTER, FAST>(a, row, rc, i0, gl, gr);
     const float pl = rc[RC_PANL], pr = rc[RC_PANR];  // master: both = output-fader gain
+    // cotangent of the fx send gain: sum_n (pl fL + pr fR)[n] y[n]  (fL, fR = cotangent of the send bus)
+    float fsum[CC];
+#pragma unroll
+    for (int i = 0; i < CC; ++i) fsum[i] = 0.0f;
+    if (!MASTER && a.gfx) {
+        const int bb = row / a.T;
+        float fl[CC], fr[CC];
+        LD8S<FAST>(a.gfx + ((int64_t)bb * 2 + 0) * a.gfx_stride, i0, a.n, fl);
+        LD8S<FAST>(a.gfx + ((int64_t)bb * 2 + 1) * a.gfx_stride, i0, a.n, fr);
+#pragma unroll
+        for (int i = 0; i < CC; ++i) fsum[i] = pl * fl[i] + pr * fr[i];
+    }
 
     if (a.comp_on) {
         const CompK k = load_comp(rc);
@@ -389,6 +424,7 @@ __device__ __forceinline__ void comp_bwd_run_body(const CompBwdArgs& a) {
                     const float yv = xd0[i] * G;
                     p[CP_PANL] = fmaf(gl[i], yv, p[CP_PANL]);
                     p[CP_PANR] = fmaf(gr[i], yv, p[CP_PANR]);
+                    p[CP_SEND] = fmaf(fsum[i], yv, p[CP_SEND]);
                 }
             }
             // side chain: d x_db / d side = (20/ln10) / side, clamp kills it below eps
@@ -411,6 +447,7 @@ __device__ __forceinline__ void comp_bwd_run_body(const CompBwdArgs& a) {
                 else {
                     p[CP_PANL] = fmaf(gl[i], x0[i], p[CP_PANL]);
                     p[CP_PANR] = fmaf(gr[i], x0[i], p[CP_PANR]);
+                    p[CP_SEND] = fmaf(fsum[i], x0[i], p[CP_SEND]);
                 }
             }
         }

@@ -6,7 +6,10 @@
 namespace mst {
 static int check_desc(const mst_console_desc* d) {
     if (!d || d->bs <= 0 || d->n_tracks <= 0 || d->n_samples <= 0) return hipErrorInvalidValue;
-    if (d->flags & MST_USE_FX_BUS) return hipErrorInvalidValue;          // SURVEY 8f rank 4, not built yet
+    if (d->flags & MST_USE_FX_BUS) {
+        if (d->fx_ir_samples < 4096 || d->fx_ir_samples % 4096 || d->fx_ir_samples > (1 << 20)) return hipErrorInvalidValue;
+        if (d->fx_bandpass_taps < 1 || d->fx_bandpass_taps > 1023 || !(d->fx_bandpass_taps & 1)) return hipErrorInvalidValue;
+    }
     if (!(d->flags & MST_USE_TRACK_PANNER)) return hipErrorInvalidValue;  // reference branch is broken (mst/modules.py:269)
     if (d->track_row_stride < d->n_samples) return hipErrorInvalidValue;
     if ((d->track_lookahead & 3) || (d->master_lookahead & 3) || d->track_lookahead < 0 || d->master_lookahead < 0)
@@ -26,7 +29,29 @@ static constexpr bool fuse_allpole() {
 #endif
 }
 
-extern "C" int mst_abi_version(void) { return 2; }
+extern "C" int mst_abi_version(void) { return 3; }
+
+extern "C" size_t mst_console_fx_tables_bytes(void) { return (size_t)8192 * 2 * sizeof(float); }
+extern "C" int mst_console_fx_init_tables(void* tables, void* stream) {
+    if (!tables) return hipErrorInvalidValue;
+    launch_fx_tables((float*)tables, (hipStream_t)stream);
+    return (int)hipGetLastError();
+}
+
+static FxPlan fx_plan(const Layout& L) {
+    FxPlan p{};
+    p.bs = L.bs;
+    p.S = L.fxS;
+    p.taps = L.fxTaps;
+    p.K = L.fxK;
+    p.nblk = L.fxBlk;
+    p.nblk_ir = L.fxBlkIr;
+    p.n = L.N;
+    p.Ns = round_up(L.N, 4);
+    p.rcfx = L.fx_rc; p.fx_in = L.fx_in; p.wnf = L.fx_wnf; p.ir = L.fx_ir; p.Xs = L.fx_Xs; p.Hs = L.fx_Hs; p.Ys = L.fx_Ys;
+    p.dXs = L.fx_dXs; p.dHs = L.fx_dHs; p.dir = L.fx_dir; p.dfx_in = L.fx_din; p.fxpart = L.fx_part;
+    return p;
+}
 
 extern "C" size_t mst_console_workspace_bytes(const mst_console_desc* d) {
     if (check_desc(d) != hipSuccess) return 0;
@@ -34,8 +59,8 @@ extern "C" size_t mst_console_workspace_bytes(const mst_console_desc* d) {
 }
 
 extern "C" int mst_console_forward(const mst_console_desc* d, const float* tracks, const float* track_params,
-                                   const float* fx_bus_params, const float* master_bus_params, float* mix,
-                                   float* mixed_tracks, int32_t* status, void* workspace, size_t workspace_bytes,
+                                   const float* fx_bus_params, const float* master_bus_params, const mst_console_fx* fx,
+                                   float* mix, float* mixed_tracks, int32_t* status, void* workspace, size_t workspace_bytes,
                                    void* stream_) {
     if (int e = check_desc(d)) return e;
     const Layout L = make_layout(d);
@@ -49,10 +74,13 @@ extern "C" int mst_console_forward(const mst_console_desc* d, const float* track
     const bool t_comp = d->flags & MST_USE_TRACK_COMPRESSOR;
     const bool m_on = d->flags & MST_USE_MASTER_BUS;
     const bool o_on = d->flags & MST_USE_OUTPUT_FADER;
+    const bool fx_on = d->flags & MST_USE_FX_BUS;
+    if (fx_on && (!fx || !fx->noise || !fx->filters || !fx->tables)) return hipErrorInvalidValue;
 
     PrepArgs pa{track_params, fx_bus_params, master_bus_params, ws + L.rc_t, ws + L.rc_m,
                 ws + L.powF_t, ws + L.powF_m, ws + L.powA_t, ws + L.powA_m, ws + L.powP_t, ws + L.powP_m,
-                ws + L.pow1F_t, ws + L.pow1F_m, ws + L.pow1A_t, ws + L.pow1A_m, status, L.R, L.bs, L.KE, L.eq1, *d};
+                ws + L.pow1F_t, ws + L.pow1F_m, ws + L.pow1A_t, ws + L.pow1A_m, fx_on ? ws + L.fx_rc : nullptr, status, L.R, L.bs, L.KE,
+                L.eq1, *d};
     launch_prep(pa, stream);
 
     // ---- tracks: EQ (zs -> carry scan -> run), compressor smoother (zs -> scan), apply + pan + bus sum
@@ -72,10 +100,14 @@ extern "C" int mst_console_forward(const mst_console_desc* d, const float* track
     else
         launch_cascade(EQ_FWD, true, tracks, d->track_row_stride, ws + L.u_t, Ns, ws + L.rc_t, L.R, sE_t, nullptr, L.ncE_pad, n, L.R, stream, p1F_t, L.ntE, ws + L.aggF_t, zP_t);
     const bool bus_is_mix = !m_on && !o_on;
+    float* busp = bus_is_mix ? mix : ws + L.bus;
+    const int64_t bus_stride = bus_is_mix ? n : Ns;
     TrackApplyArgs ta{ws + L.u_t, Ns, ws + L.rc_t, ws + L.zS_t, (save && t_comp) ? ws + L.gs_t : nullptr,
-                      bus_is_mix ? mix : ws + L.bus, bus_is_mix ? n : Ns, mixed_tracks,
+                      busp, bus_stride, mixed_tracks, fx_on ? ws + L.fx_in : nullptr,
                       L.T, L.ncC_pad, d->track_lookahead, t_comp ? 1 : 0, n, aligned};
     launch_apply_tracks(ta, L.bs, stream);
+    // ---- fx bus: reverberate the send bus and add it to the stereo bus (reference mst/modules.py:275-284)
+    if (fx_on) launch_fx_forward(fx_plan(L), fx->noise, fx->filters, (const float*)fx->tables, ws, busp, bus_stride, stream);
 
     // ---- master bus
     if (m_on) {
@@ -94,8 +126,9 @@ extern "C" int mst_console_forward(const mst_console_desc* d, const float* track
 }
 
 extern "C" int mst_console_backward(const mst_console_desc* d, const float* tracks, const float* track_params,
-                                    const float* master_bus_params, const float* grad_mix, const float* grad_mixed_tracks,
-                                    float* grad_track_params, float* grad_master_params, float* grad_tracks,
+                                    const float* fx_bus_params, const float* master_bus_params, const mst_console_fx* fx,
+                                    const float* grad_mix, const float* grad_mixed_tracks, float* grad_track_params,
+                                    float* grad_fx_params, float* grad_master_params, float* grad_tracks,
                                     void* workspace, size_t workspace_bytes, void* stream_) {
     if (int e = check_desc(d)) return e;
     const Layout L = make_layout(d);
@@ -108,6 +141,8 @@ extern "C" int mst_console_backward(const mst_console_desc* d, const float* trac
     const bool t_comp = d->flags & MST_USE_TRACK_COMPRESSOR;
     const bool m_on = d->flags & MST_USE_MASTER_BUS;
     const bool o_on = d->flags & MST_USE_OUTPUT_FADER;
+    const bool fx_on = d->flags & MST_USE_FX_BUS;
+    if (fx_on && (!fx || !fx->tables || !fx_bus_params)) return hipErrorInvalidValue;
     (void)tracks;
     const int aligned = (n % 4 == 0) && !((uintptr_t)grad_mix & 15) && !((uintptr_t)grad_mixed_tracks & 15);
 
@@ -122,7 +157,7 @@ extern "C" int mst_console_backward(const mst_console_desc* d, const float* trac
     int64_t gbus_stride = n;
     if (m_on) {
         CompBwdArgs ca{ws + L.v_m, Ns, ws + L.gs_m, ws + L.rc_m, nullptr, ws + L.zQ_m, ws + L.du_m, ws + L.cp_m,
-                       grad_mix, n, nullptr, 1, L.ncC_pad, d->master_lookahead, 1, n, aligned};
+                       grad_mix, n, nullptr, nullptr, 0, 1, L.ncC_pad, d->master_lookahead, 1, n, aligned};
         launch_comp_bwd(true, false, ca, L.bs, stream);
         ca.s0 = ws + L.zQ_m;
         launch_comp_bwd(true, true, ca, L.bs, stream);
@@ -135,7 +170,7 @@ extern "C" int mst_console_backward(const mst_console_desc* d, const float* trac
         gbus_stride = Ns;
     } else if (o_on) {
         CompBwdArgs ca{ws + L.bus, Ns, nullptr, ws + L.rc_m, nullptr, nullptr, ws + L.dbus, ws + L.cp_m,
-                       grad_mix, n, nullptr, 1, L.ncC_pad, 0, 0, n, aligned};
+                       grad_mix, n, nullptr, nullptr, 0, 1, L.ncC_pad, 0, 0, n, aligned};
         launch_comp_bwd(true, true, ca, L.bs, stream);
         gbus = ws + L.dbus;
         gbus_stride = Ns;
@@ -143,10 +178,14 @@ extern "C" int mst_console_backward(const mst_console_desc* d, const float* trac
         (void)hipMemsetAsync(ws + L.cp_m, 0, (size_t)L.bs * L.nblkC * CP_COUNT * sizeof(float), stream);
     }
 
+    // ---- fx bus: the wet signal was added to the stereo bus, so its cotangent is the bus cotangent
+    if (fx_on) launch_fx_backward(fx_plan(L), gbus, gbus_stride, (const float*)fx->tables, ws, stream);
+
     // ---- tracks
     {
         CompBwdArgs ca{ws + L.u_t, Ns, ws + L.gs_t, ws + L.rc_t, nullptr, ws + L.zQ_t, ws + L.du_t, ws + L.cp_t,
-                       gbus, gbus_stride, grad_mixed_tracks, L.T, L.ncC_pad, d->track_lookahead, t_comp ? 1 : 0, n, aligned};
+                       gbus, gbus_stride, grad_mixed_tracks, fx_on ? ws + L.fx_din : nullptr, Ns, L.T, L.ncC_pad, d->track_lookahead,
+                       t_comp ? 1 : 0, n, aligned};
         if (t_comp) {
             launch_comp_bwd(false, false, ca, L.R, stream);
             ca.s0 = ws + L.zQ_t;
@@ -163,7 +202,8 @@ extern "C" int mst_console_backward(const mst_console_desc* d, const float* trac
         }
     }
     PrepBwdArgs pb{track_params, master_bus_params, ws + L.rc_t, ws + L.rc_m, ws + L.cp_t, ws + L.cp_m, ws + L.ep_t, ws + L.ep_m,
-                   grad_track_params, grad_master_params, L.R, L.bs, L.nblkC, L.nblkE, *d};
+                   grad_track_params, grad_master_params, fx_bus_params, fx_on ? ws + L.fx_part : nullptr,
+                   fx_on ? grad_fx_params : nullptr, L.fxBlkIr, L.R, L.bs, L.nblkC, L.nblkE, *d};
     launch_prep_bwd(pb, stream);
     return (int)hipGetLastError();
 }

@@ -24,6 +24,9 @@
 //                  (loads are 3x cheaper than stores on this LDS, MI355X_MICROARCH.md)
 #pragma once
 #include "mst_common.h"
+#ifndef MST_FFT2_SWIZZLE
+#define MST_FFT2_SWIZZLE 0
+#endif
 
 namespace mst {
 
@@ -76,10 +79,20 @@ struct FftShape {
     using P = FftPlan<N>;
     static constexpr int M = P::M, NSEQ = P::NSEQ, LG = P::LG, NP = P::NP, RL = P::RL;
     static constexpr int NBL = (M / RL) / LG;      // butterflies per lane in the last pass (1, or 2 for the radix-4 pass)
-    static constexpr int SLOTS = M + M / 8;        // padded float2 slots per sequence
+    // two slot maps (measured on MI355X, both conflict-free on the store side): padding i + i/8 costs no address arithmetic
+    // (offsets fold into the ds instructions) and wins for the small transforms; the XOR swizzle makes the loads conflict-free
+    // too and needs no padding - it wins for the 4096-point sequences (8192 forward 40.5 -> 37.3 us, backward 77 -> 72 us) and
+    // loses below (2048 forward 27.9 -> 32.7 us, 512 backward 48.9 -> 58.4 us)
+    static constexpr bool SWZ = MST_FFT2_SWIZZLE ? true : (M >= 4096);
+    static constexpr int SLOTS = SWZ ? M : M + M / 8;
     static constexpr int TWSCALE = N / M;          // W_M^e = W_N^(TWSCALE e)
     static_assert(M / 8 == LG, "one radix-8 butterfly per lane and sequence in every pass but the last");
-    __device__ static __forceinline__ constexpr int slot(int i) { return i + (i >> 3); }
+    // swizzle: element bits [2:0] ^= bits [6:4], bit 3 ^= bit 6 - rows of 8 elements are permuted by (row >> 1) & 7 and pairs
+    // of rows swap halves with row bit 3, so that every access pattern of the passes (a column of 16 rows, 8 + 8 lanes into
+    // rows 8 apart, 16 / 32 consecutive elements) touches each bank once
+    __device__ static __forceinline__ constexpr int slot(int i) {
+        return SWZ ? (i ^ (((i >> 4) & 7) | ((i >> 3) & 8))) : (i + (i >> 3));
+    }
 };
 
 // ---- per-lane twiddle bases, held in registers for the lifetime of the kernel -----------------------------------
@@ -126,10 +139,10 @@ __device__ __forceinline__ void tw_apply(float2* v, const float2* base) {  // v[
 // pass 1: v[t] = input element lane + t LG; leaves its result in buf.
 template <int N>
 __device__ __forceinline__ void fft_first(float2* v, float2* __restrict__ buf, int lane) {
+    using S = FftShape<N>;
     butterfly<8>(v);
-    float2* o = buf + lane * 9;
 #pragma unroll
-    for (int t = 0; t < 8; ++t) o[t] = v[t];
+    for (int t = 0; t < 8; ++t) buf[S::slot(lane * 8 + t)] = v[t];
 }
 template <int N>
 __device__ __forceinline__ void fft_load8(float2* v, const float2* __restrict__ buf, int lane) {
@@ -212,6 +225,44 @@ __device__ __forceinline__ void fft_run2(float2* va, float2* vb, float2 (*oa)[Ff
     for (int u = 0; u < S::NBL; ++u) {
         fft_last<N>(oa[u], bufa, tw, lane, u);
         fft_last<N>(ob[u], bufb, tw, lane, u);
+    }
+}
+
+// W_16^t = (cos, -sin)(2 pi t / 16), t < 8 (the radix-2 split of the 8192-point transform: lane l owns i = l + 512 t)
+__device__ __forceinline__ float2 w16(int t) {
+    constexpr float c[8] = {1.0f, 0.92387953251128674f, 0.70710678118654752f, 0.38268343236508977f, 0.0f,
+                            -0.38268343236508977f, -0.70710678118654752f, -0.92387953251128674f};
+    constexpr float sn[8] = {0.0f, 0.38268343236508977f, 0.70710678118654752f, 0.92387953251128674f, 1.0f,
+                             0.92387953251128674f, 0.70710678118654752f, 0.38268343236508977f};
+    return make_float2(c[t], -sn[t]);
+}
+
+
+// 8192-point transform of a complex sequence z by 512 lanes: radix-2 decimation in frequency on the way in (even bins from
+// z[i] + z[i + 4096], odd bins from the twiddled difference), then two independent 4096-point transforms side by side.
+// raw(t) -> element lane + 512 t (t < 16).  WINDOW: multiply by the periodic Hann window, formed from the radix-2 twiddle the
+// split needs anyway (W_N^i = wl W_16^t for i = lane + 512 t;  hann(i) = 0.5 - 0.5 Re W_N^i,  hann(i + N/2) = 0.5 + 0.5 Re W_N^i).
+// On return (the caller adds ONE barrier) Z[2m] = bufe[slot(m)], Z[2m + 1] = bufo[slot(m)].  tw = LaneTw<8192>, wl = W_8192^lane.
+template <bool WINDOW, typename F>
+__device__ __forceinline__ void fft8192_from(F&& raw, float2* __restrict__ bufe, float2* __restrict__ bufo, const LaneTw<8192>& tw,
+                                             float2 wl, int lane) {
+    using S = FftShape<8192>;
+    float2 e[8], d[8], oe[1][8], od[1][8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const float2 w = cmul(wl, w16(t));
+        const float h0 = WINDOW ? 0.5f - 0.5f * w.x : 1.0f, h1 = WINDOW ? 0.5f + 0.5f * w.x : 1.0f;
+        const float2 za = raw(t), zb = raw(t + 8);
+        const float2 a = make_float2(h0 * za.x, h0 * za.y), b = make_float2(h1 * zb.x, h1 * zb.y);
+        e[t] = cadd(a, b);
+        d[t] = cmul(csub(a, b), w);
+    }
+    fft_run2<8192>(e, d, oe, od, bufe, bufo, tw, lane);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        bufe[S::slot(lane + t * (S::M / 8))] = oe[0][t];
+        bufo[S::slot(lane + t * (S::M / 8))] = od[0][t];
     }
 }
 

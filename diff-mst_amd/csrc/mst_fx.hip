@@ -1,0 +1,310 @@
+// mst_fx.hip - the fx bus of the console: noise-shaped reverberation on a send bus.
+//
+// Replaces dasp-pytorch's `stereo_bus` + `noise_shaped_reverberation` (reference call sites mst/modules.py:275-284;
+// algorithm SURVEY A.2 / A.6, restated in oracle/dasp_restated.py):
+//   fx_in[b,ch,n]  = sum_t 10^(send_db[b,t]/20) * mixed_tracks[b,ch,t,n]            (send bus; accumulated by k_apply_tracks)
+//   wnf[r,k,n]     = sum_j f_k[j] * noise[r,k,n+j]        r = 2b + ch, 12 octave bands, `taps`-tap FIR band-passes
+//   ir[b,ch,n]     = 1/12 sum_k gain[b,k] * exp(-(10 decay[b,k] + 1) * n/(S-1)) * wnf[r,k,n]      n < S (65536)
+//   wet[b,ch,n]    = sum_j ir[b,ch,j] * fx_in[b,ch,n-j]   (causal)            master_bus += wet   (the console forces mix = 1)
+// The noise is an INPUT (the reference draws torch.randn inside the op; the host wrapper draws it here, tests pass a fixed one).
+//
+// The 65536-tap convolution is a uniformly partitioned overlap-save convolution on the 8192-point register-radix engine
+// (mst_fft2.h): partitions and hops of 4096 samples, left and right channel packed into one complex transform,
+//   Xs[b][m]  = FFT8192(fx_in[b, L + iR, (m-1) 4096 .. (m+1) 4096))         one frame per 4096-sample block m
+//   Hs[b][p]  = FFT8192(ir[b, L + iR, p 4096 .. (p+1) 4096) ++ 4096 zeros)   one per partition p < S / 4096
+//   Ys[b][m]  = sum_p Xs[b][m-p] (.) Hs[b][p]     per channel (the packed spectra are separated by Hermitian symmetry)
+//   wet block m = last 4096 samples of IFFT8192(Ys[b][m]):  real part left, imaginary part right.
+// Backward = the adjoints of the same four steps (MAC with conj(H) / conj(X), frames placed / cropped on the other side).
+#include "mst_kernels.h"
+#include "mst_fft2.h"
+
+namespace mst {
+
+constexpr int kFxN = 8192, kFxHop = 4096, kFxLanes = FftPlan<8192>::LG;
+
+// ---- band-pass filtering of the noise: wnf[(r,k)][n] = sum_j f[k][j] noise[(r,k)][n + j] ------------------------------
+// grid (ceil(S / 2048), 12, rows): 256 lanes x 8 consecutive outputs; filter and input window staged in LDS
+constexpr int kFirOut = 2048, kFirMaxTaps = 1024;
+__global__ __launch_bounds__(256) void k_fx_fir(const float* __restrict__ noise, const float* __restrict__ filt, float* __restrict__ wnf,
+                                                int S, int taps) {
+    __shared__ __attribute__((aligned(16))) float xs[kFirOut + kFirMaxTaps + 8];
+    __shared__ __attribute__((aligned(16))) float fs[kFirMaxTaps + 8];
+    const int tid = threadIdx.x, k = blockIdx.y, r = blockIdx.z;
+    const int n0 = blockIdx.x * kFirOut;
+    const int in_len = S + taps - 1;
+    const float* src = noise + ((int64_t)r * 12 + k) * in_len;
+    const int taps8 = (taps + 7) & ~7;
+    for (int i = tid; i < kFirOut + taps8; i += 256) xs[i] = (n0 + i < in_len) ? src[n0 + i] : 0.0f;
+    for (int i = tid; i < taps8; i += 256) fs[i] = i < taps ? filt[k * taps + i] : 0.0f;
+    __syncthreads();
+    float acc[8], w[16];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) acc[o] = 0.0f;
+    const float* xp = xs + tid * 8;
+#pragma unroll
+    for (int o = 0; o < 8; ++o) w[o] = xp[o];
+    for (int j = 0; j < taps8; j += 8) {
+        const float4 fa = *reinterpret_cast<const float4*>(fs + j), fb = *reinterpret_cast<const float4*>(fs + j + 4);
+        const float4 xa = *reinterpret_cast<const float4*>(xp + j + 8), xb = *reinterpret_cast<const float4*>(xp + j + 12);
+        w[8] = xa.x; w[9] = xa.y; w[10] = xa.z; w[11] = xa.w; w[12] = xb.x; w[13] = xb.y; w[14] = xb.z; w[15] = xb.w;
+        const float f[8] = {fa.x, fa.y, fa.z, fa.w, fb.x, fb.y, fb.z, fb.w};
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+#pragma unroll
+            for (int o = 0; o < 8; ++o) acc[o] = fmaf(f[q], w[o + q], acc[o]);
+#pragma unroll
+        for (int o = 0; o < 8; ++o) w[o] = w[o + 8];
+    }
+    float* dst = wnf + ((int64_t)r * 12 + k) * S + n0 + tid * 8;
+#pragma unroll
+    for (int o = 0; o < 8; ++o)
+        if (n0 + tid * 8 + o < S) dst[o] = acc[o];
+}
+
+// ---- impulse response: ir[r][n] = 1/12 sum_k gain[b,k] exp(-rate[b,k] n/(S-1)) wnf[r,k,n];  rcfx[b] = {gain[12], rate[12]}
+__global__ __launch_bounds__(256) void k_fx_ir(const float* __restrict__ wnf, const float* __restrict__ rcfx, float* __restrict__ ir, int S) {
+    const int r = blockIdx.y, b = r >> 1, n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= S) return;
+    const float t = (float)n / (float)(S - 1);
+    const float* c = rcfx + (int64_t)b * 24;
+    float acc = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) acc += c[k] * __builtin_amdgcn_exp2f(-1.4426950408889634f * c[12 + k] * t) * wnf[((int64_t)r * 12 + k) * S + n];
+    ir[(int64_t)r * S + n] = acc * (1.0f / 12.0f);
+}
+
+// ---- 8192-point transforms of packed stereo frames -------------------------------------------------------------------
+// MODE_SIG  : frame m of a signal (bs, 2, stride): samples (m-1) 4096 .. (m+1) 4096, zero outside [0, n)
+// MODE_PART : partition p of an impulse response (bs, 2, S): 4096 samples then 4096 zeros
+// MODE_GRAD : cotangent frame m: 4096 zeros then samples m 4096 .. (m+1) 4096  (adjoint of "keep the last 4096 outputs")
+enum { FX_SIG = 0, FX_PART = 1, FX_GRAD = 2 };
+struct FxFftArgs {
+    const float* src;   // (bs, 2, stride)
+    int64_t stride;     // samples between channel rows
+    int64_t n;          // valid samples per row
+    float2* spec;       // (bs, frames, 8192)
+    const float* tables;  // twiddles (cos, -sin)(2 pi t / 8192), t < 8192
+    int frames;
+};
+template <int MODE>
+__global__ __launch_bounds__(kFxLanes, 4) void k_fx_fft(FxFftArgs a) {
+    using S = FftShape<kFxN>;
+    __shared__ __attribute__((aligned(16))) float2 buf[2][S::SLOTS];
+    const int lane = threadIdx.x, m = blockIdx.x, b = blockIdx.y;
+    const float2* twg = reinterpret_cast<const float2*>(a.tables);
+    LaneTw<kFxN> tw;
+    tw.init(twg, lane);
+    const float2 wl = twg[lane];
+    const float* xl = a.src + (int64_t)(2 * b) * a.stride;
+    const float* xr = xl + a.stride;
+    const int64_t start = MODE == FX_SIG ? (int64_t)(m - 1) * kFxHop : (MODE == FX_PART ? (int64_t)m * kFxHop : (int64_t)(m - 1) * kFxHop);
+    fft8192_from<false>([&](int t) {
+        const int e = lane + kFxLanes * t;            // element of the frame
+        const int64_t i = start + e;
+        bool live = i >= 0 && i < a.n;
+        if (MODE == FX_PART) live = live && e < kFxHop;
+        if (MODE == FX_GRAD) live = live && e >= kFxHop;
+        return live ? make_float2(xl[i], xr[i]) : make_float2(0.f, 0.f);
+    }, buf[0], buf[1], tw, wl, lane);
+    __syncthreads();
+    float2* out = a.spec + ((int64_t)b * a.frames + m) * kFxN;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const int q = lane + kFxLanes * t;  // bins 2q (even sequence) and 2q + 1 (odd sequence)
+        const float2 e = buf[0][S::slot(q)], o = buf[1][S::slot(q)];
+        *reinterpret_cast<float4*>(out + 2 * q) = make_float4(e.x, e.y, o.x, o.y);
+    }
+}
+
+// ---- frequency-domain multiply-accumulate over the partitions -----------------------------------------------------------
+// packed spectra Z = ZL + i ZR of two real signals: ZL[k] = (Z[k] + conj Z[N-k]) / 2, ZR[k] = (Z[k] - conj Z[N-k]) / (2i)
+__device__ __forceinline__ void unpack_lr(float2 zk, float2 zn, float2& L, float2& R) {
+    L = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
+    R = make_float2(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
+}
+// FX_MAC_Y : Y[m]  = sum_p X[m - p]   (.) H[p]          (forward)
+// FX_MAC_DX: dX[m] = sum_p dY[m + p]  (.) conj(H[p])    (cotangent of the signal frames)
+// FX_MAC_DH: dH[p] = sum_m dY[m]      (.) conj(X[m - p]) (cotangent of the partitions; `out` indexed by p)
+enum { FX_MAC_Y = 0, FX_MAC_DX = 1, FX_MAC_DH = 2 };
+struct FxMacArgs {
+    const float2* a;  // (bs, na, 8192): X (Y), dY (DX, DH)
+    const float2* h;  // (bs, nh, 8192): H (Y, DX), X (DH)
+    float2* out;      // (bs, nout, 8192)
+    int na, nh, nout;
+};
+template <int MODE>
+__global__ __launch_bounds__(256) void k_fx_mac(FxMacArgs g) {
+    const int k = blockIdx.x * 256 + threadIdx.x, mo = blockIdx.y, b = blockIdx.z;  // bin pair (k, N - k), output frame
+    if (k > kFxN / 2) return;
+    const int kn = (kFxN - k) & (kFxN - 1);
+    const float2* A = g.a + (int64_t)b * g.na * kFxN;
+    const float2* Hh = g.h + (int64_t)b * g.nh * kFxN;
+    float2 yl = make_float2(0.f, 0.f), yr = make_float2(0.f, 0.f);
+    const int np = MODE == FX_MAC_DH ? g.na : g.nh;
+    for (int p = 0; p < np; ++p) {
+        // (ia, ih): frame of `a` and frame of `h` that meet in this term
+        const int ia = MODE == FX_MAC_Y ? mo - p : (MODE == FX_MAC_DX ? mo + p : p);
+        const int ih = MODE == FX_MAC_DH ? p - mo : p;
+        if (ia < 0 || ia >= g.na || ih < 0 || ih >= g.nh) continue;
+        float2 al, ar, hl, hr;
+        unpack_lr(A[(int64_t)ia * kFxN + k], A[(int64_t)ia * kFxN + kn], al, ar);
+        unpack_lr(Hh[(int64_t)ih * kFxN + k], Hh[(int64_t)ih * kFxN + kn], hl, hr);
+        if (MODE != FX_MAC_Y) {
+            hl.y = -hl.y;
+            hr.y = -hr.y;
+        }
+        yl = cadd(yl, cmul(al, hl));
+        yr = cadd(yr, cmul(ar, hr));
+    }
+    float2* O = g.out + ((int64_t)b * g.nout + mo) * kFxN;
+    // repack: Z[k] = L[k] + i R[k];  Z[N - k] = conj(L[k]) + i conj(R[k])
+    O[k] = make_float2(yl.x - yr.y, yl.y + yr.x);
+    if (kn != k) O[kn] = make_float2(yl.x + yr.y, -yl.y + yr.x);
+}
+
+// ---- inverse transforms of spectrum frames ---------------------------------------------------------------------------
+// FX_OUT : dst[b, :, m 4096 .. (m+1) 4096) += last 4096 samples of IFFT(spec[b][m])          (wet signal onto the bus)
+// FX_SCAT: both halves of IFFT(spec[b][m]) are added (atomics onto a zeroed buffer: exactly two commutative
+//          contributions per sample) to dst[b, :, (m-1) 4096 .. (m+1) 4096)                  (cotangent of the send bus)
+// FX_CROP: dst[b, :, m 4096 .. (m+1) 4096) = first 4096 samples of IFFT(spec[b][m])          (cotangent of the impulse response)
+enum { FX_OUT = 0, FX_SCAT = 1, FX_CROP = 2 };
+struct FxIfftArgs {
+    const float2* spec;  // (bs, frames, 8192)
+    float* dst;          // (bs, 2, stride)
+    int64_t stride, n;
+    const float* tables;
+    int frames;
+};
+template <int MODE>
+__global__ __launch_bounds__(kFxLanes, 4) void k_fx_ifft(FxIfftArgs a) {
+    using S = FftShape<kFxN>;
+    __shared__ __attribute__((aligned(16))) float2 buf[2][S::SLOTS];
+    const int lane = threadIdx.x, m = blockIdx.x, b = blockIdx.y;
+    const float2* twg = reinterpret_cast<const float2*>(a.tables);
+    LaneTw<kFxN> tw;
+    tw.init(twg, lane);
+    const float2 wl = twg[lane];
+    const float2* in = a.spec + ((int64_t)b * a.frames + m) * kFxN;
+    // IDFT(Z) = conj(FFT(conj(Z))) / N
+    fft8192_from<false>([&](int t) {
+        const float2 z = in[lane + kFxLanes * t];
+        return make_float2(z.x, -z.y);
+    }, buf[0], buf[1], tw, wl, lane);
+    __syncthreads();
+    float* dl = a.dst + (int64_t)(2 * b) * a.stride;
+    float* dr = dl + a.stride;
+    constexpr float inv = 1.0f / (float)kFxN;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const int q = lane + kFxLanes * t;                       // output samples 2q, 2q + 1 of the frame
+        const float2 e = buf[0][S::slot(q)], o = buf[1][S::slot(q)];
+        const float le = inv * e.x, re = -inv * e.y, lo = inv * o.x, ro = -inv * o.y;
+        const int s0 = 2 * q;
+        if (MODE == FX_OUT) {
+            if (s0 < kFxHop) continue;
+            const int64_t i = (int64_t)m * kFxHop + (s0 - kFxHop);
+            if (i < a.n) { dl[i] += le; dr[i] += re; }
+            if (i + 1 < a.n) { dl[i + 1] += lo; dr[i + 1] += ro; }
+        } else if (MODE == FX_CROP) {
+            if (s0 >= kFxHop) continue;
+            const int64_t i = (int64_t)m * kFxHop + s0;
+            if (i < a.n) { dl[i] = le; dr[i] = re; }
+            if (i + 1 < a.n) { dl[i + 1] = lo; dr[i + 1] = ro; }
+        } else {
+            const int64_t i = (int64_t)(m - 1) * kFxHop + s0;
+            if (i >= 0 && i < a.n) { unsafeAtomicAdd(&dl[i], le); unsafeAtomicAdd(&dr[i], re); }
+            if (i + 1 >= 0 && i + 1 < a.n) { unsafeAtomicAdd(&dl[i + 1], lo); unsafeAtomicAdd(&dr[i + 1], ro); }
+        }
+    }
+}
+
+// ---- backward of the impulse-response synthesis: partial sums over n of dL/dgain[b,k], dL/drate[b,k] -----------------------
+// part[b][blk][24]; grid (ceil(S / 1024), bs), 256 lanes x 4 samples x both channels
+__global__ __launch_bounds__(256) void k_fx_ir_bwd(const float* __restrict__ wnf, const float* __restrict__ rcfx, const float* __restrict__ dir,
+                                                   float* __restrict__ part, int S) {
+    __shared__ float red[4][24];
+    const int tid = threadIdx.x, b = blockIdx.y;
+    const float* c = rcfx + (int64_t)b * 24;
+    float dg[12], dr[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) dg[k] = dr[k] = 0.0f;
+    for (int q = 0; q < 4; ++q) {
+        const int n = blockIdx.x * 1024 + q * 256 + tid;
+        if (n >= S) continue;
+        const float t = (float)n / (float)(S - 1);
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+            const int r = 2 * b + ch;
+            const float d = dir[(int64_t)r * S + n] * (1.0f / 12.0f);
+#pragma unroll
+            for (int k = 0; k < 12; ++k) {
+                const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * c[12 + k] * t) * wnf[((int64_t)r * 12 + k) * S + n];
+                dg[k] = fmaf(d, e, dg[k]);
+                dr[k] = fmaf(d * c[k] * (-t), e, dr[k]);
+            }
+        }
+    }
+    const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+        const float a = wave_sum(dg[k]), r = wave_sum(dr[k]);
+        if (lane == 0) {
+            red[wave][k] = a;
+            red[wave][12 + k] = r;
+        }
+    }
+    __syncthreads();
+    if (tid < 24) part[((int64_t)b * gridDim.x + blockIdx.x) * 24 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+}
+
+// ---- launch sequences (called from mst_console.hip) ------------------------------------------------------------------------
+void launch_fx_forward(const FxPlan& p, const float* noise, const float* filters, const float* tables, float* ws, float* bus,
+                       int64_t bus_stride, hipStream_t stream) {
+    const int rows = 2 * p.bs;
+    hipLaunchKernelGGL(k_fx_fir, dim3((p.S + kFirOut - 1) / kFirOut, 12, rows), dim3(256), 0, stream, noise, filters, ws + p.wnf, p.S, p.taps);
+    hipLaunchKernelGGL(k_fx_ir, dim3((p.S + 255) / 256, rows), dim3(256), 0, stream, ws + p.wnf, ws + p.rcfx, ws + p.ir, p.S);
+    FxFftArgs fs{ws + p.fx_in, p.Ns, p.n, reinterpret_cast<float2*>(ws + p.Xs), tables, p.nblk};
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fx_fft<FX_SIG>), dim3(p.nblk, p.bs), dim3(kFxLanes), 0, stream, fs);
+    FxFftArgs fh{ws + p.ir, p.S, p.S, reinterpret_cast<float2*>(ws + p.Hs), tables, p.K};
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fx_fft<FX_PART>), dim3(p.K, p.bs), dim3(kFxLanes), 0, stream, fh);
+    FxMacArgs mc{reinterpret_cast<const float2*>(ws + p.Xs), reinterpret_cast<const float2*>(ws + p.Hs), reinterpret_cast<float2*>(ws + p.Ys),
+                 p.nblk, p.K, p.nblk};
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fx_mac<FX_MAC_Y>), dim3((kFxN / 2 + 256) / 256, p.nblk, p.bs), dim3(256), 0, stream, mc);
+    FxIfftArgs io{reinterpret_cast<const float2*>(ws + p.Ys), bus, bus_stride, p.n, tables, p.nblk};
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fx_ifft<FX_OUT>), dim3(p.nblk, p.bs), dim3(kFxLanes), 0, stream, io);
+}
+
+// dbus: cotangent of the bus the wet signal was added to (bs, 2, dbus_stride).  Leaves dfx_in (cotangent of the send bus) and
+// the partial sums of the reverberation parameters in the workspace.
+void launch_fx_backward(const FxPlan& p, const float* dbus, int64_t dbus_stride, const float* tables, float* ws, hipStream_t stream) {
+    FxFftArgs fg{dbus, dbus_stride, p.n, reinterpret_cast<float2*>(ws + p.Ys), tables, p.nblk};  // dY overwrites Y
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fx_fft<FX_GRAD>), dim3(p.nblk, p.bs), dim3(kFxLanes), 0, stream, fg);
+    // cotangent of the send bus: dX[m] = sum_p dY[m + p] conj(H[p]), frames scattered back over (m-1) 4096 .. (m+1) 4096
+    FxMacArgs mx{reinterpret_cast<const float2*>(ws + p.Ys), reinterpret_cast<const float2*>(ws + p.Hs), reinterpret_cast<float2*>(ws + p.dXs),
+                 p.nblk, p.K, p.nblk};
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fx_mac<FX_MAC_DX>), dim3((kFxN / 2 + 256) / 256, p.nblk, p.bs), dim3(256), 0, stream, mx);
+    (void)hipMemsetAsync(ws + p.dfx_in, 0, (size_t)p.bs * 2 * p.Ns * sizeof(float), stream);
+    FxIfftArgs ix{reinterpret_cast<const float2*>(ws + p.dXs), ws + p.dfx_in, p.Ns, p.n, tables, p.nblk};
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fx_ifft<FX_SCAT>), dim3(p.nblk, p.bs), dim3(kFxLanes), 0, stream, ix);
+    // cotangent of the impulse response: dH[p] = sum_m dY[m] conj(X[m - p]), first 4096 samples of each inverse
+    FxMacArgs mh{reinterpret_cast<const float2*>(ws + p.Ys), reinterpret_cast<const float2*>(ws + p.Xs), reinterpret_cast<float2*>(ws + p.dHs),
+                 p.nblk, p.nblk, p.K};
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fx_mac<FX_MAC_DH>), dim3((kFxN / 2 + 256) / 256, p.K, p.bs), dim3(256), 0, stream, mh);
+    FxIfftArgs ih{reinterpret_cast<const float2*>(ws + p.dHs), ws + p.dir, p.S, p.S, tables, p.K};
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fx_ifft<FX_CROP>), dim3(p.K, p.bs), dim3(kFxLanes), 0, stream, ih);
+    hipLaunchKernelGGL(k_fx_ir_bwd, dim3(p.nblk_ir, p.bs), dim3(256), 0, stream, ws + p.wnf, ws + p.rcfx, ws + p.dir, ws + p.fxpart, p.S);
+}
+
+// twiddle table of the 8192-point engine: (cos, -sin)(2 pi t / 8192), fp64 evaluation rounded once
+__global__ void k_fx_tables(float* tables) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= kFxN) return;
+    const double ang = 6.283185307179586476925 * (double)t / (double)kFxN;
+    tables[2 * t] = (float)cos(ang);
+    tables[2 * t + 1] = (float)(-sin(ang));
+}
+void launch_fx_tables(float* tables, hipStream_t stream) {
+    hipLaunchKernelGGL(k_fx_tables, dim3(kFxN / 256), dim3(256), 0, stream, tables);
+}
+
+}  // namespace mst

@@ -21,6 +21,7 @@ struct PrepArgs {
     float* powP_t; float* powP_m;  // all-pole scan tables
     float* pow1F_t; float* pow1F_m;  // in-wave scan tables (forward / adjoint cascade)
     float* pow1A_t; float* pow1A_m;
+    float* rc_fx;   // (bs, 24): reverberation band gains and decay rates 10 d + 1 (fx bus), or nullptr
     int32_t* status;
     int R, bs;
     int KE;  // chunks per scan lane (EQ scans)
@@ -36,6 +37,10 @@ struct PrepBwdArgs {
     const float* ep_t; const float* ep_m;  // coefficient partial sums sigrows x nblkE x EP_COUNT
     float* grad_track_params;              // (R,27)
     float* grad_master_params;             // (bs,26)
+    const float* fx_params;                // (bs,25) fx bus only
+    const float* fx_part;                  // (bs, nblkF, 24) partial sums of the reverberation parameters, or nullptr
+    float* grad_fx_params;                 // (bs,25) or nullptr
+    int nblkF;
     int R, bs, nblkC, nblkE;
     mst_console_desc d;
 };
@@ -74,6 +79,7 @@ struct TrackApplyArgs {
     float* bus;          // (bs, 2, bus_stride) out
     int64_t bus_stride;
     float* mixed;        // (bs, 2, T, n) out or null
+    float* fx;           // (bs, 2, bus_stride) out or null: the fx send bus sum_t send_t * mixed_t (reference stereo_bus)
     int T, nc_pad, lookahead, comp_on;
     int64_t n;
     int aligned;         // every row base / stride is 16-byte aligned: interior blocks skip all guards
@@ -103,6 +109,8 @@ struct CompBwdArgs {
     const float* gup;     // tracks: grad wrt stereo bus ; master: grad wrt mix ; (bs,2,gup_stride)
     int64_t gup_stride;
     const float* gmixed;  // tracks only: grad wrt mixed_tracks (bs,2,T,n) or null
+    const float* gfx;     // tracks only: grad wrt the fx send bus (bs,2,gfx_stride) or null
+    int64_t gfx_stride;
     int T, nc_pad, lookahead, comp_on;
     int64_t n;
     int aligned;
@@ -112,5 +120,16 @@ void launch_comp_zs(int nch, const float* u, int64_t stride, const float* rc, fl
 void launch_apply_tracks(const TrackApplyArgs& a, int bs, hipStream_t stream);
 void launch_apply_master(const MasterApplyArgs& a, int bs, hipStream_t stream);
 void launch_comp_bwd(bool master, bool run, const CompBwdArgs& a, int rows, hipStream_t stream);
+
+// ---- mst_fx.hip: the fx bus (noise-shaped reverberation on a send bus); offsets are float offsets into the workspace
+struct FxPlan {
+    int bs, S, taps, K, nblk, nblk_ir;
+    int64_t n, Ns;
+    int64_t rcfx, fx_in, wnf, ir, Xs, Hs, Ys, dXs, dHs, dir, dfx_in, fxpart;
+};
+void launch_fx_forward(const FxPlan& p, const float* noise, const float* filters, const float* tables, float* ws, float* bus,
+                       int64_t bus_stride, hipStream_t stream);
+void launch_fx_backward(const FxPlan& p, const float* dbus, int64_t dbus_stride, const float* tables, float* ws, hipStream_t stream);
+void launch_fx_tables(float* tables, hipStream_t stream);
 
 }  // namespace mst

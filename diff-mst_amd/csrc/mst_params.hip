@@ -136,7 +136,7 @@ __device__ __forceinline__ void mat12_mul(const double* A, const double* B, doub
     const int i = e / 12, j = e % 12;
     double acc = 0.0;
 #pragma unroll
-    for (int k = 0; k < 12; ++k) acc += A[i * 12 + k] * B[k * 12 + j];
+    for (int k = 0; k < 12; ++k) acc = fma(A[i * 12 + k], B[k * 12 + j], acc);  // explicit: this file is built with -ffp-contract=off
     C[e] = acc;
 }
 
@@ -219,6 +219,16 @@ __global__ __launch_bounds__(320) void k_prep(PrepArgs a) {
             const float theta = denorm(p[25], lo[25], hi[25]) * half_pi;
             rc[RC_PANL] = sqrtf(((half_pi - theta) * two_over_pi) * (float)cos((double)theta));
             rc[RC_PANR] = sqrtf((theta * two_over_pi) * (float)sin((double)theta));
+            // fx send gain 10^(send_db / 20) (reference stereo_bus, mst/modules.py:276)
+            rc[RC_SEND] = (d.flags & MST_USE_FX_BUS) ? (float)exp2((double)(denorm(p[26], lo[26], hi[26]) / 20.0f) * 3.321928094887362) : 0.0f;
+        }
+    } else if (tid == 192 && is_master && a.rc_fx) {
+        // reverberation: band gains and decay rates 10 d + 1 (dasp noise_shaped_reverberation)
+        const float* fp = a.fx_params + (int64_t)mrow * MST_NUM_FX_PARAMS;
+        float* o = a.rc_fx + (int64_t)mrow * 24;
+        for (int k = 0; k < 12; ++k) {
+            o[k] = denorm(fp[k], d.fx_lo[k], d.fx_hi[k]);
+            o[12 + k] = denorm(fp[12 + k], d.fx_lo[12 + k], d.fx_hi[12 + k]) * 10.0f + 1.0f;
         }
     }
     __syncthreads();
@@ -278,7 +288,7 @@ __global__ __launch_bounds__(320) void k_prep(PrepArgs a) {
             double tmpv = 0.0;
             if (mat_lane) {
                 const int i = e / 12, j = e % 12;
-                for (int q = 0; q < 12; ++q) tmpv += mats[grp][2][i * 12 + q] * mats[grp][cur][q * 12 + j];
+                for (int q = 0; q < 12; ++q) tmpv = fma(mats[grp][2][i * 12 + q], mats[grp][cur][q * 12 + j], tmpv);
             }
             __syncthreads();
             if (mat_lane) mats[grp][2][e] = tmpv;
@@ -318,10 +328,10 @@ __global__ __launch_bounds__(320) void k_prep(PrepArgs a) {
         }
         double m[4] = {-c1, -c2, 1.0, 0.0}, t[4];
         auto mul = [](const double* x, const double* y, double* o) {
-            o[0] = x[0] * y[0] + x[1] * y[2];
-            o[1] = x[0] * y[1] + x[1] * y[3];
-            o[2] = x[2] * y[0] + x[3] * y[2];
-            o[3] = x[2] * y[1] + x[3] * y[3];
+            o[0] = fma(x[0], y[0], x[1] * y[2]);
+            o[1] = fma(x[0], y[1], x[1] * y[3]);
+            o[2] = fma(x[2], y[0], x[3] * y[2]);
+            o[3] = fma(x[2], y[1], x[3] * y[3]);
         };
         for (int s = 1; s < kEqChunk; s <<= 1) {
             mul(m, m, t);
@@ -469,6 +479,22 @@ __global__ __launch_bounds__(256) void k_prep_bwd(PrepBwdArgs a) {
             if (L > 0.0) dLdth = (-two_over_pi * cos(theta) - (half_pi - theta) * two_over_pi * sin(theta)) / (2.0 * L);
             if (Rr > 0.0) dRdth = (two_over_pi * sin(theta) + theta * two_over_pi * cos(theta)) / (2.0 * Rr);
             g[25] = (float)((dcp[CP_PANL] * dLdth + dcp[CP_PANR] * dRdth) * half_pi * (double)(hi[25] - lo[25]));
+            // fx send: d send / d send_db = send ln10 / 20
+            if (d.flags & MST_USE_FX_BUS)
+                g[26] = (float)(dcp[CP_SEND] * (double)rc[RC_SEND] * (double)kLn10Over20 * (double)(hi[26] - lo[26]));
+        }
+    }
+    // reverberation parameters: fixed-order reduction of k_fx_ir_bwd's partial sums (wave 1 of the master rows)
+    if (is_master && a.grad_fx_params && tid >= 64 && tid < 64 + MST_NUM_FX_PARAMS) {
+        const int k = tid - 64;
+        float* gf = a.grad_fx_params + (int64_t)mrow * MST_NUM_FX_PARAMS;
+        if (k == 24) {
+            gf[k] = 0.0f;  // "mix" is forced to 1 by the reference (mst/modules.py:420): no gradient reaches it
+        } else {
+            double acc = 0.0;
+            for (int bk = 0; bk < a.nblkF; ++bk) acc += (double)a.fx_part[((int64_t)mrow * a.nblkF + bk) * 24 + k];
+            const double scale = (double)(d.fx_hi[k] - d.fx_lo[k]) * (k >= 12 ? 10.0 : 1.0);  // rate = 10 decay + 1
+            gf[k] = (float)(acc * scale);
         }
     }
 }

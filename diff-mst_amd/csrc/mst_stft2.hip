@@ -20,15 +20,6 @@ __device__ __forceinline__ int reflect_i32(int i, int n) {
     return i >= n ? 2 * (n - 1) - i : i;
 }
 
-// W_16^t = (cos, -sin)(2 pi t / 16), t < 8 (the radix-2 split of the 8192-point transform: lane l owns i = l + 512 t)
-__device__ __forceinline__ float2 w16(int t) {
-    constexpr float c[8] = {1.0f, 0.92387953251128674f, 0.70710678118654752f, 0.38268343236508977f, 0.0f,
-                            -0.38268343236508977f, -0.70710678118654752f, -0.92387953251128674f};
-    constexpr float sn[8] = {0.0f, 0.38268343236508977f, 0.70710678118654752f, 0.92387953251128674f, 1.0f,
-                             0.92387953251128674f, 0.70710678118654752f, 0.38268343236508977f};
-    return make_float2(c[t], -sn[t]);
-}
-
 // Forward transform of ONE frame (pred + i target, windowed) by the LG lanes of a workgroup; afterwards the spectrum
 // Z sits in `buf` in natural order (padded slots): NSEQ = 1: Z[k] = buf[0][slot(k)]; NSEQ = 2 (n_fft = 8192):
 // Z[2m] = buf[0][slot(m)], Z[2m+1] = buf[1][slot(m)].  Ends with a barrier (the spectrum is readable by every lane).
@@ -56,23 +47,7 @@ struct FrameLoader {
 #pragma unroll
                 for (int t = 0; t < S::RL; ++t) buf[0][S::slot(lane + u * LG + t * (S::M / S::RL))] = o[u][t];
         } else {
-            float2 e[8], d[8], oe[1][8], od[1][8];  // radix-2 decimation in frequency: even bins from z[i] + z[i + 4096], odd bins from the twiddled difference
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const float2 w = cmul(wl, w16(t));
-                const float h0 = 0.5f - 0.5f * w.x, h1 = 0.5f + 0.5f * w.x;
-                const float2 za = raw(t), zb = raw(t + 8);
-                const float2 a = make_float2(h0 * za.x, h0 * za.y), b = make_float2(h1 * zb.x, h1 * zb.y);
-                e[t] = cadd(a, b);
-                d[t] = cmul(csub(a, b), w);
-            }
-            fft_run2<N>(e, d, oe, od, buf[0], buf[1], tw, lane);
-            __syncthreads();
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                buf[0][S::slot(lane + t * (S::M / 8))] = oe[0][t];
-                buf[1][S::slot(lane + t * (S::M / 8))] = od[0][t];
-            }
+            fft8192_from<true>(raw, buf[0], buf[1], tw, wl, lane);
         }
         __syncthreads();
     }

@@ -23,7 +23,7 @@ SAVE_FOR_BACKWARD = 0x100
 DEV_MULTIPASS_EQ = 0x200
 NO_RANGE_CHECK = 0x400
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class ConsoleDesc(C.Structure):
@@ -40,7 +40,15 @@ class ConsoleDesc(C.Structure):
         ("track_hi", C.c_float * NUM_TRACK_PARAMS),
         ("master_lo", C.c_float * NUM_MASTER_PARAMS),
         ("master_hi", C.c_float * NUM_MASTER_PARAMS),
+        ("fx_lo", C.c_float * NUM_FX_PARAMS),
+        ("fx_hi", C.c_float * NUM_FX_PARAMS),
+        ("fx_ir_samples", C.c_int32),
+        ("fx_bandpass_taps", C.c_int32),
     ]
+
+
+class ConsoleFx(C.Structure):  # mirrors mst_console_fx
+    _fields_ = [("noise", C.c_void_p), ("filters", C.c_void_p), ("tables", C.c_void_p)]
 
 
 MAX_RESOLUTIONS = 8
@@ -67,8 +75,11 @@ _P = C.c_void_p
 SIGNATURES = {
     "mst_abi_version": (C.c_int, []),
     "mst_console_workspace_bytes": (C.c_size_t, [C.POINTER(ConsoleDesc)]),
-    "mst_console_forward": (C.c_int, [C.POINTER(ConsoleDesc), _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
-    "mst_console_backward": (C.c_int, [C.POINTER(ConsoleDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
+    "mst_console_fx_tables_bytes": (C.c_size_t, []),
+    "mst_console_fx_init_tables": (C.c_int, [_P, _P]),
+    "mst_console_forward": (C.c_int, [C.POINTER(ConsoleDesc), _P, _P, _P, _P, C.POINTER(ConsoleFx), _P, _P, _P, _P, C.c_size_t, _P]),
+    "mst_console_backward": (C.c_int, [C.POINTER(ConsoleDesc), _P, _P, _P, _P, C.POINTER(ConsoleFx), _P, _P, _P, _P, _P, _P, _P,
+                                       C.c_size_t, _P]),
     "mst_mrstft_tables_bytes": (C.c_size_t, [C.POINTER(MrstftDesc)]),
     "mst_mrstft_init_tables": (C.c_int, [C.POINTER(MrstftDesc), _P, _P]),
     "mst_mrstft_workspace_bytes": (C.c_size_t, [C.POINTER(MrstftDesc)]),

@@ -56,7 +56,8 @@ def flag_word(save_for_backward: bool = False, multipass_eq: bool = False, **fla
 
 
 def make_desc(param_ranges, sample_rate, bs, n_tracks, n_samples, track_row_stride, flags_word,
-              track_lookahead=2048, master_lookahead=1024, identity_ranges=False) -> _cabi.ConsoleDesc:
+              track_lookahead=2048, master_lookahead=1024, identity_ranges=False,
+              fx_ir_samples=65536, fx_bandpass_taps=1023) -> _cabi.ConsoleDesc:
     """identity_ranges: lo = 0, hi = 1 for every parameter, i.e. v*(hi-lo)+lo == v exactly - the descriptor of a call
     whose parameter tensors already hold DENORMALISED values (forward_mix_console)."""
     d = _cabi.ConsoleDesc()
@@ -67,8 +68,12 @@ def make_desc(param_ranges, sample_rate, bs, n_tracks, n_samples, track_row_stri
     d.track_lookahead, d.master_lookahead = int(track_lookahead), int(master_lookahead)
     tlo, thi = range_vectors(param_ranges, TRACK_INDEX)
     mlo, mhi = range_vectors(param_ranges, MASTER_INDEX)
+    flo, fhi = range_vectors(param_ranges, FX_INDEX)
     if identity_ranges:
-        tlo, thi, mlo, mhi = [0.0] * 27, [1.0] * 27, [0.0] * 26, [1.0] * 26
+        tlo, thi, mlo, mhi, flo, fhi = [0.0] * 27, [1.0] * 27, [0.0] * 26, [1.0] * 26, [0.0] * 25, [1.0] * 25
+    for i in range(25):
+        d.fx_lo[i], d.fx_hi[i] = flo[i], fhi[i]
+    d.fx_ir_samples, d.fx_bandpass_taps = int(fx_ir_samples), int(fx_bandpass_taps)  # reference mst/modules.py:281-282
     for i in range(27):
         d.track_lo[i], d.track_hi[i] = tlo[i], thi[i]
     for i in range(26):

@@ -65,3 +65,22 @@ def barkscale_fbanks(n_freqs: int, f_min: float, f_max: float, n_barks: int, sam
             f"Or, the value for `n_freqs` ({n_freqs}) may be set too low."
         )
     return fb
+
+
+def octave_band_filterbank(num_taps: int, sample_rate: float) -> torch.Tensor:
+    """(12, num_taps) FIR filterbank of dasp-pytorch's ``noise_shaped_reverberation`` (``dasp_pytorch.signal``, restated
+    from the published algorithm): a 12 Hz low-pass, ten octave band-passes centred on 31.5 Hz .. 16 kHz
+    (fc / sqrt 2 .. fc sqrt 2, upper edge clipped below Nyquist), an 18 kHz high-pass - ``scipy.signal.firwin`` designs in
+    float64, rounded to float32.  A constant table per (taps, sample rate), uploaded once by the console."""
+    import numpy as np
+    from scipy.signal import firwin  # the same designer the reference's dependency calls
+
+    bands = [31.5, 63, 125, 250, 500, 1000, 2000, 4000, 8000, 16000]
+    filts = [firwin(num_taps, 12, fs=sample_rate)]
+    for fc in bands:
+        f_min, f_max = fc / np.sqrt(2), fc * np.sqrt(2)
+        f_max = float(np.clip(f_max, a_min=0, a_max=(sample_rate / 2) * 0.999))
+        filts.append(firwin(num_taps, [f_min, f_max], fs=sample_rate, pass_zero=False))
+    filts.append(firwin(num_taps, 18000, fs=sample_rate, pass_zero=False))
+    # dasp flips each (symmetric) filter and applies it with conv1d (a correlation): the flip is kept for fidelity
+    return torch.stack([torch.flip(torch.from_numpy(f.astype("float32")), dims=[0]) for f in filts], dim=0)

@@ -117,18 +117,25 @@ class _ConsoleFunction(torch.autograd.Function):
         if denormalized:  # forward_mix_console: values arrive denormalised and are NOT range-checked (reference :186-314)
             word |= _cabi.NO_RANGE_CHECK
         desc = _desc.make_desc(console.param_ranges, console.sample_rate, bs, n_tracks, n, row_stride, word,
-                               identity_ranges=denormalized)
+                               identity_ranges=denormalized, fx_ir_samples=console.fx_ir_samples,
+                               fx_bandpass_taps=console.fx_bandpass_taps)
         nbytes = lib.mst_console_workspace_bytes(ctypes.byref(desc))
         if nbytes == 0:
             raise RuntimeError("mst_console_workspace_bytes rejected the configuration")
         dev = tracks.device
+        fx, fx_keep = None, ()
+        if flags["use_fx_bus"]:
+            noise, filters, tables = console._fx_inputs(bs, dev)
+            fx = _cabi.ConsoleFx(noise.data_ptr(), filters.data_ptr(), tables.data_ptr())
+            fx_keep = (noise, filters, tables)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         mix = torch.empty(bs, 2, n, dtype=torch.float32, device=dev)
         mixed = torch.empty(bs, 2, n_tracks, n, dtype=torch.float32, device=dev) if want_mixed else None
         status = console._status_word(dev)
         with torch.cuda.device(dev):
             rc = lib.mst_console_forward(
-                ctypes.byref(desc), _cabi.ptr(rows), _cabi.ptr(tp), _cabi.ptr(fp), _cabi.ptr(mp), _cabi.ptr(mix),
+                ctypes.byref(desc), _cabi.ptr(rows), _cabi.ptr(tp), _cabi.ptr(fp), _cabi.ptr(mp),
+                ctypes.byref(fx) if fx is not None else None, _cabi.ptr(mix),
                 _cabi.ptr(mixed), _cabi.ptr(status), _cabi.ptr(ws), nbytes, _hip.current_stream_ptr(dev),
             )
         _hip.check(rc, "mst_console_forward")
@@ -136,14 +143,15 @@ class _ConsoleFunction(torch.autograd.Function):
         if need_grad:
             ctx.desc, ctx.nbytes, ctx.dev = desc, nbytes, dev
             ctx.want_mixed = want_mixed
-            ctx.save_for_backward(rows, tp, mp, ws)
+            ctx.fx_on = bool(flags["use_fx_bus"])
+            ctx.save_for_backward(rows, tp, mp, ws, fp, *fx_keep)
         ctx.set_materialize_grads(False)  # an unused mixed_tracks output must not cost a zero (bs,2,T,N) cotangent
         return mix, mixed
 
     @staticmethod
     @once_differentiable  # the backward is a hand-written kernel chain: no double backward through it
     def backward(ctx, grad_mix, grad_mixed):
-        rows, tp, mp, ws = ctx.saved_tensors
+        rows, tp, mp, ws, fp, *fx_keep = ctx.saved_tensors
         lib = _hip.lib()
         desc = ctx.desc
         bs, n_tracks, n = desc.bs, desc.n_tracks, desc.n_samples
@@ -156,14 +164,20 @@ class _ConsoleFunction(torch.autograd.Function):
         g_tp = torch.empty(bs, n_tracks, _cabi.NUM_TRACK_PARAMS, dtype=torch.float32, device=dev)
         g_mp = torch.empty(bs, _cabi.NUM_MASTER_PARAMS, dtype=torch.float32, device=dev)
         g_tracks = torch.empty(bs, n_tracks, n, dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+        fx, g_fx = None, None
+        if ctx.fx_on:
+            fx = _cabi.ConsoleFx(*(t.data_ptr() for t in fx_keep))
+            g_fx = torch.empty(bs, _cabi.NUM_FX_PARAMS, dtype=torch.float32, device=dev)
+        elif ctx.needs_input_grad[2]:
+            g_fx = torch.zeros(bs, _cabi.NUM_FX_PARAMS, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             rc = lib.mst_console_backward(
-                ctypes.byref(desc), _cabi.ptr(rows), _cabi.ptr(tp), _cabi.ptr(mp), _cabi.ptr(grad_mix),
-                _cabi.ptr(grad_mixed), _cabi.ptr(g_tp), _cabi.ptr(g_mp), _cabi.ptr(g_tracks), _cabi.ptr(ws), ctx.nbytes,
+                ctypes.byref(desc), _cabi.ptr(rows), _cabi.ptr(tp), _cabi.ptr(fp), _cabi.ptr(mp),
+                ctypes.byref(fx) if fx is not None else None, _cabi.ptr(grad_mix), _cabi.ptr(grad_mixed), _cabi.ptr(g_tp),
+                _cabi.ptr(g_fx) if ctx.fx_on else None, _cabi.ptr(g_mp), _cabi.ptr(g_tracks), _cabi.ptr(ws), ctx.nbytes,
                 _hip.current_stream_ptr(dev),
             )
         _hip.check(rc, "mst_console_backward")
-        g_fx = torch.zeros(bs, _cabi.NUM_FX_PARAMS, dtype=torch.float32, device=dev) if ctx.needs_input_grad[2] else None
         return g_tracks, g_tp, g_fx, g_mp, None, None, None, None, None
 
 
@@ -241,6 +255,13 @@ class AdvancedMixConsole(torch.nn.Module):
         if param_dicts not in ("eager", "lazy"):
             raise ValueError("param_dicts must be 'eager' or 'lazy'")
         self.param_dicts = param_dicts
+        # fx bus (reference mst/modules.py:275-284): impulse-response length / band-pass taps of noise_shaped_reverberation as the
+        # reference calls it; `fx_noise` (None = draw torch.randn on every call like the reference's op does) may be set to a
+        # fixed (bs*2, 12, fx_ir_samples + fx_bandpass_taps - 1) tensor for reproducible runs and tests
+        self.fx_ir_samples, self.fx_bandpass_taps = 65536, 1023
+        self.fx_noise = None
+        self.supports_fx_bus = True
+        self._fx_cache = {}
         self._status = {}
         self._affine_cache = {}
         self._multipass_eq = False  # test switch: EQ carries through the separate carry-scan kernel at any length
@@ -273,6 +294,29 @@ class AdvancedMixConsole(torch.nn.Module):
         err = _desc.status_to_error(worst)
         if err is not None:
             raise err
+
+    # ------------------------------------------------------------------ fx bus inputs
+    def _fx_inputs(self, bs, device):
+        """(noise, octave-band filterbank, engine tables) on `device`; the two constant tables are built once."""
+        from .filter import octave_band_filterbank
+
+        lib = _hip.lib()
+        key = (str(device), self.fx_bandpass_taps, float(self.sample_rate))
+        if key not in self._fx_cache:
+            filters = octave_band_filterbank(self.fx_bandpass_taps, self.sample_rate).contiguous().to(device)
+            tables = torch.empty(lib.mst_console_fx_tables_bytes() // 4, dtype=torch.float32, device=device)
+            with torch.cuda.device(device):
+                _hip.check(lib.mst_console_fx_init_tables(_cabi.ptr(tables), _hip.current_stream_ptr(device)), "mst_console_fx_init_tables")
+            self._fx_cache[key] = (filters, tables)
+        filters, tables = self._fx_cache[key]
+        shape = (bs * 2, 12, self.fx_ir_samples + self.fx_bandpass_taps - 1)
+        if self.fx_noise is not None:
+            noise = self.fx_noise.to(device=device, dtype=torch.float32).contiguous()
+            if tuple(noise.shape) != shape:
+                raise ValueError(f"fx_noise must have shape {shape}, got {tuple(noise.shape)}")
+        else:
+            noise = torch.randn(shape, dtype=torch.float32, device=device)  # dasp draws inside the op, on the input's device
+        return noise, filters, tables
 
     # ------------------------------------------------------------------ parameter dictionaries
     def _affine(self, index, device):
@@ -370,14 +414,6 @@ class AdvancedMixConsole(torch.nn.Module):
         return self._run(tracks, tp, fp, mp, flags, denormalized=True)
 
     def _run(self, tracks, track_params, fx_bus_params, master_bus_params, flags, denormalized=False):
-        if flags["use_fx_bus"]:
-            raise NotImplementedError(
-                "use_fx_bus=True (stereo_bus + noise_shaped_reverberation, reference mst/modules.py:275-284) is not built "
-                "in the MI355X console yet.  It is the DEFAULT of forward() / forward_mix_console() / naive_random_mix(), as in "
-                "the reference: pass use_fx_bus=False.  Under the reference's System the flag is switched on by "
-                "`active_fx_bus_epoch` (mst/system.py:129-130; every shipped config sets it to 1000) - keep that epoch beyond "
-                "the run length, or construct diffmst_hip.system.CommonStep, which refuses such a config up front."
-            )
         if not flags["use_track_panner"]:
             raise RuntimeError("use_track_panner=False is shape-inconsistent in the reference (mst/modules.py:269)")
         need_grad = torch.is_grad_enabled() and any(

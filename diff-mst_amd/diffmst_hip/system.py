@@ -65,8 +65,8 @@ class CommonStep(torch.nn.Module):
             # fail at construction, not at epoch `active_fx_bus_epoch` in the middle of a run
             raise NotImplementedError(
                 f"active_fx_bus_epoch={active_fx_bus_epoch} switches the fx bus on within max_epochs={max_epochs}, but this "
-                "console has no fx bus (reference mst/modules.py:275-284 is not built): set active_fx_bus_epoch >= max_epochs "
-                "(the reference's configs use 1000)"
+                "console has no fx bus (no `supports_fx_bus` attribute): set active_fx_bus_epoch >= max_epochs (the reference's "
+                "configs use 1000)"
             )
 
     def _reference_mix(self, tracks, instrument_id, stereo_info):

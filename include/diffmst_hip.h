@@ -40,7 +40,7 @@ extern "C" {
 #define MST_USE_TRACK_EQ 0x02u
 #define MST_USE_TRACK_COMPRESSOR 0x04u
 #define MST_USE_TRACK_PANNER 0x08u
-#define MST_USE_FX_BUS 0x10u /* not implemented: launcher returns error */
+#define MST_USE_FX_BUS 0x10u /* stereo send bus + noise-shaped reverberation (reference mst/modules.py:275-284); needs mst_console_fx */
 #define MST_USE_MASTER_BUS 0x20u
 #define MST_USE_OUTPUT_FADER 0x40u
 #define MST_SAVE_FOR_BACKWARD 0x100u /* keep intermediates in the workspace for mst_console_backward */
@@ -72,7 +72,27 @@ typedef struct mst_console_desc {
     /* denormalisation ranges v*(hi-lo)+lo, reference mst/modules.py:71-72,121-181 */
     float track_lo[MST_NUM_TRACK_PARAMS], track_hi[MST_NUM_TRACK_PARAMS];
     float master_lo[MST_NUM_MASTER_PARAMS], master_hi[MST_NUM_MASTER_PARAMS];
+    /* fx bus (MST_USE_FX_BUS): ranges of the 25 reverberation parameters (band gains, band decays, mix - the mix is
+     * forced to 1 by the reference, mst/modules.py:420), impulse-response length and band-pass length of
+     * dasp_pytorch.functional.noise_shaped_reverberation as the reference calls it (:277-283: 65536, 1023) */
+    float fx_lo[MST_NUM_FX_PARAMS], fx_hi[MST_NUM_FX_PARAMS];
+    int32_t fx_ir_samples;     /* multiple of 4096 */
+    int32_t fx_bandpass_taps;  /* odd, <= 1023 */
 } mst_console_desc;
+
+/* Inputs of the fx bus that are not parameters (all device pointers, caller-owned, read-only):
+ *   noise    (bs*2, 12, fx_ir_samples + fx_bandpass_taps - 1) standard-normal samples - the reference draws them inside the op
+ *            with torch.randn on every call; the caller draws them here (or passes fixed ones: tests)
+ *   filters  (12, fx_bandpass_taps) octave-band FIR filterbank (a constant table built by the host wrapper, like the Bark
+ *            filterbank of the AudioFeatureLoss)
+ *   tables   mst_console_fx_tables_bytes() bytes filled once by mst_console_fx_init_tables() */
+typedef struct mst_console_fx {
+    const float* noise;
+    const float* filters;
+    const void* tables;
+} mst_console_fx;
+size_t mst_console_fx_tables_bytes(void);
+int mst_console_fx_init_tables(void* tables, void* stream);
 
 /* Library / ABI version (bumped when a signature changes). */
 int mst_abi_version(void);
@@ -85,15 +105,16 @@ size_t mst_console_workspace_bytes(const mst_console_desc* d);
  * bus sum -> master gain/EQ/stereo-linked compressor -> output fader.
  *   tracks            (bs, n_tracks, n_samples) fp32, see strides above
  *   track_params      (bs, n_tracks, 27) normalised [0,1], dense
- *   fx_bus_params     (bs, 25) - range-checked only
+ *   fx_bus_params     (bs, 25) - range-checked; used when MST_USE_FX_BUS is set
+ *   fx                NULL unless MST_USE_FX_BUS
  *   master_bus_params (bs, 26)
  *   mix               (bs, 2, n_samples) out
  *   mixed_tracks      (bs, 2, n_tracks, n_samples) out, or NULL to skip the API-only copy
  *   status            one int32 on the device, see codes above
  *   workspace         >= mst_console_workspace_bytes(d), 256-byte aligned */
 int mst_console_forward(const mst_console_desc* d, const float* tracks, const float* track_params,
-                        const float* fx_bus_params, const float* master_bus_params, float* mix,
-                        float* mixed_tracks, int32_t* status, void* workspace, size_t workspace_bytes,
+                        const float* fx_bus_params, const float* master_bus_params, const mst_console_fx* fx,
+                        float* mix, float* mixed_tracks, int32_t* status, void* workspace, size_t workspace_bytes,
                         void* stream);
 
 /* Reverse-mode of the above (what autograd does through the reference's op graph).
@@ -102,11 +123,12 @@ int mst_console_forward(const mst_console_desc* d, const float* tracks, const fl
  *   grad_mixed_tracks  (bs, 2, n_tracks, n_samples) or NULL
  *   grad_track_params  (bs, n_tracks, 27) out (w.r.t. the NORMALISED parameters)
  *   grad_master_params (bs, 26) out
+ *   grad_fx_params     (bs, 25) out, or NULL (written only when MST_USE_FX_BUS; the forced-wet "mix" column gets 0)
  *   grad_tracks        (bs, n_tracks, n_samples) dense out, or NULL when tracks need no grad */
 int mst_console_backward(const mst_console_desc* d, const float* tracks, const float* track_params,
-                         const float* master_bus_params, const float* grad_mix,
-                         const float* grad_mixed_tracks, float* grad_track_params,
-                         float* grad_master_params, float* grad_tracks, void* workspace,
+                         const float* fx_bus_params, const float* master_bus_params, const mst_console_fx* fx,
+                         const float* grad_mix, const float* grad_mixed_tracks, float* grad_track_params,
+                         float* grad_fx_params, float* grad_master_params, float* grad_tracks, void* workspace,
                          size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------

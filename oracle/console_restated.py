@@ -135,10 +135,12 @@ def console_chain(
     use_master_bus=True,
     use_output_fader=True,
     time_domain: bool = False,
+    fp: dict = None,
+    fx_noise=None,
+    fx_ir_samples: int = 65536,
+    fx_bandpass_taps: int = 1023,
 ):
     """Denormalised dicts in, (mixed_tracks (bs,2,T,n), mix (bs,2,n)) out."""
-    if use_fx_bus:
-        raise NotImplementedError("fx bus (SURVEY 8f rank 4) not restated")
     bs, n_tracks, n = tracks.shape
     rows = tracks.reshape(bs * n_tracks, 1, n)
     if use_track_input_fader:
@@ -154,6 +156,11 @@ def console_chain(
         raise RuntimeError("reference non-panner branch is shape-inconsistent (modules.py:269)")
     mixed = dasp.stereo_panner(rows, sample_rate, **tp["stereo_panner"])
     bus = mixed.sum(dim=2)
+    if use_fx_bus:  # modules.py:275-284
+        fx_bus = dasp.stereo_bus(mixed, sample_rate, **tp["fx_bus"])
+        fx_bus = dasp.noise_shaped_reverberation(fx_bus, sample_rate, **fp["reverberation"], num_samples=fx_ir_samples,
+                                                 num_bandpass_taps=fx_bandpass_taps, noise=fx_noise)
+        bus = bus + fx_bus
     if use_master_bus:
         bus = dasp.gain(bus, sample_rate, **mp["input_fader"])
         bus = dasp.parametric_eq(bus, sample_rate, time_domain=time_domain, **mp["parametric_eq"])
@@ -173,7 +180,7 @@ def console_forward(
     tp = denormalize_parameters(split_track_params(track_params), ranges)
     fp = denormalize_parameters(split_fx_params(fx_bus_params), ranges)
     mp = denormalize_parameters(split_master_params(master_bus_params), ranges)
-    mixed, mix = console_chain(tracks, tp, mp, sample_rate, **flags)
+    mixed, mix = console_chain(tracks, tp, mp, sample_rate, fp=fp, **flags)
     return mixed, mix, tp, fp, mp
 
 

@@ -224,5 +224,64 @@ def compressor(
     return x * 10 ** ((g_s + makeup_gain_db) / 20.0)
 
 
-def noise_shaped_reverberation(*args, **kwargs):  # modules.py:277 - fx bus, "next" row
-    raise NotImplementedError("fx-bus reverberation is outside the round-1 hot path")
+# --------------------------------------------------------------------------- A.6
+def octave_band_filterbank(num_taps: int, sample_rate: float) -> torch.Tensor:
+    """(12, 1, num_taps): 12 Hz low-pass, ten octave band-passes 31.5 Hz .. 16 kHz, 18 kHz high-pass (scipy firwin,
+    float64 design rounded to float32, each filter flipped) - dasp_pytorch.signal.octave_band_filterbank."""
+    import numpy as np
+    import scipy.signal
+
+    bands = [31.5, 63, 125, 250, 500, 1000, 2000, 4000, 8000, 16000]
+    filts = []
+    filt = scipy.signal.firwin(num_taps, 12, fs=sample_rate)
+    filts.append(torch.flip(torch.from_numpy(filt.astype("float32")), dims=[0]))
+    for fc in bands:
+        f_min = fc / np.sqrt(2)
+        f_max = fc * np.sqrt(2)
+        f_max = np.clip(f_max, a_min=0, a_max=(sample_rate / 2) * 0.999)
+        filt = scipy.signal.firwin(num_taps, [f_min, f_max], fs=sample_rate, pass_zero=False)
+        filts.append(torch.flip(torch.from_numpy(filt.astype("float32")), dims=[0]))
+    filt = scipy.signal.firwin(num_taps, 18000, fs=sample_rate, pass_zero=False)
+    filts.append(torch.flip(torch.from_numpy(filt.astype("float32")), dims=[0]))
+    return torch.stack(filts, dim=0).unsqueeze(1)
+
+
+def noise_shaped_reverberation(
+    x: torch.Tensor,
+    sample_rate: float,
+    band0_gain, band1_gain, band2_gain, band3_gain, band4_gain, band5_gain,
+    band6_gain, band7_gain, band8_gain, band9_gain, band10_gain, band11_gain,
+    band0_decay, band1_decay, band2_decay, band3_decay, band4_decay, band5_decay,
+    band6_decay, band7_decay, band8_decay, band9_decay, band10_decay, band11_decay,
+    mix,
+    num_samples: int = 65536,
+    num_bandpass_taps: int = 1023,
+    noise: torch.Tensor = None,
+) -> torch.Tensor:
+    """modules.py:277-283.  Band-passed white noise (12 bands), per-band exponential decay exp(-(10 d + 1) t), t in [0,1],
+    per-band gain, mean over bands = a stereo impulse response of `num_samples` taps; causal convolution with the input;
+    wet / dry mix.  `noise` (bs*2, 12, num_samples + num_bandpass_taps - 1): the op draws it with torch.randn when absent -
+    an explicit argument makes the GPU kernels testable against this restatement."""
+    assert num_bandpass_taps % 2 == 1
+    bs, chs, seq_len = x.size()
+    assert chs == 2
+    gains = torch.stack([band0_gain, band1_gain, band2_gain, band3_gain, band4_gain, band5_gain, band6_gain, band7_gain,
+                         band8_gain, band9_gain, band10_gain, band11_gain], dim=1).view(bs, 12)
+    decays = torch.stack([band0_decay, band1_decay, band2_decay, band3_decay, band4_decay, band5_decay, band6_decay,
+                          band7_decay, band8_decay, band9_decay, band10_decay, band11_decay], dim=1).view(bs, 12)
+    filters = octave_band_filterbank(num_bandpass_taps, sample_rate).type_as(x)
+    num_bands = filters.shape[0]
+    pad_size = num_bandpass_taps - 1
+    wn = torch.randn(bs * 2, num_bands, num_samples + pad_size).type_as(x) if noise is None else noise.to(x.dtype)
+    wn_filt = torch.nn.functional.conv1d(wn, filters, groups=num_bands)  # (bs*2, 12, num_samples)
+    wn_filt = wn_filt.view(bs, 2, num_bands, num_samples)
+    t = torch.linspace(0, 1, steps=num_samples).type_as(x)
+    rates = (decays * 10.0) + 1.0
+    env = torch.exp(-rates.view(bs, 1, num_bands, 1) * t.view(1, 1, 1, -1))
+    wn_filt = wn_filt * env * gains.view(bs, 1, num_bands, 1)
+    ir = wn_filt.mean(2)  # (bs, 2, num_samples)
+    # y[n] = sum_j ir[j] x[n - j] (conv1d of the left-padded input with the flipped response), evaluated with FFTs
+    n_fft = 1 << int(math.ceil(math.log2(seq_len + num_samples - 1)))
+    y = torch.fft.irfft(torch.fft.rfft(x, n_fft) * torch.fft.rfft(ir, n_fft), n_fft)[..., :seq_len]
+    mix = mix.view(bs, 1, 1)
+    return (1 - mix) * x + mix * y

@@ -31,7 +31,8 @@ def lib():
 
 
 def console(param_ranges, tracks, tp, fp, mp, flags, grad_mix=None, want_mixed=True, grad_mixed=None,
-            want_grad_tracks=False, sample_rate=44100, multipass_eq=False, denormalized=False):
+            want_grad_tracks=False, sample_rate=44100, multipass_eq=False, denormalized=False, fx_noise=None,
+            fx_ir_samples=65536, fx_bandpass_taps=1023):
     """CPU tensors in; returns dict(mix, mixed, status, grad_tp, grad_mp, grad_tracks)."""
     from mst import _cabi, _desc
 
@@ -43,7 +44,8 @@ def console(param_ranges, tracks, tp, fp, mp, flags, grad_mix=None, want_mixed=T
         word |= _cabi.DEV_MULTIPASS_EQ
     if denormalized:  # tp / mp hold denormalised values (forward_mix_console): identity ranges, no range check
         word |= _cabi.NO_RANGE_CHECK
-    d = _desc.make_desc(param_ranges, sample_rate, bs, T, n, tracks.stride(1), word, identity_ranges=denormalized)
+    d = _desc.make_desc(param_ranges, sample_rate, bs, T, n, tracks.stride(1), word, identity_ranges=denormalized,
+                        fx_ir_samples=fx_ir_samples, fx_bandpass_taps=fx_bandpass_taps)
     nbytes = L.mst_console_workspace_bytes(C.byref(d))
     assert nbytes > 0
     ws = torch.zeros(nbytes // 4 + 64, dtype=torch.float32)
@@ -53,7 +55,18 @@ def console(param_ranges, tracks, tp, fp, mp, flags, grad_mix=None, want_mixed=T
     mixed = torch.zeros(bs, 2, T, n) if want_mixed else None
     status = torch.zeros(1, dtype=torch.int32)
     tp, fp, mp = tp.contiguous().float(), fp.contiguous().float(), mp.contiguous().float()
-    rc = L.mst_console_forward(C.byref(d), _cabi.ptr(tracks), _cabi.ptr(tp), _cabi.ptr(fp), _cabi.ptr(mp), _cabi.ptr(mix),
+    fx = None
+    if flags.get("use_fx_bus", True):
+        from mst.filter import octave_band_filterbank
+
+        noise = fx_noise.contiguous().float()
+        assert tuple(noise.shape) == (bs * 2, 12, fx_ir_samples + fx_bandpass_taps - 1)
+        filters = octave_band_filterbank(fx_bandpass_taps, sample_rate).contiguous()
+        tables = torch.zeros(L.mst_console_fx_tables_bytes() // 4)
+        assert L.mst_console_fx_init_tables(_cabi.ptr(tables), None) == 0
+        fx = _cabi.ConsoleFx(noise.data_ptr(), filters.data_ptr(), tables.data_ptr())
+    fxp = C.byref(fx) if fx is not None else None
+    rc = L.mst_console_forward(C.byref(d), _cabi.ptr(tracks), _cabi.ptr(tp), _cabi.ptr(fp), _cabi.ptr(mp), fxp, _cabi.ptr(mix),
                                _cabi.ptr(mixed), _cabi.ptr(status), _cabi.ptr(ws), nbytes, None)
     assert rc == 0, rc
     out = dict(mix=mix, mixed=mixed, status=int(status.item()))
@@ -63,10 +76,12 @@ def console(param_ranges, tracks, tp, fp, mp, flags, grad_mix=None, want_mixed=T
         gtr = torch.zeros(bs, T, n) if want_grad_tracks else None
         gm = grad_mix.contiguous().float()
         gmx = None if grad_mixed is None else grad_mixed.contiguous().float()
-        rc = L.mst_console_backward(C.byref(d), _cabi.ptr(tracks), _cabi.ptr(tp), _cabi.ptr(mp), _cabi.ptr(gm), _cabi.ptr(gmx),
-                                    _cabi.ptr(gtp), _cabi.ptr(gmp), _cabi.ptr(gtr), _cabi.ptr(ws), nbytes, None)
+        gfp = torch.full((bs, 25), float("nan")) if fx is not None else None
+        rc = L.mst_console_backward(C.byref(d), _cabi.ptr(tracks), _cabi.ptr(tp), _cabi.ptr(fp), _cabi.ptr(mp), fxp, _cabi.ptr(gm),
+                                    _cabi.ptr(gmx), _cabi.ptr(gtp), _cabi.ptr(gfp), _cabi.ptr(gmp), _cabi.ptr(gtr), _cabi.ptr(ws),
+                                    nbytes, None)
         assert rc == 0, rc
-        out.update(grad_tp=gtp, grad_mp=gmp, grad_tracks=gtr)
+        out.update(grad_tp=gtp, grad_mp=gmp, grad_tracks=gtr, grad_fp=gfp)
     return out
 
 

@@ -70,11 +70,15 @@ def test_workspace_sizes_and_validation(lib):
     nbytes = lib.mst_console_workspace_bytes(ctypes.byref(ok))
     assert 100e6 < nbytes < 2e9  # BASELINE cfg #2: a few hundred MB of saved intermediates
     fx = _desc.make_desc(ranges, 44100, 8, 8, 262144, 262144, _desc.flag_word(use_fx_bus=True))
-    assert lib.mst_console_workspace_bytes(ctypes.byref(fx)) == 0  # fx bus not built: rejected, not ignored
+    assert lib.mst_console_workspace_bytes(ctypes.byref(fx)) > nbytes  # fx bus: spectra of the partitioned convolution on top
+    bad = _desc.make_desc(ranges, 44100, 8, 8, 262144, 262144, _desc.flag_word(use_fx_bus=True), fx_ir_samples=65000)
+    assert lib.mst_console_workspace_bytes(ctypes.byref(bad)) == 0  # impulse response must be whole 4096-sample partitions
+    bad = _desc.make_desc(ranges, 44100, 8, 8, 262144, 262144, _desc.flag_word(use_fx_bus=True), fx_bandpass_taps=1024)
+    assert lib.mst_console_workspace_bytes(ctypes.byref(bad)) == 0  # odd band-pass length (dasp asserts it)
     nopan = _desc.make_desc(ranges, 44100, 1, 1, 1000, 1000, _desc.flag_word(use_fx_bus=False, use_track_panner=False))
     assert lib.mst_console_workspace_bytes(ctypes.byref(nopan)) == 0
     # launchers refuse bad arguments before touching the device
-    assert lib.mst_console_forward(ctypes.byref(fx), None, None, None, None, None, None, None, None, 0, None) != 0
+    assert lib.mst_console_forward(ctypes.byref(fx), None, None, None, None, None, None, None, None, None, 0, None) != 0
     d = _cabi.MrstftDesc()
     d.rows, d.n_samples, d.n_res = 16, 262144, 3
     for i, (nf, hop) in enumerate(((512, 256), (2048, 1024), (8192, 4096))):

@@ -50,8 +50,8 @@ def test_no_cpu_fallback_and_unsupported_paths():
     t = (torch.zeros(1, 2, 4096), torch.rand(1, 2, 27), torch.rand(1, 25), torch.rand(1, 26))
     with pytest.raises(RuntimeError, match="no CPU path"):
         c(*t, use_fx_bus=False)
-    with pytest.raises(NotImplementedError, match="use_fx_bus"):
-        c(*t)  # the reference's default flag; not built yet
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        c(*t)  # the reference's default flags (fx bus on) take the same device-only path
     with pytest.raises(RuntimeError, match="shape-inconsistent"):
         c(*t, use_fx_bus=False, use_track_panner=False)
     with pytest.raises(ValueError):
@@ -141,13 +141,24 @@ def test_forward_mix_console_key_handling():
     assert list(d.track_lo) == [0.0] * 27 and list(d.master_hi) == [1.0] * 26
 
 
-def test_common_step_refuses_an_fx_bus_schedule_up_front():
+def test_common_step_checks_the_fx_bus_schedule_up_front():
     from mst.system import CommonStep
 
-    c = AdvancedMixConsole(44100)
+    class NoFx(torch.nn.Module):  # a console without an fx bus: refused at construction, not at epoch `active_fx_bus_epoch`
+        pass
+
     with pytest.raises(NotImplementedError, match="active_fx_bus_epoch"):
-        CommonStep(torch.nn.Identity(), c, lambda *a, **k: None, torch.nn.Identity(), active_fx_bus_epoch=0)
-    CommonStep(torch.nn.Identity(), c, lambda *a, **k: None, torch.nn.Identity(), active_fx_bus_epoch=1000)
+        CommonStep(torch.nn.Identity(), NoFx(), lambda *a, **k: None, torch.nn.Identity(), active_fx_bus_epoch=0)
+    CommonStep(torch.nn.Identity(), NoFx(), lambda *a, **k: None, torch.nn.Identity(), active_fx_bus_epoch=1000)
+    CommonStep(torch.nn.Identity(), AdvancedMixConsole(44100), lambda *a, **k: None, torch.nn.Identity(), active_fx_bus_epoch=0)
+
+
+def test_octave_band_filterbank_matches_the_oracle():
+    from mst.filter import octave_band_filterbank
+    from oracle import dasp_restated as od
+
+    for taps in (63, 1023):
+        assert torch.equal(octave_band_filterbank(taps, 44100), od.octave_band_filterbank(taps, 44100)[:, 0, :])
 
 
 def test_basic_console_is_gain_and_pan_only():

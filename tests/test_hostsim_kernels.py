@@ -100,6 +100,38 @@ def test_console_denormalised_parameter_path(ranges):
     assert rel(b["grad_mp"] * (mhi - mlo), a["grad_mp"]) < 1e-4
 
 
+def test_console_fx_bus(ranges):
+    """use_fx_bus = True (the reference's default): send bus + noise-shaped reverberation (partitioned FFT convolution on the
+    8192-point engine) forward and backward, with a short impulse response (2 partitions) and short band-passes so that the
+    simulator finishes; ragged length (not a multiple of the 4096-sample hop)."""
+    torch.manual_seed(12)
+    bs, T, n = 1, 2, 2 * 4096 + 1237
+    S, taps = 8192, 63
+    flags = dict(FULL, use_fx_bus=True)
+    tracks = 0.1 * torch.randn(bs, T, n)
+    tp, fp, mp = torch.rand(bs, T, 27), torch.rand(bs, 25), torch.rand(bs, 26)
+    tp, mp = short_ir(tp, mp)
+    tp[..., 21] *= 0.2
+    mp[..., 20] *= 0.2
+    tp[..., 26] = 0.8 + 0.2 * tp[..., 26]  # send -6 .. +12 dB: the wet path carries weight
+    noise = torch.randn(bs * 2, 12, S + taps - 1)
+    gmix = torch.randn(bs, 2, n)
+    out = harness.console(ranges, tracks, tp, fp, mp, flags, grad_mix=gmix, want_mixed=False, want_grad_tracks=True,
+                          fx_noise=noise, fx_ir_samples=S, fx_bandpass_taps=taps)
+    assert out["status"] == 0
+    tr = tracks.double().requires_grad_(True)
+    a, f, b = tp.double().requires_grad_(True), fp.double().requires_grad_(True), mp.double().requires_grad_(True)
+    _, mix, *_ = oc.console_forward(tr, a, f, b, fx_noise=noise.double(), fx_ir_samples=S, fx_bandpass_taps=taps, **flags)
+    (mix * gmix.double()).sum().backward()
+    dry = oc.console_forward(tracks.double(), tp.double(), fp.double(), mp.double(), **FULL)[1]
+    assert rel(dry, mix.detach()) > 0.05  # the reverberated send really is part of the mix
+    assert rel(out["mix"], mix) < 1e-4
+    assert rel(out["grad_fp"][:, :24], f.grad[:, :24]) < 2e-3 and float(out["grad_fp"][:, 24].abs().max()) == 0.0
+    assert rel(out["grad_tp"][..., 26], a.grad[..., 26]) < 2e-3
+    assert rel(out["grad_tp"], a.grad) < 2e-2 and rel(out["grad_mp"], b.grad) < 2e-2
+    assert rel(out["grad_tracks"], tr.grad) < 1e-2
+
+
 def test_console_status_flag(ranges):
     tp, fp, mp = torch.rand(1, 1, 27), torch.rand(1, 25), torch.rand(1, 26)
     mp[0, 24] = 1.5
