@@ -2,7 +2,7 @@
 """Generate the golden fixtures under tests/golden/ FROM THE REAL REFERENCE.
 
 Runs ONLY in the build container (needs /root/reference, which never travels to
-the GPU box).  Usage:  python -B tests/golden/make_golden.py [system]
+the GPU box).  Usage:  python -B tests/golden/make_golden.py [system] [fx]
 
 What it does
 ------------
@@ -128,6 +128,38 @@ def console_case(name, bs, T, n, seed, flags, ref_console, full_box=False):
     print(f"console_{name}: mix rms {mix.pow(2).mean().sqrt():.4e}  |g_tp| {g_tp.abs().max():.3e}")
 
 
+def fx_case(ref_console):
+    """The REAL console with the reference's DEFAULT flags - fx bus on (mst/modules.py:275-284): stereo_bus +
+    noise_shaped_reverberation (65536-tap impulse response, 1023-tap band-passes) with the restated dasp ops at the seam.
+    The op draws its noise with torch.randn inside: the generator is seeded right before the call, the test re-draws it."""
+    bs, T, n, noise_seed = 1, 3, 65536, 900
+    torch.manual_seed(41)
+    tracks = (0.1 * torch.randn(bs, T, n)).half().float()
+    tp = torch.rand(bs, T, 27).requires_grad_(True)
+    fp = torch.rand(bs, 25).requires_grad_(True)
+    mp = torch.rand(bs, 26).requires_grad_(True)
+    gmix = torch.sign(torch.randn(bs, 2, n))
+    torch.manual_seed(noise_seed)
+    mixed, mix, tpd, fpd, mpd = ref_console(tracks, tp, fp, mp)  # no flags: every default, fx bus included
+    (mix * gmix).sum().backward()
+    torch.manual_seed(noise_seed)
+    noise = torch.randn(bs * 2, 12, 65536 + 1022)
+    tp2, fp2, mp2 = (t.detach().clone().requires_grad_(True) for t in (tp, fp, mp))
+    _, o_mix, *_ = oc.console_forward(tracks, tp2, fp2, mp2, fx_noise=noise, use_fx_bus=True)
+    (o_mix * gmix).sum().backward()
+    assert torch.equal(o_mix, mix), "oracle fx-bus orchestration != reference"
+    assert torch.equal(tp2.grad, tp.grad) and torch.equal(fp2.grad, fp.grad) and torch.equal(mp2.grad, mp.grad)
+    assert torch.equal(fpd["reverberation"]["mix"], torch.ones(bs))
+    np.savez_compressed(
+        os.path.join(HERE, "fxbus_1x3x65536.npz"), shape=np.array([bs, T, n]), tracks=tracks.numpy().astype(np.float16),
+        track_params=tp.detach().numpy(), fx_bus_params=fp.detach().numpy(), master_bus_params=mp.detach().numpy(),
+        grad_mix=gmix.numpy().astype(np.int8), noise_seed=np.array(noise_seed), noise_sub=noise.numpy()[:, :, ::4096],
+        mix=mix.detach().numpy()[..., ::4], grad_track_params=tp.grad.numpy(), grad_fx_bus_params=fp.grad.numpy(),
+        grad_master_bus_params=mp.grad.numpy(), band3_decay=fpd["reverberation"]["band3_decay"].detach().numpy(),
+    )
+    print(f"console_fxbus: mix rms {mix.pow(2).mean().sqrt():.4e}  |g_fp| {fp.grad.abs().max():.3e}")
+
+
 def system_case(rsystem, rmodules, rmixing):
     """The REAL ``System.common_step`` (mst/system.py:102-407; Lightning stood in by tests/refstubs.py) with the real
     console / naive_random_mix, the restated dasp ops at the seam and the restated MR-STFT loss: generate_mix, both
@@ -173,8 +205,11 @@ def main():
     ref_console = rmodules.AdvancedMixConsole(sample_rate=44100)
     assert ref_console.param_ranges == oc.param_ranges(44100)
     only = set(sys.argv[1:])  # e.g. `make_golden.py system` regenerates one fixture family (default: all)
-    if only == {"system"}:
-        system_case(rsystem, rmodules, rmixing)
+    if only and only <= {"system", "fx"}:
+        if "system" in only:
+            system_case(rsystem, rmodules, rmixing)
+        if "fx" in only:
+            fx_case(ref_console)
         return
 
     basic = dict(
@@ -255,6 +290,7 @@ def main():
     g = x.abs().max(dim=-1, keepdim=True)[0].max(dim=-2, keepdim=True)[0]
     assert torch.equal(x / g.clamp(1e-8), oc.batch_stereo_peak_normalize(x))
     system_case(rsystem, rmodules, rmixing)
+    fx_case(ref_console)
     print("golden fixtures written to", HERE)
 
 
