@@ -162,11 +162,103 @@ __global__ __launch_bounds__(256) void k_fx_mac(FxMacArgs g) {
     if (kn != k) O[kn] = make_float2(yl.x + yr.y, -yl.y + yr.x);
 }
 
+// The same three products for K = 16 partitions (the reference's 65536-sample response) with every spectrum bin read ONCE:
+// a lane owns the bin pair (k, N - k) of one batch item and walks the frames keeping the last 16 unpacked (L, R) values of
+// the sliding operand in a register ring (static indices: the walk is unrolled by 16) next to the 16 resident ones.  The
+// generic kernel above re-reads both operands for every term (1.07 GB of L2 traffic per launch at cfg #2: 80-110 us);
+// this one moves 67 MB.
+//   FX_MAC_Y : resident H_p, ring of X;  frames ascending in chunks of 16 (grid.y), 15 frames of run-in per chunk
+//   FX_MAC_DX: resident H_p, ring of dY; frames DESCENDING
+//   FX_MAC_DH: resident accumulators dH_p, ring of X, one walk over all frames
+template <int MODE>
+__global__ __launch_bounds__(256) void k_fx_mac16(FxMacArgs g) {
+    constexpr int K = 16;
+    const int k = blockIdx.x * 256 + threadIdx.x, chunk = blockIdx.y, b = blockIdx.z;
+    if (k > kFxN / 2) return;
+    const int kn = (kFxN - k) & (kFxN - 1);
+    const float2* A = g.a + (int64_t)b * g.na * kFxN;
+    const float2* Hh = g.h + (int64_t)b * g.nh * kFxN;
+    float2* O = g.out + (int64_t)b * g.nout * kFxN;
+    float2 hl[K], hr[K], rl[K], rr[K];  // resident operand (H, or the dH accumulators) and the ring
+#pragma unroll
+    for (int p = 0; p < K; ++p) {
+        rl[p] = rr[p] = make_float2(0.f, 0.f);
+        if (MODE == FX_MAC_DH) hl[p] = hr[p] = make_float2(0.f, 0.f);
+        else unpack_lr(Hh[(int64_t)p * kFxN + k], Hh[(int64_t)p * kFxN + kn], hl[p], hr[p]);
+    }
+    auto store = [&](int m, float2 yl, float2 yr) {
+        O[(int64_t)m * kFxN + k] = make_float2(yl.x - yr.y, yl.y + yr.x);
+        if (kn != k) O[(int64_t)m * kFxN + kn] = make_float2(yl.x + yr.y, -yl.y + yr.x);
+    };
+    if (MODE == FX_MAC_Y) {
+        const int m0 = chunk * K, m1 = m0 + K < g.nout ? m0 + K : g.nout;
+        for (int base = m0 - K; base < m1; base += K) {  // one block of run-in, then the chunk (both multiples of 16)
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                const int m = base + j;
+                float2 xl = make_float2(0.f, 0.f), xr = xl;
+                if (m >= 0 && m < g.na) unpack_lr(A[(int64_t)m * kFxN + k], A[(int64_t)m * kFxN + kn], xl, xr);
+                rl[j] = xl;
+                rr[j] = xr;
+                if (m >= m0 && m < m1) {
+                    float2 yl = make_float2(0.f, 0.f), yr = yl;
+#pragma unroll
+                    for (int p = 0; p < K; ++p) {  // X[m - p] sits in slot (j - p) mod 16
+                        yl = cadd(yl, cmul(rl[(j - p) & (K - 1)], hl[p]));
+                        yr = cadd(yr, cmul(rr[(j - p) & (K - 1)], hr[p]));
+                    }
+                    store(m, yl, yr);
+                }
+            }
+        }
+    } else if (MODE == FX_MAC_DX) {
+        const int m0 = chunk * K, m1 = m0 + K < g.nout ? m0 + K : g.nout;
+        for (int base = m0 + K; base >= m0; base -= K) {  // run-in from above: dY[m + p], p < 16
+#pragma unroll
+            for (int j = K - 1; j >= 0; --j) {
+                const int m = base + j;
+                float2 xl = make_float2(0.f, 0.f), xr = xl;
+                if (m < g.na) unpack_lr(A[(int64_t)m * kFxN + k], A[(int64_t)m * kFxN + kn], xl, xr);
+                rl[j] = xl;
+                rr[j] = xr;
+                if (m >= m0 && m < m1) {
+                    float2 yl = make_float2(0.f, 0.f), yr = yl;
+#pragma unroll
+                    for (int p = 0; p < K; ++p) {  // dY[m + p] sits in slot (j + p) mod 16
+                        yl = cadd(yl, cmul(rl[(j + p) & (K - 1)], cconj(hl[p])));
+                        yr = cadd(yr, cmul(rr[(j + p) & (K - 1)], cconj(hr[p])));
+                    }
+                    store(m, yl, yr);
+                }
+            }
+        }
+    } else {
+        for (int base = 0; base < g.na; base += K) {
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                const int m = base + j;
+                if (m >= g.na) break;
+                float2 dl, dr;
+                unpack_lr(A[(int64_t)m * kFxN + k], A[(int64_t)m * kFxN + kn], dl, dr);   // dY[m]
+                unpack_lr(Hh[(int64_t)m * kFxN + k], Hh[(int64_t)m * kFxN + kn], rl[j], rr[j]);  // X[m] enters the ring
+#pragma unroll
+                for (int p = 0; p < K; ++p) {  // dH[p] += dY[m] conj(X[m - p]); slots of frames < 0 still hold zeros
+                    hl[p] = cadd(hl[p], cmul(dl, cconj(rl[(j - p) & (K - 1)])));
+                    hr[p] = cadd(hr[p], cmul(dr, cconj(rr[(j - p) & (K - 1)])));
+                }
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < K; ++p) store(p, hl[p], hr[p]);
+    }
+}
+
 // ---- inverse transforms of spectrum frames ---------------------------------------------------------------------------
 // FX_OUT : dst[b, :, m 4096 .. (m+1) 4096) += last 4096 samples of IFFT(spec[b][m])          (wet signal onto the bus)
-// FX_SCAT: both halves of IFFT(spec[b][m]) are added (atomics onto a zeroed buffer: exactly two commutative
-//          contributions per sample) to dst[b, :, (m-1) 4096 .. (m+1) 4096)                  (cotangent of the send bus)
-// FX_CROP: dst[b, :, m 4096 .. (m+1) 4096) = first 4096 samples of IFFT(spec[b][m])          (cotangent of the impulse response)
+// FX_SCAT: dst[b, :, m 4096 .. (m+1) 4096)  = last 4096 samples of IFFT(spec[b][m]) + first 4096 samples of IFFT(spec[b][m+1])
+//          (cotangent of the send bus: frame m came from samples (m-1) 4096 .. (m+1) 4096; owner-computes - the workgroup of
+//          block m transforms both frames that overlap it, and the lane holding a sample of one holds the same sample of the other)
+// FX_CROP: dst[b, :, m 4096 .. (m+1) 4096)  = first 4096 samples of IFFT(spec[b][m])         (cotangent of the impulse response)
 enum { FX_OUT = 0, FX_SCAT = 1, FX_CROP = 2 };
 struct FxIfftArgs {
     const float2* spec;  // (bs, frames, 8192)
@@ -184,36 +276,48 @@ __global__ __launch_bounds__(kFxLanes, 4) void k_fx_ifft(FxIfftArgs a) {
     LaneTw<kFxN> tw;
     tw.init(twg, lane);
     const float2 wl = twg[lane];
-    const float2* in = a.spec + ((int64_t)b * a.frames + m) * kFxN;
-    // IDFT(Z) = conj(FFT(conj(Z))) / N
-    fft8192_from<false>([&](int t) {
-        const float2 z = in[lane + kFxLanes * t];
-        return make_float2(z.x, -z.y);
-    }, buf[0], buf[1], tw, wl, lane);
-    __syncthreads();
-    float* dl = a.dst + (int64_t)(2 * b) * a.stride;
-    float* dr = dl + a.stride;
     constexpr float inv = 1.0f / (float)kFxN;
+    // half-frame values of this lane: samples 2q, 2q + 1 for q = lane + 512 t, t = 0..3 (first half) or 4..7 (second half),
+    // i.e. offsets 2 lane + 1024 (t mod 4) + {0, 1} inside a 4096-sample block; {L even, R even, L odd, R odd} per t
+    float acc[4][4];
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
-        const int q = lane + kFxLanes * t;                       // output samples 2q, 2q + 1 of the frame
-        const float2 e = buf[0][S::slot(q)], o = buf[1][S::slot(q)];
-        const float le = inv * e.x, re = -inv * e.y, lo = inv * o.x, ro = -inv * o.y;
-        const int s0 = 2 * q;
-        if (MODE == FX_OUT) {
-            if (s0 < kFxHop) continue;
-            const int64_t i = (int64_t)m * kFxHop + (s0 - kFxHop);
-            if (i < a.n) { dl[i] += le; dr[i] += re; }
-            if (i + 1 < a.n) { dl[i + 1] += lo; dr[i + 1] += ro; }
-        } else if (MODE == FX_CROP) {
-            if (s0 >= kFxHop) continue;
-            const int64_t i = (int64_t)m * kFxHop + s0;
-            if (i < a.n) { dl[i] = le; dr[i] = re; }
-            if (i + 1 < a.n) { dl[i + 1] = lo; dr[i + 1] = ro; }
-        } else {
-            const int64_t i = (int64_t)(m - 1) * kFxHop + s0;
-            if (i >= 0 && i < a.n) { unsafeAtomicAdd(&dl[i], le); unsafeAtomicAdd(&dr[i], re); }
-            if (i + 1 >= 0 && i + 1 < a.n) { unsafeAtomicAdd(&dl[i + 1], lo); unsafeAtomicAdd(&dr[i + 1], ro); }
+    for (int t = 0; t < 4; ++t) acc[t][0] = acc[t][1] = acc[t][2] = acc[t][3] = 0.0f;
+    const int nfr = MODE == FX_SCAT ? 2 : 1;
+    for (int which = 0; which < nfr; ++which) {
+        const int f = m + which;
+        if (f >= a.frames) break;
+        const float2* in = a.spec + ((int64_t)b * a.frames + f) * kFxN;
+        if (which) __syncthreads();  // the previous frame's spectrum reads are done
+        // IDFT(Z) = conj(FFT(conj(Z))) / N
+        fft8192_from<false>([&](int t) {
+            const float2 z = in[lane + kFxLanes * t];
+            return make_float2(z.x, -z.y);
+        }, buf[0], buf[1], tw, wl, lane);
+        __syncthreads();
+        const bool second = MODE == FX_OUT || (MODE == FX_SCAT && which == 0);  // which half of this frame lands on block m
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int q = lane + kFxLanes * (second ? t + 4 : t);
+            const float2 e = buf[0][S::slot(q)], o = buf[1][S::slot(q)];
+            acc[t][0] += inv * e.x;
+            acc[t][1] -= inv * e.y;
+            acc[t][2] += inv * o.x;
+            acc[t][3] -= inv * o.y;
+        }
+    }
+    float* dl = a.dst + (int64_t)(2 * b) * a.stride + (int64_t)m * kFxHop;
+    float* dr = dl + a.stride;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int off = 2 * lane + 1024 * t;
+        const int64_t i = (int64_t)m * kFxHop + off;
+        if (i < a.n) {
+            dl[off] = MODE == FX_OUT ? dl[off] + acc[t][0] : acc[t][0];
+            dr[off] = MODE == FX_OUT ? dr[off] + acc[t][1] : acc[t][1];
+        }
+        if (i + 1 < a.n) {
+            dl[off + 1] = MODE == FX_OUT ? dl[off + 1] + acc[t][2] : acc[t][2];
+            dr[off + 1] = MODE == FX_OUT ? dr[off + 1] + acc[t][3] : acc[t][3];
         }
     }
 }
@@ -269,7 +373,8 @@ void launch_fx_forward(const FxPlan& p, const float* noise, const float* filters
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fx_fft<FX_PART>), dim3(p.K, p.bs), dim3(kFxLanes), 0, stream, fh);
     FxMacArgs mc{reinterpret_cast<const float2*>(ws + p.Xs), reinterpret_cast<const float2*>(ws + p.Hs), reinterpret_cast<float2*>(ws + p.Ys),
                  p.nblk, p.K, p.nblk};
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fx_mac<FX_MAC_Y>), dim3((kFxN / 2 + 256) / 256, p.nblk, p.bs), dim3(256), 0, stream, mc);
+    if (p.K == 16) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fx_mac16<FX_MAC_Y>), dim3((kFxN / 2 + 256) / 256, (p.nblk + 15) / 16, p.bs), dim3(256), 0, stream, mc);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fx_mac<FX_MAC_Y>), dim3((kFxN / 2 + 256) / 256, p.nblk, p.bs), dim3(256), 0, stream, mc);
     FxIfftArgs io{reinterpret_cast<const float2*>(ws + p.Ys), bus, bus_stride, p.n, tables, p.nblk};
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fx_ifft<FX_OUT>), dim3(p.nblk, p.bs), dim3(kFxLanes), 0, stream, io);
 }
@@ -282,14 +387,15 @@ void launch_fx_backward(const FxPlan& p, const float* dbus, int64_t dbus_stride,
     // cotangent of the send bus: dX[m] = sum_p dY[m + p] conj(H[p]), frames scattered back over (m-1) 4096 .. (m+1) 4096
     FxMacArgs mx{reinterpret_cast<const float2*>(ws + p.Ys), reinterpret_cast<const float2*>(ws + p.Hs), reinterpret_cast<float2*>(ws + p.dXs),
                  p.nblk, p.K, p.nblk};
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fx_mac<FX_MAC_DX>), dim3((kFxN / 2 + 256) / 256, p.nblk, p.bs), dim3(256), 0, stream, mx);
-    (void)hipMemsetAsync(ws + p.dfx_in, 0, (size_t)p.bs * 2 * p.Ns * sizeof(float), stream);
+    if (p.K == 16) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fx_mac16<FX_MAC_DX>), dim3((kFxN / 2 + 256) / 256, (p.nblk + 15) / 16, p.bs), dim3(256), 0, stream, mx);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fx_mac<FX_MAC_DX>), dim3((kFxN / 2 + 256) / 256, p.nblk, p.bs), dim3(256), 0, stream, mx);
     FxIfftArgs ix{reinterpret_cast<const float2*>(ws + p.dXs), ws + p.dfx_in, p.Ns, p.n, tables, p.nblk};
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fx_ifft<FX_SCAT>), dim3(p.nblk, p.bs), dim3(kFxLanes), 0, stream, ix);
     // cotangent of the impulse response: dH[p] = sum_m dY[m] conj(X[m - p]), first 4096 samples of each inverse
     FxMacArgs mh{reinterpret_cast<const float2*>(ws + p.Ys), reinterpret_cast<const float2*>(ws + p.Xs), reinterpret_cast<float2*>(ws + p.dHs),
                  p.nblk, p.nblk, p.K};
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fx_mac<FX_MAC_DH>), dim3((kFxN / 2 + 256) / 256, p.K, p.bs), dim3(256), 0, stream, mh);
+    if (p.K == 16) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fx_mac16<FX_MAC_DH>), dim3((kFxN / 2 + 256) / 256, 1, p.bs), dim3(256), 0, stream, mh);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fx_mac<FX_MAC_DH>), dim3((kFxN / 2 + 256) / 256, p.K, p.bs), dim3(256), 0, stream, mh);
     FxIfftArgs ih{reinterpret_cast<const float2*>(ws + p.dHs), ws + p.dir, p.S, p.S, tables, p.K};
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fx_ifft<FX_CROP>), dim3(p.K, p.bs), dim3(kFxLanes), 0, stream, ih);
     hipLaunchKernelGGL(k_fx_ir_bwd, dim3(p.nblk_ir, p.bs), dim3(256), 0, stream, ws + p.wnf, ws + p.rcfx, ws + p.dir, ws + p.fxpart, p.S);

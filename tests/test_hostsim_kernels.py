@@ -100,13 +100,15 @@ def test_console_denormalised_parameter_path(ranges):
     assert rel(b["grad_mp"] * (mhi - mlo), a["grad_mp"]) < 1e-4
 
 
-def test_console_fx_bus(ranges):
+@pytest.mark.parametrize("S,n", [(8192, 2 * 4096 + 1237), (65536, 18 * 4096 + 5)])
+def test_console_fx_bus(ranges, S, n):
     """use_fx_bus = True (the reference's default): send bus + noise-shaped reverberation (partitioned FFT convolution on the
     8192-point engine) forward and backward, with a short impulse response (2 partitions) and short band-passes so that the
-    simulator finishes; ragged length (not a multiple of the 4096-sample hop)."""
+    simulator finishes; ragged length (not a multiple of the 4096-sample hop).  S = 65536 (16 partitions, the reference's
+    size) takes the register-ring multiply-accumulate kernels and rows longer than one 16-frame chunk."""
     torch.manual_seed(12)
-    bs, T, n = 1, 2, 2 * 4096 + 1237
-    S, taps = 8192, 63
+    bs, T = 1, 2
+    taps = 63
     flags = dict(FULL, use_fx_bus=True)
     tracks = 0.1 * torch.randn(bs, T, n)
     tp, fp, mp = torch.rand(bs, T, 27), torch.rand(bs, 25), torch.rand(bs, 26)
@@ -114,22 +116,31 @@ def test_console_fx_bus(ranges):
     tp[..., 21] *= 0.2
     mp[..., 20] *= 0.2
     tp[..., 26] = 0.8 + 0.2 * tp[..., 26]  # send -6 .. +12 dB: the wet path carries weight
+    if S == 65536:
+        # 63-tap band-passes pass far more noise energy than the reference's 1023-tap ones: with full band gains the 65536-tap
+        # response drives the mix to +-60 and the master compressor's gradient becomes chaotic (the fp32 oracle then sits 270 %
+        # from its own float64 evaluation); keep the wet level comparable to the dry one
+        fp[:, :12] *= 0.03
     noise = torch.randn(bs * 2, 12, S + taps - 1)
     gmix = torch.randn(bs, 2, n)
     out = harness.console(ranges, tracks, tp, fp, mp, flags, grad_mix=gmix, want_mixed=False, want_grad_tracks=True,
                           fx_noise=noise, fx_ir_samples=S, fx_bandpass_taps=taps)
     assert out["status"] == 0
-    tr = tracks.double().requires_grad_(True)
-    a, f, b = tp.double().requires_grad_(True), fp.double().requires_grad_(True), mp.double().requires_grad_(True)
-    _, mix, *_ = oc.console_forward(tr, a, f, b, fx_noise=noise.double(), fx_ir_samples=S, fx_bandpass_taps=taps, **flags)
-    (mix * gmix.double()).sum().backward()
+    got = dict(mix=out["mix"], g_fp=out["grad_fp"][:, :24], g_send=out["grad_tp"][..., 26], g_tp=out["grad_tp"], g_mp=out["grad_mp"],
+               g_tracks=out["grad_tracks"])
+    ref = {}
+    for dt in (torch.float32, torch.float64):  # three-way: the compressors make the fp32 reference algorithm itself noisy here
+        tr = tracks.detach().clone().to(dt).requires_grad_(True)
+        a, f, b = (t.detach().clone().to(dt).requires_grad_(True) for t in (tp, fp, mp))
+        _, mix, *_ = oc.console_forward(tr, a, f, b, fx_noise=noise.to(dt), fx_ir_samples=S, fx_bandpass_taps=taps, **flags)
+        (mix * gmix.to(dt)).sum().backward()
+        ref[dt] = dict(mix=mix.detach(), g_fp=f.grad[:, :24], g_send=a.grad[..., 26], g_tp=a.grad, g_mp=b.grad, g_tracks=tr.grad)
     dry = oc.console_forward(tracks.double(), tp.double(), fp.double(), mp.double(), **FULL)[1]
-    assert rel(dry, mix.detach()) > 0.05  # the reverberated send really is part of the mix
-    assert rel(out["mix"], mix) < 1e-4
-    assert rel(out["grad_fp"][:, :24], f.grad[:, :24]) < 2e-3 and float(out["grad_fp"][:, 24].abs().max()) == 0.0
-    assert rel(out["grad_tp"][..., 26], a.grad[..., 26]) < 2e-3
-    assert rel(out["grad_tp"], a.grad) < 2e-2 and rel(out["grad_mp"], b.grad) < 2e-2
-    assert rel(out["grad_tracks"], tr.grad) < 1e-2
+    assert rel(dry, ref[torch.float64]["mix"]) > 0.05  # the reverberated send really is part of the mix
+    for k, tol in (("mix", 1e-4), ("g_fp", 2e-3), ("g_send", 2e-3), ("g_tp", 2e-2), ("g_mp", 2e-2), ("g_tracks", 1e-2)):
+        h64, r64 = rel(got[k], ref[torch.float64][k]), rel(ref[torch.float32][k], ref[torch.float64][k])
+        assert h64 <= 2 * r64 + tol, (k, h64, r64)
+    assert float(out["grad_fp"][:, 24].abs().max()) == 0.0  # the forced-wet "mix" parameter gets no gradient
 
 
 def test_console_status_flag(ranges):
