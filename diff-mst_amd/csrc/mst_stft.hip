@@ -601,27 +601,30 @@ struct LossArgs {
     float w_sc, w_log, w_lin;
     int sc_per_example;
 };
-// stage 1: one 64-lane workgroup per (row, resolution) folds that row's strip partials (fp64, fixed order)
-__global__ __launch_bounds__(64) void k_mrstft_rowsums(LossArgs a) {
-    const int tid = threadIdx.x, row = blockIdx.x, res = blockIdx.y;
-    const float* p = a.part + a.part_off[res] + (int64_t)row * a.n_groups[res] * 4;
-    double s[4] = {0, 0, 0, 0};
-    for (int g = tid; g < a.n_groups[res]; g += 64) {
-        const float4 v = *reinterpret_cast<const float4*>(p + (int64_t)g * 4);
-        s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-        for (int m = 32; m >= 1; m >>= 1) s[q] += __shfl_xor(s[q], m);
-    if (tid == 0) {
-        float* o = a.sums + ((int64_t)res * a.rows + row) * 4;
-        o[0] = (float)s[0]; o[1] = (float)s[1]; o[2] = (float)s[2]; o[3] = (float)s[3];
-    }
-}
-// stage 2: loss scalar + per-row backward coefficients (without dL/dloss, applied by k_scale_coef)
-__global__ __launch_bounds__(64) void k_mrstft_final(LossArgs a) {
+// One 1024-lane workgroup closes the loss.  Stage 1: every (row, resolution) pair is folded by ONE wave from that row's
+// strip partials (fp64, fixed order - the result does not depend on how pairs are dealt to waves); stage 2: loss scalar +
+// per-row backward coefficients (without dL/dloss, which the backward kernels apply).
+constexpr int kReduceLanes = 1024;
+__global__ __launch_bounds__(kReduceLanes) void k_mrstft_reduce(LossArgs a) {
     __shared__ double rs[kMaxRes][4];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int pair = wave; pair < a.n_res * a.rows; pair += kReduceLanes / 64) {
+        const int res = pair / a.rows, row = pair % a.rows;
+        const float* p = a.part + a.part_off[res] + (int64_t)row * a.n_groups[res] * 4;
+        double s[4] = {0, 0, 0, 0};
+        for (int g = lane; g < a.n_groups[res]; g += 64) {
+            const float4 v = *reinterpret_cast<const float4*>(p + (int64_t)g * 4);
+            s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            for (int m = 32; m >= 1; m >>= 1) s[q] += __shfl_xor(s[q], m);
+        if (lane == 0) {
+            float* o = a.sums + ((int64_t)res * a.rows + row) * 4;
+            o[0] = (float)s[0]; o[1] = (float)s[1]; o[2] = (float)s[2]; o[3] = (float)s[3];
+        }
+    }
+    __syncthreads();
     if (tid < a.n_res) {
         const int res = tid;
         double tot[4] = {0, 0, 0, 0}, sc_acc = 0.0;
@@ -640,7 +643,7 @@ __global__ __launch_bounds__(64) void k_mrstft_final(LossArgs a) {
         for (int res = 0; res < a.n_res; ++res) total += rs[res][3];
         a.loss[0] = (float)(total / a.n_res);
     }
-    for (int i = tid; i < a.n_res * a.rows; i += 64) {
+    for (int i = tid; i < a.n_res * a.rows; i += kReduceLanes) {
         const int res = i / a.rows;
         const float* sm = a.sums + (int64_t)i * 4;
         double c_sc;
@@ -812,8 +815,7 @@ extern "C" int mst_mrstft_forward(const mst_mrstft_desc* d, const float* pred, c
         la.part_off[i] = p.part_off[i];
         la.count[i] = (float)((double)d->rows * p.res[i].n_bins * p.res[i].n_frames);
     }
-    hipLaunchKernelGGL(k_mrstft_rowsums, dim3(d->rows, d->n_res), dim3(64), 0, stream, la);
-    hipLaunchKernelGGL(k_mrstft_final, dim3(1), dim3(64), 0, stream, la);
+    hipLaunchKernelGGL(k_mrstft_reduce, dim3(1), dim3(kReduceLanes), 0, stream, la);
     return (int)hipGetLastError();
 }
 

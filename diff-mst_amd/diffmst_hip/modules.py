@@ -168,8 +168,7 @@ class _ConsoleFunction(torch.autograd.Function):
         if ctx.fx_on:
             fx = _cabi.ConsoleFx(*(t.data_ptr() for t in fx_keep))
             g_fx = torch.empty(bs, _cabi.NUM_FX_PARAMS, dtype=torch.float32, device=dev)
-        elif ctx.needs_input_grad[2]:
-            g_fx = torch.zeros(bs, _cabi.NUM_FX_PARAMS, dtype=torch.float32, device=dev)
+        # fx bus off: the fx parameters never reach the mix - their gradient is None, as in the reference (no zero fill)
         with torch.cuda.device(dev):
             rc = lib.mst_console_backward(
                 ctypes.byref(desc), _cabi.ptr(rows), _cabi.ptr(tp), _cabi.ptr(fp), _cabi.ptr(mp),
