@@ -126,6 +126,7 @@ struct AfArgs {
     float* coef;          // backward coefficients
     const float* grad_losses;  // (5) upstream dL/d(loss_k)
     float* grad_pred;     // (bs, 2, n)
+    float* yframes;       // (2*bs, n_frames, kAfFft) windowed adjoint frames of the prediction's mid / side signals
     float weights[5];
     int bs, n_frames, n_groups, n_statblk;
     int64_t n;
@@ -503,32 +504,7 @@ __global__ __launch_bounds__(256) void k_af_bark_dmag(AfArgs a) {
     }
 }
 
-// energy-type features + crest: elementwise.  grid (blocks, bs)
-__global__ __launch_bounds__(256) void k_af_bwd_elem(AfArgs a) {
-    const int b = blockIdx.y;
-    const float* c = a.coef + (int64_t)b * 16;
-    const float* l = a.pred + (int64_t)b * 2 * a.n;
-    const float* r = l + a.n;
-    float* gl = a.grad_pred + (int64_t)b * 2 * a.n;
-    float* gr = gl + a.n;
-    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (i >= a.n) return;
-    const float4 lv = load4(l, i, a.n), rv = load4(r, i, a.n);
-    const float le[4] = {lv.x, lv.y, lv.z, lv.w}, re[4] = {rv.x, rv.y, rv.z, rv.w};
-    float ol[4], orr[4];
-    const int al = __float_as_int(c[5]), ar = __float_as_int(c[7]);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        ol[t] = c[0] * le[t] + c[1] * re[t];
-        orr[t] = c[2] * le[t] + c[3] * re[t];
-        if (i + t == al) ol[t] += c[4] * ((le[t] > 0.f) - (le[t] < 0.f));
-        if (i + t == ar) orr[t] += c[6] * ((re[t] > 0.f) - (re[t] < 0.f));
-    }
-    store4(gl, i, a.n, make_float4(ol[0], ol[1], ol[2], ol[3]));
-    store4(gr, i, a.n, make_float4(orr[0], orr[1], orr[2], orr[3]));
-}
-
-// bark adjoint: one frame of one prediction signal per workgroup, added to grad_pred with float atomics
+// bark adjoint: one frame of one prediction signal per workgroup
 __global__ __launch_bounds__(kAfThreads) void k_af_bark_bwd(AfArgs a) {
     __shared__ __attribute__((aligned(16))) float2 buf[kAfM];
     __shared__ AfTw T;
@@ -545,7 +521,10 @@ __global__ __launch_bounds__(kAfThreads) void k_af_bark_bwd(AfArgs a) {
     __syncthreads();
     af_load_frame<true>(buf, l, r, sign, win, f, a.n, tid);
     __syncthreads();
-    fft16k_dif<true>(buf, T, tid);
+#ifndef MST_AF_ABLATE
+#define MST_AF_ABLATE 0  // timing ablations (wrong results): 2 no inverse transform, 3 no transforms
+#endif
+    if (MST_AF_ABLATE < 3) fft16k_dif<true>(buf, T, tid);
     // For each mirror pair (k, M-k): G = dM * X / |X|, Hermitian extension H (H[k] = G[k]/2 inside,
     // real at 0 and M), then the half-size packing  A[k] = H[k] + conj(H[M-k]),
     // Bq[k] = (H[k] - conj(H[M-k])) conj(W^k);  slot(k) <- conj(A + i Bq)  (inverse = conj FFT conj).
@@ -582,20 +561,92 @@ __global__ __launch_bounds__(kAfThreads) void k_af_bark_bwd(AfArgs a) {
         }
     }
     __syncthreads();
-    fft16k_dit(buf, T, tid);
-    // conj(result) = y_even + i y_odd
-    float* gl = a.grad_pred + (int64_t)(s % a.bs) * 2 * a.n;
-    float* gr = gl + a.n;
-    const int64_t start = (int64_t)f * kAfHop - kAfFft / 2;
+    if (MST_AF_ABLATE < 2) fft16k_dit(buf, T, tid);
+    // conj(result) = y_even + i y_odd; the windowed frame goes to its own slot of `yframes` (coalesced 8-byte stores) -
+    // k_af_bwd_gather overlap-adds the frames, owner-computes (no atomics: the gradient is bitwise reproducible)
+    float2* yf = reinterpret_cast<float2*>(a.yframes + ((int64_t)s * a.n_frames + f) * kAfFft);
     for (int m = tid; m < kAfM; m += kAfThreads) {
         const float2 v = buf[swz(m)];
-        const float y0 = win[2 * m] * v.x, y1 = -win[2 * m + 1] * v.y;
-        const int64_t i0 = af_reflect(start + 2 * m, a.n), i1 = af_reflect(start + 2 * m + 1, a.n);
-        unsafeAtomicAdd(&gl[i0], y0);
-        unsafeAtomicAdd(&gr[i0], sign * y0);
-        unsafeAtomicAdd(&gl[i1], y1);
-        unsafeAtomicAdd(&gr[i1], sign * y1);
+        const float2 w = *reinterpret_cast<const float2*>(win + 2 * m);
+        yf[m] = make_float2(w.x * v.x, -w.y * v.y);
     }
+}
+
+// grad_pred = closed-form features (energy-type + crest, elementwise) + overlap-add of the Bark adjoint frames.
+// Sample i of the reflect-padded signal sits at padded position p = i + N/2; frame f covers [f hop, f hop + N).  A sample
+// collects every frame over its own position and, within N/2 of an end, over its mirror position (torch reflect padding).
+// grid (blocks, bs), 4 samples per lane.
+__device__ __forceinline__ void af_frames_over(int64_t p, int n_frames, int& f_lo, int& f_hi) {
+    const int64_t lo = p - kAfFft + 1;
+    f_lo = lo <= 0 ? 0 : (int)((lo + kAfHop - 1) / kAfHop);
+    const int64_t hi = p / kAfHop;
+    f_hi = hi > n_frames - 1 ? n_frames - 1 : (int)hi;
+}
+__global__ __launch_bounds__(256) void k_af_bwd_gather(AfArgs a) {
+    const int b = blockIdx.y;
+    const float* c = a.coef + (int64_t)b * 16;
+    const float* l = a.pred + (int64_t)b * 2 * a.n;
+    const float* r = l + a.n;
+    float* gl = a.grad_pred + (int64_t)b * 2 * a.n;
+    float* gr = gl + a.n;
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= a.n) return;
+    const float4 lv = load4(l, i, a.n), rv = load4(r, i, a.n);
+    const float le[4] = {lv.x, lv.y, lv.z, lv.w}, re[4] = {rv.x, rv.y, rv.z, rv.w};
+    float ol[4], orr[4];
+    const int al = __float_as_int(c[5]), ar = __float_as_int(c[7]);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        ol[t] = c[0] * le[t] + c[1] * re[t];
+        orr[t] = c[2] * le[t] + c[3] * re[t];
+        if (i + t == al) ol[t] += c[4] * ((le[t] > 0.f) - (le[t] < 0.f));
+        if (i + t == ar) orr[t] += c[6] * ((re[t] > 0.f) - (re[t] < 0.f));
+    }
+    const float* ym = a.yframes + (int64_t)b * a.n_frames * kAfFft;            // mid  = L + R
+    const float* ys = a.yframes + (int64_t)(a.bs + b) * a.n_frames * kAfFft;   // side = L - R
+    float m[4] = {0.f, 0.f, 0.f, 0.f}, sd[4] = {0.f, 0.f, 0.f, 0.f};
+    {   // own position: the four samples share their frames (hop and frame length are multiples of 4)
+        const int64_t p = i + kAfFft / 2;
+        int f_lo, f_hi;
+        af_frames_over(p, a.n_frames, f_lo, f_hi);
+        for (int f = f_lo; f <= f_hi; ++f) {
+            const int64_t at = (int64_t)f * kAfFft + (p - (int64_t)f * kAfHop);
+            const float4 vm = *reinterpret_cast<const float4*>(ym + at), vs = *reinterpret_cast<const float4*>(ys + at);
+            m[0] += vm.x; m[1] += vm.y; m[2] += vm.z; m[3] += vm.w;
+            sd[0] += vs.x; sd[1] += vs.y; sd[2] += vs.z; sd[3] += vs.w;
+        }
+    }
+    if (i <= kAfFft / 2 || i + 3 >= a.n - 1 - kAfFft / 2) {  // mirror positions near the two ends
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int64_t it = i + t;
+            if (it >= a.n) break;
+            for (int side = 0; side < 2; ++side) {
+                int64_t p;
+                if (side == 0) {
+                    if (it < 1 || it > kAfFft / 2) continue;
+                    p = kAfFft / 2 - it;
+                } else {
+                    if (it < a.n - 1 - kAfFft / 2 || it > a.n - 2) continue;
+                    p = kAfFft / 2 + 2 * (a.n - 1) - it;
+                }
+                int f_lo, f_hi;
+                af_frames_over(p, a.n_frames, f_lo, f_hi);
+                for (int f = f_lo; f <= f_hi; ++f) {
+                    const int64_t at = (int64_t)f * kAfFft + (p - (int64_t)f * kAfHop);
+                    m[t] += ym[at];
+                    sd[t] += ys[at];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        ol[t] += m[t] + sd[t];
+        orr[t] += m[t] - sd[t];
+    }
+    store4(gl, i, a.n, make_float4(ol[0], ol[1], ol[2], ol[3]));
+    store4(gr, i, a.n, make_float4(orr[0], orr[1], orr[2], orr[3]));
 }
 
 __global__ void k_af_tables(float* tables) {
@@ -618,7 +669,7 @@ __global__ void k_af_tables(float* tables) {
 
 struct AfPlan {
     int n_frames, n_groups, n_statblk;
-    int64_t magpart, meanmag, bark, statpart, bandpart, stats, coef, total;
+    int64_t magpart, meanmag, bark, statpart, bandpart, stats, coef, yframes, total;
     bool ok;
 };
 // frames of a signal are cut into G strips (one workgroup each, one 128 KiB workgroup per CU, 256 CUs): choose G to
@@ -649,6 +700,7 @@ static AfPlan af_plan(int bs, int64_t n) {
     p.bandpart = take((int64_t)4 * bs * kAfBinSlices * kAfBands);
     p.stats = take((int64_t)2 * bs * 8 * 2);  // doubles
     p.coef = take((int64_t)bs * 16);
+    p.yframes = take((int64_t)2 * bs * p.n_frames * kAfFft);  // backward only
     p.total = o;
     return p;
 }
@@ -658,6 +710,7 @@ static AfArgs af_args(const AfPlan& p, int bs, int64_t n, const float* pred, con
     a.pred = pred; a.target = target; a.tables = tables; a.fb = fb;
     a.magpart = ws + p.magpart; a.meanmag = ws + p.meanmag; a.bark = ws + p.bark;
     a.statpart = ws + p.statpart; a.coef = ws + p.coef;
+    a.yframes = ws + p.yframes;
     a.bandpart = ws + p.bandpart; a.stats = reinterpret_cast<double*>(ws + p.stats);
     for (int i = 0; i < 5; ++i) a.weights[i] = weights[i];
     a.bs = bs; a.n_frames = p.n_frames; a.n_groups = p.n_groups; a.n_statblk = p.n_statblk; a.n = n;
@@ -705,8 +758,8 @@ extern "C" int mst_afloss_backward(const float* pred, const float* target, int32
     a.grad_losses = grad_losses5;
     a.grad_pred = grad_pred;
     hipLaunchKernelGGL(k_af_coef, dim3(1), dim3(64), 0, stream, a);
-    hipLaunchKernelGGL(k_af_bwd_elem, dim3((unsigned)((n_samples + 1023) / 1024), bs), dim3(256), 0, stream, a);
     hipLaunchKernelGGL(k_af_bark_dmag, dim3((kAfBins + 255) / 256, 2 * bs), dim3(256), 0, stream, a);
     hipLaunchKernelGGL(k_af_bark_bwd, dim3(p.n_frames, 2 * bs), dim3(kAfThreads), 0, stream, a);
+    hipLaunchKernelGGL(k_af_bwd_gather, dim3((unsigned)((n_samples + 1023) / 1024), bs), dim3(256), 0, stream, a);
     return (int)hipGetLastError();
 }

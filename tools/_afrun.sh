@@ -1,0 +1,7 @@
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+cd $R && timeout 900 python -m pytest tests/test_loss_gpu.py -m gpu -q -k "afloss or mrstft" 2>&1 | tail -5
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace -d $R/gpurun_out/afprof_g8 -o r -- python $R/tools/af_bench.py 8 2>&1 | grep "bs="
+timeout 600 rocprofv3 --kernel-trace -d $R/gpurun_out/afprof_g32 -o r -- python $R/tools/af_bench.py 32 2>&1 | grep "bs="
+cd $R && python tools/kavg.py "af_" $(find gpurun_out/afprof_g* -name "*.db" | sort) 2>&1 | head -80
