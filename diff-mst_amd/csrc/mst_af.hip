@@ -4,266 +4,11 @@
 //   frames -> (24 x 16385) filterbank -> log(. + 1e-8)
 // each compared with the target by MSE and weighted.  Forward and reverse-mode.
 //
-// The 32768-point real transform of a frame is one 16384-point complex FFT of (even + i odd)
-// samples living entirely in LDS (128 KiB of the CU's 160 KiB): in-place radix-4 decimation in
-// frequency (natural in, base-4 digit-reversed out) with an XOR bank swizzle, the real-input
-// untangling done on the digit-reversed image; the adjoint writes its Hermitian-packed input back
-// to the same slots and runs the mirror decimation-in-time network (digit-reversed in, natural
-// out), so nothing but partial magnitude sums and the final gradient ever reaches HBM.
-#include "mst_common.h"
+// The transforms live in mst_af2.hip (register-radix engine); this file holds the closed-form features, the reductions
+// around the Bark spectrum, the overlap-add gather of the adjoint frames and the C ABI.
+#include "mst_af.h"
 
 namespace mst {
-
-constexpr int kAfFft = 32768;       // reference default fft_size (mst/loss.py:64)
-constexpr int kAfM = kAfFft / 2;    // complex points
-constexpr int kAfHop = kAfFft / 4;  // reference hop_length = fft_size // 4 (mst/loss.py:106)
-constexpr int kAfBins = kAfM + 1;
-constexpr int kAfBands = 24;
-constexpr int kAfThreads = 1024;
-
-// tables (floats): twM: kAfM float2 (W_M^t) | twN: (kAfM + 1) float2 (W_N^k) | win: kAfFft floats
-constexpr int64_t kAfTwM = 0, kAfTwN = 2 * kAfM, kAfWin = kAfTwN + 2 * (kAfM + 1), kAfTablesFloats = kAfWin + kAfFft;
-
-__device__ __forceinline__ float2 cmulf(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
-__device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
-// bank swizzle: fold the top index bits into the low 5 so that digit-reversed neighbours spread over banks
-// SWZ = false: plain slots.  Measured: the forward kernel is 35 % faster WITHOUT the swizzle (273 -> 178 us at bs 8:
-// its address arithmetic costs more than the epilogue's bank conflicts), the backward kernel is not (345 vs 358 us).
-template <bool SWZ>
-__device__ __forceinline__ int swzT(int a) { return SWZ ? a ^ ((a >> 9) & 31) : a; }
-__device__ __forceinline__ int swz(int a) { return swzT<true>(a); }
-__device__ __forceinline__ int rev4_7(int k) {  // reverse the 7 base-4 digits of a 14-bit index
-    int r = 0;
-#pragma unroll
-    for (int i = 0; i < 7; ++i) {
-        r = (r << 2) | (k & 3);
-        k >>= 2;
-    }
-    return r;
-}
-
-struct AfTw {
-    float2 coarse[kAfM / 64];
-    float2 fine[64];
-    __device__ __forceinline__ float2 get(int t) const { return cmulf(coarse[t >> 6], fine[t & 63]); }
-};
-
-// in-place radix-4 DIF, forward sign: natural order in, digit-reversed out
-template <bool SWZ>
-__device__ void fft16k_dif(float2* buf, const AfTw& T, int tid) {
-    for (int L = kAfM / 4; L >= 1; L >>= 2) {
-        const int tstep = kAfM / (4 * L);
-#pragma unroll
-        for (int b = tid; b < kAfM / 4; b += kAfThreads) {
-            const int k = b & (L - 1);
-            const int i0 = ((b - k) << 2) + k;
-            const int p0 = swzT<SWZ>(i0), p1 = swzT<SWZ>(i0 + L), p2 = swzT<SWZ>(i0 + 2 * L), p3 = swzT<SWZ>(i0 + 3 * L);
-            const float2 u0 = buf[p0], u1 = buf[p1], u2 = buf[p2], u3 = buf[p3];
-            const float2 s02 = make_float2(u0.x + u2.x, u0.y + u2.y), d02 = make_float2(u0.x - u2.x, u0.y - u2.y);
-            const float2 s13 = make_float2(u1.x + u3.x, u1.y + u3.y), d13 = make_float2(u1.x - u3.x, u1.y - u3.y);
-            float2 y0 = make_float2(s02.x + s13.x, s02.y + s13.y);
-            float2 y1 = make_float2(d02.x + d13.y, d02.y - d13.x);
-            float2 y2 = make_float2(s02.x - s13.x, s02.y - s13.y);
-            float2 y3 = make_float2(d02.x - d13.y, d02.y + d13.x);
-            if (k) {
-                const float2 w1 = T.get(k * tstep);
-                const float2 w2 = cmulf(w1, w1);
-                y1 = cmulf(y1, w1);
-                y2 = cmulf(y2, w2);
-                y3 = cmulf(y3, cmulf(w2, w1));
-            }
-            buf[p0] = y0; buf[p1] = y1; buf[p2] = y2; buf[p3] = y3;
-        }
-        __syncthreads();
-    }
-}
-// in-place radix-4 DIT, forward sign: digit-reversed in, natural order out
-__device__ void fft16k_dit(float2* buf, const AfTw& T, int tid) {
-    for (int L = 1; L < kAfM; L <<= 2) {
-        const int tstep = kAfM / (4 * L);
-#pragma unroll
-        for (int b = tid; b < kAfM / 4; b += kAfThreads) {
-            const int k = b & (L - 1);
-            const int i0 = ((b - k) << 2) + k;
-            const int p0 = swz(i0), p1 = swz(i0 + L), p2 = swz(i0 + 2 * L), p3 = swz(i0 + 3 * L);
-            float2 u0 = buf[p0], u1 = buf[p1], u2 = buf[p2], u3 = buf[p3];
-            if (k) {
-                const float2 w1 = T.get(k * tstep);
-                const float2 w2 = cmulf(w1, w1);
-                u1 = cmulf(u1, w1);
-                u2 = cmulf(u2, w2);
-                u3 = cmulf(u3, cmulf(w2, w1));
-            }
-            const float2 s02 = make_float2(u0.x + u2.x, u0.y + u2.y), d02 = make_float2(u0.x - u2.x, u0.y - u2.y);
-            const float2 s13 = make_float2(u1.x + u3.x, u1.y + u3.y), d13 = make_float2(u1.x - u3.x, u1.y - u3.y);
-            buf[p0] = make_float2(s02.x + s13.x, s02.y + s13.y);
-            buf[p1] = make_float2(d02.x + d13.y, d02.y - d13.x);
-            buf[p2] = make_float2(s02.x - s13.x, s02.y - s13.y);
-            buf[p3] = make_float2(d02.x - d13.y, d02.y + d13.x);
-        }
-        __syncthreads();
-    }
-}
-
-__device__ __forceinline__ int64_t af_reflect(int64_t i, int64_t n) {
-    if (i < 0) i = -i;
-    if (i >= n) i = 2 * (n - 1) - i;
-    return i;
-}
-
-struct AfArgs {
-    const float* pred;    // (bs, 2, n)
-    const float* target;  // (bs, 2, n)
-    const float* tables;
-    const float* fb;      // (kAfBins, 24) filterbank, row-major like the reference's (n_freqs, n_barks)
-    float* magpart;       // (4*bs, n_groups, kAfBins) partial sums of |X| over a strip of frames
-    float* meanmag;       // (4*bs, kAfBins)
-    float* bark;          // (4*bs, 24) log band energies; (4*bs, 24) linear band energies follow
-    double* stats;        // (2*bs, 8) reduced statistics per (signal set, b), see k_af_stats / k_af_stats_reduce
-    float* statpart;      // partials of the above
-    float* bandpart;      // (4*bs, kAfBinSlices, 24) partial band energies
-    float* losses;        // 5 weighted loss scalars out
-    float* coef;          // backward coefficients
-    const float* grad_losses;  // (5) upstream dL/d(loss_k)
-    float* grad_pred;     // (bs, 2, n)
-    float* yframes;       // (2*bs, n_frames, kAfFft) windowed adjoint frames of the prediction's mid / side signals
-    float weights[5];
-    int bs, n_frames, n_groups, n_statblk;
-    int64_t n;
-};
-
-// signal index s in [0, 4*bs): which = s / bs (0 pred mid, 1 pred side, 2 target mid, 3 target side), b = s % bs
-__device__ __forceinline__ void af_signal(const AfArgs& a, int s, const float*& l, const float*& r, float& sign) {
-    const int which = s / a.bs, b = s % a.bs;
-    const float* base = (which < 2 ? a.pred : a.target) + (int64_t)b * 2 * a.n;
-    l = base;
-    r = base + a.n;
-    sign = (which & 1) ? -1.0f : 1.0f;
-}
-
-// pack frame f of (L + sign R) as z[m] = w[2m] x[2m] + i w[2m+1] x[2m+1]
-template <bool SWZ>
-__device__ __forceinline__ void af_load_frame(float2* buf, const float* l, const float* r, float sign, const float* win, int f,
-                                              int64_t n, int tid) {
-    const int64_t start = (int64_t)f * kAfHop - kAfFft / 2;
-    // interior frames of 16-byte aligned rows (all but the two reflected ends): eight samples per lane and step
-    if (start >= 0 && start + kAfFft <= n && !(((uintptr_t)l | (uintptr_t)r) & 15) && !(n & 3)) {
-        for (int q = tid; q < kAfM / 4; q += kAfThreads) {
-            const int m = 4 * q;
-            const float4 l0 = *reinterpret_cast<const float4*>(l + start + 2 * m), l1 = *reinterpret_cast<const float4*>(l + start + 2 * m + 4);
-            const float4 r0 = *reinterpret_cast<const float4*>(r + start + 2 * m), r1 = *reinterpret_cast<const float4*>(r + start + 2 * m + 4);
-            const float2* w2 = reinterpret_cast<const float2*>(win + 2 * m);  // the window table is 8-byte aligned
-            const float2 wa = w2[0], wb = w2[1], wc = w2[2], wd = w2[3];
-            buf[swzT<SWZ>(m)] = make_float2(wa.x * (l0.x + sign * r0.x), wa.y * (l0.y + sign * r0.y));
-            buf[swzT<SWZ>(m + 1)] = make_float2(wb.x * (l0.z + sign * r0.z), wb.y * (l0.w + sign * r0.w));
-            buf[swzT<SWZ>(m + 2)] = make_float2(wc.x * (l1.x + sign * r1.x), wc.y * (l1.y + sign * r1.y));
-            buf[swzT<SWZ>(m + 3)] = make_float2(wd.x * (l1.z + sign * r1.z), wd.y * (l1.w + sign * r1.w));
-        }
-        return;
-    }
-    for (int m = tid; m < kAfM; m += kAfThreads) {
-        const int64_t i0 = af_reflect(start + 2 * m, n), i1 = af_reflect(start + 2 * m + 1, n);
-        const float x0 = l[i0] + sign * r[i0], x1 = l[i1] + sign * r[i1];
-        buf[swzT<SWZ>(m)] = make_float2(win[2 * m] * x0, win[2 * m + 1] * x1);
-    }
-}
-
-// X[k] and X[M-k] of the real frame from the digit-reversed half-size spectrum
-__device__ __forceinline__ int rev4_6(int k) {  // reverse the 6 base-4 digits of a 12-bit index
-    int r = 0;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        r = (r << 2) | (k & 3);
-        k >>= 2;
-    }
-    return r;
-}
-// X[k], X[M-k] from the half-size spectrum values z[k], z[M-k] and w = W_N^k
-__device__ __forceinline__ void af_untangle_core(float2 zk, float2 zm, float2 w, float2& Xk, float2& Xm) {
-    const float2 E = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
-    const float2 O = make_float2(0.5f * (zk.y + zm.y), -0.5f * (zk.x - zm.x));
-    const float2 wo = cmulf(w, O);
-    Xk = make_float2(E.x + wo.x, E.y + wo.y);
-    Xm = make_float2(E.x - wo.x, -(E.y - wo.y));
-}
-template <bool SWZ>
-__device__ __forceinline__ void af_untangle(const float2* buf, const float2* twN, int k, float2& Xk, float2& Xm) {
-    const float2 zk = buf[swzT<SWZ>(rev4_7(k))], zm = buf[swzT<SWZ>(rev4_7((kAfM - k) & (kAfM - 1)))];
-    const float2 E = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));      // even-sample spectrum
-    const float2 O = make_float2(0.5f * (zk.y + zm.y), -0.5f * (zk.x - zm.x));     // odd-sample spectrum
-    const float2 wo = cmulf(twN[k], O);
-    Xk = make_float2(E.x + wo.x, E.y + wo.y);
-    Xm = make_float2(E.x - wo.x, -(E.y - wo.y));  // X[M-k] = conj(E - W^k O)
-}
-
-__global__ __launch_bounds__(kAfThreads) void k_af_bark_fwd(AfArgs a) {
-    __shared__ __attribute__((aligned(16))) float2 buf[kAfM];
-    __shared__ AfTw T;
-    const int tid = threadIdx.x, s = blockIdx.y, grp = blockIdx.x;
-    const float2* twM = reinterpret_cast<const float2*>(a.tables + kAfTwM);
-    const float2* twN = reinterpret_cast<const float2*>(a.tables + kAfTwN);
-    const float* win = a.tables + kAfWin;
-    for (int i = tid; i < kAfM / 64; i += kAfThreads) T.coarse[i] = twM[i * 64];
-    for (int i = tid; i < 64; i += kAfThreads) T.fine[i] = twM[i];
-    const float *l, *r;
-    float sign;
-    af_signal(a, s, l, r, sign);
-    // The spectrum sits digit-reversed in plain (unswizzled) slots.  Lane tid owns the slot groups m = tid + 1024 j
-    // (j < 4): slots 4m, 4m+1 hold bins k = d 4096 + r (d = 0, 1; r = rev4_6(m)) and their mirrors M - k sit in slots
-    // 4m'+3, 4m'+2 with m' = rev4_6(4096 - r) - two 16-byte LDS reads per group, consecutive lanes on consecutive
-    // groups.  (m = 0 pairs bins 0 / M and 4096 / 12288 in slots 0, 1, 3; lane 0 also owns bin M/2.)
-    int rr[4], mp[4];
-    float2 w0[4], w1[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int m = tid + kAfThreads * j;
-        rr[j] = rev4_6(m);
-        mp[j] = rev4_6((4096 - rr[j]) & 4095);
-        w0[j] = twN[rr[j]];
-        w1[j] = twN[4096 + rr[j]];
-    }
-    float acc_lo[8], acc_hi[8], acc_mid = 0.0f;  // [2 j + d]: bin k = d 4096 + rr[j]  and its mirror
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc_lo[j] = acc_hi[j] = 0.0f;
-    // strips of near-equal length: frames [grp F / G, (grp+1) F / G)
-    const int f0 = (int)(((int64_t)grp * a.n_frames) / a.n_groups), f1 = (int)(((int64_t)(grp + 1) * a.n_frames) / a.n_groups);
-    for (int f = f0; f < f1; ++f) {
-        __syncthreads();
-        af_load_frame<false>(buf, l, r, sign, win, f, a.n, tid);
-        __syncthreads();
-        fft16k_dif<false>(buf, T, tid);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int m = tid + kAfThreads * j;
-            const float4 zk2 = *reinterpret_cast<const float4*>(&buf[4 * m]);
-            float4 zm2 = *reinterpret_cast<const float4*>(&buf[4 * mp[j] + 2]);
-            if (m == 0) zm2 = make_float4(buf[3].x, buf[3].y, buf[0].x, buf[0].y);  // mirrors of bins 4096 and 0
-            float2 Xk, Xm;
-            af_untangle_core(make_float2(zk2.x, zk2.y), make_float2(zm2.z, zm2.w), w0[j], Xk, Xm);
-            acc_lo[2 * j] += sqrtf(Xk.x * Xk.x + Xk.y * Xk.y);
-            acc_hi[2 * j] += sqrtf(Xm.x * Xm.x + Xm.y * Xm.y);  // k = 0 -> bin M (Nyquist)
-            af_untangle_core(make_float2(zk2.z, zk2.w), make_float2(zm2.x, zm2.y), w1[j], Xk, Xm);
-            acc_lo[2 * j + 1] += sqrtf(Xk.x * Xk.x + Xk.y * Xk.y);
-            acc_hi[2 * j + 1] += sqrtf(Xm.x * Xm.x + Xm.y * Xm.y);
-        }
-        if (tid == 0) {
-            float2 Xk, Xm;
-            af_untangle<false>(buf, twN, kAfM / 2, Xk, Xm);
-            acc_mid += sqrtf(Xk.x * Xk.x + Xk.y * Xk.y);
-        }
-    }
-    float* out = a.magpart + ((int64_t)s * a.n_groups + grp) * kAfBins;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-#pragma unroll
-        for (int d = 0; d < 2; ++d) {
-            const int k = d * 4096 + rr[j];
-            out[k] = acc_lo[2 * j + d];
-            out[kAfM - k] = acc_hi[2 * j + d];  // k = 0 writes bin M
-        }
-    }
-    if (tid == 0) out[kAfM / 2] = acc_mid;
-}
 
 // mean over frames + filterbank, one slice of the bins per workgroup.  grid (kAfBinSlices, 4*bs), 256 lanes.
 constexpr int kAfStatSpan = 256 * 16;  // samples per k_af_stats workgroup
@@ -504,74 +249,6 @@ __global__ __launch_bounds__(256) void k_af_bark_dmag(AfArgs a) {
     }
 }
 
-// bark adjoint: one frame of one prediction signal per workgroup
-__global__ __launch_bounds__(kAfThreads) void k_af_bark_bwd(AfArgs a) {
-    __shared__ __attribute__((aligned(16))) float2 buf[kAfM];
-    __shared__ AfTw T;
-    const int tid = threadIdx.x, s = blockIdx.y, f = blockIdx.x;  // s < 2*bs
-    const float2* twM = reinterpret_cast<const float2*>(a.tables + kAfTwM);
-    const float2* twN = reinterpret_cast<const float2*>(a.tables + kAfTwN);
-    const float* win = a.tables + kAfWin;
-    for (int i = tid; i < kAfM / 64; i += kAfThreads) T.coarse[i] = twM[i * 64];
-    for (int i = tid; i < 64; i += kAfThreads) T.fine[i] = twM[i];
-    const float *l, *r;
-    float sign;
-    af_signal(a, s, l, r, sign);
-    const float* dM = a.meanmag + (int64_t)(4 * a.bs + s) * kAfBins;
-    __syncthreads();
-    af_load_frame<true>(buf, l, r, sign, win, f, a.n, tid);
-    __syncthreads();
-#ifndef MST_AF_ABLATE
-#define MST_AF_ABLATE 0  // timing ablations (wrong results): 2 no inverse transform, 3 no transforms
-#endif
-    if (MST_AF_ABLATE < 3) fft16k_dif<true>(buf, T, tid);
-    // For each mirror pair (k, M-k): G = dM * X / |X|, Hermitian extension H (H[k] = G[k]/2 inside,
-    // real at 0 and M), then the half-size packing  A[k] = H[k] + conj(H[M-k]),
-    // Bq[k] = (H[k] - conj(H[M-k])) conj(W^k);  slot(k) <- conj(A + i Bq)  (inverse = conj FFT conj).
-    for (int j = 0; j <= 8; ++j) {
-        const int k = tid + kAfThreads * j;
-        if (k > kAfM / 2) break;
-        float2 Xk, Xm;
-        af_untangle<true>(buf, twN, k, Xk, Xm);
-        const float ak = sqrtf(Xk.x * Xk.x + Xk.y * Xk.y), am = sqrtf(Xm.x * Xm.x + Xm.y * Xm.y);
-        const float gk = ak > 0.f ? dM[k] / ak : 0.f, gm = am > 0.f ? dM[kAfM - k] / am : 0.f;
-        float2 Hk = make_float2(gk * Xk.x, gk * Xk.y), Hm = make_float2(gm * Xm.x, gm * Xm.y);  // G[k], G[M-k]
-        if (k == 0) {
-            Hk = make_float2(Hk.x, 0.f);  // H[0] = Re G[0]
-            Hm = make_float2(Hm.x, 0.f);  // H[M] = Re G[M]
-        } else {
-            Hk = make_float2(0.5f * Hk.x, 0.5f * Hk.y);
-            Hm = make_float2(0.5f * Hm.x, 0.5f * Hm.y);
-        }
-        const float2 w = twN[k];             // W^k ; W^(M-k) = -conj(W^k)
-        // index k:    A = Hk + conj(Hm) ;  Bq = (Hk - conj(Hm)) conj(W^k)
-        const float2 Ak = make_float2(Hk.x + Hm.x, Hk.y - Hm.y);
-        const float2 Bk = cmulf(make_float2(Hk.x - Hm.x, Hk.y + Hm.y), cconj(w));
-        // index M-k:  A = Hm + conj(Hk) ;  Bq = (Hm - conj(Hk)) conj(W^(M-k)) = (Hm - conj(Hk)) (-W^k)
-        const float2 Am = make_float2(Hm.x + Hk.x, Hm.y - Hk.y);
-        const float2 Bm = cmulf(make_float2(Hm.x - Hk.x, Hm.y + Hk.y), make_float2(-w.x, -w.y));
-        // value = A + i Bq = (A.x - B.y, A.y + B.x); store its conjugate
-        const int pk = swz(rev4_7(k & (kAfM - 1))), pm = swz(rev4_7((kAfM - k) & (kAfM - 1)));
-        if (k == 0) {
-            // slot 0 combines H[0] and H[M]: A[0] = H[0] + H[M], Bq[0] = H[0] - H[M] (both real)
-            buf[pk] = make_float2(Hk.x + Hm.x, -(Hk.x - Hm.x));
-        } else {
-            buf[pk] = make_float2(Ak.x - Bk.y, -(Ak.y + Bk.x));
-            if (k != kAfM / 2) buf[pm] = make_float2(Am.x - Bm.y, -(Am.y + Bm.x));
-        }
-    }
-    __syncthreads();
-    if (MST_AF_ABLATE < 2) fft16k_dit(buf, T, tid);
-    // conj(result) = y_even + i y_odd; the windowed frame goes to its own slot of `yframes` (coalesced 8-byte stores) -
-    // k_af_bwd_gather overlap-adds the frames, owner-computes (no atomics: the gradient is bitwise reproducible)
-    float2* yf = reinterpret_cast<float2*>(a.yframes + ((int64_t)s * a.n_frames + f) * kAfFft);
-    for (int m = tid; m < kAfM; m += kAfThreads) {
-        const float2 v = buf[swz(m)];
-        const float2 w = *reinterpret_cast<const float2*>(win + 2 * m);
-        yf[m] = make_float2(w.x * v.x, -w.y * v.y);
-    }
-}
-
 // grad_pred = closed-form features (energy-type + crest, elementwise) + overlap-add of the Bark adjoint frames.
 // Sample i of the reflect-padded signal sits at padded position p = i + N/2; frame f covers [f hop, f hop + N).  A sample
 // collects every frame over its own position and, within N/2 of an end, over its mirror position (torch reflect padding).
@@ -661,6 +338,11 @@ __global__ void k_af_tables(float* tables) {
         tables[kAfTwN + 2 * t] = (float)cos(ang);
         tables[kAfTwN + 2 * t + 1] = (float)(-sin(ang));
     }
+    if (t < kAfHalf) {
+        const double ang = 6.283185307179586476925 * (double)t / (double)kAfHalf;
+        tables[kAfTwH + 2 * t] = (float)cos(ang);
+        tables[kAfTwH + 2 * t + 1] = (float)(-sin(ang));
+    }
     if (t < kAfFft) {
         const float ph = 6.283185307179586f * (float)t / (float)kAfFft;  // torch.hann_window(32768), periodic
         tables[kAfWin + t] = 0.5f - 0.5f * (float)cos((double)ph);
@@ -672,13 +354,13 @@ struct AfPlan {
     int64_t magpart, meanmag, bark, statpart, bandpart, stats, coef, yframes, total;
     bool ok;
 };
-// frames of a signal are cut into G strips (one workgroup each, one 128 KiB workgroup per CU, 256 CUs): choose G to
-// minimise  rounds x longest strip  = ceil(G S / 256) x ceil(F / G);  e.g. F = 33, S = 32: G = 8 -> 1 x 5 (G = 9: 2 x 4)
+// frames of a (signal, half) unit are cut into G strips (one workgroup each, kAf2Slots co-resident): choose G to
+// minimise  rounds x longest strip  = ceil(G U / slots) x ceil(F / G);  e.g. F = 33, U = 64: G = 8 -> 1 x 5 (G = 9: 2 x 4)
 static int af_groups(int n_frames, int n_signals) {
     int best = 1;
     int64_t best_cost = INT64_MAX;
     for (int g = 1; g <= n_frames; ++g) {
-        const int64_t rounds = ((int64_t)g * n_signals + 255) / 256, len = (n_frames + g - 1) / g;
+        const int64_t rounds = ((int64_t)g * n_signals + kAf2Slots - 1) / kAf2Slots, len = (n_frames + g - 1) / g;
         const int64_t cost = rounds * len * 1024 + g;  // ties: fewer partial-sum rows
         if (cost < best_cost) { best_cost = cost; best = g; }
     }
@@ -689,7 +371,7 @@ static AfPlan af_plan(int bs, int64_t n) {
     p.ok = bs > 0 && n > kAfFft / 2;
     if (!p.ok) return p;
     p.n_frames = 1 + (int)(n / kAfHop);
-    p.n_groups = af_groups(p.n_frames, 4 * bs);
+    p.n_groups = af_groups(p.n_frames, 8 * bs);
     p.n_statblk = (int)((n + kAfStatSpan - 1) / kAfStatSpan);
     int64_t o = 0;
     auto take = [&](int64_t k) { int64_t at = o; o += round_up(k, 64); return at; };
@@ -740,7 +422,7 @@ extern "C" int mst_afloss_forward(const float* pred, const float* target, int32_
     AfArgs a = af_args(p, bs, n_samples, pred, target, (const float*)tables, filterbank, weights5, (float*)workspace);
     a.losses = losses5;
     hipLaunchKernelGGL(k_af_stats, dim3(p.n_statblk, 2 * bs), dim3(256), 0, stream, a);
-    hipLaunchKernelGGL(k_af_bark_fwd, dim3(p.n_groups, 4 * bs), dim3(kAfThreads), 0, stream, a);
+    launch_af2_bark_fwd(a, stream);
     hipLaunchKernelGGL(k_af_bark_reduce, dim3(kAfBinSlices, 4 * bs), dim3(256), 0, stream, a);
     hipLaunchKernelGGL(k_af_finish, dim3(4 * bs), dim3(64), 0, stream, a);
     hipLaunchKernelGGL(k_af_final, dim3(1), dim3(64), 0, stream, a);
@@ -759,7 +441,7 @@ extern "C" int mst_afloss_backward(const float* pred, const float* target, int32
     a.grad_pred = grad_pred;
     hipLaunchKernelGGL(k_af_coef, dim3(1), dim3(64), 0, stream, a);
     hipLaunchKernelGGL(k_af_bark_dmag, dim3((kAfBins + 255) / 256, 2 * bs), dim3(256), 0, stream, a);
-    hipLaunchKernelGGL(k_af_bark_bwd, dim3(p.n_frames, 2 * bs), dim3(kAfThreads), 0, stream, a);
+    launch_af2_bark_bwd(a, stream);
     hipLaunchKernelGGL(k_af_bwd_gather, dim3((unsigned)((n_samples + 1023) / 1024), bs), dim3(256), 0, stream, a);
     return (int)hipGetLastError();
 }
