@@ -209,6 +209,7 @@ __global__ __launch_bounds__(320) void k_prep(PrepArgs a) {
         const int gi = is_master ? 25 : 0;
         if (gin_on) gin = (float)exp2((double)(denorm(p[gi], lo[gi], hi[gi]) / 20.0f) * 3.321928094887362);
         rc[RC_GIN] = gin;
+        coef[30] = gin;
         if (is_master) {
             float gout = 1.0f;
             if (d.flags & MST_USE_OUTPUT_FADER) gout = (float)exp2((double)(denorm(p[24], lo[24], hi[24]) / 20.0f) * 3.321928094887362);
@@ -234,14 +235,15 @@ __global__ __launch_bounds__(320) void k_prep(PrepArgs a) {
     __syncthreads();
     if (tid < 30) {
         float v = coef[tid];
-        if (tid < 3) v *= rc[RC_GIN];  // fold the input fader into section 0's numerator
+        if (tid < 3) v *= coef[30];  // fold the input fader (this row's gin, parked in LDS by lane 128) into section 0's numerator
         rc[RC_SOS + tid] = v;
+        coef[tid] = v;  // the table chains below read the folded coefficients from LDS, not back from HBM
     }
     __syncthreads();
 
     // ---- one-sample transition matrices of the forward and the adjoint cascade (zero input)
     double c64[30];
-    for (int i = 0; i < 30; ++i) c64[i] = (double)rc[RC_SOS + i];
+    for (int i = 0; i < 30; ++i) c64[i] = (double)coef[i];
     const int part = blockIdx.y;
     if (part == 0) {
     if (tid < 24) {

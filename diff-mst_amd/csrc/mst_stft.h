@@ -31,6 +31,12 @@ struct StftArgs {
     int64_t n;
     float eps;
     int accumulate;        // round-2 backward: 0 = this launch owns grad_pred (plain stores), 1 = it adds to what is there
+    // Seam hand-over between launches (null: a seam-mode launch adds both seam halves with atomics onto a zeroed buffer).
+    // A seam-mode launch (8192) stores every block once - a strip's trailing half frame goes to grad_pred, the half frame that
+    // opens the NEXT strip goes to the same samples of `seam` - and the first halo-mode launch after it adds `seam` back at
+    // exactly those blocks (seam_frames / seam_groups describe the seam launch's strips; seam_hop its block length).
+    float* seam;           // (rows, n) scratch, only seam blocks are ever touched
+    int seam_frames, seam_groups, seam_hop;
 };
 
 constexpr float kLn2 = 0.6931471805599453f;

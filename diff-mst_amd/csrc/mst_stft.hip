@@ -601,30 +601,29 @@ struct LossArgs {
     float w_sc, w_log, w_lin;
     int sc_per_example;
 };
-// One 1024-lane workgroup closes the loss.  Stage 1: every (row, resolution) pair is folded by ONE wave from that row's
-// strip partials (fp64, fixed order - the result does not depend on how pairs are dealt to waves); stage 2: loss scalar +
-// per-row backward coefficients (without dL/dloss, which the backward kernels apply).
-constexpr int kReduceLanes = 1024;
-__global__ __launch_bounds__(kReduceLanes) void k_mrstft_reduce(LossArgs a) {
-    __shared__ double rs[kMaxRes][4];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int pair = wave; pair < a.n_res * a.rows; pair += kReduceLanes / 64) {
-        const int res = pair / a.rows, row = pair % a.rows;
-        const float* p = a.part + a.part_off[res] + (int64_t)row * a.n_groups[res] * 4;
-        double s[4] = {0, 0, 0, 0};
-        for (int g = lane; g < a.n_groups[res]; g += 64) {
-            const float4 v = *reinterpret_cast<const float4*>(p + (int64_t)g * 4);
-            s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            for (int m = 32; m >= 1; m >>= 1) s[q] += __shfl_xor(s[q], m);
-        if (lane == 0) {
-            float* o = a.sums + ((int64_t)res * a.rows + row) * 4;
-            o[0] = (float)s[0]; o[1] = (float)s[1]; o[2] = (float)s[2]; o[3] = (float)s[3];
-        }
+// (One merged 1024-lane launch measured 15.5-21.6 us against 5.0 + 6.7 us for these two: sixteen waves on one CU walking three
+// pairs each lose more to their serial fp64 chains than the second launch costs.)
+// stage 1: one 64-lane workgroup per (row, resolution) folds that row's strip partials (fp64, fixed order)
+__global__ __launch_bounds__(64) void k_mrstft_rowsums(LossArgs a) {
+    const int tid = threadIdx.x, row = blockIdx.x, res = blockIdx.y;
+    const float* p = a.part + a.part_off[res] + (int64_t)row * a.n_groups[res] * 4;
+    double s[4] = {0, 0, 0, 0};
+    for (int g = tid; g < a.n_groups[res]; g += 64) {
+        const float4 v = *reinterpret_cast<const float4*>(p + (int64_t)g * 4);
+        s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
     }
-    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        for (int m = 32; m >= 1; m >>= 1) s[q] += __shfl_xor(s[q], m);
+    if (tid == 0) {
+        float* o = a.sums + ((int64_t)res * a.rows + row) * 4;
+        o[0] = (float)s[0]; o[1] = (float)s[1]; o[2] = (float)s[2]; o[3] = (float)s[3];
+    }
+}
+// stage 2: loss scalar + per-row backward coefficients (without dL/dloss, applied by k_scale_coef)
+__global__ __launch_bounds__(64) void k_mrstft_final(LossArgs a) {
+    __shared__ double rs[kMaxRes][4];
+    const int tid = threadIdx.x;
     if (tid < a.n_res) {
         const int res = tid;
         double tot[4] = {0, 0, 0, 0}, sc_acc = 0.0;
@@ -643,7 +642,7 @@ __global__ __launch_bounds__(kReduceLanes) void k_mrstft_reduce(LossArgs a) {
         for (int res = 0; res < a.n_res; ++res) total += rs[res][3];
         a.loss[0] = (float)(total / a.n_res);
     }
-    for (int i = tid; i < a.n_res * a.rows; i += kReduceLanes) {
+    for (int i = tid; i < a.n_res * a.rows; i += 64) {
         const int res = i / a.rows;
         const float* sm = a.sums + (int64_t)i * 4;
         double c_sc;
@@ -670,7 +669,8 @@ struct Plan {
     int64_t part_off[kMaxRes];
     int64_t tables_floats;
     // workspace (floats): part | sums | coef | coef_scaled
-    int64_t part_total, sums_off, coef_off, coefs_off, ws_floats;
+    int64_t part_total, sums_off, coef_off, coefs_off, seam_off, ws_floats;
+    int seam_res;  // index of the one seam-mode resolution whose seams are handed to a halo-mode launch, or -1
     bool ok;
 };
 Plan make_plan(const mst_mrstft_desc* d) {
@@ -729,7 +729,22 @@ Plan make_plan(const mst_mrstft_desc* d) {
     p.sums_off = p.part_total;
     p.coef_off = p.sums_off + round_up((int64_t)d->n_res * d->rows * 4, 64);
     p.coefs_off = p.coef_off + round_up((int64_t)d->n_res * d->rows * 4, 64);
-    p.ws_floats = p.coefs_off + round_up((int64_t)d->n_res * d->rows * 4, 64);
+    p.seam_off = p.coefs_off + round_up((int64_t)d->n_res * d->rows * 4, 64);
+    p.ws_floats = p.seam_off;
+    // backward seam hand-over (mst_stft.h): exactly one seam-mode resolution, at least one halo-mode one, all on the round-2 kernels
+    p.seam_res = -1;
+    {
+        int n_seam = 0, n_halo = 0, which = -1;
+        bool all2 = true;
+        for (int i = 0; i < d->n_res; ++i) {
+            all2 = all2 && p.engine2[i];
+            if (stft2_bwd_needs_zero(p.res[i].n_fft)) { ++n_seam; which = i; } else ++n_halo;
+        }
+        if (all2 && n_seam == 1 && n_halo >= 1) {
+            p.seam_res = which;
+            p.ws_floats += round_up((int64_t)d->rows * d->n_samples, 64);
+        }
+    }
     p.ok = true;
     return p;
 }
@@ -815,7 +830,8 @@ extern "C" int mst_mrstft_forward(const mst_mrstft_desc* d, const float* pred, c
         la.part_off[i] = p.part_off[i];
         la.count[i] = (float)((double)d->rows * p.res[i].n_bins * p.res[i].n_frames);
     }
-    hipLaunchKernelGGL(k_mrstft_reduce, dim3(1), dim3(kReduceLanes), 0, stream, la);
+    hipLaunchKernelGGL(k_mrstft_rowsums, dim3(d->rows, d->n_res), dim3(64), 0, stream, la);
+    hipLaunchKernelGGL(k_mrstft_final, dim3(1), dim3(64), 0, stream, la);
     return (int)hipGetLastError();
 }
 
@@ -832,10 +848,14 @@ extern "C" int mst_mrstft_backward(const mst_mrstft_desc* d, const float* pred, 
     if (all2) {
         // round-2 kernels: owner-computes overlap-add.  Seam-mode resolutions (8192) go first, onto a zeroed buffer; the
         // halo-mode ones follow and add to it; with no seam-mode resolution the first launch owns the buffer (no memset).
+        // With exactly one seam-mode resolution and a halo-mode one behind it the seams are handed over through a scratch slab
+        // instead (no memset, no atomics: every sample is stored once by the seam launch and read-modified once per later launch).
         bool zero = false;
         for (int i = 0; i < d->n_res; ++i) zero = zero || stft2_bwd_needs_zero(p.res[i].n_fft);
-        if (zero) (void)hipMemsetAsync(grad_pred, 0, (size_t)d->rows * d->n_samples * sizeof(float), stream);
+        const bool handover = p.seam_res >= 0;
+        if (zero && !handover) (void)hipMemsetAsync(grad_pred, 0, (size_t)d->rows * d->n_samples * sizeof(float), stream);
         bool written = zero;
+        bool pending = handover;  // the parked seam halves still wait for a halo-mode launch
         for (int pass = 0; pass < 2; ++pass) {
             for (int i = 0; i < d->n_res; ++i) {
                 if (stft2_bwd_needs_zero(p.res[i].n_fft) != (pass == 0)) continue;
@@ -852,6 +872,14 @@ extern "C" int mst_mrstft_backward(const mst_mrstft_desc* d, const float* pred, 
                 a.n = d->n_samples;
                 a.eps = d->eps;
                 a.accumulate = (pass == 1 && written) ? 1 : 0;
+                if (handover && (pass == 0 || pending)) {
+                    const ResInfo& sr = p.res[p.seam_res];
+                    a.seam = ws + p.seam_off;
+                    a.seam_frames = sr.n_frames;
+                    a.seam_groups = stft2_bwd_groups(sr.n_fft, sr.n_frames);
+                    a.seam_hop = sr.n_fft / 2;
+                    if (pass == 1) pending = false;
+                }
                 launch_stft2_bwd(a, stft2_bwd_groups(a.r.n_fft, a.r.n_frames), d->rows, stream);
                 written = true;
             }

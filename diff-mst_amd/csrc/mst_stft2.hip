@@ -236,9 +236,23 @@ __global__ __launch_bounds__(FftPlan<N>::LG, (N == 8192 ? MST_STFT2_W8192_BWD : 
     }
     // offset, inside a hop block, of half-frame value q of this lane
     auto pos = [&](int q) { return PAIR ? lane + LG * q : 2 * lane + 1024 * (q >> 1) + (q & 1); };
+    // halo-mode launch that follows a seam-mode one: does the seam launch's block holding sample `at` have its second
+    // contribution parked in a.seam?  (frame t opens a strip of the seam launch iff t = floor(j F / G) for some 1 <= j < G)
+    auto parked = [&](int at) {
+        if (SEAMS || !a.seam) return false;
+        const int t = at / a.seam_hop + 1, F = a.seam_frames, G = a.seam_groups;
+        const int j = (int)(((unsigned)t * (unsigned)G + (unsigned)F - 1u) / (unsigned)F);
+        return j >= 1 && j < G && (int)(((unsigned)j * (unsigned)F) / (unsigned)G) == t;
+    };
     auto put = [&](int block, const float* v, bool rmw) {  // write one complete block
         float* g = gx + block * H;
         if constexpr (PAIR) {
+            if (parked(block * H)) {  // workgroup-uniform
+                const float* sc = a.seam + (int64_t)row * a.n + block * H;
+#pragma unroll
+                for (int q = 0; q < K; ++q) g[pos(q)] = (rmw ? g[pos(q)] : 0.0f) + sc[pos(q)] + v[q];
+                return;
+            }
 #pragma unroll
             for (int q = 0; q < K; ++q) g[pos(q)] = rmw ? g[pos(q)] + v[q] : v[q];
         } else {
@@ -250,7 +264,20 @@ __global__ __launch_bounds__(FftPlan<N>::LG, (N == 8192 ? MST_STFT2_W8192_BWD : 
             }
         }
     };
-    auto seam = [&](int block, const float* v) {  // SEAM mode: one of the two contributions to a shared block
+    // SEAM mode: one of the two contributions to a block shared with a neighbour strip.  `opening` = the first half of this
+    // strip's first frame (the other one is the previous strip's trailing half).
+    auto seam = [&](int block, const float* v, bool opening) {
+        if (a.seam) {  // hand-over: each half is stored once, the next launch adds the parked one
+            if (opening) {
+                float* sc = a.seam + (int64_t)row * a.n + block * H;
+#pragma unroll
+                for (int t = 0; t < K / 2; ++t)
+                    *reinterpret_cast<float2*>(sc + 2 * lane + 1024 * t) = make_float2(v[2 * t], v[2 * t + 1]);
+            } else {
+                put(block, v, a.accumulate != 0);
+            }
+            return;
+        }
         float* g = gx + block * H;
 #pragma unroll
         for (int q = 0; q < K; ++q) unsafeAtomicAdd(&g[pos(q)], v[q]);
@@ -284,7 +311,7 @@ __global__ __launch_bounds__(FftPlan<N>::LG, (N == 8192 ? MST_STFT2_W8192_BWD : 
                 for (int q = 0; q < K; ++q) first[q] += carry[q];
                 put(f - 1, first, a.accumulate != 0);
             } else if (SEAMS) {
-                seam(f - 1, first);
+                seam(f - 1, first, true);
             }
         }
         if (f == B) {
@@ -422,7 +449,7 @@ __global__ __launch_bounds__(FftPlan<N>::LG, (N == 8192 ? MST_STFT2_W8192_BWD : 
     }
     // trailing second half of a strip that does not end the row: the seam shared with the next strip (halo mode: the next
     // strip recomputes this frame and owns the block)
-    if (SEAMS && have_carry) seam(F1 - 1, carry);
+    if (SEAMS && have_carry) seam(F1 - 1, carry, false);
 }
 
 int stft2_bwd_groups(int n_fft, int n_frames) {
