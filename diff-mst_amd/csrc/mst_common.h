@@ -21,6 +21,7 @@ constexpr int kScanLevels = 9;         // log2(kScanThreads)
 constexpr int kPow = 1 + kScanLevels;  // matrices per scan table: M, then M^(K*2^j)
 constexpr int kTile = kEqWG * kEqChunk;  // samples one single-wave workgroup of the EQ kernels covers (4096)
 constexpr int kPow1 = 12;              // in-wave scan tables: M^(2^j), j = 0..5 lanes of a tile, 6..11 tiles of a row
+constexpr int kFxDhChunks = 4;          // fx bus backward: frame chunks of the dH product (partials summed by the inverse transform)
 constexpr int kMaxTiles1 = 64;         // rows of up to 64 tiles (262144 samples) scan in-wave (no carry-scan kernel)
 
 // ---- per-filter-row constants ("rc"), written by k_prep, floats -------------------------------
@@ -168,7 +169,7 @@ struct Layout {
     int64_t aggF_t, aggF_m, aggA_t, aggA_m;      // tile aggregates sigrows x 12 x kMaxTiles1 (forward / adjoint cascade)
     // fx bus (only laid out when MST_USE_FX_BUS is set)
     int fxS, fxTaps, fxK, fxBlk, fxBlkIr;         // impulse-response samples, band-pass taps, partitions, signal blocks, ir-bwd blocks
-    int64_t fx_rc, fx_in, fx_wnf, fx_ir, fx_Xs, fx_Hs, fx_Ys, fx_dXs, fx_dHs, fx_dir, fx_din, fx_part;
+    int64_t fx_rc, fx_in, fx_wnf, fx_ir, fx_Xs, fx_Hs, fx_Ys, fx_dXs, fx_dHs, fx_dir, fx_din, fx_part, fx_Hf;
     int64_t total;                       // floats
 };
 
@@ -260,10 +261,11 @@ inline Layout make_layout(const mst_console_desc* d) {
         L.fx_Hs = take(B * (int64_t)L.fxK * 8192 * 2);
         L.fx_Ys = take(B * (int64_t)L.fxBlk * 8192 * 2);
         L.fx_dXs = take(B * (int64_t)L.fxBlk * 8192 * 2);
-        L.fx_dHs = take(B * (int64_t)L.fxK * 8192 * 2);
+        L.fx_dHs = take(B * (int64_t)L.fxK * 8192 * 2 * kFxDhChunks);  // partial dH spectra, one set per frame chunk
         L.fx_dir = take(B * 2 * (int64_t)L.fxS);
         L.fx_din = take(B * 2 * N);
         L.fx_part = take(B * (int64_t)L.fxBlkIr * 24);
+        L.fx_Hf = take((int64_t)12 * 8192 * 2);  // conjugated spectra of the twelve band-pass filters
     }
     L.total = o;
     return L;

@@ -49,7 +49,7 @@ static FxPlan fx_plan(const Layout& L) {
     p.n = L.N;
     p.Ns = round_up(L.N, 4);
     p.rcfx = L.fx_rc; p.fx_in = L.fx_in; p.wnf = L.fx_wnf; p.ir = L.fx_ir; p.Xs = L.fx_Xs; p.Hs = L.fx_Hs; p.Ys = L.fx_Ys;
-    p.dXs = L.fx_dXs; p.dHs = L.fx_dHs; p.dir = L.fx_dir; p.dfx_in = L.fx_din; p.fxpart = L.fx_part;
+    p.dXs = L.fx_dXs; p.dHs = L.fx_dHs; p.dir = L.fx_dir; p.dfx_in = L.fx_din; p.fxpart = L.fx_part; p.Hf = L.fx_Hf;
     return p;
 }
 

@@ -23,42 +23,75 @@ namespace mst {
 constexpr int kFxN = 8192, kFxHop = 4096, kFxLanes = FftPlan<8192>::LG;
 
 // ---- band-pass filtering of the noise: wnf[(r,k)][n] = sum_j f[k][j] noise[(r,k)][n + j] ------------------------------
-// grid (ceil(S / 2048), 12, rows): 256 lanes x 8 consecutive outputs; filter and input window staged in LDS
-constexpr int kFirOut = 2048, kFirMaxTaps = 1024;
-__global__ __launch_bounds__(256) void k_fx_fir(const float* __restrict__ noise, const float* __restrict__ filt, float* __restrict__ wnf,
-                                                int S, int taps) {
-    __shared__ __attribute__((aligned(16))) float xs[kFirOut + kFirMaxTaps + 8];
-    __shared__ __attribute__((aligned(16))) float fs[kFirMaxTaps + 8];
-    const int tid = threadIdx.x, k = blockIdx.y, r = blockIdx.z;
-    const int n0 = blockIdx.x * kFirOut;
-    const int in_len = S + taps - 1;
-    const float* src = noise + ((int64_t)r * 12 + k) * in_len;
-    const int taps8 = (taps + 7) & ~7;
-    for (int i = tid; i < kFirOut + taps8; i += 256) xs[i] = (n0 + i < in_len) ? src[n0 + i] : 0.0f;
-    for (int i = tid; i < taps8; i += 256) fs[i] = i < taps ? filt[k * taps + i] : 0.0f;
+// Overlap-save correlation on the 8192-point engine (the direct form was the most expensive kernel of the bus: 25.7 GFLOP at
+// bs 8, 277 us at 57 % of the fp32 VALU peak; this way it is two transforms per 8192 - (taps - 1) outputs of a stereo pair).
+// The left and right noise rows of a band travel as the real and imaginary part of one complex sequence: the filter is real,
+// so the filtered pair comes back the same way and nothing has to be separated.
+//   Hc[k]   = conj(FFT8192(f[k] ++ zeros))                                   k_fx_filt_spec, 12 workgroups
+//   block c = first V = 8192 - (taps - 1) samples of IFFT8192(FFT8192(z[c V .. c V + 8192)) (.) Hc[k])
+constexpr int kFirMaxTaps = 1024;
+__global__ __launch_bounds__(kFxLanes, 4) void k_fx_filt_spec(const float* __restrict__ filt, float2* __restrict__ Hc, const float* tables, int taps) {
+    using S = FftShape<kFxN>;
+    __shared__ __attribute__((aligned(16))) float2 buf[2][S::SLOTS];
+    const int lane = threadIdx.x, k = blockIdx.x;
+    const float2* twg = reinterpret_cast<const float2*>(tables);
+    LaneTw<kFxN> tw;
+    tw.init(twg, lane);
+    fft8192_from<false>([&](int t) {
+        const int e = lane + kFxLanes * t;
+        return make_float2(e < taps ? filt[k * taps + e] : 0.0f, 0.0f);
+    }, buf[0], buf[1], tw, twg[lane], lane);
     __syncthreads();
-    float acc[8], w[16];
 #pragma unroll
-    for (int o = 0; o < 8; ++o) acc[o] = 0.0f;
-    const float* xp = xs + tid * 8;
-#pragma unroll
-    for (int o = 0; o < 8; ++o) w[o] = xp[o];
-    for (int j = 0; j < taps8; j += 8) {
-        const float4 fa = *reinterpret_cast<const float4*>(fs + j), fb = *reinterpret_cast<const float4*>(fs + j + 4);
-        const float4 xa = *reinterpret_cast<const float4*>(xp + j + 8), xb = *reinterpret_cast<const float4*>(xp + j + 12);
-        w[8] = xa.x; w[9] = xa.y; w[10] = xa.z; w[11] = xa.w; w[12] = xb.x; w[13] = xb.y; w[14] = xb.z; w[15] = xb.w;
-        const float f[8] = {fa.x, fa.y, fa.z, fa.w, fb.x, fb.y, fb.z, fb.w};
-#pragma unroll
-        for (int q = 0; q < 8; ++q)
-#pragma unroll
-            for (int o = 0; o < 8; ++o) acc[o] = fmaf(f[q], w[o + q], acc[o]);
-#pragma unroll
-        for (int o = 0; o < 8; ++o) w[o] = w[o + 8];
+    for (int t = 0; t < 16; ++t) {
+        const int q = lane + kFxLanes * t;
+        const float2 z = buf[q & 1][S::slot(q >> 1)];
+        Hc[(int64_t)k * kFxN + q] = make_float2(z.x, -z.y);
     }
-    float* dst = wnf + ((int64_t)r * 12 + k) * S + n0 + tid * 8;
+}
+// grid (ceil(S / V), 12, bs), 512 lanes
+__global__ __launch_bounds__(kFxLanes, 2) void k_fx_fir(const float* __restrict__ noise, const float2* __restrict__ Hc, float* __restrict__ wnf,
+                                                        const float* tables, int S, int taps) {
+    using Sh = FftShape<kFxN>;
+    __shared__ __attribute__((aligned(16))) float2 buf[2][Sh::SLOTS];
+    const int lane = threadIdx.x, k = blockIdx.y, b = blockIdx.z;
+    const int V = kFxN - (taps - 1), n0 = blockIdx.x * V, in_len = S + taps - 1;
+    const float2* twg = reinterpret_cast<const float2*>(tables);
+    LaneTw<kFxN> tw;
+    tw.init(twg, lane);
+    const float2 wl = twg[lane];
+    const float* xl = noise + ((int64_t)(2 * b) * 12 + k) * in_len;
+    const float* xr = noise + ((int64_t)(2 * b + 1) * 12 + k) * in_len;
+    fft8192_from<false>([&](int t) {
+        const int i = n0 + lane + kFxLanes * t;
+        return i < in_len ? make_float2(xl[i], xr[i]) : make_float2(0.f, 0.f);
+    }, buf[0], buf[1], tw, wl, lane);
+    __syncthreads();
+    // product with the filter spectrum, conjugated for the inverse (IFFT(P) = conj(FFT(conj P)) / N); element q = lane + 512 t
+    // is both what this lane reads here and what it feeds to the first pass of the second transform
+    float2 vin[16];
+    const float2* h = Hc + (int64_t)k * kFxN;
 #pragma unroll
-    for (int o = 0; o < 8; ++o)
-        if (n0 + tid * 8 + o < S) dst[o] = acc[o];
+    for (int t = 0; t < 16; ++t) {
+        const int q = lane + kFxLanes * t;
+        const float2 pz = cmul(buf[q & 1][Sh::slot(q >> 1)], h[q]);
+        vin[t] = make_float2(pz.x, -pz.y);
+    }
+    __syncthreads();  // every lane's spectrum reads are done before the first pass overwrites the buffer
+    fft8192_from<false>([&](int t) { return vin[t]; }, buf[0], buf[1], tw, wl, lane);
+    __syncthreads();
+    float* dl = wnf + ((int64_t)(2 * b) * 12 + k) * S;
+    float* dr = wnf + ((int64_t)(2 * b + 1) * 12 + k) * S;
+    constexpr float inv = 1.0f / (float)kFxN;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const int m = lane + kFxLanes * t;
+        if (m < V && n0 + m < S) {
+            const float2 y = buf[m & 1][Sh::slot(m >> 1)];
+            dl[n0 + m] = inv * y.x;
+            dr[n0 + m] = -inv * y.y;
+        }
+    }
 }
 
 // ---- impulse response: ir[r][n] = 1/12 sum_k gain[b,k] exp(-rate[b,k] n/(S-1)) wnf[r,k,n];  rcfx[b] = {gain[12], rate[12]}
@@ -233,14 +266,20 @@ __global__ __launch_bounds__(256) void k_fx_mac16(FxMacArgs g) {
             }
         }
     } else {
-        for (int base = 0; base < g.na; base += K) {
+        // the frames are dealt to gridDim.y workgroups in runs of whole 16-blocks (one block of run-in fills the ring); each
+        // writes its own partial dH, and the inverse transform behind it adds the partials (k_fx_ifft<FX_CROP>, nsum)
+        const int nb16 = (g.na + K - 1) / K, per = (nb16 + (int)gridDim.y - 1) / (int)gridDim.y;
+        const int m0 = chunk * per * K, m1 = m0 + per * K < g.na ? m0 + per * K : g.na;
+        for (int base = m0 - K; base < m1; base += K) {
 #pragma unroll
             for (int j = 0; j < K; ++j) {
                 const int m = base + j;
-                if (m >= g.na) break;
+                if (m >= m1) break;
+                if (m < 0) continue;  // the ring slots still hold zeros
+                unpack_lr(Hh[(int64_t)m * kFxN + k], Hh[(int64_t)m * kFxN + kn], rl[j], rr[j]);  // X[m] enters the ring
+                if (m < m0) continue;
                 float2 dl, dr;
                 unpack_lr(A[(int64_t)m * kFxN + k], A[(int64_t)m * kFxN + kn], dl, dr);   // dY[m]
-                unpack_lr(Hh[(int64_t)m * kFxN + k], Hh[(int64_t)m * kFxN + kn], rl[j], rr[j]);  // X[m] enters the ring
 #pragma unroll
                 for (int p = 0; p < K; ++p) {  // dH[p] += dY[m] conj(X[m - p]); slots of frames < 0 still hold zeros
                     hl[p] = cadd(hl[p], cmul(dl, cconj(rl[(j - p) & (K - 1)])));
@@ -249,15 +288,14 @@ __global__ __launch_bounds__(256) void k_fx_mac16(FxMacArgs g) {
             }
         }
 #pragma unroll
-        for (int p = 0; p < K; ++p) store(p, hl[p], hr[p]);
+        for (int p = 0; p < K; ++p) store(chunk * K + p, hl[p], hr[p]);
     }
 }
 
 // ---- inverse transforms of spectrum frames ---------------------------------------------------------------------------
 // FX_OUT : dst[b, :, m 4096 .. (m+1) 4096) += last 4096 samples of IFFT(spec[b][m])          (wet signal onto the bus)
 // FX_SCAT: dst[b, :, m 4096 .. (m+1) 4096)  = last 4096 samples of IFFT(spec[b][m]) + first 4096 samples of IFFT(spec[b][m+1])
-//          (cotangent of the send bus: frame m came from samples (m-1) 4096 .. (m+1) 4096; owner-computes - the workgroup of
-//          block m transforms both frames that overlap it, and the lane holding a sample of one holds the same sample of the other)
+//          (cotangent of the send bus: frame m came from samples (m-1) 4096 .. (m+1) 4096; owner-computes, one transform per block)
 // FX_CROP: dst[b, :, m 4096 .. (m+1) 4096)  = first 4096 samples of IFFT(spec[b][m])         (cotangent of the impulse response)
 enum { FX_OUT = 0, FX_SCAT = 1, FX_CROP = 2 };
 struct FxIfftArgs {
@@ -266,6 +304,7 @@ struct FxIfftArgs {
     int64_t stride, n;
     const float* tables;
     int frames;
+    int nsum;            // FX_CROP: the spectrum is the sum of nsum partials, `frames` frames apart (the frame axis holds nsum * frames)
 };
 template <int MODE>
 __global__ __launch_bounds__(kFxLanes, 4) void k_fx_ifft(FxIfftArgs a) {
@@ -280,30 +319,30 @@ __global__ __launch_bounds__(kFxLanes, 4) void k_fx_ifft(FxIfftArgs a) {
     // half-frame values of this lane: samples 2q, 2q + 1 for q = lane + 512 t, t = 0..3 (first half) or 4..7 (second half),
     // i.e. offsets 2 lane + 1024 (t mod 4) + {0, 1} inside a 4096-sample block; {L even, R even, L odd, R odd} per t
     float acc[4][4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t][0] = acc[t][1] = acc[t][2] = acc[t][3] = 0.0f;
-    const int nfr = MODE == FX_SCAT ? 2 : 1;
-    for (int which = 0; which < nfr; ++which) {
-        const int f = m + which;
-        if (f >= a.frames) break;
-        const float2* in = a.spec + ((int64_t)b * a.frames + f) * kFxN;
-        if (which) __syncthreads();  // the previous frame's spectrum reads are done
-        // IDFT(Z) = conj(FFT(conj(Z))) / N
-        fft8192_from<false>([&](int t) {
-            const float2 z = in[lane + kFxLanes * t];
-            return make_float2(z.x, -z.y);
-        }, buf[0], buf[1], tw, wl, lane);
-        __syncthreads();
-        const bool second = MODE == FX_OUT || (MODE == FX_SCAT && which == 0);  // which half of this frame lands on block m
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int q = lane + kFxLanes * (second ? t + 4 : t);
-            const float2 e = buf[0][S::slot(q)], o = buf[1][S::slot(q)];
-            acc[t][0] += inv * e.x;
-            acc[t][1] -= inv * e.y;
-            acc[t][2] += inv * o.x;
-            acc[t][3] -= inv * o.y;
+    const int ns = MODE == FX_CROP ? a.nsum : 1;
+    const float2* in = a.spec + ((int64_t)b * a.frames * ns + m) * kFxN;
+    const bool next = MODE == FX_SCAT && m + 1 < a.frames;
+    // IDFT(Z) = conj(FFT(conj(Z))) / N.  FX_SCAT: the last half of IFFT(Z_m) is the first half of IFFT((-1)^k Z_m) (a circular
+    // shift by N/2), so block m = first half of ONE inverse transform of (-1)^k Z_m + Z_(m+1)
+    fft8192_from<false>([&](int t) {
+        const int q = lane + kFxLanes * t;
+        float2 z = in[q];
+        for (int c = 1; c < ns; ++c) z = cadd(z, in[(int64_t)c * a.frames * kFxN + q]);
+        if (MODE == FX_SCAT) {
+            if (lane & 1) z = make_float2(-z.x, -z.y);  // q = lane + 512 t has the parity of lane
+            if (next) z = cadd(z, in[kFxN + q]);
         }
+        return make_float2(z.x, -z.y);
+    }, buf[0], buf[1], tw, wl, lane);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int q = lane + kFxLanes * (MODE == FX_OUT ? t + 4 : t);
+        const float2 e = buf[0][S::slot(q)], o = buf[1][S::slot(q)];
+        acc[t][0] = inv * e.x;
+        acc[t][1] = -inv * e.y;
+        acc[t][2] = inv * o.x;
+        acc[t][3] = -inv * o.y;
     }
     float* dl = a.dst + (int64_t)(2 * b) * a.stride + (int64_t)m * kFxHop;
     float* dr = dl + a.stride;
@@ -365,7 +404,10 @@ __global__ __launch_bounds__(256) void k_fx_ir_bwd(const float* __restrict__ wnf
 void launch_fx_forward(const FxPlan& p, const float* noise, const float* filters, const float* tables, float* ws, float* bus,
                        int64_t bus_stride, hipStream_t stream) {
     const int rows = 2 * p.bs;
-    hipLaunchKernelGGL(k_fx_fir, dim3((p.S + kFirOut - 1) / kFirOut, 12, rows), dim3(256), 0, stream, noise, filters, ws + p.wnf, p.S, p.taps);
+    float2* Hc = reinterpret_cast<float2*>(ws + p.Hf);
+    const int V = kFxN - (p.taps - 1);
+    hipLaunchKernelGGL(k_fx_filt_spec, dim3(12), dim3(kFxLanes), 0, stream, filters, Hc, tables, p.taps);
+    hipLaunchKernelGGL(k_fx_fir, dim3((p.S + V - 1) / V, 12, p.bs), dim3(kFxLanes), 0, stream, noise, Hc, ws + p.wnf, tables, p.S, p.taps);
     hipLaunchKernelGGL(k_fx_ir, dim3((p.S + 255) / 256, rows), dim3(256), 0, stream, ws + p.wnf, ws + p.rcfx, ws + p.ir, p.S);
     FxFftArgs fs{ws + p.fx_in, p.Ns, p.n, reinterpret_cast<float2*>(ws + p.Xs), tables, p.nblk};
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fx_fft<FX_SIG>), dim3(p.nblk, p.bs), dim3(kFxLanes), 0, stream, fs);
@@ -375,7 +417,7 @@ void launch_fx_forward(const FxPlan& p, const float* noise, const float* filters
                  p.nblk, p.K, p.nblk};
     if (p.K == 16) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fx_mac16<FX_MAC_Y>), dim3((kFxN / 2 + 256) / 256, (p.nblk + 15) / 16, p.bs), dim3(256), 0, stream, mc);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fx_mac<FX_MAC_Y>), dim3((kFxN / 2 + 256) / 256, p.nblk, p.bs), dim3(256), 0, stream, mc);
-    FxIfftArgs io{reinterpret_cast<const float2*>(ws + p.Ys), bus, bus_stride, p.n, tables, p.nblk};
+    FxIfftArgs io{reinterpret_cast<const float2*>(ws + p.Ys), bus, bus_stride, p.n, tables, p.nblk, 1};
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fx_ifft<FX_OUT>), dim3(p.nblk, p.bs), dim3(kFxLanes), 0, stream, io);
 }
 
@@ -389,14 +431,17 @@ void launch_fx_backward(const FxPlan& p, const float* dbus, int64_t dbus_stride,
                  p.nblk, p.K, p.nblk};
     if (p.K == 16) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fx_mac16<FX_MAC_DX>), dim3((kFxN / 2 + 256) / 256, (p.nblk + 15) / 16, p.bs), dim3(256), 0, stream, mx);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fx_mac<FX_MAC_DX>), dim3((kFxN / 2 + 256) / 256, p.nblk, p.bs), dim3(256), 0, stream, mx);
-    FxIfftArgs ix{reinterpret_cast<const float2*>(ws + p.dXs), ws + p.dfx_in, p.Ns, p.n, tables, p.nblk};
+    FxIfftArgs ix{reinterpret_cast<const float2*>(ws + p.dXs), ws + p.dfx_in, p.Ns, p.n, tables, p.nblk, 1};
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fx_ifft<FX_SCAT>), dim3(p.nblk, p.bs), dim3(kFxLanes), 0, stream, ix);
     // cotangent of the impulse response: dH[p] = sum_m dY[m] conj(X[m - p]), first 4096 samples of each inverse
+    // K = 16: the frame walk of the dH product is dealt to up to kFxDhChunks workgroups per bin slice (partials summed by the
+    // inverse transform); the generic kernel writes one spectrum per partition
+    const int nb16 = (p.nblk + 15) / 16, chunks = p.K == 16 ? (nb16 < kFxDhChunks ? nb16 : kFxDhChunks) : 1;
     FxMacArgs mh{reinterpret_cast<const float2*>(ws + p.Ys), reinterpret_cast<const float2*>(ws + p.Xs), reinterpret_cast<float2*>(ws + p.dHs),
-                 p.nblk, p.nblk, p.K};
-    if (p.K == 16) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fx_mac16<FX_MAC_DH>), dim3((kFxN / 2 + 256) / 256, 1, p.bs), dim3(256), 0, stream, mh);
+                 p.nblk, p.nblk, p.K * chunks};
+    if (p.K == 16) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fx_mac16<FX_MAC_DH>), dim3((kFxN / 2 + 256) / 256, chunks, p.bs), dim3(256), 0, stream, mh);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fx_mac<FX_MAC_DH>), dim3((kFxN / 2 + 256) / 256, p.K, p.bs), dim3(256), 0, stream, mh);
-    FxIfftArgs ih{reinterpret_cast<const float2*>(ws + p.dHs), ws + p.dir, p.S, p.S, tables, p.K};
+    FxIfftArgs ih{reinterpret_cast<const float2*>(ws + p.dHs), ws + p.dir, p.S, p.S, tables, p.K, chunks};
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fx_ifft<FX_CROP>), dim3(p.K, p.bs), dim3(kFxLanes), 0, stream, ih);
     hipLaunchKernelGGL(k_fx_ir_bwd, dim3(p.nblk_ir, p.bs), dim3(256), 0, stream, ws + p.wnf, ws + p.rcfx, ws + p.dir, ws + p.fxpart, p.S);
 }

@@ -125,7 +125,7 @@ void launch_comp_bwd(bool master, bool run, const CompBwdArgs& a, int rows, hipS
 struct FxPlan {
     int bs, S, taps, K, nblk, nblk_ir;
     int64_t n, Ns;
-    int64_t rcfx, fx_in, wnf, ir, Xs, Hs, Ys, dXs, dHs, dir, dfx_in, fxpart;
+    int64_t rcfx, fx_in, wnf, ir, Xs, Hs, Ys, dXs, dHs, dir, dfx_in, fxpart, Hf;
 };
 void launch_fx_forward(const FxPlan& p, const float* noise, const float* filters, const float* tables, float* ws, float* bus,
                        int64_t bus_stride, hipStream_t stream);
