@@ -177,6 +177,8 @@ def make_workload(dev, bs, n_tracks, n, loss_kind, seed, lean=True, flags=FLAGS,
     ref = batch_stereo_peak_normalize(ref)  # reference mst/system.py:149-176
     track_params = torch.rand(bs, n_tracks, 27).to(dev).requires_grad_(True)
     fx_params = torch.rand(bs, 25).to(dev)
+    if flags.get("use_fx_bus"):
+        fx_params.requires_grad_(True)
     master_params = torch.rand(bs, 26).to(dev).requires_grad_(True)
     if loss_kind == "mrstft":
         loss_fn = MultiResolutionSTFTLoss(**RESOLUTIONS)
@@ -189,6 +191,7 @@ def make_workload(dev, bs, n_tracks, n, loss_kind, seed, lean=True, flags=FLAGS,
     def step(marks=None):
         track_params.grad = None
         master_params.grad = None
+        fx_params.grad = None
         if basic:
             _, mix, *_ = console(tracks, track_params)
         else:
@@ -227,6 +230,9 @@ def secondary_lines(dev):
     specs = [
         ("cfg #2 API-faithful: mixed_tracks (bs,2,T,N) materialised, validate='sync' (one flag readback per call), eager "
          "parameter dictionaries", dict(bs=BS, n_tracks=T, n=N, loss_kind="mrstft", lean=False), True, 20, 5),
+        ("cfg #2 with the fx bus on (the reference's DEFAULT call flags; its configs keep the bus off): send bus + 65536-tap "
+         "noise-shaped reverberation, fresh noise drawn on the device every call, gradients to the 25 fx parameters too; lean console",
+         dict(bs=BS, n_tracks=T, n=N, loss_kind="mrstft", lean=True, flags=dict(FLAGS, use_fx_bus=True)), False, 20, 5),
         ("cfg #3: AdvancedMixConsole 16 tracks x 262144, batch 32, AudioFeatureLoss, lean console",
          dict(bs=32, n_tracks=16, n=N, loss_kind="af", lean=True), False, 6, 2),
         ("cfg #1: BasicMixConsole (gain + pan + bus sum) 4 tracks x 65536, batch 2, fwd+bwd",
