@@ -20,7 +20,8 @@ constexpr int kScanThreads = 512;      // lanes per row in the carry-scan kernel
 constexpr int kScanLevels = 9;         // log2(kScanThreads)
 constexpr int kPow = 1 + kScanLevels;  // matrices per scan table: M, then M^(K*2^j)
 constexpr int kTile = kEqWG * kEqChunk;  // samples one single-wave workgroup of the EQ kernels covers (4096)
-constexpr int kPow1 = 12;              // in-wave scan tables: M^(2^j), j = 0..5 lanes of a tile, 6..11 tiles of a row
+constexpr int kPow1 = 12;              // in-wave scans use M^(2^j), j = 0..5 (lanes of a tile) and 6..11 (tiles of a row)
+constexpr int kTri2 = 2 * 208;         // ... stored as two block-triangular table sets per row (mst_mat.h: kTriFloats each)
 constexpr int kFxDhChunks = 4;          // fx bus backward: frame chunks of the dH product (partials summed by the inverse transform)
 constexpr int kMaxTiles1 = 64;         // rows of up to 64 tiles (262144 samples) scan in-wave (no carry-scan kernel)
 
@@ -165,7 +166,7 @@ struct Layout {
     int64_t zA_t, sA_t, zA_m, sA_m;      // EQ-adjoint chunk states
     int64_t zP_t, sP_t, zP_m, sP_m;      // all-pole (coefficient-gradient) chunk states
     int64_t cp_t, cp_m, ep_t, ep_m;      // partial sums
-    int64_t pow1F_t, pow1F_m, pow1A_t, pow1A_m;  // in-wave scan tables rows x kPow1 x 144
+    int64_t pow1F_t, pow1F_m, pow1A_t, pow1A_m;  // in-wave scan tables rows x kTri2
     int64_t aggF_t, aggF_m, aggA_t, aggA_m;      // tile aggregates sigrows x 12 x kMaxTiles1 (forward / adjoint cascade)
     // fx bus (only laid out when MST_USE_FX_BUS is set)
     int fxS, fxTaps, fxK, fxBlk, fxBlkIr;         // impulse-response samples, band-pass taps, partitions, signal blocks, ir-bwd blocks
@@ -239,10 +240,10 @@ inline Layout make_layout(const mst_console_desc* d) {
     L.cp_m = take(B * L.nblkC * CP_COUNT);
     L.ep_t = take((R + 2 * B) * L.nblkE * EP_COUNT);
     L.ep_m = L.ep_t + R * L.nblkE * EP_COUNT;
-    L.pow1F_t = take((R + B) * kPow1 * 144);
-    L.pow1F_m = L.pow1F_t + R * kPow1 * 144;
-    L.pow1A_t = take((R + B) * kPow1 * 144);
-    L.pow1A_m = L.pow1A_t + R * kPow1 * 144;
+    L.pow1F_t = take((R + B) * kTri2);
+    L.pow1F_m = L.pow1F_t + R * kTri2;
+    L.pow1A_t = take((R + B) * kTri2);
+    L.pow1A_m = L.pow1A_t + R * kTri2;
     L.aggF_t = take((R + 2 * B) * kStates * kMaxTiles1);
     L.aggF_m = L.aggF_t + R * kStates * kMaxTiles1;
     L.aggA_t = take((R + 2 * B) * kStates * kMaxTiles1);

@@ -140,34 +140,39 @@ __device__ __forceinline__ void cascade_body(const float* __restrict__ in, int64
     for (int i = 0; i < 5 * kSections; ++i) c[i] = coef[i];
     float st[kStates];
     const int pos = DIR == EQ_FWD ? tid : kEqWG - 1 - tid;  // position of my chunk in recurrence order inside the tile
-    const float* tab = SCAN1 ? pw1 + (int64_t)filter_row(sig, split) * kPow1 * 144 : nullptr;
-    static_assert(kTabFloats <= kEqWG * kLdw, "a scan table is staged through the slab buffer");
-    TabRegs tlo, thi;  // M^(2^j): j = 0..5 (lanes of a tile) and j = 6..11 (tiles of a row)
-    if (SCAN1 && !MODE_RUN) tab_fetch(tlo, tab, tid);
+    const float* tab = SCAN1 ? pw1 + (int64_t)filter_row(sig, split) * kTri2 : nullptr;
+    TabRegs tlo, thi;  // table sets of M (lanes of a tile) and M^64 (tiles of a row), mst_mat.h
+    if (SCAN1) tab_fetch(tlo, tab, tid);
     if (MODE_RUN && SCAN1) {
-        tab_fetch(thi, tab + kTabFloats, tid);
-        // s0 = the zs kernel's in-tile end states.  Mine starts from my predecessor lane's ...
+        tab_fetch(thi, tab + kTriFloats, tid);
+        // s0 = the zs kernel's zero-state chunk end states.  The state entering chunk `pos` is the inclusive scan, over the
+        // positions of the tile, of the forcing  { S at position 0, end state of chunk pos-1 elsewhere }  with S = the state
+        // entering the tile = the scan over the aggregates of the preceding tiles.
         const int nb = DIR == EQ_FWD ? chunk - 1 : chunk + 1;
 #pragma unroll
         for (int i = 0; i < kStates; ++i) st[i] = pos > 0 ? s0[((int64_t)sig * kStates + i) * nc_pad + nb] : 0.0f;
-        // ... + M^pos S, S = state entering the tile = scan over the aggregates of the preceding tiles
         const int wt = DIR == EQ_FWD ? (int)blockIdx.x : ntiles - 1 - (int)blockIdx.x;  // my tile in recurrence order
-        if (wt > 0) {
-            float zz[kStates], v[kStates];  // lane q looks at the tile at recurrence position q
+#ifndef MST_DBG_NOSCAN
+#define MST_DBG_NOSCAN 0  // timing diagnostics only: 1 skips the in-wave carry scans (wrong results)
+#endif
+        if (wt > 0 && !MST_DBG_NOSCAN) {
+            float zz[kStates];  // lane q looks at the tile at recurrence position q
 #pragma unroll
             for (int d = 0; d < kStates; ++d) zz[d] = tid < wt ? agg[((int64_t)sig * kStates + d) * kMaxTiles1 + tid] : 0.0f;
             tab_stash(thi, tile, tid);
-            tab_fetch(tlo, tab, tid);  // in flight during the scan over the tiles
             __syncthreads();
-            wave_scan12<false>(zz, tile, tid, wt);
+            wave_scan_tri<false>(zz, tile, tid, wt);
 #pragma unroll
-            for (int d = 0; d < kStates; ++d) v[d] = __shfl(zz[d], wt - 1);
+            for (int d = 0; d < kStates; ++d) {
+                const float S = __shfl(zz[d], wt - 1);
+                if (pos == 0) st[d] = S;
+            }
             __syncthreads();
+        }
+        if (!MST_DBG_NOSCAN) {
             tab_stash(tlo, tile, tid);
             __syncthreads();
-            apply_pow12(v, tile, pos);
-#pragma unroll
-            for (int d = 0; d < kStates; ++d) st[d] += v[d];
+            wave_scan_tri<DIR == EQ_ADJ>(st, tile, pos, kEqWG);
             __syncthreads();  // the slab image overwrites the table next
         }
     } else {
@@ -246,18 +251,18 @@ __device__ __forceinline__ void cascade_body(const float* __restrict__ in, int64
         slab_fence();
     }
     if (!MODE_RUN) {
-        if (SCAN1) {
+#pragma unroll
+        for (int i = 0; i < kStates; ++i) z[((int64_t)sig * kStates + i) * nc_pad + chunk] = st[i];
+        if (SCAN1 && !MST_DBG_NOSCAN) {  // tile aggregate = the last position of the scan over the tile's chunk end states
             tab_stash(tlo, tile, tid);  // the slab buffer is free now
             __syncthreads();
-            wave_scan12<DIR == EQ_ADJ>(st, tile, pos, kEqWG);
-            if (pos == kEqWG - 1) {  // tile aggregate, indexed by the tile's position in recurrence order
+            wave_scan_tri<DIR == EQ_ADJ>(st, tile, pos, kEqWG);
+            if (pos == kEqWG - 1) {  // indexed by the tile's position in recurrence order
                 const int wt = DIR == EQ_FWD ? (int)blockIdx.x : ntiles - 1 - (int)blockIdx.x;
 #pragma unroll
                 for (int i = 0; i < kStates; ++i) agg[((int64_t)sig * kStates + i) * kMaxTiles1 + wt] = st[i];
             }
         }
-#pragma unroll
-        for (int i = 0; i < kStates; ++i) z[((int64_t)sig * kStates + i) * nc_pad + chunk] = st[i];
     }
     if (FUSE_AP) {
 #pragma unroll
@@ -294,7 +299,8 @@ __global__ __launch_bounds__(kEqWG) void k_cascade(const float* __restrict__ in,
                                                  int nblk_comp = 0, const float* __restrict__ pw1 = nullptr, int ntiles = 0,
                                                  float* __restrict__ agg = nullptr, float* __restrict__ zp = nullptr) {
     static_assert(!FUSE_AP || (MODE_RUN && DIR == EQ_FWD), "the all-pole bank rides on the forward run only");
-    __shared__ __attribute__((aligned(16))) float tile[kEqWG * kLdw];
+    // the slab image; a scan table set (kTriFloats) is staged through the same buffer
+    __shared__ __attribute__((aligned(16))) float tile[kEqWG * kLdw > kTriFloats ? kEqWG * kLdw : kTriFloats];
     const int64_t tile_base = (int64_t)blockIdx.x * kTile;
     const bool fast = tile_fast(in + (int64_t)blockIdx.y * in_stride, tile_base, n) &&
                       (!MODE_RUN || !((uintptr_t)(out + (int64_t)blockIdx.y * out_stride) & 15));

@@ -29,7 +29,6 @@ constexpr int kFxN = 8192, kFxHop = 4096, kFxLanes = FftPlan<8192>::LG;
 // so the filtered pair comes back the same way and nothing has to be separated.
 //   Hc[k]   = conj(FFT8192(f[k] ++ zeros))                                   k_fx_filt_spec, 12 workgroups
 //   block c = first V = 8192 - (taps - 1) samples of IFFT8192(FFT8192(z[c V .. c V + 8192)) (.) Hc[k])
-constexpr int kFirMaxTaps = 1024;
 __global__ __launch_bounds__(kFxLanes, 4) void k_fx_filt_spec(const float* __restrict__ filt, float2* __restrict__ Hc, const float* tables, int taps) {
     using S = FftShape<kFxN>;
     __shared__ __attribute__((aligned(16))) float2 buf[2][S::SLOTS];

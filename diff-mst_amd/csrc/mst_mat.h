@@ -36,53 +36,60 @@ __device__ __forceinline__ void matvec_acc(const float* M, const float* v, float
     }
 }
 
-// Six 12x12 matrices (864 floats) of a scan table travel global -> registers -> LDS: the loads are issued
-// early (4 x 16 B per lane of a 64-lane wave) and parked in LDS right before the scan that uses them, where
-// every matrix read is a broadcast.  (Scalar loads of the same data measured 3-5x slower per scan level.)
-constexpr int kTabFloats = 6 * 144;
+// ---- in-wave carry scans of the 12-state cascade, section by section -------------------------------------------------
+// The chunk transition P of a cascade is block lower-triangular in 2x2 blocks (section k sees sections j <= k only), so
+//     x[pos] = P x[pos-1] + v[pos]
+// splits into six 2-state scans run one after the other: section k scans  f = v_k + sum_{j<k} P_kj x_j[pos-1]  (x_j: the finished
+// scan of an earlier section, one position back) with its own diagonal block D_k = P_kk:
+//     x_k[pos] = D_k x_k[pos-1] + f[pos].
+// 204 FMAs and 82 shuffles per scan instead of six 12x12 triangular mat-vecs (504 FMAs, 144 16-byte LDS reads, 72 shuffles);
+// measured at cfg #2: the scans were 46 us of the step (ablation MST_DBG_NOSCAN).
+// One table set (kTriFloats floats, wave-uniform, staged through LDS):
+//   D[k][j][4]   at (6 k + j) 4          D_k^(2^j), j = 0..5, row-major 2x2
+//   C[k][jj][4]  at 144 + (k (k-1) / 2 + jj) 4     P_k,jj for jj < k
+constexpr int kTriFloats = 208;  // 204 used, padded to whole 16-byte vectors
 struct TabRegs {
-    float4 v[4];
+    float4 v;
 };
 __device__ __forceinline__ void tab_fetch(TabRegs& r, const float* __restrict__ g, int lane) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int q = lane + 64 * k;
-        r.v[k] = q < kTabFloats / 4 ? *reinterpret_cast<const float4*>(g + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    r.v = lane < kTriFloats / 4 ? *reinterpret_cast<const float4*>(g + 4 * lane) : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 __device__ __forceinline__ void tab_stash(const TabRegs& r, float* __restrict__ lds, int lane) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int q = lane + 64 * k;
-        if (q < kTabFloats / 4) *reinterpret_cast<float4*>(lds + 4 * q) = r.v[k];
-    }
+    if (lane < kTriFloats / 4) *reinterpret_cast<float4*>(lds + 4 * lane) = r.v;
 }
-
-// In-place inclusive scan over the lanes of one wave of  s[pos] = P s[pos-1] + v[pos]  (pos = position in
-// recurrence order; lane = pos, or 63 - pos when REV).  tab[j] = P^(2^j), wave-uniform.  Levels whose
-// stride reaches `limit` (wave-uniform: number of populated positions) are skipped.
+// In-place inclusive scan over the lanes of one wave (pos = position in recurrence order; lane = pos, or 63 - pos when REV).
+// Levels whose stride reaches `limit` (wave-uniform: number of populated positions) are skipped.
 template <bool REV>
-__device__ __forceinline__ void wave_scan12(float* v, const float* __restrict__ tab, int pos, int limit) {
+__device__ __forceinline__ void wave_scan_tri(float* v, const float* __restrict__ tab, int pos, int limit) {
+    float prev[kStates];
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-        if ((1 << j) >= limit) break;
-        float o[kStates];
+    for (int k = 0; k < kSections; ++k) {
+        float f0 = v[2 * k], f1 = v[2 * k + 1];
 #pragma unroll
-        for (int d = 0; d < kStates; ++d) o[d] = REV ? __shfl_down(v[d], 1u << j) : __shfl_up(v[d], 1u << j);
-        if (pos >= (1 << j)) matvec_acc<kStates>(tab + j * 144, o, v);
-    }
-}
-// v <- P^pos v for a per-lane exponent pos in [0, 64): six conditional applications of tab[j] = P^(2^j)
-__device__ __forceinline__ void apply_pow12(float* v, const float* __restrict__ tab, int pos) {
+        for (int jj = 0; jj < k; ++jj) {
+            const float4 c = *reinterpret_cast<const float4*>(tab + 144 + (k * (k - 1) / 2 + jj) * 4);
+            f0 = fmaf(c.x, prev[2 * jj], fmaf(c.y, prev[2 * jj + 1], f0));
+            f1 = fmaf(c.z, prev[2 * jj], fmaf(c.w, prev[2 * jj + 1], f1));
+        }
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-        float nv[kStates];
-#pragma unroll
-        for (int d = 0; d < kStates; ++d) nv[d] = 0.0f;
-        matvec_acc<kStates>(tab + j * 144, v, nv);
-        const bool take = (pos >> j) & 1;
-#pragma unroll
-        for (int d = 0; d < kStates; ++d) v[d] = take ? nv[d] : v[d];
+        for (int j = 0; j < 6; ++j) {
+            if ((1 << j) >= limit) break;
+            const float o0 = REV ? __shfl_down(f0, 1u << j) : __shfl_up(f0, 1u << j);
+            const float o1 = REV ? __shfl_down(f1, 1u << j) : __shfl_up(f1, 1u << j);
+            if (pos >= (1 << j)) {
+                const float4 d = *reinterpret_cast<const float4*>(tab + (6 * k + j) * 4);
+                f0 = fmaf(d.x, o0, fmaf(d.y, o1, f0));
+                f1 = fmaf(d.z, o0, fmaf(d.w, o1, f1));
+            }
+        }
+        v[2 * k] = f0;
+        v[2 * k + 1] = f1;
+        if (k + 1 < kSections) {
+            const float p0 = REV ? __shfl_down(f0, 1u) : __shfl_up(f0, 1u);
+            const float p1 = REV ? __shfl_down(f1, 1u) : __shfl_up(f1, 1u);
+            prev[2 * k] = pos >= 1 ? p0 : 0.0f;
+            prev[2 * k + 1] = pos >= 1 ? p1 : 0.0f;
+        }
     }
 }
 

@@ -270,11 +270,19 @@ __global__ __launch_bounds__(320) void k_prep(PrepArgs a) {
     }
     if (mat_lane) pw[0 * 144 + e] = (float)mats[grp][cur][e];
     if (a.eq1) {
-        // in-wave scans: M^(2^j), j = 0..kPow1-1 (M = one-chunk transition), by repeated squaring
-        float* pw1 = grp == 0 ? (is_master ? a.pow1F_m + (int64_t)mrow * kPow1 * 144 : a.pow1F_t + (int64_t)row * kPow1 * 144)
-                              : (is_master ? a.pow1A_m + (int64_t)mrow * kPow1 * 144 : a.pow1A_t + (int64_t)row * kPow1 * 144);
+        // in-wave scans: M^(2^j), j = 0..kPow1-1 (M = one-chunk transition), by repeated squaring; what is kept of each power is
+        // its six diagonal 2x2 blocks (the diagonal blocks of a power of a block-triangular matrix are the powers of its diagonal
+        // blocks) and, of M and M^64 themselves, the 15 blocks below the diagonal (layout: mst_mat.h, two sets of kTriFloats)
+        float* pw1 = grp == 0 ? (is_master ? a.pow1F_m + (int64_t)mrow * kTri2 : a.pow1F_t + (int64_t)row * kTri2)
+                              : (is_master ? a.pow1A_m + (int64_t)mrow * kTri2 : a.pow1A_t + (int64_t)row * kTri2);
+        const int ei = e / 12, ec = e % 12, bk = ei >> 1, bj = ec >> 1, sub = (ei & 1) * 2 + (ec & 1);
         for (int j = 0; j < kPow1; ++j) {
-            if (mat_lane) pw1[j * 144 + e] = (float)mats[grp][cur][e];
+            if (mat_lane) {
+                float* set = pw1 + (j / 6) * (kTri2 / 2);
+                const float val = (float)mats[grp][cur][e];
+                if (bk == bj) set[(6 * bk + j % 6) * 4 + sub] = val;
+                else if (j % 6 == 0 && bj < bk) set[144 + (bk * (bk - 1) / 2 + bj) * 4 + sub] = val;
+            }
             if (j + 1 < kPow1) {
                 if (mat_lane) mat12_mul(mats[grp][cur], mats[grp][cur], mats[grp][cur ^ 1], e);
                 __syncthreads();
