@@ -184,15 +184,14 @@ __device__ __forceinline__ void cascade_body(const float* __restrict__ in, int64
     CompK ck{};
     float zacc = 0.0f;
     if (FUSE_GC) ck = load_comp(rc + (int64_t)filter_row(sig, split) * RC_STRIDE);
-    f2 ak1[kSections], ak2[kSections], akin[kSections], aw1[kSections], aw2[kSections];  // see k_coefgrad
+    // the all-pole bank of k_coefgrad, zero state: 1/A_k on (wa1, wa2), b0/B_k on (wb1, wb2); a1, a2 are c[5s+3], c[5s+4]
+    float bc1[kSections], bc2[kSections], wa1[kSections], wa2[kSections], wb1[kSections], wb2[kSections];
     if (FUSE_AP) {
 #pragma unroll
         for (int s = 0; s < kSections; ++s) {
-            const float ib0 = 1.0f / c[5 * s];
-            ak1[s] = f2{-c[5 * s + 3], -(c[5 * s + 1] / c[5 * s])};
-            ak2[s] = f2{-c[5 * s + 4], -(c[5 * s + 2] / c[5 * s])};
-            akin[s] = f2{1.0f, ib0};
-            aw1[s] = aw2[s] = f2{0.0f, 0.0f};
+            bc1[s] = c[5 * s + 1] / c[5 * s];
+            bc2[s] = c[5 * s + 2] / c[5 * s];
+            wa1[s] = wa2[s] = wb1[s] = wb2[s] = 0.0f;
         }
     }
 
@@ -215,12 +214,14 @@ __device__ __forceinline__ void cascade_body(const float* __restrict__ in, int64
                     const float ys[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
-                        const f2 xx = {ys[t], ys[t]};
 #pragma unroll
                         for (int s = 0; s < kSections; ++s) {
-                            const f2 w = ak2[s] * aw2[s] + (ak1[s] * aw1[s] + xx * akin[s]);
-                            aw2[s] = aw1[s];
-                            aw1[s] = w;
+                            const float wa = fmaf(-c[5 * s + 4], wa2[s], fmaf(-c[5 * s + 3], wa1[s], ys[t]));
+                            wa2[s] = wa1[s];
+                            wa1[s] = wa;
+                            const float wb = fmaf(-bc2[s], wb2[s], fmaf(-bc1[s], wb1[s], ys[t]));
+                            wb2[s] = wb1[s];
+                            wb1[s] = wb;
                         }
                     }
                 }
@@ -268,10 +269,10 @@ __device__ __forceinline__ void cascade_body(const float* __restrict__ in, int64
 #pragma unroll
         for (int s = 0; s < kSections; ++s) {
             const int64_t base = ((int64_t)sig * 24 + 4 * s) * nc_pad + chunk;
-            zp[base] = aw1[s][0];
-            zp[base + nc_pad] = aw2[s][0];
-            zp[base + 2 * (int64_t)nc_pad] = aw1[s][1];
-            zp[base + 3 * (int64_t)nc_pad] = aw2[s][1];
+            zp[base] = wa1[s];
+            zp[base + nc_pad] = wa2[s];
+            zp[base + 2 * (int64_t)nc_pad] = wb1[s];
+            zp[base + 3 * (int64_t)nc_pad] = wb2[s];
         }
     }
     if (FUSE_GC) {
@@ -309,7 +310,8 @@ __global__ __launch_bounds__(kEqWG) void k_cascade(const float* __restrict__ in,
 }
 
 // ---- all-pole bank for the coefficient gradients ------------------------------------------------
-// filter f = 2k : w = u - a1 w1 - a2 w2 (1/A_k);  f = 2k+1 : w = u/b0 - (b1/b0) w1 - (b2/b0) w2 (1/B_k)
+// filter f = 2k : w = u - a1 w1 - a2 w2 (1/A_k);  f = 2k+1 : w = u - (b1/b0) w1 - (b2/b0) w2 (b0/B_k: the 1/b0 of 1/B_k is
+// applied once, to the finished inner products - one multiply per sample and section less in all three kernels)
 struct ApCoef {
     float a1[kSections], a2[kSections], ib0[kSections], c1[kSections], c2[kSections];
 };
@@ -355,7 +357,7 @@ __device__ __forceinline__ void allpole_zs_body(const float* __restrict__ u, int
                 const float wa = fmaf(-k.a2[s], wa2[s], fmaf(-k.a1[s], wa1[s], x));
                 wa2[s] = wa1[s];
                 wa1[s] = wa;
-                const float wb = fmaf(-k.c2[s], wb2[s], fmaf(-k.c1[s], wb1[s], x * k.ib0[s]));
+                const float wb = fmaf(-k.c2[s], wb2[s], fmaf(-k.c1[s], wb1[s], x));
                 wb2[s] = wb1[s];
                 wb1[s] = wb;
             }
@@ -392,27 +394,21 @@ __device__ __forceinline__ void coefgrad_body(const float* __restrict__ u, int64
     const int tid = threadIdx.x, sig = blockIdx.y;
     const int64_t tile_base = (int64_t)blockIdx.x * kEqWG * kEqChunk;
     const int chunk = blockIdx.x * kEqWG + tid;
-    // The two all-pole filters of a section, 1/A_k (lane .x) and 1/B_k (lane .y), advance as ONE packed
-    // recurrence  w = x*{1, 1/b0} - {a1, b1/b0} w1 - {a2, b2/b0} w2, and their five inner products with the
-    // cotangent accumulate in three packed sums: a section costs 1 v_pk_mul + 5 v_pk_fma per sample.
-    f2 k1[kSections], k2[kSections], kin[kSections];
-    {
-        const float* coef = rc + (int64_t)filter_row(sig, split) * RC_STRIDE + RC_SOS;
-#pragma unroll
-        for (int s = 0; s < kSections; ++s) {
-            const float ib0 = 1.0f / coef[5 * s];
-            k1[s] = f2{-coef[5 * s + 3], -(coef[5 * s + 1] / coef[5 * s])};
-            k2[s] = f2{-coef[5 * s + 4], -(coef[5 * s + 2] / coef[5 * s])};
-            kin[s] = f2{1.0f, ib0};
-        }
-    }
-    f2 w1[kSections], w2[kSections], a0[kSections], a1[kSections], a2[kSections];
+    // Per sample and section: 1/A_k and b0/B_k advance (2 FMAs each) and their five inner products with the cotangent
+    // accumulate (5 FMAs) - 9 plain FMAs.  (Round 1 packed the filter pair into v_pk_fma_f32: 6 packed operations, which on
+    // gfx950 issue at HALF rate - 12 issue slots where these take 9, and a lane of one product was idle.)
+    ApCoef k;
+    load_ap(rc + (int64_t)filter_row(sig, split) * RC_STRIDE + RC_SOS, k);
+    float wa1[kSections], wa2[kSections], wb1[kSections], wb2[kSections];
+    float db0[kSections], db1[kSections], db2[kSections], da1[kSections], da2[kSections];
 #pragma unroll
     for (int s = 0; s < kSections; ++s) {
         const int64_t base = ((int64_t)sig * 24 + 4 * s) * nc_pad + chunk;
-        w1[s] = f2{s0[base], s0[base + 2 * (int64_t)nc_pad]};
-        w2[s] = f2{s0[base + nc_pad], s0[base + 3 * (int64_t)nc_pad]};
-        a0[s] = a1[s] = a2[s] = f2{0.0f, 0.0f};
+        wa1[s] = s0[base];
+        wa2[s] = s0[base + nc_pad];
+        wb1[s] = s0[base + 2 * (int64_t)nc_pad];
+        wb2[s] = s0[base + 3 * (int64_t)nc_pad];
+        db0[s] = db1[s] = db2[s] = da1[s] = da2[s] = 0.0f;
     }
     const float* urow = u + (int64_t)sig * u_stride;
     const float* grow = g + (int64_t)sig * g_stride;
@@ -436,15 +432,20 @@ __device__ __forceinline__ void coefgrad_body(const float* __restrict__ u, int64
             const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, gs[4] = {gv.x, gv.y, gv.z, gv.w};
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const f2 xx = {xs[t], xs[t]}, gp = {gs[t], gs[t]}, gm = {-gs[t], gs[t]};
+                const float x = xs[t], gp = gs[t], gm = -gs[t];
 #pragma unroll
                 for (int s = 0; s < kSections; ++s) {
-                    const f2 w = k2[s] * w2[s] + (k1[s] * w1[s] + xx * kin[s]);
-                    a0[s] += gp * w;       // .y: dL/db0
-                    a1[s] += gm * w1[s];   // .x: dL/da1   .y: dL/db1
-                    a2[s] += gm * w2[s];   // .x: dL/da2   .y: dL/db2
-                    w2[s] = w1[s];
-                    w1[s] = w;
+                    const float wa = fmaf(-k.a2[s], wa2[s], fmaf(-k.a1[s], wa1[s], x));
+                    const float wb = fmaf(-k.c2[s], wb2[s], fmaf(-k.c1[s], wb1[s], x));
+                    db0[s] = fmaf(gp, wb, db0[s]);
+                    db1[s] = fmaf(gp, wb1[s], db1[s]);
+                    db2[s] = fmaf(gp, wb2[s], db2[s]);
+                    da1[s] = fmaf(gm, wa1[s], da1[s]);
+                    da2[s] = fmaf(gm, wa2[s], da2[s]);
+                    wa2[s] = wa1[s];
+                    wa1[s] = wa;
+                    wb2[s] = wb1[s];
+                    wb1[s] = wb;
                 }
             }
         }
@@ -454,11 +455,11 @@ __device__ __forceinline__ void coefgrad_body(const float* __restrict__ u, int64
     float acc[EP_COUNT];
 #pragma unroll
     for (int s = 0; s < kSections; ++s) {
-        acc[5 * s + 0] = a0[s][1];
-        acc[5 * s + 1] = a1[s][1];
-        acc[5 * s + 2] = a2[s][1];
-        acc[5 * s + 3] = a1[s][0];
-        acc[5 * s + 4] = a2[s][0];
+        acc[5 * s + 0] = db0[s] * k.ib0[s];
+        acc[5 * s + 1] = db1[s] * k.ib0[s];
+        acc[5 * s + 2] = db2[s] * k.ib0[s];
+        acc[5 * s + 3] = da1[s];
+        acc[5 * s + 4] = da2[s];
     }
     // deterministic workgroup reduction: wave shuffle tree, then 4 wave partials in fixed order
     const int wave = tid >> 6, lane = tid & 63;
