@@ -137,10 +137,22 @@ __device__ __forceinline__ float4 load4_shift(const float* __restrict__ row, int
     return v;
 }
 
+// Sum over the 64 lanes of a wave, the same value returned to every lane.  Six DPP additions (row shifts by 1, 2, 4, 8 leave
+// each 16-lane row's total in its last lane, two row broadcasts carry the totals into lane 63) and one v_readlane, all
+// full-rate VALU work - `v += __shfl_xor(v, m)` compiles to six ds_bpermute_b32 round trips through the LDS crossbar
+// (180 of them closed every k_coefgrad tile).  Fixed order: results are reproducible.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
-    return v;
+    v = dpp_add<0x111, 0xf>(v);  // row_shr:1
+    v = dpp_add<0x112, 0xf>(v);  // row_shr:2
+    v = dpp_add<0x114, 0xf>(v);  // row_shr:4
+    v = dpp_add<0x118, 0xf>(v);  // row_shr:8
+    v = dpp_add<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+    v = dpp_add<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 // ---- workspace layout (element offsets in floats), computed on the host ------------------------

@@ -177,6 +177,30 @@ static inline int __all(int pred) {
     return v;
 }
 static inline int __builtin_amdgcn_readfirstlane(int v) { return hostsim::shfl_idx(v, 0u); }
+static inline int __builtin_amdgcn_readlane(int v, int lane) { return hostsim::shfl_idx(v, (unsigned)lane); }
+// DPP data movement of one 64-lane wave (the controls the kernels use: row_shr:n = 0x110 + n, row_bcast:15 = 0x142,
+// row_bcast:31 = 0x143).  Lanes outside row_mask / bank_mask keep `old`; enabled lanes without a source get 0 when
+// bound_ctrl is set and `old` otherwise.
+static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
+    const unsigned lane = hostsim::t_tid & 63u, row = lane >> 4, in_row = lane & 15u;
+    bool valid = false;
+    unsigned from = lane;
+    if (ctrl > 0x110 && ctrl <= 0x11f) {
+        const unsigned n = (unsigned)ctrl - 0x110u;
+        valid = in_row >= n;
+        from = valid ? lane - n : lane;
+    } else if (ctrl == 0x142) {
+        valid = row >= 1;
+        from = valid ? 16u * row - 1u : lane;
+    } else if (ctrl == 0x143) {
+        valid = row >= 2;
+        from = valid ? 31u : lane;
+    }
+    const int got = hostsim::shfl_idx(src, from);
+    const bool enabled = ((row_mask >> row) & 1) && ((bank_mask >> (in_row >> 2)) & 1);
+    if (!enabled) return old;
+    return valid ? got : (bound_ctrl ? 0 : old);
+}
 static inline void __builtin_amdgcn_s_sleep(int) { std::this_thread::yield(); }
 static inline void __builtin_amdgcn_sched_barrier(int) {}
 

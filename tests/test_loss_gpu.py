@@ -160,15 +160,20 @@ def test_afloss_golden(dev, golden_dir, record):
     import os
 
     from mst.loss import AF_KEYS, AudioFeatureLoss
+    from oracle import loss_restated as ol
 
     g = np.load(os.path.join(golden_dir, "af_loss.npz"))
     x = torch.from_numpy(g["input"]).to(dev).requires_grad_(True)
     y = torch.from_numpy(g["target"]).to(dev)
     ld = AudioFeatureLoss(weights=list(g["weights"]), sample_rate=44100)(x, y)
     assert tuple(ld.keys()) == AF_KEYS
+    # three-way: the reference's own fp32 value sits up to 1e-5 from the float64 evaluation (stereo width: a squared difference
+    # of two ratios of sums) - HIP must be no further from float64 than twice that, and within 5e-5 of the reference outright
+    truth = ol.audio_feature_loss(torch.from_numpy(g["input"]).double(), y.double().cpu(), list(g["weights"]))
     for k in AF_KEYS:
-        ref = float(g["loss." + k])
-        assert abs(ld[k].item() - ref) <= 2e-5 * abs(ref) + 1e-12, (k, ld[k].item(), ref)
+        ref, t64 = float(g["loss." + k]), truth[k].item()
+        assert abs(ld[k].item() - ref) <= 5e-5 * abs(ref) + 1e-12, (k, ld[k].item(), ref)
+        assert abs(ld[k].item() - t64) <= 2 * abs(ref - t64) + 1e-5 * abs(t64), (k, ld[k].item(), ref, t64)
     sum(v.mean() for v in ld.values()).backward()  # reference mst/system.py:334-336
     gsub = torch.from_numpy(g["grad_input_sub"])
     record(grad_vs_reference=rel(x.grad[..., ::16], gsub),
