@@ -465,8 +465,11 @@ __device__ __forceinline__ void comp_bwd_run_body(const CompBwdArgs& a) {
     if (tid < CP_COUNT)
         a.part[((int64_t)row * gridDim.x + blockIdx.x) * CP_COUNT + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
 }
+#ifndef MST_COMP_BWD_W
+#define MST_COMP_BWD_W 1  // min waves per SIMD asked of the compressor backward (A/B switch)
+#endif
 template <bool MASTER>
-__global__ __launch_bounds__(kWG) void k_comp_bwd_run(CompBwdArgs a) {
+__global__ __launch_bounds__(kWG, MST_COMP_BWD_W) void k_comp_bwd_run(CompBwdArgs a) {
     if (block_interior(a.n, a.lookahead, a.aligned)) comp_bwd_run_body<MASTER, true>(a);
     else comp_bwd_run_body<MASTER, false>(a);
 }

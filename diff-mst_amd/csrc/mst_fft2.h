@@ -95,42 +95,65 @@ struct FftShape {
     }
 };
 
-// ---- per-lane twiddle bases, held in registers for the lifetime of the kernel -----------------------------------
-// A butterfly with base exponent e multiplies input t by W^(e t), t = 1..R-1.  Only W^e, W^2e, W^4e are stored (exactly
-// rounded table entries); the other four are single products of two of them.
+// ---- per-lane twiddles, held in registers for the lifetime of the kernel ------------------------------------------
+// A butterfly with base exponent e multiplies input t by W^(e t), t = 1..R-1.
+//   default: only W^e, W^2e, W^4e are stored (exactly rounded table entries) and the other four are single products of two
+//        of them - 12 complex multiplies per radix-8 butterfly, 5 of them on twiddles alone;
+//   MST_FFT2_FULL_TW=1 (n_fft <= 2048 only): all R-1 factors fetched from the table, 7 multiplies.  Measured: no gain
+//        (2048 forward 27.9 -> 30.2 us, 512 backward 51.8 -> 52.4 us) - these passes wait on LDS and barriers, not on the VALU.
+#ifndef MST_FFT2_FULL_TW
+#define MST_FFT2_FULL_TW 0
+#endif
 template <int N>
 struct LaneTw {
     using S = FftShape<N>;
-    float2 mid[S::NP - 2][3];                    // passes 2 .. NP-1 (radix 8, Ns = 8^(p-1))
-    float2 last[S::NBL][ilog2c(S::RL)];          // pass NP (radix RL, Ns = M / RL, k = j)
+    static constexpr bool FULL = MST_FFT2_FULL_TW && N <= 2048;
+    static constexpr int LB = ilog2c(S::RL);                       // bases of the last pass
+    float2 mid[S::NP - 2][FULL ? 7 : 3];                           // passes 2 .. NP-1 (radix 8, Ns = 8^(p-1))
+    float2 last[S::NBL][FULL ? S::RL - 1 : LB];                    // pass NP (radix RL, Ns = M / RL, k = j)
     // tw = (cos, -sin)(2 pi t / N), t < N
     __device__ __forceinline__ void init(const float2* __restrict__ tw, int lane) {
         int Ns = 8;
 #pragma unroll
         for (int p = 0; p < S::NP - 2; ++p) {
             const int e = (lane & (Ns - 1)) * (S::M / (Ns * 8));  // W_(8 Ns)^(k t) = W_M^(k t M / (8 Ns))
+            if constexpr (FULL) {
 #pragma unroll
-            for (int b = 0; b < 3; ++b) mid[p][b] = tw[(S::TWSCALE * (e << b)) & (N - 1)];
+                for (int t = 1; t < 8; ++t) mid[p][t - 1] = tw[(S::TWSCALE * (e * t)) & (N - 1)];
+            } else {
+#pragma unroll
+                for (int b = 0; b < 3; ++b) mid[p][b] = tw[(S::TWSCALE * (e << b)) & (N - 1)];
+            }
             Ns *= 8;
         }
 #pragma unroll
         for (int u = 0; u < S::NBL; ++u) {
             const int j = lane + u * S::LG;
+            if constexpr (FULL) {
 #pragma unroll
-            for (int b = 0; b < ilog2c(S::RL); ++b) last[u][b] = tw[(S::TWSCALE * (j << b)) & (N - 1)];
+                for (int t = 1; t < S::RL; ++t) last[u][t - 1] = tw[(S::TWSCALE * (j * t)) & (N - 1)];
+            } else {
+#pragma unroll
+                for (int b = 0; b < LB; ++b) last[u][b] = tw[(S::TWSCALE * (j << b)) & (N - 1)];
+            }
         }
     }
 };
-template <int R>
+template <int R, bool FULL>
 __device__ __forceinline__ void tw_apply(float2* v, const float2* base) {  // v[t] *= W^(e t)
-    v[1] = cmul(v[1], base[0]);
-    v[2] = cmul(v[2], base[1]);
-    v[3] = cmul(v[3], cmul(base[0], base[1]));
-    if (R == 8) {
-        v[4] = cmul(v[4], base[2]);
-        v[5] = cmul(v[5], cmul(base[0], base[2]));
-        v[6] = cmul(v[6], cmul(base[1], base[2]));
-        v[7] = cmul(v[7], cmul(cmul(base[0], base[1]), base[2]));
+    if constexpr (FULL) {
+#pragma unroll
+        for (int t = 1; t < R; ++t) v[t] = cmul(v[t], base[t - 1]);
+    } else {
+        v[1] = cmul(v[1], base[0]);
+        v[2] = cmul(v[2], base[1]);
+        v[3] = cmul(v[3], cmul(base[0], base[1]));
+        if (R == 8) {
+            v[4] = cmul(v[4], base[2]);
+            v[5] = cmul(v[5], cmul(base[0], base[2]));
+            v[6] = cmul(v[6], cmul(base[1], base[2]));
+            v[7] = cmul(v[7], cmul(cmul(base[0], base[1]), base[2]));
+        }
     }
 }
 
@@ -156,7 +179,7 @@ __device__ __forceinline__ void fft_mid_store(float2* v, float2* __restrict__ bu
     using S = FftShape<N>;
     constexpr int Ns = P == 2 ? 8 : 64;
     static_assert(P == 2 || P == 3, "middle passes");
-    tw_apply<8>(v, tw.mid[P - 2]);
+    tw_apply<8, LaneTw<N>::FULL>(v, tw.mid[P - 2]);
     butterfly<8>(v);
     const int k = lane & (Ns - 1);
     const int base = (lane - k) * 8 + k;  // element base + t Ns
@@ -170,7 +193,7 @@ __device__ __forceinline__ void fft_last(float2* v, const float2* __restrict__ b
     const int j = lane + u * S::LG;
 #pragma unroll
     for (int t = 0; t < S::RL; ++t) v[t] = buf[S::slot(j + t * (S::M / S::RL))];
-    tw_apply<S::RL>(v, tw.last[u]);
+    tw_apply<S::RL, LaneTw<N>::FULL>(v, tw.last[u]);
     butterfly<S::RL>(v);
 }
 

@@ -5,6 +5,7 @@ usage: python tools/pmc_table.py <tag> <steps_executed> [--md out.md] [--json ou
 Reads gpurun_out/<tag>_{stats,sq1,sq2,fetch,write}/.  Durations come from the un-instrumented kernel-trace
 pass (counter passes serialise dispatches and run at a lower clock), counters are means over dispatches.
 Derived columns (MI355X: 256 CUs x 4 SIMD-32, 2.4 GHz nominal; SQ_* "cycles" are quad-cycles summed over waves):
+  VGPR        = 2 x rocprofv3's vgpr_count (it reports half the allocation of a wave64 kernel, see counters())
   waves/SIMD  = resident waves per SIMD if the whole grid is resident (min with the VGPR / LDS / 8-wave limits)
   VALU issue  = SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x duration x 2.4 GHz)   (a wave64 VALU op occupies a SIMD-32 for 2 cycles)
   VALUBusy    = SQ_ACTIVE_INST_VALU x 4 / (SQ_BUSY_CYCLES-normalised) is NOT used: the gfx94x formula is not valid here
@@ -44,7 +45,9 @@ def counters(path):
     for k, c, v, vg, ag, sg, lds, wg, grid in cur.execute(q):
         k = short(k)
         acc[k][c].append(v)
-        meta[k] = dict(vgpr=vg, agpr=ag, sgpr=sg, lds=lds, wg=wg, grid=grid)
+        # rocprofv3 7.2 reports HALF the per-lane VGPR allocation of wave64 gfx950 kernels (k_stft2_fwd<8192>: 64 here, 128 in
+        # hipcc -Rpass-analysis=kernel-resource-usage and in the code-object metadata; same factor for every kernel checked)
+        meta[k] = dict(vgpr=2 * vg, agpr=2 * ag, sgpr=sg, lds=lds, wg=wg, grid=grid)
     return acc, meta
 
 
