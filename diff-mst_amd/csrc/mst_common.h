@@ -38,7 +38,9 @@ constexpr int RC_PANR = 37;    // tracks: right pan gain  | master: output-fader
 constexpr int RC_GIN = 38;     // input-fader linear gain (already folded into section 0)
 constexpr int RC_LOG2A_C = 39; // log2(alpha^kCompChunk), from fp64
 constexpr int RC_SEND = 40;    // tracks: linear fx-bus send gain 10^(send_db/20)
-constexpr int RC_STRIDE = 44;
+constexpr int RC_AP = 44;      // 6 x {b1/b0, b2/b0, 1/b0}: the all-pole bank's constants, made by k_prep so that every kernel
+                               // fetches them as wave-uniform scalars (a division in the kernel puts them into 18 vector registers)
+constexpr int RC_STRIDE = 64;
 
 // partial-sum slots of the compressor backward kernel
 constexpr int CP_THR = 0, CP_KAPPA = 1, CP_KNEE = 2, CP_ALPHA = 3, CP_MAKEUP = 4, CP_PANL = 5, CP_PANR = 6, CP_SEND = 7;

@@ -335,7 +335,8 @@ __global__ __launch_bounds__(kWG) void k_comp_bwd_zs(CompBwdArgs a) {
     else comp_bwd_zs_body<MASTER, false>(a);
 }
 
-template <bool MASTER, bool FAST>
+// FXS: the fx send bus is on (tracks only) - its cotangent rows are read and the send-gain sum is formed
+template <bool MASTER, bool FAST, bool FXS>
 __device__ __forceinline__ void comp_bwd_run_body(const CompBwdArgs& a) {
     constexpr int NCH = MASTER ? 2 : 1;
     __shared__ float red[4][CP_COUNT];  // red[0] doubles as the 8-float scan scratch
@@ -351,10 +352,8 @@ __device__ __forceinline__ void comp_bwd_run_body(const CompBwdArgs& a) {
     load_gy<MASTER, FAST>(a, row, rc, i0, gl, gr);
     const float pl = rc[RC_PANL], pr = rc[RC_PANR];  // master: both = output-fader gain
     // cotangent of the fx send gain: sum_n (pl fL + pr fR)[n] y[n]  (fL, fR = cotangent of the send bus)
-    float fsum[CC];
-#pragma unroll
-    for (int i = 0; i < CC; ++i) fsum[i] = 0.0f;
-    if (!MASTER && a.gfx) {
+    float fsum[FXS ? CC : 1];
+    if (FXS) {
         const int bb = row / a.T;
         float fl[CC], fr[CC];
         LD8S<FAST>(a.gfx + ((int64_t)bb * 2 + 0) * a.gfx_stride, i0, a.n, fl);
@@ -365,7 +364,22 @@ __device__ __forceinline__ void comp_bwd_run_body(const CompBwdArgs& a) {
 
     if (a.comp_on) {
         const CompK k = load_comp(rc);
-        float x0[CC], x1[CC], xd0[CC], xd1[CC], g[CC], gF[CC], glF[CC], grF[CC];
+        float x0[CC], x1[CC], xd0[CC], xd1[CC], g[CC];
+        // look-ahead branch: du[i] += gy[i+L] * G[i+L].  Folded to one (two: master) value per sample right after the loads -
+        // three arrays less are alive across the block scan (the kernel ran at 152 registers = 3 waves per SIMD)
+        float fwd0[CC], fwd1[MASTER ? CC : 1];
+        {
+            float gF[CC], glF[CC], grF[CC];
+            LD8S<FAST>(a.gs + (int64_t)row * a.stride, i0 + a.lookahead, a.n, gF);
+            load_gy<MASTER, FAST>(a, row, rc, i0 + a.lookahead, glF, grF);
+#pragma unroll
+            for (int i = 0; i < CC; ++i) {
+                const bool liveF = FAST || i0 + i + a.lookahead < a.n;
+                const float GF = lin_gain(gF[i], k);
+                fwd0[i] = liveF ? (MASTER ? pl * glF[i] : pl * glF[i] + pr * grF[i]) * GF : 0.0f;
+                if (MASTER) fwd1[i] = liveF ? pr * grF[i] * GF : 0.0f;
+            }
+        }
         LD8<FAST>(u0, i0, a.n, x0);
         LD8S<FAST>(u0, i0 - a.lookahead, a.n, xd0);
         if (MASTER) {
@@ -373,17 +387,14 @@ __device__ __forceinline__ void comp_bwd_run_body(const CompBwdArgs& a) {
             LD8S<FAST>(u1, i0 - a.lookahead, a.n, xd1);
         }
         LD8<FAST>(a.gs + (int64_t)row * a.stride, i0, a.n, g);
-        // look-ahead branch: du[i] += gy[i+L] * G[i+L]
-        LD8S<FAST>(a.gs + (int64_t)row * a.stride, i0 + a.lookahead, a.n, gF);
-        load_gy<MASTER, FAST>(a, row, rc, i0 + a.lookahead, glF, grF);
         const float g_prev0 = (i0 > 0 && i0 - 1 < a.n) ? a.gs[(int64_t)row * a.stride + i0 - 1] : 0.0f;
-        float dgsv[CC], Gv[CC];
+        float dgsv[CC];
         float zq = 0.0f;
 #pragma unroll
         for (int i = CC - 1; i >= 0; --i) {
-            Gv[i] = lin_gain(g[i], k);
+            const float Gi = lin_gain(g[i], k);
             const float dot = MASTER ? pl * (gl[i] * xd0[i] + gr[i] * xd1[i]) : (pl * gl[i] + pr * gr[i]) * xd0[i];
-            dgsv[i] = (FAST || i0 + i < a.n) ? dot * Gv[i] * kLn10Over20 : 0.0f;
+            dgsv[i] = (FAST || i0 + i < a.n) ? dot * Gi * kLn10Over20 : 0.0f;
             zq = fmaf(k.alpha, zq, dgsv[i]);
         }
         const float ac = rc[RC_ALPHA_C], l2a = rc[RC_LOG2A_C];
@@ -392,7 +403,7 @@ __device__ __forceinline__ void comp_bwd_run_body(const CompBwdArgs& a) {
 #pragma unroll
         for (int i = CC - 1; i >= 0; --i) {
             const bool live = FAST || i0 + i < a.n;
-            const float G = Gv[i];
+            const float G = lin_gain(g[i], k);  // recomputed (one exp2): eight registers less across the block scan
             const float dgs = dgsv[i];
             q = fmaf(k.alpha, q, dgs);
             const float dgc = k.oma * q;
@@ -424,15 +435,13 @@ __device__ __forceinline__ void comp_bwd_run_body(const CompBwdArgs& a) {
                     const float yv = xd0[i] * G;
                     p[CP_PANL] = fmaf(gl[i], yv, p[CP_PANL]);
                     p[CP_PANR] = fmaf(gr[i], yv, p[CP_PANR]);
-                    p[CP_SEND] = fmaf(fsum[i], yv, p[CP_SEND]);
+                    if (FXS) p[CP_SEND] = fmaf(fsum[i], yv, p[CP_SEND]);
                 }
             }
             // side chain: d x_db / d side = (20/ln10) / side, clamp kills it below eps
             const float ds = (fabsf(side) >= kCompEps) ? dxdb * 8.685889638065035f * __builtin_amdgcn_rcpf(side) : 0.0f;
-            const float GF = lin_gain(gF[i], k);
-            const bool liveF = FAST || i0 + i + a.lookahead < a.n;
-            du0[i] = ds + (liveF ? (MASTER ? pl * glF[i] : pl * glF[i] + pr * grF[i]) * GF : 0.0f);
-            if (MASTER) du1[i] = ds + (liveF ? pr * grF[i] * GF : 0.0f);
+            du0[i] = ds + fwd0[i];
+            if (MASTER) du1[i] = ds + fwd1[i];
         }
     } else {
         float x0[CC], x1[CC];
@@ -447,7 +456,7 @@ __device__ __forceinline__ void comp_bwd_run_body(const CompBwdArgs& a) {
                 else {
                     p[CP_PANL] = fmaf(gl[i], x0[i], p[CP_PANL]);
                     p[CP_PANR] = fmaf(gr[i], x0[i], p[CP_PANR]);
-                    p[CP_SEND] = fmaf(fsum[i], x0[i], p[CP_SEND]);
+                    if (FXS) p[CP_SEND] = fmaf(fsum[i], x0[i], p[CP_SEND]);
                 }
             }
         }
@@ -468,10 +477,10 @@ __device__ __forceinline__ void comp_bwd_run_body(const CompBwdArgs& a) {
 #ifndef MST_COMP_BWD_W
 #define MST_COMP_BWD_W 1  // min waves per SIMD asked of the compressor backward (A/B switch)
 #endif
-template <bool MASTER>
-__global__ __launch_bounds__(kWG, MST_COMP_BWD_W) void k_comp_bwd_run(CompBwdArgs a) {
-    if (block_interior(a.n, a.lookahead, a.aligned)) comp_bwd_run_body<MASTER, true>(a);
-    else comp_bwd_run_body<MASTER, false>(a);
+template <bool MASTER, bool FXS = false>
+__global__ __launch_bounds__(kWG, (!MASTER && !FXS) ? 4 : MST_COMP_BWD_W) void k_comp_bwd_run(CompBwdArgs a) {  // tracks without fx: 130 registers uncapped, two short of four waves per SIMD
+    if (block_interior(a.n, a.lookahead, a.aligned)) comp_bwd_run_body<MASTER, true, FXS>(a);
+    else comp_bwd_run_body<MASTER, false, FXS>(a);
 }
 
 // ---- launch helpers ---------------------------------------------------------------------------------
@@ -492,6 +501,7 @@ void launch_comp_bwd(bool master, bool run, const CompBwdArgs& a, int rows, hipS
     if (master && !run) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_comp_bwd_zs<true>), grid, block, 0, stream, a);
     else if (master && run) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_comp_bwd_run<true>), grid, block, 0, stream, a);
     else if (!master && !run) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_comp_bwd_zs<false>), grid, block, 0, stream, a);
+    else if (a.gfx) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_comp_bwd_run<false, true>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_comp_bwd_run<false>), grid, block, 0, stream, a);
 }
 

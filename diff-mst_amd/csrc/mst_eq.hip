@@ -189,8 +189,8 @@ __device__ __forceinline__ void cascade_body(const float* __restrict__ in, int64
     if (FUSE_AP) {
 #pragma unroll
         for (int s = 0; s < kSections; ++s) {
-            bc1[s] = c[5 * s + 1] / c[5 * s];
-            bc2[s] = c[5 * s + 2] / c[5 * s];
+            bc1[s] = coef[RC_AP - RC_SOS + 3 * s];
+            bc2[s] = coef[RC_AP - RC_SOS + 3 * s + 1];
             wa1[s] = wa2[s] = wb1[s] = wb2[s] = 0.0f;
         }
     }
@@ -315,15 +315,14 @@ __global__ __launch_bounds__(kEqWG) void k_cascade(const float* __restrict__ in,
 struct ApCoef {
     float a1[kSections], a2[kSections], ib0[kSections], c1[kSections], c2[kSections];
 };
-__device__ __forceinline__ void load_ap(const float* coef, ApCoef& k) {
+__device__ __forceinline__ void load_ap(const float* rcrow, ApCoef& k) {  // rcrow = the filter row's constants
 #pragma unroll
     for (int s = 0; s < kSections; ++s) {
-        const float b0 = coef[5 * s], b1 = coef[5 * s + 1], b2 = coef[5 * s + 2];
-        k.a1[s] = coef[5 * s + 3];
-        k.a2[s] = coef[5 * s + 4];
-        k.ib0[s] = 1.0f / b0;
-        k.c1[s] = b1 / b0;
-        k.c2[s] = b2 / b0;
+        k.a1[s] = rcrow[RC_SOS + 5 * s + 3];
+        k.a2[s] = rcrow[RC_SOS + 5 * s + 4];
+        k.c1[s] = rcrow[RC_AP + 3 * s];
+        k.c2[s] = rcrow[RC_AP + 3 * s + 1];
+        k.ib0[s] = rcrow[RC_AP + 3 * s + 2];
     }
 }
 
@@ -336,7 +335,7 @@ __device__ __forceinline__ void allpole_zs_body(const float* __restrict__ u, int
     const int64_t tile_base = (int64_t)blockIdx.x * kEqWG * kEqChunk;
     const int chunk = blockIdx.x * kEqWG + tid;
     ApCoef k;
-    load_ap(rc + (int64_t)filter_row(sig, split) * RC_STRIDE + RC_SOS, k);
+    load_ap(rc + (int64_t)filter_row(sig, split) * RC_STRIDE, k);
     float wa1[kSections], wa2[kSections], wb1[kSections], wb2[kSections];
 #pragma unroll
     for (int s = 0; s < kSections; ++s) wa1[s] = wa2[s] = wb1[s] = wb2[s] = 0.0f;
@@ -398,7 +397,7 @@ __device__ __forceinline__ void coefgrad_body(const float* __restrict__ u, int64
     // accumulate (5 FMAs) - 9 plain FMAs.  (Round 1 packed the filter pair into v_pk_fma_f32: 6 packed operations, which on
     // gfx950 issue at HALF rate - 12 issue slots where these take 9, and a lane of one product was idle.)
     ApCoef k;
-    load_ap(rc + (int64_t)filter_row(sig, split) * RC_STRIDE + RC_SOS, k);
+    load_ap(rc + (int64_t)filter_row(sig, split) * RC_STRIDE, k);
     float wa1[kSections], wa2[kSections], wb1[kSections], wb2[kSections];
     float db0[kSections], db1[kSections], db2[kSections], da1[kSections], da2[kSections];
 #pragma unroll

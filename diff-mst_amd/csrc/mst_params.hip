@@ -240,6 +240,12 @@ __global__ __launch_bounds__(320) void k_prep(PrepArgs a) {
         coef[tid] = v;  // the table chains below read the folded coefficients from LDS, not back from HBM
     }
     __syncthreads();
+    if (tid < kSections) {  // all-pole constants of section tid (fp32 divisions, as the kernels did them)
+        const float b0 = coef[5 * tid];
+        rc[RC_AP + 3 * tid] = coef[5 * tid + 1] / b0;
+        rc[RC_AP + 3 * tid + 1] = coef[5 * tid + 2] / b0;
+        rc[RC_AP + 3 * tid + 2] = 1.0f / b0;
+    }
 
     // ---- one-sample transition matrices of the forward and the adjoint cascade (zero input)
     double c64[30];
