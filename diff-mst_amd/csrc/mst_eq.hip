@@ -292,7 +292,13 @@ __device__ __forceinline__ void cascade_body(const float* __restrict__ in, int64
 }
 
 template <int DIR, bool MODE_RUN, bool FUSE_GC = false, bool SCAN1 = false, bool FUSE_AP = false>
-__global__ __launch_bounds__(kEqWG) void k_cascade(const float* __restrict__ in, int64_t in_stride,
+// The track rows' forward run (compressor curve + all-pole bank riding along) takes 152 registers uncapped = 3 waves per SIMD =
+// 1.33 rounds of its 4096 one-wave workgroups at cfg #2; capped at 128 (28 spilled) it runs in one round: 57.8 -> 52.8 us.
+// The 16-row master kernels are lone waves and lose 0.2-0.4 us to the same cap, so they stay uncapped.
+#ifndef MST_EQ_RUN_W
+#define MST_EQ_RUN_W 4
+#endif
+__global__ __launch_bounds__(kEqWG, (MODE_RUN && FUSE_GC && FUSE_AP) ? MST_EQ_RUN_W : 1) void k_cascade(const float* __restrict__ in, int64_t in_stride,
                                                  float* __restrict__ out, int64_t out_stride,
                                                  const float* __restrict__ rc, int split,
                                                  const float* __restrict__ s0, float* __restrict__ z,

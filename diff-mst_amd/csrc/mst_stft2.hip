@@ -196,14 +196,17 @@ __device__ __forceinline__ float2 cotangent(const float2 (*buf)[FftShape<N>::SLO
 }
 
 #ifndef MST_STFT2_BWD_L512
-#define MST_STFT2_BWD_L512 5   // hop blocks per strip (halo mode): 6 frames per one-wave workgroup, 20 % recomputed
+#define MST_STFT2_BWD_L512 4  // 5 frames per workgroup, 25 % recomputed: 4096 one-wave workgroups = exactly the 4 waves per SIMD that 128 registers allow
 #endif
 #ifndef MST_STFT2_BWD_L2048
-#define MST_STFT2_BWD_L2048 7  // 8 frames per 256-lane workgroup, 14 % recomputed
+#define MST_STFT2_BWD_L2048 6  // 7 frames per 256-lane workgroup, 17 % recomputed: 672 workgroups = one round of the 768 the CUs hold at 144 registers
 #endif
 
+#ifndef MST_STFT2_W2048_BWD
+#define MST_STFT2_W2048_BWD 1  // min waves per SIMD asked of the 2048-point backward (A/B switch; uncapped it takes 144 registers)
+#endif
 template <int N>
-__global__ __launch_bounds__(FftPlan<N>::LG, (N == 8192 ? MST_STFT2_W8192_BWD : 1)) void k_stft2_bwd(StftArgs a) {
+__global__ __launch_bounds__(FftPlan<N>::LG, (N == 8192 ? MST_STFT2_W8192_BWD : (N == 2048 ? MST_STFT2_W2048_BWD : 1))) void k_stft2_bwd(StftArgs a) {
     using S = FftShape<N>;
     using L = FrameLoader<N>;
     constexpr int LG = S::LG, H = N / 2;
