@@ -92,6 +92,18 @@ __device__ __forceinline__ float block_carry(const float* __restrict__ agg, int 
     return S;
 }
 
+// zero-entry aggregate of the workgroup's block alone (what the zero-state passes publish): a weighted SUM, not a scan -
+//   forward: sum_t a^(255 - t) z_t,   REV: sum_t a^t z_t   (t = lane chunk index in the block, a = alpha^8)
+// one exp2, six DPP additions and one barrier instead of block_enter's seven ds_bpermute and two barriers.
+template <bool REV>
+__device__ __forceinline__ float block_aggregate(float z, float log2a, float* lds, int tid) {
+    const float w = __builtin_amdgcn_exp2f((float)(REV ? tid : kWG - 1 - tid) * log2a);
+    const float v = wave_sum(w * z);
+    if ((tid & 63) == 0) lds[tid >> 6] = v;
+    __syncthreads();
+    return (lds[0] + lds[1]) + (lds[2] + lds[3]);
+}
+
 // ---- forward: zero-state end value of the smoother per 2048-sample block ---------------------------
 // u: [(row*NCH+ch)][stride]; zs: [row][nc_pad]
 template <int NCH, bool FAST>
@@ -117,10 +129,8 @@ __device__ __forceinline__ void comp_zs_body(const float* __restrict__ u, int64_
         // samples past the end contribute nothing (their state is never consumed)
         acc = fmaf(k.alpha, acc, k.oma * gc);
     }
-    const float* rcr = rc + (int64_t)row * RC_STRIDE;
-    const float a = rcr[RC_ALPHA_C], log2a = rcr[RC_LOG2A_C];
-    const float enter = block_enter<false>(acc, a, log2a, 0.0f, lds, threadIdx.x);
-    if (threadIdx.x == kWG - 1) zs[(int64_t)row * gridDim.x + blockIdx.x] = fmaf(a, enter, acc);
+    const float agg = block_aggregate<false>(acc, rc[(int64_t)row * RC_STRIDE + RC_LOG2A_C], lds, threadIdx.x);
+    if (threadIdx.x == 0) zs[(int64_t)row * gridDim.x + blockIdx.x] = agg;
 }
 template <int NCH>
 __global__ __launch_bounds__(kWG) void k_comp_zs(const float* __restrict__ u, int64_t stride, const float* __restrict__ rc,
@@ -325,9 +335,8 @@ __device__ __forceinline__ void comp_bwd_zs_body(const CompBwdArgs& a) {
         const float dgs = (FAST || i0 + i < a.n) ? dot * G * kLn10Over20 : 0.0f;
         acc = fmaf(k.alpha, acc, dgs);
     }
-    const float ac = rc[RC_ALPHA_C], l2a = rc[RC_LOG2A_C];
-    const float enter = block_enter<true>(acc, ac, l2a, 0.0f, lds, threadIdx.x);
-    if (threadIdx.x == 0) a.zq[(int64_t)row * gridDim.x + blockIdx.x] = fmaf(ac, enter, acc);
+    const float agg = block_aggregate<true>(acc, rc[RC_LOG2A_C], lds, threadIdx.x);
+    if (threadIdx.x == 0) a.zq[(int64_t)row * gridDim.x + blockIdx.x] = agg;
 }
 template <bool MASTER>
 __global__ __launch_bounds__(kWG) void k_comp_bwd_zs(CompBwdArgs a) {

@@ -481,7 +481,10 @@ __device__ __forceinline__ void coefgrad_body(const float* __restrict__ u, int64
     }
 }
 
-__global__ __launch_bounds__(kEqWG) void k_coefgrad(const float* __restrict__ u, int64_t u_stride,
+#ifndef MST_COEFGRAD_W
+#define MST_COEFGRAD_W 1  // min waves per SIMD asked of k_coefgrad (A/B switch)
+#endif
+__global__ __launch_bounds__(kEqWG, MST_COEFGRAD_W) void k_coefgrad(const float* __restrict__ u, int64_t u_stride,
                                                   const float* __restrict__ g, int64_t g_stride,
                                                   const float* __restrict__ rc, int split,
                                                   const float* __restrict__ s0, int nc_pad,
