@@ -389,47 +389,54 @@ __global__ __launch_bounds__(kEqWG) void k_allpole_zs(const float* __restrict__ 
 }
 
 // coefficient-gradient partial sums: part[sig][block][30] = {db0 db1 db2 da1 da2} x 6 sections
+// TWO waves per tile: both walk the same 64 chunks, wave h owns sections 3h .. 3h+2 (the bank's sections are independent:
+// every one filters the same u and is correlated with the same g).  Wave 0 stages the u slabs, wave 1 the g slabs, each lane
+// reads both images.  One wave per tile needed 144 registers (3 waves per SIMD, 5120 workgroups = 1.67 rounds at cfg #2);
+// half the sections per wave halve the arithmetic per wave and the register count with it.
+constexpr int kCgSec = kSections / 2;
 template <bool FAST>
 __device__ __forceinline__ void coefgrad_body(const float* __restrict__ u, int64_t u_stride,
                                               const float* __restrict__ g, int64_t g_stride,
                                               const float* __restrict__ rc, int split,
                                               const float* __restrict__ s0, int nc_pad,
                                               float* __restrict__ part, int64_t n, float* __restrict__ tile_u,
-                                              float* __restrict__ tile_g, float (*red)[EP_COUNT]) {
-    const int tid = threadIdx.x, sig = blockIdx.y;
+                                              float* __restrict__ tile_g, float (*red)[EP_COUNT / 2]) {
+    const int tid = threadIdx.x & 63, half = threadIdx.x >> 6, sig = blockIdx.y;
     const int64_t tile_base = (int64_t)blockIdx.x * kEqWG * kEqChunk;
     const int chunk = blockIdx.x * kEqWG + tid;
     // Per sample and section: 1/A_k and b0/B_k advance (2 FMAs each) and their five inner products with the cotangent
     // accumulate (5 FMAs) - 9 plain FMAs.  (Round 1 packed the filter pair into v_pk_fma_f32: 6 packed operations, which on
     // gfx950 issue at HALF rate - 12 issue slots where these take 9, and a lane of one product was idle.)
-    ApCoef k;
-    load_ap(rc + (int64_t)filter_row(sig, split) * RC_STRIDE, k);
-    float wa1[kSections], wa2[kSections], wb1[kSections], wb2[kSections];
-    float db0[kSections], db1[kSections], db2[kSections], da1[kSections], da2[kSections];
+    const float* rcrow = rc + (int64_t)filter_row(sig, split) * RC_STRIDE;
+    float ka1[kCgSec], ka2[kCgSec], kc1[kCgSec], kc2[kCgSec], kib0[kCgSec];
+    float wa1[kCgSec], wa2[kCgSec], wb1[kCgSec], wb2[kCgSec];
+    float db0[kCgSec], db1[kCgSec], db2[kCgSec], da1[kCgSec], da2[kCgSec];
 #pragma unroll
-    for (int s = 0; s < kSections; ++s) {
+    for (int j = 0; j < kCgSec; ++j) {
+        const int s = kCgSec * half + j;
+        ka1[j] = rcrow[RC_SOS + 5 * s + 3];
+        ka2[j] = rcrow[RC_SOS + 5 * s + 4];
+        kc1[j] = rcrow[RC_AP + 3 * s];
+        kc2[j] = rcrow[RC_AP + 3 * s + 1];
+        kib0[j] = rcrow[RC_AP + 3 * s + 2];
         const int64_t base = ((int64_t)sig * 24 + 4 * s) * nc_pad + chunk;
-        wa1[s] = s0[base];
-        wa2[s] = s0[base + nc_pad];
-        wb1[s] = s0[base + 2 * (int64_t)nc_pad];
-        wb2[s] = s0[base + 3 * (int64_t)nc_pad];
-        db0[s] = db1[s] = db2[s] = da1[s] = da2[s] = 0.0f;
+        wa1[j] = s0[base];
+        wa2[j] = s0[base + nc_pad];
+        wb1[j] = s0[base + 2 * (int64_t)nc_pad];
+        wb2[j] = s0[base + 3 * (int64_t)nc_pad];
+        db0[j] = db1[j] = db2[j] = da1[j] = da2[j] = 0.0f;
     }
-    const float* urow = u + (int64_t)sig * u_stride;
-    const float* grow = g + (int64_t)sig * g_stride;
+    const float* srow = half == 0 ? u + (int64_t)sig * u_stride : g + (int64_t)sig * g_stride;  // the stream this wave stages
+    float* simg = half == 0 ? tile_u : tile_g;
     float* mu = &tile_u[tid * kLdw];
     float* mg = &tile_g[tid * kLdw];
-    SlabRegs pu, pg;
-    slab_first<FAST>(pu, urow, tile_base, 0, n, tid);
-    slab_first<FAST>(pg, grow, tile_base, 0, n, tid);
+    SlabRegs pre;
+    slab_first<FAST>(pre, srow, tile_base, 0, n, tid);
     for (int j = 0; j < kNSlab; ++j) {
-        slab_enter<FAST>(pu, urow, tile_base, j, n, tid);
-        slab_enter<FAST>(pg, grow, tile_base, j, n, tid);
-        slab_stash(pu, tile_u, tid);
-        slab_stash(pg, tile_g, tid);
+        slab_enter<FAST>(pre, srow, tile_base, j, n, tid);
+        slab_stash(pre, simg, tid);
         __syncthreads();
-        slab_next<FAST>(pu, urow, tile_base, j + 1, j + 1 < kNSlab, n, tid);
-        slab_next<FAST>(pg, grow, tile_base, j + 1, j + 1 < kNSlab, n, tid);
+        slab_next<FAST>(pre, srow, tile_base, j + 1, j + 1 < kNSlab, n, tid);
 #pragma unroll 1
         for (int i4 = 0; i4 < kSlab; i4 += 4) {
             const float4 xv = *reinterpret_cast<const float4*>(&mu[i4]);
@@ -439,59 +446,55 @@ __device__ __forceinline__ void coefgrad_body(const float* __restrict__ u, int64
             for (int t = 0; t < 4; ++t) {
                 const float x = xs[t], gp = gs[t], gm = -gs[t];
 #pragma unroll
-                for (int s = 0; s < kSections; ++s) {
-                    const float wa = fmaf(-k.a2[s], wa2[s], fmaf(-k.a1[s], wa1[s], x));
-                    const float wb = fmaf(-k.c2[s], wb2[s], fmaf(-k.c1[s], wb1[s], x));
-                    db0[s] = fmaf(gp, wb, db0[s]);
-                    db1[s] = fmaf(gp, wb1[s], db1[s]);
-                    db2[s] = fmaf(gp, wb2[s], db2[s]);
-                    da1[s] = fmaf(gm, wa1[s], da1[s]);
-                    da2[s] = fmaf(gm, wa2[s], da2[s]);
-                    wa2[s] = wa1[s];
-                    wa1[s] = wa;
-                    wb2[s] = wb1[s];
-                    wb1[s] = wb;
+                for (int q = 0; q < kCgSec; ++q) {
+                    const float wa = fmaf(-ka2[q], wa2[q], fmaf(-ka1[q], wa1[q], x));
+                    const float wb = fmaf(-kc2[q], wb2[q], fmaf(-kc1[q], wb1[q], x));
+                    db0[q] = fmaf(gp, wb, db0[q]);
+                    db1[q] = fmaf(gp, wb1[q], db1[q]);
+                    db2[q] = fmaf(gp, wb2[q], db2[q]);
+                    da1[q] = fmaf(gm, wa1[q], da1[q]);
+                    da2[q] = fmaf(gm, wa2[q], da2[q]);
+                    wa2[q] = wa1[q];
+                    wa1[q] = wa;
+                    wb2[q] = wb1[q];
+                    wb1[q] = wb;
                 }
             }
         }
         __syncthreads();
         slab_fence();
     }
-    float acc[EP_COUNT];
+    float acc[EP_COUNT / 2];
 #pragma unroll
-    for (int s = 0; s < kSections; ++s) {
-        acc[5 * s + 0] = db0[s] * k.ib0[s];
-        acc[5 * s + 1] = db1[s] * k.ib0[s];
-        acc[5 * s + 2] = db2[s] * k.ib0[s];
-        acc[5 * s + 3] = da1[s];
-        acc[5 * s + 4] = da2[s];
+    for (int q = 0; q < kCgSec; ++q) {
+        acc[5 * q + 0] = db0[q] * kib0[q];
+        acc[5 * q + 1] = db1[q] * kib0[q];
+        acc[5 * q + 2] = db2[q] * kib0[q];
+        acc[5 * q + 3] = da1[q];
+        acc[5 * q + 4] = da2[q];
     }
-    // deterministic workgroup reduction: wave shuffle tree, then 4 wave partials in fixed order
-    const int wave = tid >> 6, lane = tid & 63;
+    // deterministic reduction: one DPP sum per value, lane 0 of each wave parks its 15
 #pragma unroll
-    for (int i = 0; i < EP_COUNT; ++i) {
+    for (int i = 0; i < EP_COUNT / 2; ++i) {
         const float v = wave_sum(acc[i]);
-        if (lane == 0) red[wave][i] = v;
+        if (tid == 0) red[half][i] = v;
     }
     __syncthreads();
-    if (tid < EP_COUNT) {
-        float v = red[0][tid];
-        for (int w = 1; w < kEqWG / 64; ++w) v += red[w][tid];
-        part[((int64_t)sig * gridDim.x + blockIdx.x) * EP_COUNT + tid] = v;
-    }
+    if (threadIdx.x < EP_COUNT)
+        part[((int64_t)sig * gridDim.x + blockIdx.x) * EP_COUNT + threadIdx.x] = red[threadIdx.x / (EP_COUNT / 2)][threadIdx.x % (EP_COUNT / 2)];
 }
 
 #ifndef MST_COEFGRAD_W
 #define MST_COEFGRAD_W 1  // min waves per SIMD asked of k_coefgrad (A/B switch)
 #endif
-__global__ __launch_bounds__(kEqWG, MST_COEFGRAD_W) void k_coefgrad(const float* __restrict__ u, int64_t u_stride,
+__global__ __launch_bounds__(2 * kEqWG, MST_COEFGRAD_W) void k_coefgrad(const float* __restrict__ u, int64_t u_stride,
                                                   const float* __restrict__ g, int64_t g_stride,
                                                   const float* __restrict__ rc, int split,
                                                   const float* __restrict__ s0, int nc_pad,
                                                   float* __restrict__ part, int64_t n) {
     __shared__ __attribute__((aligned(16))) float tile_u[kEqWG * kLdw];
     __shared__ __attribute__((aligned(16))) float tile_g[kEqWG * kLdw];
-    __shared__ float red[kEqWG / 64][EP_COUNT];
+    __shared__ float red[2][EP_COUNT / 2];
     const int64_t tile_base = (int64_t)blockIdx.x * kTile;
     if (tile_fast(u + (int64_t)blockIdx.y * u_stride, tile_base, n) && !((uintptr_t)(g + (int64_t)blockIdx.y * g_stride) & 15))
         coefgrad_body<true>(u, u_stride, g, g_stride, rc, split, s0, nc_pad, part, n, tile_u, tile_g, red);
@@ -563,7 +566,7 @@ void launch_allpole_zs(const float* u, int64_t u_stride, const float* rc, int sp
 
 void launch_coefgrad(const float* u, int64_t u_stride, const float* g, int64_t g_stride, const float* rc, int split,
                      const float* s0, int nc_pad, float* part, int64_t n, int nsig, hipStream_t stream) {
-    dim3 grid(nc_pad / kEqWG, nsig), block(kEqWG);
+    dim3 grid(nc_pad / kEqWG, nsig), block(2 * kEqWG);
     hipLaunchKernelGGL(k_coefgrad, grid, block, 0, stream, u, u_stride, g, g_stride, rc, split, s0, nc_pad, part, n);
 }
 
