@@ -378,6 +378,8 @@ __global__ __launch_bounds__(320) void k_prep(PrepArgs a) {
 __global__ __launch_bounds__(256) void k_prep_bwd(PrepBwdArgs a) {
     __shared__ double dsos[EP_COUNT];
     __shared__ double dcp[CP_COUNT];
+    __shared__ double lanesum[64][EP_COUNT + CP_COUNT + 1];  // per-lane fp64 sums of wave 0 (odd row length: conflict-free columns)
+    __shared__ double Jd[kSections][5][3];                   // design Jacobians d{b0 b1 b2 a1 a2} / d{gain, freq, q}
     const int row = blockIdx.x, tid = threadIdx.x;
     const bool is_master = row >= a.R;
     const int mrow = row - a.R;
@@ -397,9 +399,10 @@ __global__ __launch_bounds__(256) void k_prep_bwd(PrepBwdArgs a) {
     const bool gin_on = is_master ? (d.flags & MST_USE_MASTER_BUS) : (d.flags & MST_USE_TRACK_INPUT_FADER);
     const bool chain_on = is_master ? (d.flags & MST_USE_MASTER_BUS) : true;  // does the EQ/gain stage exist
 
-    // deterministic reduction of the partial sums (wave 0).  All of a lane's loads are issued before anything is
-    // summed (one memory round trip instead of one per sum): lane l takes workgroup-partials l, l+64, ...
-    // as fp64, then a fixed shuffle tree folds the 64 lanes.
+    // deterministic reduction of the partial sums.  Wave 0: lane l takes workgroup-partials l, l+64, ... as fp64, every load of a
+    // lane issued before anything is summed (one memory round trip), and parks its 38 sums in LDS; then lane q < 38 adds the 64
+    // lane values of sum q in lane order (a fp64 shuffle tree here was 456 ds_bpermute).  Wave 1 meanwhile runs the fp64
+    // dual-number biquad design (exp2, sincos) whose Jacobian the chain rule below needs - it used to wait for the reduction.
     if (tid < 64) {
         const int nsig = is_master ? 2 : 1;
         const float* ep = is_master ? a.ep_m + ((int64_t)(mrow * 2) * a.nblkE) * EP_COUNT
@@ -430,32 +433,37 @@ __global__ __launch_bounds__(256) void k_prep_bwd(PrepBwdArgs a) {
             sc[4] += (double)v1.x; sc[5] += (double)v1.y; sc[6] += (double)v1.z; sc[7] += (double)v1.w;
         }
 #pragma unroll
-        for (int q = 0; q < EP_COUNT; ++q) {
-            double s = se[q];
-            for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
-            if (tid == 0) dsos[q] = s;
-        }
+        for (int q = 0; q < EP_COUNT; ++q) lanesum[tid][q] = se[q];
 #pragma unroll
-        for (int q = 0; q < CP_COUNT; ++q) {
-            double s = sc[q];
-            for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
-            if (tid == 0) dcp[q] = s;
+        for (int q = 0; q < CP_COUNT; ++q) lanesum[tid][EP_COUNT + q] = sc[q];
+    } else if (tid < 64 + kSections) {
+        const int k = tid - 64, i = eq0 + 3 * k;
+        if (eq_on) {
+            D3 J[5];
+            design_section_dual(section_kind(k), (double)denorm(p[i], lo[i], hi[i]), (double)denorm(p[i + 1], lo[i + 1], hi[i + 1]),
+                                (double)denorm(p[i + 2], lo[i + 2], hi[i + 2]), sr, J);
+            for (int j = 0; j < 5; ++j)
+                for (int v = 0; v < 3; ++v) Jd[k][j][v] = J[j].d[v];
         }
     }
     if (tid < np) g[tid] = 0.0f;
+    __syncthreads();
+    if (tid < EP_COUNT + CP_COUNT) {
+        double s = 0.0;
+        for (int l = 0; l < 64; ++l) s += lanesum[l][tid];
+        if (tid < EP_COUNT) dsos[tid] = s;
+        else dcp[tid - EP_COUNT] = s;
+    }
     __syncthreads();
 
     const double gin = rc[RC_GIN];
     if (tid < kSections) {
         if (eq_on) {
             const int k = tid, i = eq0 + 3 * k;
-            D3 J[5];
-            design_section_dual(section_kind(k), (double)denorm(p[i], lo[i], hi[i]), (double)denorm(p[i + 1], lo[i + 1], hi[i + 1]),
-                                (double)denorm(p[i + 2], lo[i + 2], hi[i + 2]), sr, J);
             const double bs0 = (k == 0) ? gin : 1.0;  // section 0's numerator was scaled by the fader
             for (int v = 0; v < 3; ++v) {
                 double acc = 0.0;
-                for (int j = 0; j < 5; ++j) acc += dsos[5 * k + j] * J[j].d[v] * (j < 3 ? bs0 : 1.0);
+                for (int j = 0; j < 5; ++j) acc += dsos[5 * k + j] * Jd[k][j][v] * (j < 3 ? bs0 : 1.0);
                 g[i + v] = (float)(acc * (double)(hi[i + v] - lo[i + v]));
             }
         }
