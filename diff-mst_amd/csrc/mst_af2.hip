@@ -205,11 +205,8 @@ __device__ __forceinline__ void af2_bwd_half(const AfArgs& a, float2 (*buf)[AfS:
     __syncthreads();
     af2_cotangent<HALF>(a, buf, dM, twN, lane);
     __syncthreads();
-    float2 vin[16];  // every lane's inputs leave LDS before the first pass overwrites it
-#pragma unroll
-    for (int t = 0; t < 16; ++t) vin[t] = af2_at(buf, lane + kAf2Lanes * t);
-    __syncthreads();
-    fft8192_from<false>([&](int t) { return vin[t]; }, buf[0], buf[1], tw, wl, lane);
+    // the second transform reads its inputs straight from the buffers it is about to overwrite (barrier inside)
+    fft8192_from<false, true>([&](int t) { return af2_at(buf, lane + kAf2Lanes * t); }, buf[0], buf[1], tw, wl, lane);
     __syncthreads();
     // Ph[m] = af2_at(buf, m).  Half 0 parks P0 in the frame's slab; half 1 reads it back (the same lane wrote it), combines
     // Y[m], Y[m + 8192] = P0 +- W_16384^m P1 and stores the windowed frame  y[2m] = w Re Y[m],  y[2m+1] = -w Im Y[m].

@@ -266,7 +266,9 @@ __device__ __forceinline__ float2 w16(int t) {
 // raw(t) -> element lane + 512 t (t < 16).  WINDOW: multiply by the periodic Hann window, formed from the radix-2 twiddle the
 // split needs anyway (W_N^i = wl W_16^t for i = lane + 512 t;  hann(i) = 0.5 - 0.5 Re W_N^i,  hann(i + N/2) = 0.5 + 0.5 Re W_N^i).
 // On return (the caller adds ONE barrier) Z[2m] = bufe[slot(m)], Z[2m + 1] = bufo[slot(m)].  tw = LaneTw<8192>, wl = W_8192^lane.
-template <bool WINDOW, typename F>
+// RAW_IN_LDS: raw() reads the transform's own LDS buffers (the previous transform's output, modified in place) - a barrier
+// separates the last read from the first pass's stores, so that callers need not park 16 values in registers.
+template <bool WINDOW, bool RAW_IN_LDS = false, typename F>
 __device__ __forceinline__ void fft8192_from(F&& raw, float2* __restrict__ bufe, float2* __restrict__ bufo, const LaneTw<8192>& tw,
                                              float2 wl, int lane) {
     using S = FftShape<8192>;
@@ -280,6 +282,7 @@ __device__ __forceinline__ void fft8192_from(F&& raw, float2* __restrict__ bufe,
         e[t] = cadd(a, b);
         d[t] = cmul(csub(a, b), w);
     }
+    if (RAW_IN_LDS) __syncthreads();
     fft_run2<8192>(e, d, oe, od, bufe, bufo, tw, lane);
     __syncthreads();
 #pragma unroll

@@ -66,18 +66,14 @@ __global__ __launch_bounds__(kFxLanes, 2) void k_fx_fir(const float* __restrict_
         return i < in_len ? make_float2(xl[i], xr[i]) : make_float2(0.f, 0.f);
     }, buf[0], buf[1], tw, wl, lane);
     __syncthreads();
-    // product with the filter spectrum, conjugated for the inverse (IFFT(P) = conj(FFT(conj P)) / N); element q = lane + 512 t
-    // is both what this lane reads here and what it feeds to the first pass of the second transform
-    float2 vin[16];
+    // product with the filter spectrum, conjugated for the inverse (IFFT(P) = conj(FFT(conj P)) / N), formed while the second
+    // transform gathers its inputs from the buffers it is about to overwrite (barrier inside)
     const float2* h = Hc + (int64_t)k * kFxN;
-#pragma unroll
-    for (int t = 0; t < 16; ++t) {
+    fft8192_from<false, true>([&](int t) {
         const int q = lane + kFxLanes * t;
         const float2 pz = cmul(buf[q & 1][Sh::slot(q >> 1)], h[q]);
-        vin[t] = make_float2(pz.x, -pz.y);
-    }
-    __syncthreads();  // every lane's spectrum reads are done before the first pass overwrites the buffer
-    fft8192_from<false>([&](int t) { return vin[t]; }, buf[0], buf[1], tw, wl, lane);
+        return make_float2(pz.x, -pz.y);
+    }, buf[0], buf[1], tw, wl, lane);
     __syncthreads();
     float* dl = wnf + ((int64_t)(2 * b) * 12 + k) * S;
     float* dr = wnf + ((int64_t)(2 * b + 1) * 12 + k) * S;
