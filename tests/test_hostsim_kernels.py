@@ -100,7 +100,7 @@ def test_console_denormalised_parameter_path(ranges):
     assert rel(b["grad_mp"] * (mhi - mlo), a["grad_mp"]) < 1e-4
 
 
-@pytest.mark.parametrize("S,n", [(8192, 2 * 4096 + 1237), (65536, 18 * 4096 + 5)])
+@pytest.mark.parametrize("S,n", [(8192, 2 * 4096 + 1237), (65536, 16 * 4096 + 465)])  # 17 blocks: two frame chunks of the dH walk
 def test_console_fx_bus(ranges, S, n):
     """use_fx_bus = True (the reference's default): send bus + noise-shaped reverberation (partitioned FFT convolution on the
     8192-point engine) forward and backward, with a short impulse response (2 partitions) and short band-passes so that the
@@ -207,8 +207,9 @@ def test_mrstft_register_radix_engine():
         lo.backward()
         assert abs(out["loss"].item() - lo.item()) / lo.item() < 1e-6
         assert rel(out["grad_pred"], xo.grad) < 1e-5, res
-        again = harness.mrstft(x, y, res, w_sc=1.0, w_log_mag=0.0)
-        assert torch.equal(out["grad_pred"], again["grad_pred"])  # reproducible bit for bit
+        if len(res) == 3:  # the seam hand-over between launches: reproducible bit for bit (every combination is on the GPU)
+            again = harness.mrstft(x, y, res, w_sc=1.0, w_log_mag=0.0)
+            assert torch.equal(out["grad_pred"], again["grad_pred"])
     # the shortest row the round-2 kernels take (two 8192-frames deep) and the full loss (log-magnitude term included)
     xs, ys = x[..., :16384].contiguous(), y[..., :16384].contiguous()
     res = ((512, 256, 512), (2048, 1024, 2048), (8192, 4096, 8192))
