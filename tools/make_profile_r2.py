@@ -70,5 +70,53 @@ def main(steps):
                 json.dump(json.loads(line), open(os.path.join(P, "round2_bench.json"), "w"), indent=1)
 
 
+ROUND1_US = {  # profiles/round1_summary.md, us per step
+    "k_stft_bwd_ip<8192>": 92.2, "k_comp_bwd_run<false>": 74.3, "k_cascade<0, true, true, true, true>": 66.6,
+    "k_stft_bwd<2048, true>": 61.1, "k_coefgrad": 56.7, "k_stft_fwd<8192>": 54.6, "k_stft_bwd<512, true>": 52.2,
+    "k_stft_fwd<2048>": 41.1, "k_apply_tracks": 35.6, "k_stft_fwd<512>": 33.6, "k_comp_bwd_zs<false>": 27.7,
+    "k_prep": 16.0, "k_prep_bwd": 14.0, "k_scan<2, false, 8>": 14.0,
+}
+SAME_AS_ROUND1 = {"k_stft2_bwd<8192>": "k_stft_bwd_ip<8192>", "k_stft2_bwd<2048>": "k_stft_bwd<2048, true>",
+                  "k_stft2_bwd<512>": "k_stft_bwd<512, true>", "k_stft2_fwd<8192>": "k_stft_fwd<8192>",
+                  "k_stft2_fwd<2048>": "k_stft_fwd<2048>", "k_stft2_fwd<512>": "k_stft_fwd<512>",
+                  "k_comp_bwd_run<false, false>": "k_comp_bwd_run<false>"}
+
+
+def summary():
+    b = json.load(open(os.path.join(P, "round2_bench.json")))
+    t = json.load(open(os.path.join(P, "round2_traffic.json")))
+    rows = json.load(open(os.path.join(P, "round2_counters.json")))
+    rows = rows["rows"] if isinstance(rows, dict) else rows
+    r = b["roofline"]
+    out = ["# Round 2 profile - `python bench.py` on one MI355X (final build of the round)", "",
+           "Made by `tools/_final.sh` on the GPU box (full `-m gpu` suite, `smoke()`, `tools/pmc_passes.sh r2`, `bench.py`) and "
+           "`tools/make_profile_r2.py` here.  Raw: `round2_bench_kernel_stats.csv` (rocprofv3 --kernel-trace --stats of "
+           "`bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-secondary`), `round2_counters.md/json` (separate --pmc passes), "
+           "`round2_traffic.json`, `round2_bench.json` (the un-profiled bench line), `parity_r02.json` (measured parity numbers).", "",
+           f"**Bench line: {b['value']:.0f} mixes/s, {b['ms_per_step']:.4f} ms per step** (median of per-step HIP events "
+           f"{r['gpu_ms_per_step_median']:.4f} ms), {r['achieved']:.0f} GB/s algorithmic = {100 * r['frac']:.2f} % of 8 TB/s; raw HBM "
+           f"traffic {t['hbm_bytes_per_step_raw'] / 1e9:.3f} GB per step = {t['hbm_bytes_per_step_raw'] / t['algorithmic_bytes_per_step']:.1f}x "
+           f"the algorithmic bytes; VALU {t['valu_lane_instructions_per_step']:.3g} lane-instructions per step "
+           f"(issue share {100 * (r['valu'].get('issue_frac') or 0):.0f} %).  Round 1: 9983 mixes/s, 0.801 ms.", "",
+           "Stages (ms): " + ", ".join(f"{k.replace('_ms', '').replace('_', ' ')} {v:.3f}" for k, v in r["stages"].items()) + ".", "",
+           "| secondary line | ms per step (median) | mixes/s |", "|---|---:|---:|"]
+    for s_ in b.get("secondary", []):
+        out.append(f"| {s_['workload'][:110]} | {s_['ms_per_step_median']:.3f} | {s_['mixes_per_s']:.0f} |")
+    cb = b.get("cpu_baseline") or {}
+    if cb:
+        out += ["", f"CPU baseline (oracle, `kind: {cb.get('kind')}`): {cb.get('value'):.2f} mixes/s on {cb.get('cores')} threads; by thread count: "
+                + ", ".join(f"{k}: {v['value']:.2f}" for k, v in (cb.get("by_threads") or {}).items()) + "."]
+    out += ["", "| kernel | us per step | round 1 | VGPR | waves/SIMD | VALU issue % | wait % |", "|---|---:|---:|---:|---:|---:|---:|"]
+    for k in rows[:26]:
+        name = k["kernel"]
+        r1 = ROUND1_US.get(SAME_AS_ROUND1.get(name, name))
+        out.append(f"| {name} | {k['us_per_step']:.1f} | {'' if r1 is None else r1} | {k['vgpr']} | {k['waves_per_simd']:.1f} | "
+                   f"{100 * k['valu_issue']:.0f} | {100 * k['wait']:.0f} |")
+    out += ["", "VGPR = 2 x rocprofv3's `vgpr_count` (it reports half the wave64 allocation; checked against "
+            "`-Rpass-analysis=kernel-resource-usage`).  What the numbers mean and what was done with them: DESIGN.md section 8."]
+    open(os.path.join(P, "round2_summary.md"), "w").write("\n".join(out) + "\n")
+
+
 if __name__ == "__main__":
     main(int(sys.argv[1]) if len(sys.argv) > 1 else 15)
+    summary()
