@@ -397,42 +397,53 @@ __global__ __launch_bounds__(FftPlan<N>::LG, (N == 8192 ? MST_STFT2_W8192_BWD : 
             asm volatile("" : "+v"(li));
             const float2 wlf = twg[li];
             L::transform([&](int t) { return fetch(f, t); }, win, buf, tw, wlf, lane);
-            float2 Vk[PER], Vm[PER];
-#pragma unroll
-            for (int i = 0; i < PER; ++i) {
-                const int k = lane + i * LG;
-                Vk[i] = Vm[i] = make_float2(0.f, 0.f);
-                if (k <= M / 2) {
-                    float2 Hk = cotangent<N>(buf, k, a.eps, coef), Hm = cotangent<N>(buf, M - k, a.eps, coef);
-                    if (k == 0) {
-                        Vk[i] = make_float2(Hk.x + Hm.x, -(Hk.x - Hm.x));  // V[0] = (H0 + HM) + i (H0 - HM), both real; conj
-                    } else {
-                        Hk = make_float2(0.5f * Hk.x, 0.5f * Hk.y);
-                        Hm = make_float2(0.5f * Hm.x, 0.5f * Hm.y);
-                        const float2 w = twg[k];  // W_N^k ; W_N^(M-k) = -conj(W_N^k)
-                        const float2 Ak = make_float2(Hk.x + Hm.x, Hk.y - Hm.y);
-                        const float2 Bk = cmul(make_float2(Hk.x - Hm.x, Hk.y + Hm.y), make_float2(w.x, -w.y));
-                        Vk[i] = make_float2(Ak.x - Bk.y, -(Ak.y + Bk.x));
-                        const float2 Am = make_float2(Hm.x + Hk.x, Hm.y - Hk.y);
-                        const float2 Bm = cmul(make_float2(Hm.x - Hk.x, Hm.y + Hk.y), make_float2(-w.x, -w.y));
-                        Vm[i] = make_float2(Am.x - Bm.y, -(Am.y + Bm.x));
-                    }
+            // Pair (k, M - k) of the half-size inverse reads the 8192-point bins k, M - k, M + k, N - k: all of k's parity, i.e.
+            // all in ONE of the two spectrum buffers (even bins in buf[0], odd in buf[1]).  The odd pairs go first and wait in
+            // registers (2 per lane); once every lane has read its odd bins buf[1] is free, and the even pairs (which read
+            // buf[0] only) write their values - and the waiting odd ones - straight into buf[1]: 8 staging registers
+            // instead of 40 (all pairs parked across one barrier).
+            auto pair_v = [&](int k, float2& vk, float2& vm) {
+                float2 Hk = cotangent<N>(buf, k, a.eps, coef), Hm = cotangent<N>(buf, M - k, a.eps, coef);
+                if (k == 0) {
+                    vk = make_float2(Hk.x + Hm.x, -(Hk.x - Hm.x));  // V[0] = (H0 + HM) + i (H0 - HM), both real; conj
+                    vm = vk;
+                    return;
                 }
+                Hk = make_float2(0.5f * Hk.x, 0.5f * Hk.y);
+                Hm = make_float2(0.5f * Hm.x, 0.5f * Hm.y);
+                const float2 w = twg[k];  // W_N^k ; W_N^(M-k) = -conj(W_N^k)
+                const float2 Ak = make_float2(Hk.x + Hm.x, Hk.y - Hm.y);
+                const float2 Bk = cmul(make_float2(Hk.x - Hm.x, Hk.y + Hm.y), make_float2(w.x, -w.y));
+                vk = make_float2(Ak.x - Bk.y, -(Ak.y + Bk.x));
+                const float2 Am = make_float2(Hm.x + Hk.x, Hm.y - Hk.y);
+                const float2 Bm = cmul(make_float2(Hm.x - Hk.x, Hm.y + Hk.y), make_float2(-w.x, -w.y));
+                vm = make_float2(Am.x - Bm.y, -(Am.y + Bm.x));
+            };
+            static_assert(M / 4 == 2 * LG, "two odd and two even pairs per lane (plus k = M/2 on lane 0)");
+            float2 Ok[2], Om[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) pair_v(2 * (lane + i * LG) + 1, Ok[i], Om[i]);
+            __syncthreads();  // every lane has read its odd bins: buf[1] is free
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                if (i == 2 && lane != 0) break;
+                const int k = i == 2 ? M / 2 : 2 * (lane + i * LG);
+                float2 vk, vm;
+                pair_v(k, vk, vm);
+                buf[1][S::slot(k)] = vk;
+                if (k != 0 && k != M / 2) buf[1][S::slot(M - k)] = vm;
             }
-            __syncthreads();  // every lane has read its bins
 #pragma unroll
-            for (int i = 0; i < PER; ++i) {
-                const int k = lane + i * LG;
-                if (k <= M / 2) {
-                    buf[0][S::slot(k)] = Vk[i];
-                    if (k != 0 && k != M / 2) buf[0][S::slot(M - k)] = Vm[i];
-                }
+            for (int i = 0; i < 2; ++i) {
+                const int k = 2 * (lane + i * LG) + 1;
+                buf[1][S::slot(k)] = Ok[i];
+                buf[1][S::slot(M - k)] = Om[i];
             }
             __syncthreads();
             float2 v[8], o[1][8];
 #pragma unroll
-            for (int t = 0; t < 8; ++t) v[t] = buf[0][S::slot(lane + LG * t)];
-            __syncthreads();
+            for (int t = 0; t < 8; ++t) v[t] = buf[1][S::slot(lane + LG * t)];
+            // (the first pass of the inverse stores into buf[0], which nobody reads any more: no barrier needed here)
             fft_run<N>(v, o, buf[0], tw, lane);  // = conj(y_even + i y_odd) at m = lane + 512 t
             float h1[8], h2[8];
 #pragma unroll
