@@ -21,7 +21,7 @@ constexpr int kScanLevels = 9;         // log2(kScanThreads)
 constexpr int kPow = 1 + kScanLevels;  // matrices per scan table: M, then M^(K*2^j)
 constexpr int kTile = kEqWG * kEqChunk;  // samples one single-wave workgroup of the EQ kernels covers (4096)
 constexpr int kPow1 = 12;              // in-wave scans use M^(2^j), j = 0..5 (lanes of a tile) and 6..11 (tiles of a row)
-constexpr int kTri2 = 2 * 208;         // ... stored as two block-triangular table sets per row (mst_mat.h: kTriFloats each)
+constexpr int kTri2 = 2 * 592;         // ... stored as two block-triangular table sets per row (mst_mat.h: kTriFloats each)
 constexpr int kFxDhChunks = 4;          // fx bus backward: frame chunks of the dH product (partials summed by the inverse transform)
 constexpr int kMaxTiles1 = 64;         // rows of up to 64 tiles (262144 samples) scan in-wave (no carry-scan kernel)
 

@@ -161,7 +161,7 @@ __device__ __forceinline__ void cascade_body(const float* __restrict__ in, int64
             for (int d = 0; d < kStates; ++d) zz[d] = tid < wt ? agg[((int64_t)sig * kStates + d) * kMaxTiles1 + tid] : 0.0f;
             tab_stash(thi, tile, tid);
             __syncthreads();
-            wave_scan_tri<false>(zz, tile, tid, wt);
+            wave_scan_tri<false>(zz, tile, tid);
 #pragma unroll
             for (int d = 0; d < kStates; ++d) {
                 const float S = __shfl(zz[d], wt - 1);
@@ -172,7 +172,7 @@ __device__ __forceinline__ void cascade_body(const float* __restrict__ in, int64
         if (!MST_DBG_NOSCAN) {
             tab_stash(tlo, tile, tid);
             __syncthreads();
-            wave_scan_tri<DIR == EQ_ADJ>(st, tile, pos, kEqWG);
+            wave_scan_tri<DIR == EQ_ADJ>(st, tile, pos);
             __syncthreads();  // the slab image overwrites the table next
         }
     } else {
@@ -257,7 +257,7 @@ __device__ __forceinline__ void cascade_body(const float* __restrict__ in, int64
         if (SCAN1 && !MST_DBG_NOSCAN) {  // tile aggregate = the last position of the scan over the tile's chunk end states
             tab_stash(tlo, tile, tid);  // the slab buffer is free now
             __syncthreads();
-            wave_scan_tri<DIR == EQ_ADJ>(st, tile, pos, kEqWG);
+            wave_scan_tri<DIR == EQ_ADJ>(st, tile, pos);
             if (pos == kEqWG - 1) {  // indexed by the tile's position in recurrence order
                 const int wt = DIR == EQ_FWD ? (int)blockIdx.x : ntiles - 1 - (int)blockIdx.x;
 #pragma unroll

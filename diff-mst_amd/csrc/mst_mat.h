@@ -42,25 +42,48 @@ __device__ __forceinline__ void matvec_acc(const float* M, const float* v, float
 // splits into six 2-state scans run one after the other: section k scans  f = v_k + sum_{j<k} P_kj x_j[pos-1]  (x_j: the finished
 // scan of an earlier section, one position back) with its own diagonal block D_k = P_kk:
 //     x_k[pos] = D_k x_k[pos-1] + f[pos].
-// 204 FMAs and 82 shuffles per scan instead of six 12x12 triangular mat-vecs (504 FMAs, 144 16-byte LDS reads, 72 shuffles);
-// measured at cfg #2: the scans were 46 us of the step (ablation MST_DBG_NOSCAN).
-// One table set (kTriFloats floats, wave-uniform, staged through LDS):
-//   D[k][j][4]   at (6 k + j) 4          D_k^(2^j), j = 0..5, row-major 2x2
+// Each 2-state scan runs on DPP data movement alone (no ds_bpermute: an ablation build without the scans was 31 us per step
+// faster while they used 82 shuffles each): a Kogge-Stone pass inside every 16-lane row (row shifts by 1, 2, 4, 8 with the
+// wave-uniform D^(2^j)), the three row totals fetched with v_readlane and chained with D^16 into wave-uniform carries, and one
+// lane-dependent fix-up  x += D^(pin+1) carry  (pin = position inside the row).  "One position back" is a wave shift by 1.
+// One table set (kTriFloats floats, staged through LDS):
+//   D[k][j][4]   at (6 k + j) 4                    D_k^(2^j), j = 0..5, row-major 2x2 (j <= 4 used)
 //   C[k][jj][4]  at 144 + (k (k-1) / 2 + jj) 4     P_k,jj for jj < k
-constexpr int kTriFloats = 208;  // 204 used, padded to whole 16-byte vectors
+//   Dp[k][q][4]  at 208 + (16 k + q) 4             D_k^(q+1), q = 0..15
+constexpr int kTriFloats = 592;
 struct TabRegs {
-    float4 v;
+    float4 v[3];
 };
 __device__ __forceinline__ void tab_fetch(TabRegs& r, const float* __restrict__ g, int lane) {
-    r.v = lane < kTriFloats / 4 ? *reinterpret_cast<const float4*>(g + 4 * lane) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int q = lane + 64 * k;
+        r.v[k] = q < kTriFloats / 4 ? *reinterpret_cast<const float4*>(g + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
 }
 __device__ __forceinline__ void tab_stash(const TabRegs& r, float* __restrict__ lds, int lane) {
-    if (lane < kTriFloats / 4) *reinterpret_cast<float4*>(lds + 4 * lane) = r.v;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int q = lane + 64 * k;
+        if (q < kTriFloats / 4) *reinterpret_cast<float4*>(lds + 4 * q) = r.v[k];
+    }
 }
-// In-place inclusive scan over the lanes of one wave (pos = position in recurrence order; lane = pos, or 63 - pos when REV).
-// Levels whose stride reaches `limit` (wave-uniform: number of populated positions) are skipped.
+// value of the lane CTRL points at; 0 where that lane does not exist (row / wave edge)
+template <int CTRL>
+__device__ __forceinline__ float dpp_get(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float lane_get(float v, int lane) {  // wave-uniform
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+// In-place inclusive scan over the 64 lanes of one wave (pos = position in recurrence order; lane = pos, or 63 - pos when REV).
+// Positions that hold no data must carry zeros (they only receive).
 template <bool REV>
-__device__ __forceinline__ void wave_scan_tri(float* v, const float* __restrict__ tab, int pos, int limit) {
+__device__ __forceinline__ void wave_scan_tri(float* v, const float* __restrict__ tab, int pos) {
+    // one position back / d positions back inside the row: towards lower pos = lower lanes, or higher lanes when REV
+    constexpr int kBack1 = REV ? 0x130 : 0x138;   // wave_shl:1 / wave_shr:1
+    constexpr int kRow = REV ? 0x100 : 0x110;     // row_shl:d / row_shr:d
+    const int prow = pos >> 4, pin = pos & 15;
     float prev[kStates];
 #pragma unroll
     for (int k = 0; k < kSections; ++k) {
@@ -71,24 +94,49 @@ __device__ __forceinline__ void wave_scan_tri(float* v, const float* __restrict_
             f0 = fmaf(c.x, prev[2 * jj], fmaf(c.y, prev[2 * jj + 1], f0));
             f1 = fmaf(c.z, prev[2 * jj], fmaf(c.w, prev[2 * jj + 1], f1));
         }
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            if ((1 << j) >= limit) break;
-            const float o0 = REV ? __shfl_down(f0, 1u << j) : __shfl_up(f0, 1u << j);
-            const float o1 = REV ? __shfl_down(f1, 1u << j) : __shfl_up(f1, 1u << j);
-            if (pos >= (1 << j)) {
-                const float4 d = *reinterpret_cast<const float4*>(tab + (6 * k + j) * 4);
-                f0 = fmaf(d.x, o0, fmaf(d.y, o1, f0));
-                f1 = fmaf(d.z, o0, fmaf(d.w, o1, f1));
-            }
+        // inside the rows
+        {
+            const float4 d = *reinterpret_cast<const float4*>(tab + (6 * k + 0) * 4);
+            const float o0 = dpp_get<kRow + 1>(f0), o1 = dpp_get<kRow + 1>(f1);
+            f0 = fmaf(d.x, o0, fmaf(d.y, o1, f0));
+            f1 = fmaf(d.z, o0, fmaf(d.w, o1, f1));
+        }
+        {
+            const float4 d = *reinterpret_cast<const float4*>(tab + (6 * k + 1) * 4);
+            const float o0 = dpp_get<kRow + 2>(f0), o1 = dpp_get<kRow + 2>(f1);
+            f0 = fmaf(d.x, o0, fmaf(d.y, o1, f0));
+            f1 = fmaf(d.z, o0, fmaf(d.w, o1, f1));
+        }
+        {
+            const float4 d = *reinterpret_cast<const float4*>(tab + (6 * k + 2) * 4);
+            const float o0 = dpp_get<kRow + 4>(f0), o1 = dpp_get<kRow + 4>(f1);
+            f0 = fmaf(d.x, o0, fmaf(d.y, o1, f0));
+            f1 = fmaf(d.z, o0, fmaf(d.w, o1, f1));
+        }
+        {
+            const float4 d = *reinterpret_cast<const float4*>(tab + (6 * k + 3) * 4);
+            const float o0 = dpp_get<kRow + 8>(f0), o1 = dpp_get<kRow + 8>(f1);
+            f0 = fmaf(d.x, o0, fmaf(d.y, o1, f0));
+            f1 = fmaf(d.z, o0, fmaf(d.w, o1, f1));
+        }
+        // across the rows: E_r = value at the last position of row r with everything before it included (wave-uniform)
+        const float4 d16 = *reinterpret_cast<const float4*>(tab + (6 * k + 4) * 4);
+        const float e00 = lane_get(f0, REV ? 48 : 15), e01 = lane_get(f1, REV ? 48 : 15);
+        const float r10 = lane_get(f0, REV ? 32 : 31), r11 = lane_get(f1, REV ? 32 : 31);
+        const float r20 = lane_get(f0, REV ? 16 : 47), r21 = lane_get(f1, REV ? 16 : 47);
+        const float e10 = fmaf(d16.x, e00, fmaf(d16.y, e01, r10)), e11 = fmaf(d16.z, e00, fmaf(d16.w, e01, r11));
+        const float e20 = fmaf(d16.x, e10, fmaf(d16.y, e11, r20)), e21 = fmaf(d16.z, e10, fmaf(d16.w, e11, r21));
+        const float c0 = prow == 1 ? e00 : (prow == 2 ? e10 : e20), c1 = prow == 1 ? e01 : (prow == 2 ? e11 : e21);
+        const float4 dp = *reinterpret_cast<const float4*>(tab + 208 + (16 * k + pin) * 4);
+        if (prow >= 1) {
+            f0 = fmaf(dp.x, c0, fmaf(dp.y, c1, f0));
+            f1 = fmaf(dp.z, c0, fmaf(dp.w, c1, f1));
         }
         v[2 * k] = f0;
         v[2 * k + 1] = f1;
         if (k + 1 < kSections) {
-            const float p0 = REV ? __shfl_down(f0, 1u) : __shfl_up(f0, 1u);
-            const float p1 = REV ? __shfl_down(f1, 1u) : __shfl_up(f1, 1u);
-            prev[2 * k] = pos >= 1 ? p0 : 0.0f;
-            prev[2 * k + 1] = pos >= 1 ? p1 : 0.0f;
+            prev[2 * k] = dpp_get<kBack1>(f0);
+            prev[2 * k + 1] = dpp_get<kBack1>(f1);
         }
     }
 }

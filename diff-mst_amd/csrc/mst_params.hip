@@ -145,6 +145,7 @@ __device__ __forceinline__ void mat12_mul(const double* A, const double* B, doub
 // all-pole tables - two serial fp64 chains that would otherwise run back to back.
 __global__ __launch_bounds__(320) void k_prep(PrepArgs a) {
     __shared__ double mats[2][3][144];  // [fwd|adj][cur, tmp, acc]
+    __shared__ double dblk[2][2][kSections][4];  // diagonal 2x2 blocks of M and M^64, [set][fwd|adj][section]
     __shared__ float coef[32];
     const int row = blockIdx.x, tid = threadIdx.x;
     const bool is_master = row >= a.R;
@@ -289,11 +290,40 @@ __global__ __launch_bounds__(320) void k_prep(PrepArgs a) {
                 if (bk == bj) set[(6 * bk + j % 6) * 4 + sub] = val;
                 else if (j % 6 == 0 && bj < bk) set[144 + (bk * (bk - 1) / 2 + bj) * 4 + sub] = val;
             }
+            if (j % 6 == 0 && tid >= 288 && tid < 300) {  // park the diagonal blocks of M (j = 0) and M^64 (j = 6) for the Dp tables
+                const int g2 = (tid - 288) / 6, k = (tid - 288) % 6;
+                const double* Mm = mats[g2][cur];
+                double* o = dblk[j / 6][g2][k];
+                o[0] = Mm[(2 * k) * 12 + 2 * k];
+                o[1] = Mm[(2 * k) * 12 + 2 * k + 1];
+                o[2] = Mm[(2 * k + 1) * 12 + 2 * k];
+                o[3] = Mm[(2 * k + 1) * 12 + 2 * k + 1];
+            }
             if (j + 1 < kPow1) {
                 if (mat_lane) mat12_mul(mats[grp][cur], mats[grp][cur], mats[grp][cur ^ 1], e);
                 __syncthreads();
                 cur ^= 1;
             }
+        }
+        // Dp[k][q] = D_k^(q+1), q < 16 (the in-row fix-up of the scans): 24 (set, cascade, section) blocks x 16 powers, one
+        // (block, power) per lane and pass, by binary exponentiation in fp64 (at most 7 products of 2x2 matrices)
+        __syncthreads();
+        for (int item = tid; item < 24 * 16; item += 320) {
+            const int blk = item >> 4, q = item & 15, set = blk / 12, g2 = (blk / 6) & 1, k = blk % 6;
+            const double* d = dblk[set][g2][k];
+            double b0 = d[0], b1 = d[1], b2 = d[2], b3 = d[3];      // running square
+            double r0 = 1.0, r1 = 0.0, r2 = 0.0, r3 = 1.0;          // result
+            for (int ebit = q + 1; ebit > 0; ebit >>= 1) {
+                if (ebit & 1) {
+                    const double n0 = fma(r0, b0, r1 * b2), n1 = fma(r0, b1, r1 * b3), n2 = fma(r2, b0, r3 * b2), n3 = fma(r2, b1, r3 * b3);
+                    r0 = n0; r1 = n1; r2 = n2; r3 = n3;
+                }
+                const double s0_ = fma(b0, b0, b1 * b2), s1_ = fma(b0, b1, b1 * b3), s2_ = fma(b2, b0, b3 * b2), s3_ = fma(b2, b1, b3 * b3);
+                b0 = s0_; b1 = s1_; b2 = s2_; b3 = s3_;
+            }
+            float* base = g2 == 0 ? (is_master ? a.pow1F_m + (int64_t)mrow * kTri2 : a.pow1F_t + (int64_t)row * kTri2)
+                                  : (is_master ? a.pow1A_m + (int64_t)mrow * kTri2 : a.pow1A_t + (int64_t)row * kTri2);
+            *reinterpret_cast<float4*>(base + set * (kTri2 / 2) + 208 + (16 * k + q) * 4) = make_float4((float)r0, (float)r1, (float)r2, (float)r3);
         }
     } else {
     // acc (slot 2) = cur^KE by binary exponentiation; `cur`/`cur^1` ping-pong the running square

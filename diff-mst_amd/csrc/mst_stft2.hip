@@ -389,7 +389,6 @@ __global__ __launch_bounds__(FftPlan<N>::LG, (N == 8192 ? MST_STFT2_W8192_BWD : 
         }
     } else {
         constexpr int M = S::M;                                    // 4096
-        constexpr int PER = (M / 2 + 1 + LG - 1) / LG;             // (k, M - k) pairs per lane
         // window of samples 2m, 2m + 1 (m = lane + 512 t): 0.5 - 0.5 Re(W_N^(2 lane + c) W_8^t)
         const float2 we = twg[2 * lane], wo = twg[2 * lane + 1];
         for (int f = F0; f < F1; ++f) {

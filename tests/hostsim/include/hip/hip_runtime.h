@@ -185,10 +185,20 @@ static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int ro
     const unsigned lane = hostsim::t_tid & 63u, row = lane >> 4, in_row = lane & 15u;
     bool valid = false;
     unsigned from = lane;
-    if (ctrl > 0x110 && ctrl <= 0x11f) {
+    if (ctrl > 0x110 && ctrl <= 0x11f) {          // row_shr:n
         const unsigned n = (unsigned)ctrl - 0x110u;
         valid = in_row >= n;
         from = valid ? lane - n : lane;
+    } else if (ctrl > 0x100 && ctrl <= 0x10f) {   // row_shl:n
+        const unsigned n = (unsigned)ctrl - 0x100u;
+        valid = in_row + n < 16u;
+        from = valid ? lane + n : lane;
+    } else if (ctrl == 0x130) {                   // wave_shl:1
+        valid = lane < 63u;
+        from = valid ? lane + 1u : lane;
+    } else if (ctrl == 0x138) {                   // wave_shr:1
+        valid = lane >= 1u;
+        from = valid ? lane - 1u : lane;
     } else if (ctrl == 0x142) {
         valid = row >= 1;
         from = valid ? 16u * row - 1u : lane;

@@ -1,4 +1,4 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-cd $R && timeout 1500 python -m pytest tests/test_console_gpu.py -m gpu -q -x 2>&1 | tail -3
-KPAT="cascade" bash tools/_ab.sh 2>&1 | tail -10
+cd $R && timeout 1500 python -m pytest tests/test_console_gpu.py tests/test_parity_r02_gpu.py -m gpu -q -x 2>&1 | tail -3
+KPAT="cascade|prep" bash tools/_ab.sh 2>&1 | tail -12
