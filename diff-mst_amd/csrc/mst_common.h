@@ -139,6 +139,16 @@ __device__ __forceinline__ float4 load4_shift(const float* __restrict__ row, int
     return v;
 }
 
+// LDS hand-over between the lanes of ONE wave (the 64-lane workgroups of the EQ kernels): a wave's DS instructions execute in
+// order, so the lanes see each other's LDS writes without waiting - all that is needed is that the compiler keeps the order.
+// __syncthreads() here costs `s_waitcnt vmcnt(0)` as well: it drains the global prefetch of the NEXT slab at every slab, which is
+// exactly the latency the prefetch was issued early to hide.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // Sum over the 64 lanes of a wave, the same value returned to every lane.  Six DPP additions (row shifts by 1, 2, 4, 8 leave
 // each 16-lane row's total in its last lane, two row broadcasts carry the totals into lane 63) and one v_readlane, all
 // full-rate VALU work - `v += __shfl_xor(v, m)` compiles to six ds_bpermute_b32 round trips through the LDS crossbar

@@ -160,20 +160,20 @@ __device__ __forceinline__ void cascade_body(const float* __restrict__ in, int64
 #pragma unroll
             for (int d = 0; d < kStates; ++d) zz[d] = tid < wt ? agg[((int64_t)sig * kStates + d) * kMaxTiles1 + tid] : 0.0f;
             tab_stash(thi, tile, tid);
-            __syncthreads();
+            wave_lds_sync();
             wave_scan_tri<false>(zz, tile, tid);
 #pragma unroll
             for (int d = 0; d < kStates; ++d) {
                 const float S = __shfl(zz[d], wt - 1);
                 if (pos == 0) st[d] = S;
             }
-            __syncthreads();
+            wave_lds_sync();
         }
         if (!MST_DBG_NOSCAN) {
             tab_stash(tlo, tile, tid);
-            __syncthreads();
+            wave_lds_sync();
             wave_scan_tri<DIR == EQ_ADJ>(st, tile, pos);
-            __syncthreads();  // the slab image overwrites the table next
+            wave_lds_sync();  // the slab image overwrites the table next
         }
     } else {
 #pragma unroll
@@ -199,7 +199,7 @@ __device__ __forceinline__ void cascade_body(const float* __restrict__ in, int64
         const int j = order(jj);
         slab_enter<FAST>(pre, inrow, tile_base, j, n, tid);
         slab_stash(pre, tile, tid);
-        __syncthreads();
+        wave_lds_sync();
         slab_next<FAST>(pre, inrow, tile_base, order(jj + 1 < kNSlab ? jj + 1 : jj), jj + 1 < kNSlab, n, tid);
         if (DIR == EQ_FWD) {
 #pragma unroll
@@ -244,10 +244,10 @@ __device__ __forceinline__ void cascade_body(const float* __restrict__ in, int64
                 if (MODE_RUN) *reinterpret_cast<float4*>(&mine[i4]) = v;
             }
         }
-        __syncthreads();
+        wave_lds_sync();
         if (MODE_RUN) {
             slab_store<FAST>(tile, outrow, tile_base, j, n, tid);
-            __syncthreads();  // the image is read by other lanes' stores before the next stash overwrites it
+            wave_lds_sync();  // the image is read by other lanes' stores before the next stash overwrites it
         }
         slab_fence();
     }
@@ -256,7 +256,7 @@ __device__ __forceinline__ void cascade_body(const float* __restrict__ in, int64
         for (int i = 0; i < kStates; ++i) z[((int64_t)sig * kStates + i) * nc_pad + chunk] = st[i];
         if (SCAN1 && !MST_DBG_NOSCAN) {  // tile aggregate = the last position of the scan over the tile's chunk end states
             tab_stash(tlo, tile, tid);  // the slab buffer is free now
-            __syncthreads();
+            wave_lds_sync();
             wave_scan_tri<DIR == EQ_ADJ>(st, tile, pos);
             if (pos == kEqWG - 1) {  // indexed by the tile's position in recurrence order
                 const int wt = DIR == EQ_FWD ? (int)blockIdx.x : ntiles - 1 - (int)blockIdx.x;
@@ -352,7 +352,7 @@ __device__ __forceinline__ void allpole_zs_body(const float* __restrict__ u, int
     for (int j = 0; j < kNSlab; ++j) {
         slab_enter<FAST>(pre, urow, tile_base, j, n, tid);
         slab_stash(pre, tile, tid);
-        __syncthreads();
+        wave_lds_sync();
         slab_next<FAST>(pre, urow, tile_base, j + 1, j + 1 < kNSlab, n, tid);
 #pragma unroll 4
         for (int i = 0; i < kSlab; ++i) {
@@ -367,7 +367,7 @@ __device__ __forceinline__ void allpole_zs_body(const float* __restrict__ u, int
                 wb1[s] = wb;
             }
         }
-        __syncthreads();
+        wave_lds_sync();
         slab_fence();
     }
 #pragma unroll
