@@ -118,9 +118,9 @@ __device__ __forceinline__ void af2_fwd_body(const AfArgs& a, float2 (*buf)[AfS:
         int li = lane;
         asm volatile("" : "+v"(li));  // the two per-lane twiddles are re-fetched per frame (L1 hits) instead of living in registers
         const float2 wl = twH[li], wm = reinterpret_cast<const float2*>(a.tables + kAfTwM)[li];
-        __syncthreads();  // the previous frame's spectrum has been read
+        lds_barrier();  // the previous frame's spectrum has been read
         af2_forward<HALF>(buf, l, r, sign, win, f, n, fast, tw, wl, wm, li);
-        __syncthreads();
+        lds_barrier();
         // (li, not lane: the bin addresses are rebuilt per frame - hoisted out of the loop they would pin 32 registers)
 #pragma unroll 2
         for (int j = 0; j < 8; ++j) {
@@ -202,12 +202,12 @@ __device__ __forceinline__ void af2_bwd_half(const AfArgs& a, float2 (*buf)[AfS:
     asm volatile("" : "+v"(li));
     const float2 wl = twH[li], wm = reinterpret_cast<const float2*>(a.tables + kAfTwM)[li];
     af2_forward<HALF>(buf, l, r, sign, win, f, n, fast, tw, wl, wm, lane);
-    __syncthreads();
+    lds_barrier();
     af2_cotangent<HALF>(a, buf, dM, twN, lane);
-    __syncthreads();
+    lds_barrier();
     // the second transform reads its inputs straight from the buffers it is about to overwrite (barrier inside)
     fft8192_from<false, true>([&](int t) { return af2_at(buf, lane + kAf2Lanes * t); }, buf[0], buf[1], tw, wl, lane);
-    __syncthreads();
+    lds_barrier();
     // Ph[m] = af2_at(buf, m).  Half 0 parks P0 in the frame's slab; half 1 reads it back (the same lane wrote it), combines
     // Y[m], Y[m + 8192] = P0 +- W_16384^m P1 and stores the windowed frame  y[2m] = w Re Y[m],  y[2m+1] = -w Im Y[m].
     float2* yf = reinterpret_cast<float2*>(a.yframes + ((int64_t)s * a.n_frames + f) * kAfFft);
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(kAf2Lanes, MST_AF2_W_BWD) void k_af2_bark_bwd(AfArg
     const int n = (int)a.n;
     const bool fast = !(((uintptr_t)l | (uintptr_t)r) & 7);
     af2_bwd_half<0>(a, buf, l, r, sign, f, s, n, fast, tw, lane);
-    __syncthreads();
+    lds_barrier();
     af2_bwd_half<1>(a, buf, l, r, sign, f, s, n, fast, tw, lane);
 }
 

@@ -149,6 +149,21 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Workgroup barrier that orders LDS only: `s_waitcnt lgkmcnt(0); s_barrier`.  __syncthreads() is a fence over ALL address spaces -
+// it adds `vmcnt(0)`, i.e. every global load in flight (the next frame / slab, requested early on purpose) is drained at
+// every barrier.  Use where the waves hand each other LDS data and nothing else.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+// ... for a group of LANES threads that is the whole workgroup
+template <int LANES>
+__device__ __forceinline__ void group_lds_sync() {
+    if (LANES <= 64) wave_lds_sync();
+    else lds_barrier();
+}
+
 // Sum over the 64 lanes of a wave, the same value returned to every lane.  Six DPP additions (row shifts by 1, 2, 4, 8 leave
 // each 16-lane row's total in its last lane, two row broadcasts carry the totals into lane 63) and one v_readlane, all
 // full-rate VALU work - `v += __shfl_xor(v, m)` compiles to six ds_bpermute_b32 round trips through the LDS crossbar

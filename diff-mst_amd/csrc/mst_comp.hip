@@ -66,12 +66,12 @@ __device__ __forceinline__ float block_enter(float z, float a, float log2a, floa
         p *= p;
     }
     if (rl == 63) lds[rw] = v;  // zero-entry aggregate of this wave
-    __syncthreads();
+    lds_barrier();
     float sw = S;  // state entering this wave
     for (int w = 0; w < rw; ++w) sw = fmaf(p, sw, lds[w]);  // p == a^64
     float ex = REV ? __shfl_down(v, 1) : __shfl_up(v, 1);
     if (rl == 0) ex = 0.0f;
-    __syncthreads();  // lds may be reused by the caller's next call
+    lds_barrier();  // lds may be reused by the caller's next call
     return fmaf(__builtin_amdgcn_exp2f((float)rl * log2a), sw, ex);
 }
 // state entering block `blk` from the aggregates of the blocks before it (after it when REV):
@@ -86,9 +86,9 @@ __device__ __forceinline__ float block_carry(const float* __restrict__ agg, int 
     }
     acc = wave_sum(acc);
     if ((tid & 63) == 0) lds[4 + (tid >> 6)] = acc;
-    __syncthreads();
+    lds_barrier();
     const float S = (lds[4] + lds[5]) + (lds[6] + lds[7]);
-    __syncthreads();
+    lds_barrier();
     return S;
 }
 
@@ -100,7 +100,7 @@ __device__ __forceinline__ float block_aggregate(float z, float log2a, float* ld
     const float w = __builtin_amdgcn_exp2f((float)(REV ? tid : kWG - 1 - tid) * log2a);
     const float v = wave_sum(w * z);
     if ((tid & 63) == 0) lds[tid >> 6] = v;
-    __syncthreads();
+    lds_barrier();
     return (lds[0] + lds[1]) + (lds[2] + lds[3]);
 }
 
@@ -479,7 +479,7 @@ __device__ __forceinline__ void comp_bwd_run_body(const CompBwdArgs& a) {
         const float v = wave_sum(p[i]);
         if (lane == 0) red[wave][i] = v;
     }
-    __syncthreads();
+    lds_barrier();
     if (tid < CP_COUNT)
         a.part[((int64_t)row * gridDim.x + blockIdx.x) * CP_COUNT + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
 }

@@ -435,7 +435,7 @@ __device__ __forceinline__ void coefgrad_body(const float* __restrict__ u, int64
     for (int j = 0; j < kNSlab; ++j) {
         slab_enter<FAST>(pre, srow, tile_base, j, n, tid);
         slab_stash(pre, simg, tid);
-        __syncthreads();
+        lds_barrier();
         slab_next<FAST>(pre, srow, tile_base, j + 1, j + 1 < kNSlab, n, tid);
 #pragma unroll 1
         for (int i4 = 0; i4 < kSlab; i4 += 4) {
@@ -461,7 +461,7 @@ __device__ __forceinline__ void coefgrad_body(const float* __restrict__ u, int64
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
         slab_fence();
     }
     float acc[EP_COUNT / 2];
@@ -479,7 +479,7 @@ __device__ __forceinline__ void coefgrad_body(const float* __restrict__ u, int64
         const float v = wave_sum(acc[i]);
         if (tid == 0) red[half][i] = v;
     }
-    __syncthreads();
+    lds_barrier();
     if (threadIdx.x < EP_COUNT)
         part[((int64_t)sig * gridDim.x + blockIdx.x) * EP_COUNT + threadIdx.x] = red[threadIdx.x / (EP_COUNT / 2)][threadIdx.x % (EP_COUNT / 2)];
 }

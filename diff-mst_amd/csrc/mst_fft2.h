@@ -203,20 +203,20 @@ template <int N>
 __device__ __forceinline__ void fft_run(float2* v, float2 (*o)[FftShape<N>::RL], float2* __restrict__ buf, const LaneTw<N>& tw, int lane) {
     using S = FftShape<N>;
     fft_first<N>(v, buf, lane);
-    __syncthreads();
+    group_lds_sync<S::LG>();
 #ifdef MST_FFT2_FIRST_PASS_ONLY
     for (int u = 0; u < S::NBL; ++u) for (int t = 0; t < S::RL; ++t) o[u][t] = buf[S::slot(lane + t)];
     return;
 #endif
     fft_load8<N>(v, buf, lane);
-    __syncthreads();
+    group_lds_sync<S::LG>();
     fft_mid_store<N, 2>(v, buf, tw, lane);
-    __syncthreads();
+    group_lds_sync<S::LG>();
     if constexpr (S::NP == 4) {
         fft_load8<N>(v, buf, lane);
-        __syncthreads();
+        group_lds_sync<S::LG>();
         fft_mid_store<N, 3>(v, buf, tw, lane);
-        __syncthreads();
+        group_lds_sync<S::LG>();
     }
 #pragma unroll
     for (int u = 0; u < S::NBL; ++u) fft_last<N>(o[u], buf, tw, lane, u);
@@ -229,20 +229,20 @@ __device__ __forceinline__ void fft_run2(float2* va, float2* vb, float2 (*oa)[Ff
     using S = FftShape<N>;
     fft_first<N>(va, bufa, lane);
     fft_first<N>(vb, bufb, lane);
-    __syncthreads();
+    group_lds_sync<S::LG>();
     fft_load8<N>(va, bufa, lane);
     fft_load8<N>(vb, bufb, lane);
-    __syncthreads();
+    group_lds_sync<S::LG>();
     fft_mid_store<N, 2>(va, bufa, tw, lane);
     fft_mid_store<N, 2>(vb, bufb, tw, lane);
-    __syncthreads();
+    group_lds_sync<S::LG>();
     if constexpr (S::NP == 4) {
         fft_load8<N>(va, bufa, lane);
         fft_load8<N>(vb, bufb, lane);
-        __syncthreads();
+        group_lds_sync<S::LG>();
         fft_mid_store<N, 3>(va, bufa, tw, lane);
         fft_mid_store<N, 3>(vb, bufb, tw, lane);
-        __syncthreads();
+        group_lds_sync<S::LG>();
     }
 #pragma unroll
     for (int u = 0; u < S::NBL; ++u) {
@@ -282,9 +282,9 @@ __device__ __forceinline__ void fft8192_from(F&& raw, float2* __restrict__ bufe,
         e[t] = cadd(a, b);
         d[t] = cmul(csub(a, b), w);
     }
-    if (RAW_IN_LDS) __syncthreads();
+    if (RAW_IN_LDS) group_lds_sync<FftShape<8192>::LG>();
     fft_run2<8192>(e, d, oe, od, bufe, bufo, tw, lane);
-    __syncthreads();
+    group_lds_sync<FftShape<8192>::LG>();
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
         bufe[S::slot(lane + t * (S::M / 8))] = oe[0][t];

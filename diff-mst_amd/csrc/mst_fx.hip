@@ -40,7 +40,7 @@ __global__ __launch_bounds__(kFxLanes, 4) void k_fx_filt_spec(const float* __res
         const int e = lane + kFxLanes * t;
         return make_float2(e < taps ? filt[k * taps + e] : 0.0f, 0.0f);
     }, buf[0], buf[1], tw, twg[lane], lane);
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
         const int q = lane + kFxLanes * t;
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(kFxLanes, 2) void k_fx_fir(const float* __restrict_
         const int i = n0 + lane + kFxLanes * t;
         return i < in_len ? make_float2(xl[i], xr[i]) : make_float2(0.f, 0.f);
     }, buf[0], buf[1], tw, wl, lane);
-    __syncthreads();
+    lds_barrier();
     // product with the filter spectrum, conjugated for the inverse (IFFT(P) = conj(FFT(conj P)) / N), formed while the second
     // transform gathers its inputs from the buffers it is about to overwrite (barrier inside)
     const float2* h = Hc + (int64_t)k * kFxN;
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(kFxLanes, 2) void k_fx_fir(const float* __restrict_
         const float2 pz = cmul(buf[q & 1][Sh::slot(q >> 1)], h[q]);
         return make_float2(pz.x, -pz.y);
     }, buf[0], buf[1], tw, wl, lane);
-    __syncthreads();
+    lds_barrier();
     float* dl = wnf + ((int64_t)(2 * b) * 12 + k) * S;
     float* dr = wnf + ((int64_t)(2 * b + 1) * 12 + k) * S;
     constexpr float inv = 1.0f / (float)kFxN;
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(kFxLanes, 4) void k_fx_fft(FxFftArgs a) {
         if (MODE == FX_GRAD) live = live && e >= kFxHop;
         return live ? make_float2(xl[i], xr[i]) : make_float2(0.f, 0.f);
     }, buf[0], buf[1], tw, wl, lane);
-    __syncthreads();
+    lds_barrier();
     float2* out = a.spec + ((int64_t)b * a.frames + m) * kFxN;
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(kFxLanes, 4) void k_fx_ifft(FxIfftArgs a) {
         }
         return make_float2(z.x, -z.y);
     }, buf[0], buf[1], tw, wl, lane);
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int q = lane + kFxLanes * (MODE == FX_OUT ? t + 4 : t);
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(256) void k_fx_ir_bwd(const float* __restrict__ wnf
             red[wave][12 + k] = r;
         }
     }
-    __syncthreads();
+    lds_barrier();
     if (tid < 24) part[((int64_t)b * gridDim.x + blockIdx.x) * 24 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
 }
 

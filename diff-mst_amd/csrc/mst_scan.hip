@@ -130,7 +130,7 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const float* __restrict__
             }
         }
     }
-    __syncthreads();  // table staged
+    lds_barrier();  // table staged
     RegMat<D> M1;
     M1.load(T);
     float agg[D];
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const float* __restrict__
     int cur = 0;
 #pragma unroll
     for (int d = 0; d < D; ++d) buf[0][d][tid] = agg[d];
-    __syncthreads();
+    lds_barrier();
     for (int j = 0; j < kScanLevels && (1 << j) < active; ++j) {
         const int off = 1 << j;
         if (tid >= off) {
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(const float* __restrict__
         }
 #pragma unroll
         for (int d = 0; d < D; ++d) buf[cur ^ 1][d][tid] = agg[d];
-        __syncthreads();
+        lds_barrier();
         cur ^= 1;
     }
     // 3. exclusive start of my span = inclusive value of the previous lane

@@ -41,7 +41,7 @@ struct FrameLoader {
                 v[t] = make_float2(win[t] * z.x, win[t] * z.y);
             }
             fft_run<N>(v, o, buf[0], tw, lane);
-            __syncthreads();
+            group_lds_sync<LG>();
 #pragma unroll
             for (int u = 0; u < S::NBL; ++u)
 #pragma unroll
@@ -49,7 +49,7 @@ struct FrameLoader {
         } else {
             fft8192_from<true>(raw, buf[0], buf[1], tw, wl, lane);
         }
-        __syncthreads();
+        group_lds_sync<LG>();
     }
     // spectrum bin k of the frame transformed last
     __device__ static __forceinline__ float2 bin(const float2 (*buf)[S::SLOTS], int k) {
@@ -144,13 +144,13 @@ __global__ __launch_bounds__(FftPlan<N>::LG, (N == 8192 ? MST_STFT2_W8192 : 1)) 
             s3 += fabsf(__builtin_amdgcn_logf(xm) - __builtin_amdgcn_logf(ym));  // log2; scaled by ln2 below
             s4 += fabsf(d);
         }
-        __syncthreads();  // the next frame's first pass overwrites the spectrum
+        group_lds_sync<LG>();  // the next frame's first pass overwrites the spectrum
     }
     s3 *= kLn2;
     const int wave = lane >> 6, wl_ = lane & 63;
     s1 = wave_sum(s1); s2 = wave_sum(s2); s3 = wave_sum(s3); s4 = wave_sum(s4);
     if (wl_ == 0) { red[wave][0] = s1; red[wave][1] = s2; red[wave][2] = s3; red[wave][3] = s4; }
-    __syncthreads();
+    group_lds_sync<LG>();
     if (lane < 4) {
         float v = 0.f;
         for (int w = 0; w < LG / 64; ++w) v += red[w][lane];
@@ -291,19 +291,19 @@ __global__ __launch_bounds__(FftPlan<N>::LG, (N == 8192 ? MST_STFT2_W8192_BWD : 
     // one finished frame: `first` -> block f - 1, `second` -> block f
     auto emit = [&](int f, float* first, float* second) {
         if (f == 0) {  // the first half lies before the row: sample -p reflects to +p, i.e. element i = H - p lands on block 0, offset p
-            __syncthreads();
+            group_lds_sync<LG>();
 #pragma unroll
             for (int q = 0; q < K; ++q) fold[pos(q)] = first[q];
-            __syncthreads();
+            group_lds_sync<LG>();
 #pragma unroll
             for (int q = 0; q < K; ++q)
                 if (pos(q) >= 1) second[q] += fold[H - pos(q)];
-            __syncthreads();
+            group_lds_sync<LG>();
         } else if (f == B) {  // the second half lies beyond the row: element H + i' reflects to sample n - 2 - i'
-            __syncthreads();
+            group_lds_sync<LG>();
 #pragma unroll
             for (int q = 0; q < K; ++q) fold[pos(q)] = second[q];
-            __syncthreads();
+            group_lds_sync<LG>();
 #pragma unroll
             for (int q = 0; q < K; ++q)
                 if (pos(q) <= H - 2) first[q] += fold[H - 2 - pos(q)];
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(FftPlan<N>::LG, (N == 8192 ? MST_STFT2_W8192_BWD : 
         if (f == B) {
             // i' = H - 1 reflects to sample n - H - 1 = the last sample of block B - 2, which this lane stored one frame ago
             if (pos(K - 1) == H - 1) gx[nrow - H - 1] += fold[H - 1];
-            __syncthreads();
+            group_lds_sync<LG>();
             have_carry = false;
         } else {
 #pragma unroll
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(FftPlan<N>::LG, (N == 8192 ? MST_STFT2_W8192_BWD : 
                         hb[sn] = make_float2(h1.x + 0.5f * G.y, h1.y - 0.5f * G.x);
                     }
                 }
-                __syncthreads();  // the spectrum has been consumed (the next transform overwrites it); hb is complete
+                group_lds_sync<LG>();  // the spectrum has been consumed (the next transform overwrites it); hb is complete
             }
             // FFT(conj(h)) = conj(r_a + i r_b)  =>  r_a = Re, r_b = -Im
             float2 v[8], o[S::NBL][S::RL];
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(FftPlan<N>::LG, (N == 8192 ? MST_STFT2_W8192_BWD : 
                 if (q < 4) { fa1[q] = ra; fb1[q] = rb; }
                 else { fa2[q - 4] = ra; fb2[q - 4] = rb; }
             }
-            __syncthreads();  // the inverse has left buf[0]: emit() may use it as mirror scratch, the next transform as work space
+            group_lds_sync<LG>();  // the inverse has left buf[0]: emit() may use it as mirror scratch, the next transform as work space
             emit(fa, fa1, fa2);
             if (have_b) emit(fa + 1, fb1, fb2);
         }
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(FftPlan<N>::LG, (N == 8192 ? MST_STFT2_W8192_BWD : 
             float2 Ok[2], Om[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) pair_v(2 * (lane + i * LG) + 1, Ok[i], Om[i]);
-            __syncthreads();  // every lane has read its odd bins: buf[1] is free
+            group_lds_sync<LG>();  // every lane has read its odd bins: buf[1] is free
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 if (i == 2 && lane != 0) break;
@@ -438,7 +438,7 @@ __global__ __launch_bounds__(FftPlan<N>::LG, (N == 8192 ? MST_STFT2_W8192_BWD : 
                 buf[1][S::slot(k)] = Ok[i];
                 buf[1][S::slot(M - k)] = Om[i];
             }
-            __syncthreads();
+            group_lds_sync<LG>();
             float2 v[8], o[1][8];
 #pragma unroll
             for (int t = 0; t < 8; ++t) v[t] = buf[1][S::slot(lane + LG * t)];
@@ -456,7 +456,7 @@ __global__ __launch_bounds__(FftPlan<N>::LG, (N == 8192 ? MST_STFT2_W8192_BWD : 
                 if (t < 4) { h1[2 * t] = ye; h1[2 * t + 1] = yo; }
                 else { h2[2 * (t - 4)] = ye; h2[2 * (t - 4) + 1] = yo; }
             }
-            __syncthreads();
+            group_lds_sync<LG>();
             emit(f, h1, h2);
         }
     }

@@ -134,7 +134,8 @@ void launch(K kernel, dim3 grid, dim3 block, Args... args) {
 static inline void __syncthreads() { hostsim::t_ctx->block_bar->arrive_and_wait(); }
 // wave-scope fence / barrier: the simulator's lanes are OS threads, so "the wave runs in lockstep" has to be a real rendezvous
 static inline void __builtin_amdgcn_wave_barrier() { hostsim::t_ctx->wave_bar[hostsim::t_tid >> 6]->arrive_and_wait(); }
-#define __builtin_amdgcn_fence(order, scope) __atomic_thread_fence(order)
+#define __builtin_amdgcn_fence(order, ...) __atomic_thread_fence(order)
+static inline void __builtin_amdgcn_s_barrier() { hostsim::t_ctx->block_bar->arrive_and_wait(); }
 template <typename T> inline T __shfl(T v, int src, int = 64) { return hostsim::shfl_idx(v, (unsigned)src); }
 template <typename T> inline T __shfl_xor(T v, int m, int = 64) { return hostsim::shfl_idx(v, (hostsim::t_tid & 63u) ^ (unsigned)m); }
 template <typename T> inline T __shfl_up(T v, unsigned d, int = 64) {

@@ -1,4 +1,6 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-cd $R && timeout 1500 python -m pytest tests/test_console_gpu.py tests/test_parity_r02_gpu.py -m gpu -q -x 2>&1 | tail -3
-KPAT="cascade|prep" bash tools/_ab.sh 2>&1 | tail -12
+cd $R && timeout 2400 python -m pytest tests -m gpu -q -x 2>&1 | tail -3
+KPAT="." bash tools/_ab.sh 2>&1 | grep -v "torch\|at::\|rocclr\|tables" | head -40
+timeout 300 python tools/af_bench.py 8 32 2>&1 | grep "bs="
+timeout 300 python tools/fx_bench.py 2>&1 | grep use_fx
