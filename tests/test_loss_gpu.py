@@ -86,6 +86,31 @@ def test_mrstft_well_conditioned_terms(kw, dev):
     assert rel(xd.grad, xo.grad) < 5e-6
 
 
+@pytest.mark.parametrize("blocks", [4, 5, 6, 7, 9, 12, 17, 31])
+def test_mrstft_strip_layouts(blocks, dev):
+    """Row lengths of `blocks` 8192-point hops: every one cuts the rows into a different set of strips (seam strips of 2 frames
+    with a longer last one for 8192, halo strips for 512 / 2048), and the seam halves parked by the 8192 launch must be picked up at
+    exactly the right blocks by the next one.  Smooth term only, so the gradient is pinned to fp32 round-off."""
+    from oracle import loss_restated as ol
+
+    torch.manual_seed(blocks)
+    n = blocks * 4096
+    x = 0.3 * torch.randn(1, 2, n)
+    y = 0.5 * x + 0.2 * torch.randn(1, 2, n)
+    kw = dict(w_sc=1.0, w_log_mag=0.0)
+    xd = x.to(dev).requires_grad_(True)
+    loss = make_loss(**kw)(xd, y.to(dev))
+    loss.backward()
+    xo = x.double().requires_grad_(True)
+    lo = ol.mrstft_loss(xo, y.double(), RES, **kw)
+    lo.backward()
+    assert abs(loss.item() - lo.item()) / lo.item() < 1e-5
+    assert rel(xd.grad, xo.grad) < 5e-6
+    again = x.to(dev).requires_grad_(True)
+    make_loss(**kw)(again, y.to(dev)).backward()
+    assert torch.equal(again.grad, xd.grad)  # no atomics left on this path: bit for bit
+
+
 def test_mrstft_known_answers(dev):
     """MR-STFT(x, x) = 0 and MR-STFT(c*y, y) = |1 - c| + |ln c| (away from the 1e-8 clamp)."""
     torch.manual_seed(0)
