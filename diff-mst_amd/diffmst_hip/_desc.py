@@ -37,6 +37,9 @@ FLAG_BITS = {
 }
 
 
+_IDENTITY = ([0.0] * 27, [1.0] * 27, [0.0] * 26, [1.0] * 26, [0.0] * 25, [1.0] * 25)
+
+
 def range_vectors(param_ranges: dict, index):
     lo = [float(param_ranges[e][p][0]) for e, p in index]
     hi = [float(param_ranges[e][p][1]) for e, p in index]
@@ -66,18 +69,16 @@ def make_desc(param_ranges, sample_rate, bs, n_tracks, n_samples, track_row_stri
     d.sample_rate = float(sample_rate)
     d.flags = int(flags_word)
     d.track_lookahead, d.master_lookahead = int(track_lookahead), int(master_lookahead)
-    tlo, thi = range_vectors(param_ranges, TRACK_INDEX)
-    mlo, mhi = range_vectors(param_ranges, MASTER_INDEX)
-    flo, fhi = range_vectors(param_ranges, FX_INDEX)
     if identity_ranges:
-        tlo, thi, mlo, mhi, flo, fhi = [0.0] * 27, [1.0] * 27, [0.0] * 26, [1.0] * 26, [0.0] * 25, [1.0] * 25
-    for i in range(25):
-        d.fx_lo[i], d.fx_hi[i] = flo[i], fhi[i]
+        tlo, thi, mlo, mhi, flo, fhi = _IDENTITY
+    else:  # read on every call, like the reference does (a caller may edit console.param_ranges between calls)
+        tlo, thi = range_vectors(param_ranges, TRACK_INDEX)
+        mlo, mhi = range_vectors(param_ranges, MASTER_INDEX)
+        flo, fhi = range_vectors(param_ranges, FX_INDEX)
+    d.fx_lo[:], d.fx_hi[:] = flo, fhi  # slice assignment: one call per array instead of one per element
     d.fx_ir_samples, d.fx_bandpass_taps = int(fx_ir_samples), int(fx_bandpass_taps)  # reference mst/modules.py:281-282
-    for i in range(27):
-        d.track_lo[i], d.track_hi[i] = tlo[i], thi[i]
-    for i in range(26):
-        d.master_lo[i], d.master_hi[i] = mlo[i], mhi[i]
+    d.track_lo[:], d.track_hi[:] = tlo, thi
+    d.master_lo[:], d.master_hi[:] = mlo, mhi
     return d
 
 

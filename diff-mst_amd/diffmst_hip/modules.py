@@ -48,8 +48,8 @@ def denormalize_parameters(param_dict: dict, param_ranges: dict):
 
 def _nested(index, tensor):
     d = {}
-    for k, (effect, name) in enumerate(index):
-        d.setdefault(effect, {})[name] = tensor[..., k]
+    for (effect, name), col in zip(index, tensor.unbind(-1)):  # one call makes all the column views
+        d.setdefault(effect, {})[name] = col
     return d
 
 
