@@ -46,7 +46,7 @@ void launch_stft2_fwd(const StftArgs& a, int n_groups, int rows, hipStream_t str
 // backward: n_fft = 8192 runs in seam mode (every frame once; a strip's two half-frame seams are added atomically, exactly two
 // contributions per sample onto a zeroed buffer, hence order-independent); 512 / 2048 in halo mode (a strip owns whole hop
 // blocks and recomputes the one frame it shares with its neighbour).  n_groups from stft2_bwd_groups().
-int stft2_bwd_groups(int n_fft, int n_frames);
+int stft2_bwd_groups(int n_fft, int n_frames, int rows);
 bool stft2_bwd_needs_zero(int n_fft);
 void launch_stft2_bwd(const StftArgs& a, int n_groups, int rows, hipStream_t stream);
 

@@ -876,11 +876,11 @@ extern "C" int mst_mrstft_backward(const mst_mrstft_desc* d, const float* pred, 
                     const ResInfo& sr = p.res[p.seam_res];
                     a.seam = ws + p.seam_off;
                     a.seam_frames = sr.n_frames;
-                    a.seam_groups = stft2_bwd_groups(sr.n_fft, sr.n_frames);
+                    a.seam_groups = stft2_bwd_groups(sr.n_fft, sr.n_frames, d->rows);
                     a.seam_hop = sr.n_fft / 2;
                     if (pass == 1) pending = false;
                 }
-                launch_stft2_bwd(a, stft2_bwd_groups(a.r.n_fft, a.r.n_frames), d->rows, stream);
+                launch_stft2_bwd(a, stft2_bwd_groups(a.r.n_fft, a.r.n_frames, d->rows), d->rows, stream);
                 written = true;
             }
         }

@@ -205,6 +205,7 @@ __device__ __forceinline__ float2 cotangent(const float2 (*buf)[FftShape<N>::SLO
 #ifndef MST_STFT2_W2048_BWD
 #define MST_STFT2_W2048_BWD 1  // min waves per SIMD asked of the 2048-point backward (A/B switch; uncapped it takes 144 registers)
 #endif
+constexpr int kStft2Bwd8192Slots = 256;  // resident workgroups of k_stft2_bwd<8192> on the 256 CUs
 template <int N>
 __global__ __launch_bounds__(FftPlan<N>::LG, (N == 8192 ? MST_STFT2_W8192_BWD : (N == 2048 ? MST_STFT2_W2048_BWD : 1))) void k_stft2_bwd(StftArgs a) {
     using S = FftShape<N>;
@@ -465,10 +466,18 @@ __global__ __launch_bounds__(FftPlan<N>::LG, (N == 8192 ? MST_STFT2_W8192_BWD : 
     if (SEAMS && have_carry) seam(F1 - 1, carry, false);
 }
 
-int stft2_bwd_groups(int n_fft, int n_frames) {
+int stft2_bwd_groups(int n_fft, int n_frames, int rows) {
     const int B = n_frames - 1;
-    if (n_fft == 8192) {  // seam mode: strips of >= 2 frames, the last one of >= 3 (it finishes block B - 2 itself)
+    if (n_fft == 8192) {
+        // seam mode: strips of >= 2 frames, the last one of >= 3 (it finishes block B - 2 itself).  The kernel takes 192 registers:
+        // one 512-lane workgroup per CU, 256 resident.  When two-frame strips would need more than one round, the rows are cut
+        // into 256 / rows longer strips instead - the same frame-times per CU, but one prologue and one pair of seams per
+        // strip less (cfg #2: 512 x 2 frames = 66.8 us, 256 x 4 frames = 56.9 us; 3 frames = 1.4 rounds = 75.8 us)
         int G = n_frames / 2;
+        if ((int64_t)rows * G > kStft2Bwd8192Slots) {
+            const int fit = kStft2Bwd8192Slots / (rows > 0 ? rows : 1);
+            G = fit >= 1 ? (fit < G ? fit : G) : 1;
+        }
         while (G > 1 && n_frames - (int)(((int64_t)(G - 1) * n_frames) / G) < 3) --G;
         return G > 0 ? G : 1;
     }
