@@ -199,7 +199,7 @@ __device__ __forceinline__ float2 cotangent(const float2 (*buf)[FftShape<N>::SLO
 #define MST_STFT2_BWD_L512 4  // 5 frames per workgroup, 25 % recomputed: 4096 one-wave workgroups = exactly the 4 waves per SIMD that 128 registers allow
 #endif
 #ifndef MST_STFT2_BWD_L2048
-#define MST_STFT2_BWD_L2048 6  // 7 frames per 256-lane workgroup, 17 % recomputed: 672 workgroups = one round of the 768 the CUs hold at 144 registers
+#define MST_STFT2_BWD_L2048 4  // 5 frames per 256-lane workgroup, 25 % recomputed: 1024 workgroups = one round at 127 registers (55.7 -> 46.8 us)
 #endif
 
 #ifndef MST_STFT2_W2048_BWD
@@ -335,9 +335,16 @@ __global__ __launch_bounds__(FftPlan<N>::LG, (N == 8192 ? MST_STFT2_W8192_BWD : 
     };
 
     if constexpr (PAIR) {
-        float2 nxt[8];
+#ifndef MST_STFT2_BWD2048_PREFETCH
+#define MST_STFT2_BWD2048_PREFETCH 0  // the 2048-point backward fetches each frame when it needs it: 16 registers less = 127, i.e. four
+                                      // workgroups per CU instead of three, which is what lets 1024 five-frame strips run in one round
+#endif
+        constexpr bool PREF = N != 2048 || MST_STFT2_BWD2048_PREFETCH;
+        float2 nxt[PREF ? 8 : 1];
+        if (PREF) {
 #pragma unroll
-        for (int t = 0; t < 8; ++t) nxt[t] = fetch(F0, t);
+            for (int t = 0; t < 8; ++t) nxt[t] = fetch(F0, t);
+        }
         for (int fa = F0; fa < F1; fa += 2) {
             const bool have_b = fa + 1 < F1;
 #pragma unroll 1
@@ -345,11 +352,16 @@ __global__ __launch_bounds__(FftPlan<N>::LG, (N == 8192 ? MST_STFT2_W8192_BWD : 
                 if (which == 1 && !have_b) break;
                 const int f = fa + which;
                 float2 cur[8];
+                if (PREF) {
 #pragma unroll
-                for (int t = 0; t < 8; ++t) cur[t] = nxt[t];
-                if (f + 1 < F1) {
+                    for (int t = 0; t < 8; ++t) cur[t] = nxt[t];
+                    if (f + 1 < F1) {
 #pragma unroll
-                    for (int t = 0; t < 8; ++t) nxt[t] = fetch(f + 1, t);
+                        for (int t = 0; t < 8; ++t) nxt[t] = fetch(f + 1, t);
+                    }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) cur[t] = fetch(f, t);
                 }
                 L::transform([&](int t) { return cur[t]; }, win, buf, tw, wl, lane);
                 for (int k = lane; k <= N / 2; k += LG) {
