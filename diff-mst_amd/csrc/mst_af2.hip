@@ -22,7 +22,7 @@ constexpr int kAf2Lanes = 512;
 #define MST_AF2_W 4      // min waves per SIMD asked of the forward kernel (4 = two workgroups per CU)
 #endif
 #ifndef MST_AF2_W_BWD
-#define MST_AF2_W_BWD 2  // the adjoint keeps 16 parked inputs next to the transform: 2 (256 registers) measured 4 % faster than 4 with spills
+#define MST_AF2_W_BWD 4  // one half per launch: 121-124 registers, two workgroups per CU
 #endif
 
 // W_32^t = (cos, -sin)(2 pi t / 32), t < 16: W_16384^(lane + 512 t) = W_16384^lane W_32^t
@@ -226,6 +226,11 @@ __device__ __forceinline__ void af2_bwd_half(const AfArgs& a, float2 (*buf)[AfS:
         }
     }
 }
+// One launch per half (half 0 parks P0 in the frame's slab, half 1 reads it back).  Both halves in one kernel take 229 registers
+// (85 spills when capped at 128): the compiler interleaves them, half 1's 80 frame loads float up into half 0's transforms.  One
+// half alone fits 128 registers without a spill = two workgroups per CU, and 2 x ceil(frames / 512) half-length rounds beat
+// ceil(frames / 256) full ones (bs 32: 2112 frames = 2 x 5 half rounds instead of 9 whole ones).
+template <int HALF>
 __global__ __launch_bounds__(kAf2Lanes, MST_AF2_W_BWD) void k_af2_bark_bwd(AfArgs a) {
     __shared__ __attribute__((aligned(16))) float2 buf[2][AfS::SLOTS];
     const int lane = threadIdx.x, f = blockIdx.x, s = blockIdx.y;  // s < 2*bs
@@ -236,16 +241,15 @@ __global__ __launch_bounds__(kAf2Lanes, MST_AF2_W_BWD) void k_af2_bark_bwd(AfArg
     af_signal(a, s, l, r, sign);
     const int n = (int)a.n;
     const bool fast = !(((uintptr_t)l | (uintptr_t)r) & 7);
-    af2_bwd_half<0>(a, buf, l, r, sign, f, s, n, fast, tw, lane);
-    lds_barrier();
-    af2_bwd_half<1>(a, buf, l, r, sign, f, s, n, fast, tw, lane);
+    af2_bwd_half<HALF>(a, buf, l, r, sign, f, s, n, fast, tw, lane);
 }
 
 void launch_af2_bark_fwd(const AfArgs& a, hipStream_t stream) {
     hipLaunchKernelGGL(k_af2_bark_fwd, dim3(a.n_groups, 4 * a.bs, 2), dim3(kAf2Lanes), 0, stream, a);
 }
 void launch_af2_bark_bwd(const AfArgs& a, hipStream_t stream) {
-    hipLaunchKernelGGL(k_af2_bark_bwd, dim3(a.n_frames, 2 * a.bs), dim3(kAf2Lanes), 0, stream, a);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_af2_bark_bwd<0>), dim3(a.n_frames, 2 * a.bs), dim3(kAf2Lanes), 0, stream, a);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_af2_bark_bwd<1>), dim3(a.n_frames, 2 * a.bs), dim3(kAf2Lanes), 0, stream, a);
 }
 
 }  // namespace mst
