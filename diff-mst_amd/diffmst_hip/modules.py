@@ -459,10 +459,13 @@ class BasicMixConsole(AdvancedMixConsole):
 
     def forward(self, tracks, track_params, fx_bus_params=None, master_bus_params=None, **_ignored):
         bs = tracks.shape[0]
-        if fx_bus_params is None:
-            fx_bus_params = torch.zeros(bs, 25, device=tracks.device)
-        if master_bus_params is None:
-            master_bus_params = torch.zeros(bs, 26, device=tracks.device)
+        if fx_bus_params is None or master_bus_params is None:  # unused stages: one cached pair of zero tensors per (bs, device)
+            key = ("basic-zeros", bs, str(tracks.device))
+            if key not in self._affine_cache:
+                self._affine_cache[key] = (torch.zeros(bs, 25, device=tracks.device), torch.zeros(bs, 26, device=tracks.device))
+            zf, zm = self._affine_cache[key]
+            fx_bus_params = zf if fx_bus_params is None else fx_bus_params
+            master_bus_params = zm if master_bus_params is None else master_bus_params
         return super().forward(
             tracks, track_params, fx_bus_params, master_bus_params, use_track_input_fader=True, use_track_eq=False,
             use_track_compressor=False, use_track_panner=True, use_master_bus=False, use_fx_bus=False,
