@@ -86,8 +86,8 @@ def test_mrstft_well_conditioned_terms(kw, dev):
     assert rel(xd.grad, xo.grad) < 5e-6
 
 
-@pytest.mark.parametrize("blocks", [4, 5, 6, 7, 9, 12, 17, 31])
-def test_mrstft_strip_layouts(blocks, dev):
+@pytest.mark.parametrize("blocks,bs", [(4, 1), (5, 1), (6, 1), (7, 1), (9, 1), (12, 1), (17, 1), (31, 1), (16, 20), (33, 70)])
+def test_mrstft_strip_layouts(blocks, bs, dev):
     """Row lengths of `blocks` 8192-point hops: every one cuts the rows into a different set of strips (seam strips of 2 frames
     with a longer last one for 8192, halo strips for 512 / 2048), and the seam halves parked by the 8192 launch must be picked up at
     exactly the right blocks by the next one.  Smooth term only, so the gradient is pinned to fp32 round-off."""
@@ -95,8 +95,8 @@ def test_mrstft_strip_layouts(blocks, dev):
 
     torch.manual_seed(blocks)
     n = blocks * 4096
-    x = 0.3 * torch.randn(1, 2, n)
-    y = 0.5 * x + 0.2 * torch.randn(1, 2, n)
+    x = 0.3 * torch.randn(bs, 2, n)  # bs 20 / 70: 40 / 140 rows, where the 8192-point strips are lengthened to fit one round
+    y = 0.5 * x + 0.2 * torch.randn(bs, 2, n)
     kw = dict(w_sc=1.0, w_log_mag=0.0)
     xd = x.to(dev).requires_grad_(True)
     loss = make_loss(**kw)(xd, y.to(dev))
