@@ -1,4 +1,4 @@
-# A/B of kernel libraries on the bench step: tools/_ab.sh <lib basename> ...   (libs in diff-mst_amd/lib, "" = default)
+# A/B of kernel libraries on the bench step: tools/ab_bench.sh <lib basename> ...   (libs in diff-mst_amd/lib, "" = default)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 for v in base "$@"; do

@@ -4,5 +4,5 @@ R=$GRAFT_REPO_ROOT
 cd $R
 timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -4
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
-bash tools/pmc_passes.sh r2 > gpurun_out/r2_passes.log 2>&1; tail -3 gpurun_out/r2_passes.log
-cd $R && timeout 900 python bench.py > gpurun_out/r2_bench.log 2>&1; tail -c 300 gpurun_out/r2_bench.log
+bash tools/pmc_passes.sh ${1:-r3} > gpurun_out/${1:-r3}_passes.log 2>&1; tail -3 gpurun_out/${1:-r3}_passes.log
+cd $R && timeout 900 python bench.py > gpurun_out/${1:-r3}_bench.log 2>&1; tail -c 300 gpurun_out/${1:-r3}_bench.log
