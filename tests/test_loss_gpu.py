@@ -32,38 +32,49 @@ def make_loss(res=RES, **kw):
                                    win_lengths=[r[2] for r in res], **kw)
 
 
-@pytest.mark.parametrize("bs,n,kw", [
-    (2, 65536, {}),
-    (8, 262144, {}),                                                   # BASELINE cfg #2 loss shape
-    (2, 131072, dict(w_sc=0.0, w_log_mag=1.0, w_lin_mag=1.0)),          # evaluation instance mst/system.py:61-69
-    (1, 50000, dict(sc_per_example=False)),                            # pre-0.4.0 global spectral convergence
+@pytest.mark.parametrize("bs,n,kw,seeds", [
+    (2, 65536, {}, 5),
+    (8, 262144, {}, 3),                                                   # BASELINE cfg #2 loss shape
+    (2, 131072, dict(w_sc=0.0, w_log_mag=1.0, w_lin_mag=1.0), 5),          # evaluation instance mst/system.py:61-69
+    (1, 50000, dict(sc_per_example=False), 5),                            # pre-0.4.0 global spectral convergence
 ])
-def test_mrstft_three_way(bs, n, kw, dev, record):
+def test_mrstft_three_way(bs, n, kw, seeds, dev, record):
+    """Loss to 1e-5 of float64; gradient three-way over several seeds.
+
+    d log|X| / dX ~ 1/|X|: the rel-L2 error of the log-magnitude gradient is carried by a handful of near-zero bins of the two
+    reflect-padded edge frames (real-even frames: X[k] = (-1)^k R[k] with R real, so |X| crosses zero between bins), for BOTH
+    fp32 implementations.  Which of the two lands closer to float64 on one draw is a coin toss with a heavy tail - per seed and
+    resolution the ratio (HIP distance) / (fp32 reference distance) ranges 0.08 .. 4.1 (tools/dbg_logmag.py, round 3) - so the
+    bound is on the statistic that is stable: the MEDIAN ratio over the seeds must be <= 1.5 (HIP is as close to float64 as the
+    path it replaces), every single draw within 10x (measured worst 8.8x, best 0.08x), and the smooth terms are pinned to 5e-6 separately below."""
     from oracle import loss_restated as ol
 
-    torch.manual_seed(bs * 7 + n)
-    x = 0.3 * torch.randn(bs, 2, n)
-    y = 0.5 * x + 0.2 * torch.randn(bs, 2, n)
-    xd = x.to(dev).requires_grad_(True)
-    loss = make_loss(**kw)(xd, y.to(dev))
-    loss.backward()
-    outs = {}
-    for dt in (torch.float32, torch.float64):
-        xo = x.clone().to(dt).requires_grad_(True)
-        lo = ol.mrstft_loss(xo, y.to(dt), RES, **kw)
-        lo.backward()
-        outs[dt] = (lo.item(), xo.grad)
-    l32, g32 = outs[torch.float32]
-    l64, g64 = outs[torch.float64]
-    assert abs(loss.item() - l64) / l64 < 1e-5, (loss.item(), l32, l64)
-    h32, h64, r = rel(xd.grad, g32), rel(xd.grad, g64), rel(g32, g64)
-    record(loss_rel_err_vs_f64=abs(loss.item() - l64) / l64, grad=(h32, h64, r))
-    print(f"\n[mrstft {bs}x2x{n} {kw}] loss hip {loss.item():.7f} ref32 {l32:.7f} f64 {l64:.7f}; grad hip-ref32 {h32:.2e} hip-f64 {h64:.2e} ref32-f64 {r:.2e}")
-    # d log|X| / dX ~ 1/|X| : among 1e6..1e7 bins a few are nearly zero and dominate the fp32 error of
-    # BOTH fp32 implementations (ref32 sits 5e-4..1e-2 from float64).  The statistic is heavy-tailed: two correct fp32
-    # FFTs (the ping-pong and the in-place kernels here) land 1.3-1.8x apart on the same input, so the bound is
-    # "within an order of magnitude of the reference's own fp32 distance"; the smooth terms are pinned to 1e-5 below.
-    assert h64 <= 10 * r + 5e-4 and h32 <= 2 * (h64 + r)
+    ratios, worst = [], None
+    for s in range(seeds):
+        torch.manual_seed(bs * 7 + n + 1000 * s)
+        x = 0.3 * torch.randn(bs, 2, n)
+        y = 0.5 * x + 0.2 * torch.randn(bs, 2, n)
+        xd = x.to(dev).requires_grad_(True)
+        loss = make_loss(**kw)(xd, y.to(dev))
+        loss.backward()
+        outs = {}
+        for dt in (torch.float32, torch.float64):
+            xo = x.clone().to(dt).requires_grad_(True)
+            lo = ol.mrstft_loss(xo, y.to(dt), RES, **kw)
+            lo.backward()
+            outs[dt] = (lo.item(), xo.grad)
+        l32, g32 = outs[torch.float32]
+        l64, g64 = outs[torch.float64]
+        assert abs(loss.item() - l64) / l64 < 1e-5, (loss.item(), l32, l64)
+        h32, h64, r = rel(xd.grad, g32), rel(xd.grad, g64), rel(g32, g64)
+        ratios.append(h64 / r)
+        if worst is None or h64 / r > worst[0]:
+            worst = (h64 / r, h32, h64, r, abs(loss.item() - l64) / l64)
+        print(f"\n[mrstft {bs}x2x{n} {kw} seed {s}] loss hip {loss.item():.7f} ref32 {l32:.7f} f64 {l64:.7f}; grad hip-ref32 {h32:.2e} hip-f64 {h64:.2e} ref32-f64 {r:.2e}")
+        assert h64 <= 10 * r + 1e-5 and h32 <= 2 * (h64 + r)
+    med = sorted(ratios)[len(ratios) // 2]
+    record(loss_rel_err_vs_f64=worst[4], grad=worst[1:4], ratios_hip_over_ref32=ratios, median_ratio=med)
+    assert med <= 1.5, ratios
 
 
 @pytest.mark.parametrize("kw", [dict(w_sc=1.0, w_log_mag=0.0), dict(w_sc=1.0, w_log_mag=0.0, sc_per_example=False)])
