@@ -209,7 +209,7 @@ struct Layout {
     int64_t aggF_t, aggF_m, aggA_t, aggA_m;      // tile aggregates sigrows x 12 x kMaxTiles1 (forward / adjoint cascade)
     // fx bus (only laid out when MST_USE_FX_BUS is set)
     int fxS, fxTaps, fxK, fxBlk, fxBlkIr;         // impulse-response samples, band-pass taps, partitions, signal blocks, ir-bwd blocks
-    int64_t fx_rc, fx_in, fx_wnf, fx_ir, fx_Xs, fx_Hs, fx_Ys, fx_dXs, fx_dHs, fx_dir, fx_din, fx_part, fx_Hf;
+    int64_t fx_rc, fx_in, fx_wnf, fx_ir, fx_Xs, fx_Hs, fx_Ys, fx_dXs, fx_dHs, fx_dir, fx_din, fx_part, fx_Hf, fx_mix, fx_dry;
     int64_t total;                       // floats
 };
 
@@ -306,6 +306,8 @@ inline Layout make_layout(const mst_console_desc* d) {
         L.fx_din = take(B * 2 * N);
         L.fx_part = take(B * (int64_t)L.fxBlkIr * 24);
         L.fx_Hf = take((int64_t)12 * 8192 * 2);  // conjugated spectra of the twelve band-pass filters
+        L.fx_mix = take(B);                       // wet/dry mix per batch item (1 unless forward_mix_console hands one over)
+        L.fx_dry = take(B * (int64_t)L.fxBlk);    // per-block partial sums <dbus, fx_in> of the mix gradient
     }
     L.total = o;
     return L;

@@ -49,7 +49,7 @@ static FxPlan fx_plan(const Layout& L) {
     p.n = L.N;
     p.Ns = round_up(L.N, 4);
     p.rcfx = L.fx_rc; p.fx_in = L.fx_in; p.wnf = L.fx_wnf; p.ir = L.fx_ir; p.Xs = L.fx_Xs; p.Hs = L.fx_Hs; p.Ys = L.fx_Ys;
-    p.dXs = L.fx_dXs; p.dHs = L.fx_dHs; p.dir = L.fx_dir; p.dfx_in = L.fx_din; p.fxpart = L.fx_part; p.Hf = L.fx_Hf;
+    p.dXs = L.fx_dXs; p.dHs = L.fx_dHs; p.dir = L.fx_dir; p.dfx_in = L.fx_din; p.fxpart = L.fx_part; p.Hf = L.fx_Hf; p.mixv = L.fx_mix; p.dry = L.fx_dry;
     return p;
 }
 
@@ -79,7 +79,7 @@ extern "C" int mst_console_forward(const mst_console_desc* d, const float* track
 
     PrepArgs pa{track_params, fx_bus_params, master_bus_params, ws + L.rc_t, ws + L.rc_m,
                 ws + L.powF_t, ws + L.powF_m, ws + L.powA_t, ws + L.powA_m, ws + L.powP_t, ws + L.powP_m,
-                ws + L.pow1F_t, ws + L.pow1F_m, ws + L.pow1A_t, ws + L.pow1A_m, fx_on ? ws + L.fx_rc : nullptr, status, L.R, L.bs, L.KE,
+                ws + L.pow1F_t, ws + L.pow1F_m, ws + L.pow1A_t, ws + L.pow1A_m, fx_on ? ws + L.fx_rc : nullptr, fx_on ? ws + L.fx_mix : nullptr, status, L.R, L.bs, L.KE,
                 L.eq1, *d};
     launch_prep(pa, stream);
 
@@ -203,7 +203,7 @@ extern "C" int mst_console_backward(const mst_console_desc* d, const float* trac
     }
     PrepBwdArgs pb{track_params, master_bus_params, ws + L.rc_t, ws + L.rc_m, ws + L.cp_t, ws + L.cp_m, ws + L.ep_t, ws + L.ep_m,
                    grad_track_params, grad_master_params, fx_bus_params, fx_on ? ws + L.fx_part : nullptr,
-                   fx_on ? grad_fx_params : nullptr, L.fxBlkIr, L.R, L.bs, L.nblkC, L.nblkE, *d};
+                   fx_on ? grad_fx_params : nullptr, L.fxBlkIr, fx_on ? ws + L.fx_mix : nullptr, fx_on ? ws + L.fx_dry : nullptr, L.fxBlk, L.R, L.bs, L.nblkC, L.nblkE, *d};
     launch_prep_bwd(pb, stream);
     return (int)hipGetLastError();
 }

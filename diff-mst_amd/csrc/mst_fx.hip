@@ -300,6 +300,13 @@ struct FxIfftArgs {
     const float* tables;
     int frames;
     int nsum;            // FX_CROP: the spectrum is the sum of nsum partials, `frames` frames apart (the frame axis holds nsum * frames)
+    // wet/dry mix (forward_mix_console may hand over mix != 1; AdvancedMixConsole.forward always runs with 1):
+    const float* mixv;   // (bs) or null
+    const float* dry;    // FX_OUT: the send bus fx_in, FX_SCAT: the bus cotangent dbus   (bs, 2, dry_stride)
+    int64_t dry_stride;
+    const float* dry2;   // FX_SCAT: fx_in (bs, 2, dry2_stride) for the mix gradient <dbus, fx_in>
+    int64_t dry2_stride;
+    float* dry_part;     // FX_SCAT: (bs, frames) partial sums of <dbus, fx_in>
 };
 template <int MODE>
 __global__ __launch_bounds__(kFxLanes, 4) void k_fx_ifft(FxIfftArgs a) {
@@ -341,6 +348,43 @@ __global__ __launch_bounds__(kFxLanes, 4) void k_fx_ifft(FxIfftArgs a) {
     }
     float* dl = a.dst + (int64_t)(2 * b) * a.stride + (int64_t)m * kFxHop;
     float* dr = dl + a.stride;
+    if (MODE != FX_CROP && a.mixv) {
+        // y = (1 - mix) fx_in + mix wet: the wet share rides on the band gains (k_prep); the dry share and its adjoints are added here
+        const float dryw = 1.0f - a.mixv[b];
+        float dot = 0.0f;
+        if (dryw != 0.0f) {  // uniform per workgroup; mix = 1 (every AdvancedMixConsole.forward call) touches nothing
+            const float* sl = a.dry + (int64_t)(2 * b) * a.dry_stride + (int64_t)m * kFxHop;
+            const float* sr = sl + a.dry_stride;
+            const float* xl = MODE == FX_SCAT ? a.dry2 + (int64_t)(2 * b) * a.dry2_stride + (int64_t)m * kFxHop : nullptr;
+            const float* xr = MODE == FX_SCAT ? xl + a.dry2_stride : nullptr;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int off = 2 * lane + 1024 * t;
+                const int64_t i = (int64_t)m * kFxHop + off;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (i + j < a.n) {
+                        const float vl = sl[off + j], vr = sr[off + j];
+                        acc[t][2 * j] = fmaf(dryw, vl, acc[t][2 * j]);
+                        acc[t][2 * j + 1] = fmaf(dryw, vr, acc[t][2 * j + 1]);
+                        if (MODE == FX_SCAT) dot = fmaf(vl, xl[off + j], fmaf(vr, xr[off + j], dot));
+                    }
+                }
+            }
+        }
+        if (MODE == FX_SCAT) {  // fixed-order block sum (lanes -> waves -> workgroup): the mix gradient stays reproducible
+            float* red = reinterpret_cast<float*>(&buf[1][0]);
+            const float w = wave_sum(dot);
+            lds_barrier();
+            if ((lane & 63) == 0) red[lane >> 6] = w;
+            lds_barrier();
+            if (lane == 0) {
+                float s = 0.0f;
+                for (int i = 0; i < kFxLanes / 64; ++i) s += red[i];
+                a.dry_part[(int64_t)b * a.frames + m] = s;
+            }
+        }
+    }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int off = 2 * lane + 1024 * t;
@@ -412,7 +456,8 @@ void launch_fx_forward(const FxPlan& p, const float* noise, const float* filters
                  p.nblk, p.K, p.nblk};
     if (p.K == 16) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fx_mac16<FX_MAC_Y>), dim3((kFxN / 2 + 256) / 256, (p.nblk + 15) / 16, p.bs), dim3(256), 0, stream, mc);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fx_mac<FX_MAC_Y>), dim3((kFxN / 2 + 256) / 256, p.nblk, p.bs), dim3(256), 0, stream, mc);
-    FxIfftArgs io{reinterpret_cast<const float2*>(ws + p.Ys), bus, bus_stride, p.n, tables, p.nblk, 1};
+    FxIfftArgs io{reinterpret_cast<const float2*>(ws + p.Ys), bus, bus_stride, p.n, tables, p.nblk, 1,
+                  ws + p.mixv, ws + p.fx_in, p.Ns, nullptr, 0, nullptr};
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fx_ifft<FX_OUT>), dim3(p.nblk, p.bs), dim3(kFxLanes), 0, stream, io);
 }
 
@@ -426,7 +471,8 @@ void launch_fx_backward(const FxPlan& p, const float* dbus, int64_t dbus_stride,
                  p.nblk, p.K, p.nblk};
     if (p.K == 16) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fx_mac16<FX_MAC_DX>), dim3((kFxN / 2 + 256) / 256, (p.nblk + 15) / 16, p.bs), dim3(256), 0, stream, mx);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fx_mac<FX_MAC_DX>), dim3((kFxN / 2 + 256) / 256, p.nblk, p.bs), dim3(256), 0, stream, mx);
-    FxIfftArgs ix{reinterpret_cast<const float2*>(ws + p.dXs), ws + p.dfx_in, p.Ns, p.n, tables, p.nblk, 1};
+    FxIfftArgs ix{reinterpret_cast<const float2*>(ws + p.dXs), ws + p.dfx_in, p.Ns, p.n, tables, p.nblk, 1,
+                  ws + p.mixv, dbus, dbus_stride, ws + p.fx_in, p.Ns, ws + p.dry};
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fx_ifft<FX_SCAT>), dim3(p.nblk, p.bs), dim3(kFxLanes), 0, stream, ix);
     // cotangent of the impulse response: dH[p] = sum_m dY[m] conj(X[m - p]), first 4096 samples of each inverse
     // K = 16: the frame walk of the dH product is dealt to up to kFxDhChunks workgroups per bin slice (partials summed by the
@@ -436,7 +482,7 @@ void launch_fx_backward(const FxPlan& p, const float* dbus, int64_t dbus_stride,
                  p.nblk, p.nblk, p.K * chunks};
     if (p.K == 16) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fx_mac16<FX_MAC_DH>), dim3((kFxN / 2 + 256) / 256, chunks, p.bs), dim3(256), 0, stream, mh);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fx_mac<FX_MAC_DH>), dim3((kFxN / 2 + 256) / 256, p.K, p.bs), dim3(256), 0, stream, mh);
-    FxIfftArgs ih{reinterpret_cast<const float2*>(ws + p.dHs), ws + p.dir, p.S, p.S, tables, p.K, chunks};
+    FxIfftArgs ih{reinterpret_cast<const float2*>(ws + p.dHs), ws + p.dir, p.S, p.S, tables, p.K, chunks, nullptr, nullptr, 0, nullptr, 0, nullptr};
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fx_ifft<FX_CROP>), dim3(p.K, p.bs), dim3(kFxLanes), 0, stream, ih);
     hipLaunchKernelGGL(k_fx_ir_bwd, dim3(p.nblk_ir, p.bs), dim3(256), 0, stream, ws + p.wnf, ws + p.rcfx, ws + p.dir, ws + p.fxpart, p.S);
 }

@@ -21,7 +21,8 @@ struct PrepArgs {
     float* powP_t; float* powP_m;  // all-pole scan tables
     float* pow1F_t; float* pow1F_m;  // in-wave scan tables (forward / adjoint cascade)
     float* pow1A_t; float* pow1A_m;
-    float* rc_fx;   // (bs, 24): reverberation band gains and decay rates 10 d + 1 (fx bus), or nullptr
+    float* rc_fx;   // (bs, 24): reverberation band gains (times the wet/dry mix) and decay rates 10 d + 1 (fx bus), or nullptr
+    float* fx_mix;  // (bs): wet/dry mix - 1 (reference mst/modules.py:420) unless MST_NO_RANGE_CHECK hands a value over
     int32_t* status;
     int R, bs;
     int KE;  // chunks per scan lane (EQ scans)
@@ -41,6 +42,9 @@ struct PrepBwdArgs {
     const float* fx_part;                  // (bs, nblkF, 24) partial sums of the reverberation parameters, or nullptr
     float* grad_fx_params;                 // (bs,25) or nullptr
     int nblkF;
+    const float* fx_mix;                   // (bs) wet/dry mix used by forward
+    const float* fx_dry;                   // (bs, nblkX) partial sums <dbus, fx_in>
+    int nblkX;
     int R, bs, nblkC, nblkE;
     mst_console_desc d;
 };
@@ -125,7 +129,7 @@ void launch_comp_bwd(bool master, bool run, const CompBwdArgs& a, int rows, hipS
 struct FxPlan {
     int bs, S, taps, K, nblk, nblk_ir;
     int64_t n, Ns;
-    int64_t rcfx, fx_in, wnf, ir, Xs, Hs, Ys, dXs, dHs, dir, dfx_in, fxpart, Hf;
+    int64_t rcfx, fx_in, wnf, ir, Xs, Hs, Ys, dXs, dHs, dir, dfx_in, fxpart, Hf, mixv, dry;
 };
 void launch_fx_forward(const FxPlan& p, const float* noise, const float* filters, const float* tables, float* ws, float* bus,
                        int64_t bus_stride, hipStream_t stream);

@@ -228,8 +228,13 @@ __global__ __launch_bounds__(320) void k_prep(PrepArgs a) {
         // reverberation: band gains and decay rates 10 d + 1 (dasp noise_shaped_reverberation)
         const float* fp = a.fx_params + (int64_t)mrow * MST_NUM_FX_PARAMS;
         float* o = a.rc_fx + (int64_t)mrow * 24;
+        // wet/dry mix: AdvancedMixConsole.forward forces it to 1 (mst/modules.py:420); forward_mix_console applies the value it is
+        // given (MST_NO_RANGE_CHECK).  mix * wet = fx_in * (mix * ir): the mix rides on the band gains, the dry share
+        // (1 - mix) * fx_in is added where the wet block is written (k_fx_ifft<FX_OUT>).
+        const float mix = check ? 1.0f : denorm(fp[24], d.fx_lo[24], d.fx_hi[24]);
+        a.fx_mix[mrow] = mix;
         for (int k = 0; k < 12; ++k) {
-            o[k] = denorm(fp[k], d.fx_lo[k], d.fx_hi[k]);
+            o[k] = denorm(fp[k], d.fx_lo[k], d.fx_hi[k]) * mix;
             o[12 + k] = denorm(fp[12 + k], d.fx_lo[12 + k], d.fx_hi[12 + k]) * 10.0f + 1.0f;
         }
     }
@@ -542,12 +547,25 @@ __global__ __launch_bounds__(256) void k_prep_bwd(PrepBwdArgs a) {
     if (is_master && a.grad_fx_params && tid >= 64 && tid < 64 + MST_NUM_FX_PARAMS) {
         const int k = tid - 64;
         float* gf = a.grad_fx_params + (int64_t)mrow * MST_NUM_FX_PARAMS;
+        const double mix = (double)a.fx_mix[mrow];
         if (k == 24) {
-            gf[k] = 0.0f;  // "mix" is forced to 1 by the reference (mst/modules.py:420): no gradient reaches it
+            // forward(): "mix" is forced to 1 by the reference (mst/modules.py:420), no gradient reaches it.  forward_mix_console:
+            // y = (1 - mix) fx_in + mix wet  =>  dL/dmix = <dbus, wet> - <dbus, fx_in> = sum_k gain_k dL/d(mix gain_k) - dry sums
+            double acc = 0.0;
+            if (d.flags & MST_NO_RANGE_CHECK) {
+                for (int j = 0; j < 12; ++j) {
+                    double aj = 0.0;
+                    for (int bk = 0; bk < a.nblkF; ++bk) aj += (double)a.fx_part[((int64_t)mrow * a.nblkF + bk) * 24 + j];
+                    acc += aj * (double)denorm(a.fx_params[(int64_t)mrow * MST_NUM_FX_PARAMS + j], d.fx_lo[j], d.fx_hi[j]);
+                }
+                for (int bk = 0; bk < a.nblkX; ++bk) acc -= (double)a.fx_dry[(int64_t)mrow * a.nblkX + bk];
+                acc *= (double)(d.fx_hi[24] - d.fx_lo[24]);
+            }
+            gf[k] = (float)acc;
         } else {
             double acc = 0.0;
             for (int bk = 0; bk < a.nblkF; ++bk) acc += (double)a.fx_part[((int64_t)mrow * a.nblkF + bk) * 24 + k];
-            const double scale = (double)(d.fx_hi[k] - d.fx_lo[k]) * (k >= 12 ? 10.0 : 1.0);  // rate = 10 decay + 1
+            const double scale = (double)(d.fx_hi[k] - d.fx_lo[k]) * (k >= 12 ? 10.0 : mix);  // rate = 10 decay + 1; gains carry the mix
             gf[k] = (float)(acc * scale);
         }
     }

@@ -75,7 +75,7 @@ def install(strict: bool = True) -> dict:
         if getattr(sys.modules.get(modname.split(".")[0]), "__diffmst_alias__", False):
             raise RuntimeError(
                 f"`{modname}` resolves to diffmst_hip's own alias package, not to a checkout of the reference: put the "
-                "reference on sys.path (and drop diff-mst_amd/mst from it, or import the reference first)"
+                "reference on sys.path (and drop diff-mst_amd/standalone from it, or import the reference first)"
             )
         old = getattr(mod, attr, None)
         if old is new or (modname, attr) in _installed:

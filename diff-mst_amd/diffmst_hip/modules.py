@@ -144,7 +144,8 @@ class _ConsoleFunction(torch.autograd.Function):
             ctx.desc, ctx.nbytes, ctx.dev = desc, nbytes, dev
             ctx.want_mixed = want_mixed
             ctx.fx_on = bool(flags["use_fx_bus"])
-            ctx.save_for_backward(rows, tp, mp, ws, fp, *fx_keep)
+            # the backward needs the engine tables only: the filtered noise and the spectra are already in the workspace
+            ctx.save_for_backward(rows, tp, mp, ws, fp, *fx_keep[2:])
         ctx.set_materialize_grads(False)  # an unused mixed_tracks output must not cost a zero (bs,2,T,N) cotangent
         return mix, mixed
 
@@ -166,7 +167,7 @@ class _ConsoleFunction(torch.autograd.Function):
         g_tracks = torch.empty(bs, n_tracks, n, dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
         fx, g_fx = None, None
         if ctx.fx_on:
-            fx = _cabi.ConsoleFx(*(t.data_ptr() for t in fx_keep))
+            fx = _cabi.ConsoleFx(None, None, fx_keep[0].data_ptr())
             g_fx = torch.empty(bs, _cabi.NUM_FX_PARAMS, dtype=torch.float32, device=dev)
         # fx bus off: the fx parameters never reach the mix - their gradient is None, as in the reference (no zero fill)
         with torch.cuda.device(dev):
@@ -319,9 +320,9 @@ class AdvancedMixConsole(torch.nn.Module):
 
     # ------------------------------------------------------------------ parameter dictionaries
     def _affine(self, index, device):
-        key = (id(index), str(device))
+        lo, hi = _desc.range_vectors(self.param_ranges, index)  # read on every call: param_ranges may be edited between calls
+        key = (id(index), str(device), tuple(lo), tuple(hi))
         if key not in self._affine_cache:
-            lo, hi = _desc.range_vectors(self.param_ranges, index)
             lo_t = torch.tensor(lo, dtype=torch.float32, device=device)
             hi_t = torch.tensor(hi, dtype=torch.float32, device=device)
             self._affine_cache[key] = (hi_t - lo_t, lo_t)
@@ -336,12 +337,13 @@ class AdvancedMixConsole(torch.nn.Module):
             return _nested(_desc.TRACK_INDEX, track_params * scale + lo)
 
         def fx():
-            key = ("fx-forced-wet", str(fx_bus_params.device))
+            base = self._affine(_desc.FX_INDEX, fx_bus_params.device)
+            key = ("fx-forced-wet", id(base[0]))  # follows the range-keyed entry above
             if key not in self._affine_cache:
-                scale, lo = (t.clone() for t in self._affine(_desc.FX_INDEX, fx_bus_params.device))
+                scale, lo = (t.clone() for t in base)
                 scale[24], lo[24] = 0.0, 1.0  # reference :420 forces the reverb mix to ones
-                self._affine_cache[key] = (scale, lo)
-            scale, lo = self._affine_cache[key]
+                self._affine_cache[key] = (scale, lo, base)  # `base` kept alive so that its id stays unique
+            scale, lo = self._affine_cache[key][:2]
             return _nested(_desc.FX_INDEX, fx_bus_params * scale + lo)
 
         def master():
@@ -394,7 +396,8 @@ class AdvancedMixConsole(torch.nn.Module):
         """DENORMALISED dictionaries in, ``(mixed_tracks (bs,2,T,N), master_bus (bs,2,N))`` out (reference :186-314).
 
         Like the reference this entry point applies whatever values it is given: no range check, no clamping, and
-        the gradients flow to the dictionary entries.  Flags are positional in the reference's callers
+        the gradients flow to the dictionary entries - including the reverberation's wet/dry ``mix``
+        (``(1 - mix) * fx_in + mix * wet``; only ``forward`` forces it to 1, reference :420).  Flags are positional in the reference's callers
         (mst/mixing.py:1076-1087), so their order is part of the interface.
         """
         flags = dict(

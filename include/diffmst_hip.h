@@ -72,8 +72,8 @@ typedef struct mst_console_desc {
     /* denormalisation ranges v*(hi-lo)+lo, reference mst/modules.py:71-72,121-181 */
     float track_lo[MST_NUM_TRACK_PARAMS], track_hi[MST_NUM_TRACK_PARAMS];
     float master_lo[MST_NUM_MASTER_PARAMS], master_hi[MST_NUM_MASTER_PARAMS];
-    /* fx bus (MST_USE_FX_BUS): ranges of the 25 reverberation parameters (band gains, band decays, mix - the mix is
-     * forced to 1 by the reference, mst/modules.py:420), impulse-response length and band-pass length of
+    /* fx bus (MST_USE_FX_BUS): ranges of the 25 reverberation parameters (band gains, band decays, mix - forward() forces the mix to
+     * 1, mst/modules.py:420; under MST_NO_RANGE_CHECK the given value is applied), impulse-response length and band-pass length of
      * dasp_pytorch.functional.noise_shaped_reverberation as the reference calls it (:277-283: 65536, 1023) */
     float fx_lo[MST_NUM_FX_PARAMS], fx_hi[MST_NUM_FX_PARAMS];
     int32_t fx_ir_samples;     /* multiple of 4096 */
@@ -123,7 +123,9 @@ int mst_console_forward(const mst_console_desc* d, const float* tracks, const fl
  *   grad_mixed_tracks  (bs, 2, n_tracks, n_samples) or NULL
  *   grad_track_params  (bs, n_tracks, 27) out (w.r.t. the NORMALISED parameters)
  *   grad_master_params (bs, 26) out
- *   grad_fx_params     (bs, 25) out, or NULL (written only when MST_USE_FX_BUS; the forced-wet "mix" column gets 0)
+ *   grad_fx_params     (bs, 25) out, or NULL (written only when MST_USE_FX_BUS; the "mix" column gets 0 when the call forced it to 1 -
+ *                      AdvancedMixConsole.forward, reference mst/modules.py:420 - and the true gradient of
+ *                      (1 - mix) fx_in + mix wet under MST_NO_RANGE_CHECK, i.e. forward_mix_console)
  *   grad_tracks        (bs, n_tracks, n_samples) dense out, or NULL when tracks need no grad */
 int mst_console_backward(const mst_console_desc* d, const float* tracks, const float* track_params,
                          const float* fx_bus_params, const float* master_bus_params, const mst_console_fx* fx,

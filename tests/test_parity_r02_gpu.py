@@ -320,6 +320,55 @@ def test_fx_bus_three_way(bs, T, n, dev, record):
     assert torch.equal(mix2, mix) and torch.equal(f2.grad, f.grad) and torch.equal(a2.grad, a.grad)
 
 
+@pytest.mark.parametrize("mixval", [0.3, 0.0])
+def test_fx_bus_wet_dry_mix_forward_mix_console(mixval, dev, record):
+    """forward_mix_console applies the reverberation's wet/dry `mix` it is given - (1 - mix) * fx_in + mix * wet, reference
+    mst/modules.py:186-314 through dasp's noise_shaped_reverberation - and returns its gradient; only forward() forces 1
+    (:420).  Against oracle.console_chain in fp32 and float64 on the same noise, per-item mix values."""
+    from mst.modules import AdvancedMixConsole
+    from oracle import console_restated as oc
+
+    bs, T, n = 2, 3, 65536
+    torch.manual_seed(7)
+    tracks = 0.1 * torch.randn(bs, T, n)
+    tpn, fpn, mpn = torch.rand(bs, T, 27), torch.rand(bs, 25), torch.rand(bs, 26)
+    fpn[:, 24] = torch.tensor([mixval, 0.5 * mixval + 0.2])
+    noise = fx_noise(bs, 72)
+    gmix = torch.randn(bs, 2, n)
+    ranges = oc.param_ranges(44100)
+
+    def dicts(dt, device):
+        leaves = [t.detach().clone().to(dt).to(device).requires_grad_(True) for t in (tpn, fpn, mpn)]
+        tp = oc.denormalize_parameters(oc.split_track_params(leaves[0]), ranges)
+        mp = oc.denormalize_parameters(oc.split_master_params(leaves[2]), ranges)
+        fp = oc.denormalize_parameters(oc.split_fx_params(leaves[1]), ranges)
+        fp["reverberation"]["mix"] = leaves[1][..., 24] * 1.0  # the caller's value, not the forced 1
+        return leaves, tp, fp, mp
+
+    console = AdvancedMixConsole(44100)
+    console.fx_noise = noise
+    leaves, tp, fp, mp = dicts(torch.float32, dev)
+    _, mix = console.forward_mix_console(tracks.to(dev), tp, fp, mp, True, True, True, True, True, True, True)
+    (mix * gmix.to(dev)).sum().backward()
+    hip = dict(mix=mix, g_tp=leaves[0].grad, g_fp=leaves[1].grad, g_mixparam=leaves[1].grad[:, 24], g_mp=leaves[2].grad)
+    refs = {}
+    for dt in (torch.float32, torch.float64):
+        lv, tpo, fpo, mpo = dicts(dt, "cpu")
+        _, omix = oc.console_chain(tracks.to(dt), tpo, mpo, 44100, fp=fpo, fx_noise=noise.to(dt), **FX)
+        (omix * gmix.to(dt)).sum().backward()
+        refs[dt] = dict(mix=omix, g_tp=lv[0].grad, g_fp=lv[1].grad, g_mixparam=lv[1].grad[:, 24], g_mp=lv[2].grad)
+    rep = {k: (rel(hip[k], refs[torch.float32][k]), rel(hip[k], refs[torch.float64][k]), rel(refs[torch.float32][k], refs[torch.float64][k]))
+           for k in hip}
+    print(f"\n[fx wet/dry mix {mixval}] (hip vs ref32, hip vs f64, ref32 vs f64)")
+    for k, v in rep.items():
+        print(f"  {k:10s} {v[0]:.2e} {v[1]:.2e} {v[2]:.2e}")
+    record(**rep)
+    assert rep["mix"][0] < 1e-4 and rep["mix"][1] <= rep["mix"][2] + 3e-5, rep["mix"]
+    assert float(refs[torch.float64]["g_mixparam"].abs().min()) > 0  # the gradient is real on this entry point
+    for k in ("g_fp", "g_mixparam", "g_tp", "g_mp"):
+        assert rep[k][1] <= 2 * rep[k][2] + 2e-4 and rep[k][0] < 1e-2, (k, rep[k])
+
+
 def test_default_flags_run_like_the_reference(dev):
     """`console(tracks, tp, fp, mp)` and `naive_random_mix(tracks, console)` with NO flags - fx bus on - work (round 1 raised
     NotImplementedError); the op's noise is drawn per call, so two calls differ unless `fx_noise` is pinned."""
