@@ -29,7 +29,7 @@ static constexpr bool fuse_allpole() {
 #endif
 }
 
-extern "C" int mst_abi_version(void) { return 3; }
+extern "C" int mst_abi_version(void) { return 4; }
 
 extern "C" size_t mst_console_fx_tables_bytes(void) { return (size_t)8192 * 2 * sizeof(float); }
 extern "C" int mst_console_fx_init_tables(void* tables, void* stream) {

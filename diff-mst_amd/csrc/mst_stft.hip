@@ -600,6 +600,11 @@ struct LossArgs {
     float count[kMaxRes];  // rows * n_bins * n_frames
     float w_sc, w_log, w_lin;
     int sc_per_example;
+    // sharded evaluation (rows of the batch split over ranks): per-resolution totals of THIS rank's rows out (k_mrstft_totals),
+    // all-reduced totals in (k_mrstft_final) for the batch-global spectral-convergence ratio
+    double* totals;         // (n_res, 4) out, or null
+    const double* gtotals;  // (n_res, 4) in, or null
+    int world;              // ranks that contributed to gtotals (1 when null)
 };
 // (One merged 1024-lane launch measured 15.5-21.6 us against 5.0 + 6.7 us for these two: sixteen waves on one CU walking three
 // pairs each lose more to their serial fp64 chains than the second launch costs.)
@@ -620,6 +625,16 @@ __global__ __launch_bounds__(64) void k_mrstft_rowsums(LossArgs a) {
         o[0] = (float)s[0]; o[1] = (float)s[1]; o[2] = (float)s[2]; o[3] = (float)s[3];
     }
 }
+// sharded evaluation only: this rank's totals per resolution, fixed order over the rows
+__global__ __launch_bounds__(64) void k_mrstft_totals(LossArgs a) {
+    const int tid = threadIdx.x;
+    if (tid < a.n_res * 4) {
+        const int res = tid >> 2, q = tid & 3;
+        double t = 0.0;
+        for (int row = 0; row < a.rows; ++row) t += (double)a.sums[((int64_t)res * a.rows + row) * 4 + q];
+        a.totals[tid] = t;
+    }
+}
 // stage 2: loss scalar + per-row backward coefficients (without dL/dloss, applied by k_scale_coef)
 __global__ __launch_bounds__(64) void k_mrstft_final(LossArgs a) {
     __shared__ double rs[kMaxRes][4];
@@ -633,7 +648,11 @@ __global__ __launch_bounds__(64) void k_mrstft_final(LossArgs a) {
             sc_acc += sqrt((double)sm[0]) / sqrt((double)sm[1]);
         }
         for (int q = 0; q < 4; ++q) rs[res][q] = tot[q];
-        const double sc = a.sc_per_example ? sc_acc / a.rows : sqrt(tot[0]) / sqrt(tot[1]);
+        if (a.gtotals) {  // batch-global ratio over the rows of every rank
+            rs[res][0] = a.gtotals[res * 4 + 0];
+            rs[res][1] = a.gtotals[res * 4 + 1];
+        }
+        const double sc = a.sc_per_example ? sc_acc / a.rows : sqrt(rs[res][0]) / sqrt(rs[res][1]);
         rs[res][3] = a.w_sc * sc + a.w_log * tot[2] / a.count[res] + a.w_lin * tot[3] / a.count[res];
     }
     __syncthreads();
@@ -647,7 +666,7 @@ __global__ __launch_bounds__(64) void k_mrstft_final(LossArgs a) {
         const float* sm = a.sums + (int64_t)i * 4;
         double c_sc;
         if (a.sc_per_example) c_sc = a.w_sc / ((double)a.rows * sqrt((double)sm[0]) * sqrt((double)sm[1]));
-        else c_sc = a.w_sc / (sqrt(rs[res][0]) * sqrt(rs[res][1]));
+        else c_sc = a.w_sc * (double)a.world / (sqrt(rs[res][0]) * sqrt(rs[res][1]));  // world: see mst_mrstft_forward_finish
         if (!(c_sc == c_sc) || c_sc > 1e30) c_sc = 0.0;  // identical signals: 0/0 -> no SC gradient
         float* c = a.coef + (int64_t)i * 4;
         c[0] = (float)(c_sc / a.n_res);
@@ -790,10 +809,14 @@ extern "C" int mst_mrstft_init_tables(const mst_mrstft_desc* d, void* tables, vo
     return (int)hipGetLastError();
 }
 
-extern "C" int mst_mrstft_forward(const mst_mrstft_desc* d, const float* pred, const float* target, const void* tables,
-                                  float* loss, void* workspace, size_t workspace_bytes, void* stream_) {
+// stages: 1 = transforms + row sums (+ totals when asked for), 2 = loss + backward coefficients
+static int mrstft_forward_stages(const mst_mrstft_desc* d, const float* pred, const float* target, const void* tables, float* loss,
+                                 double* totals, const double* gtotals, int world, int stages, void* workspace,
+                                 size_t workspace_bytes, void* stream_) {
     const Plan p = make_plan(d);
-    if (!p.ok || !pred || !target || !tables || !loss || !workspace) return hipErrorInvalidValue;
+    if (!p.ok || !workspace) return hipErrorInvalidValue;
+    if ((stages & 1) && (!pred || !target || !tables)) return hipErrorInvalidValue;
+    if ((stages & 2) && (!loss || world < 1)) return hipErrorInvalidValue;
     if (workspace_bytes < (size_t)p.ws_floats * sizeof(float)) return hipErrorInvalidValue;
     hipStream_t stream = (hipStream_t)stream_;
     float* ws = (float*)workspace;
@@ -808,7 +831,14 @@ extern "C" int mst_mrstft_forward(const mst_mrstft_desc* d, const float* pred, c
     la.w_log = d->w_log_mag;
     la.w_lin = d->w_lin_mag;
     la.sc_per_example = d->sc_per_example;
+    la.totals = totals;
+    la.gtotals = gtotals;
+    la.world = gtotals ? world : 1;
     for (int i = 0; i < d->n_res; ++i) {
+        la.n_groups[i] = p.n_groups[i];
+        la.part_off[i] = p.part_off[i];
+        la.count[i] = (float)((double)d->rows * p.res[i].n_bins * p.res[i].n_frames);
+        if (!(stages & 1)) continue;
         StftArgs a{};
         a.pred = pred;
         a.target = target;
@@ -826,13 +856,27 @@ extern "C" int mst_mrstft_forward(const mst_mrstft_desc* d, const float* pred, c
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stft_fwd_ip<8192>), grid, dim3(kIpThreads), 0, stream, a);
         else
             MST_FOR_NFFT(a.r.n_fft, MST_LAUNCH_FWD)
-        la.n_groups[i] = p.n_groups[i];
-        la.part_off[i] = p.part_off[i];
-        la.count[i] = (float)((double)d->rows * p.res[i].n_bins * p.res[i].n_frames);
     }
-    hipLaunchKernelGGL(k_mrstft_rowsums, dim3(d->rows, d->n_res), dim3(64), 0, stream, la);
-    hipLaunchKernelGGL(k_mrstft_final, dim3(1), dim3(64), 0, stream, la);
+    if (stages & 1) {
+        hipLaunchKernelGGL(k_mrstft_rowsums, dim3(d->rows, d->n_res), dim3(64), 0, stream, la);
+        if (totals) hipLaunchKernelGGL(k_mrstft_totals, dim3(1), dim3(64), 0, stream, la);
+    }
+    if (stages & 2) hipLaunchKernelGGL(k_mrstft_final, dim3(1), dim3(64), 0, stream, la);
     return (int)hipGetLastError();
+}
+
+extern "C" int mst_mrstft_forward(const mst_mrstft_desc* d, const float* pred, const float* target, const void* tables,
+                                  float* loss, void* workspace, size_t workspace_bytes, void* stream) {
+    return mrstft_forward_stages(d, pred, target, tables, loss, nullptr, nullptr, 1, 3, workspace, workspace_bytes, stream);
+}
+extern "C" int mst_mrstft_forward_partial(const mst_mrstft_desc* d, const float* pred, const float* target, const void* tables,
+                                          double* totals, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!totals) return hipErrorInvalidValue;
+    return mrstft_forward_stages(d, pred, target, tables, nullptr, totals, nullptr, 1, 1, workspace, workspace_bytes, stream);
+}
+extern "C" int mst_mrstft_forward_finish(const mst_mrstft_desc* d, const double* global_totals, int32_t world, float* loss,
+                                         void* workspace, size_t workspace_bytes, void* stream) {
+    return mrstft_forward_stages(d, nullptr, nullptr, nullptr, loss, nullptr, global_totals, world, 2, workspace, workspace_bytes, stream);
 }
 
 extern "C" int mst_mrstft_backward(const mst_mrstft_desc* d, const float* pred, const float* target, const void* tables,

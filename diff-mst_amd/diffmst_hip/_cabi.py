@@ -23,7 +23,7 @@ SAVE_FOR_BACKWARD = 0x100
 DEV_MULTIPASS_EQ = 0x200
 NO_RANGE_CHECK = 0x400
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class ConsoleDesc(C.Structure):
@@ -84,6 +84,8 @@ SIGNATURES = {
     "mst_mrstft_init_tables": (C.c_int, [C.POINTER(MrstftDesc), _P, _P]),
     "mst_mrstft_workspace_bytes": (C.c_size_t, [C.POINTER(MrstftDesc)]),
     "mst_mrstft_forward": (C.c_int, [C.POINTER(MrstftDesc), _P, _P, _P, _P, _P, C.c_size_t, _P]),
+    "mst_mrstft_forward_partial": (C.c_int, [C.POINTER(MrstftDesc), _P, _P, _P, _P, _P, C.c_size_t, _P]),
+    "mst_mrstft_forward_finish": (C.c_int, [C.POINTER(MrstftDesc), _P, C.c_int32, _P, _P, C.c_size_t, _P]),
     "mst_mrstft_backward": (C.c_int, [C.POINTER(MrstftDesc), _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "mst_peak_normalize_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int64]),
     "mst_peak_normalize_forward": (C.c_int, [_P, _P, C.c_int32, C.c_int64, _P, C.c_size_t, _P]),

@@ -67,9 +67,32 @@ class _MrstftFunction(torch.autograd.Function):
             raise ValueError("unsupported STFT configuration for this input length")
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         loss = torch.empty(1, dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
-            _hip.check(lib.mst_mrstft_forward(ctypes.byref(desc), _cabi.ptr(x), _cabi.ptr(y), _cabi.ptr(tables), _cabi.ptr(loss),
-                                              _cabi.ptr(ws), nbytes, _hip.current_stream_ptr(dev)), "mst_mrstft_forward")
+        group = cfg.get("sync_group")
+        if group is not None and not cfg["sc_per_example"]:
+            # batch rows sharded over ranks + batch-global spectral convergence: the two squared norms are summed over the
+            # ranks before the division (include/diffmst_hip.h, mst_mrstft_forward_partial / _finish)
+            import torch.distributed as dist
+
+            totals = torch.empty(len(cfg["resolutions"]) * 4, dtype=torch.float64, device=dev)
+            with torch.cuda.device(dev):
+                _hip.check(lib.mst_mrstft_forward_partial(ctypes.byref(desc), _cabi.ptr(x), _cabi.ptr(y), _cabi.ptr(tables),
+                                                          _cabi.ptr(totals), _cabi.ptr(ws), nbytes, _hip.current_stream_ptr(dev)),
+                           "mst_mrstft_forward_partial")
+            grp = None if group is True else group
+            if dist.get_backend(grp) == "gloo":  # CPU collectives: a 96-byte round trip through the host
+                host = totals.cpu()
+                dist.all_reduce(host, group=grp)
+                totals.copy_(host)
+            else:
+                dist.all_reduce(totals, group=grp)
+            with torch.cuda.device(dev):
+                _hip.check(lib.mst_mrstft_forward_finish(ctypes.byref(desc), _cabi.ptr(totals), dist.get_world_size(grp),
+                                                         _cabi.ptr(loss), _cabi.ptr(ws), nbytes, _hip.current_stream_ptr(dev)),
+                           "mst_mrstft_forward_finish")
+        else:
+            with torch.cuda.device(dev):
+                _hip.check(lib.mst_mrstft_forward(ctypes.byref(desc), _cabi.ptr(x), _cabi.ptr(y), _cabi.ptr(tables), _cabi.ptr(loss),
+                                                  _cabi.ptr(ws), nbytes, _hip.current_stream_ptr(dev)), "mst_mrstft_forward")
         ctx.desc, ctx.nbytes, ctx.shape = desc, nbytes, pred.shape
         ctx.save_for_backward(x, y, tables, ws)
         return loss.reshape(())
@@ -96,6 +119,11 @@ class MultiResolutionSTFTLoss(torch.nn.Module):
     batch-global ratio of older releases (SURVEY A.7 - the pinned package is not available to verify).
     Phase loss, mel / chroma scaling, perceptual weighting and scale invariance are not part of the
     reference's configuration and raise ``NotImplementedError``.
+
+    ``sync_group`` (``True`` = the default process group, or a ``torch.distributed`` group; only matters with
+    ``sc_per_example=False``): the batch is sharded over the ranks of the group and the batch-global ratio is formed from
+    norms summed over all ranks, so that the mean of the rank losses - and rank-averaged gradients - equal the
+    single-process values over the global batch.  Every other term is a mean over examples and needs no exchange.
     """
 
     def __init__(
@@ -115,6 +143,7 @@ class MultiResolutionSTFTLoss(torch.nn.Module):
         scale_invariance: bool = False,
         eps: float = 1e-8,
         sc_per_example: bool = True,
+        sync_group=None,
         **kwargs,
     ):
         super().__init__()
@@ -128,6 +157,7 @@ class MultiResolutionSTFTLoss(torch.nn.Module):
         self.cfg = dict(
             resolutions=tuple(zip(self.fft_sizes, self.hop_sizes, self.win_lengths)),
             w_sc=w_sc, w_log_mag=w_log_mag, w_lin_mag=w_lin_mag, sc_per_example=sc_per_example, eps=eps,
+            sync_group=sync_group,
         )
 
     def forward(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:

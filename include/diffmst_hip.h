@@ -158,6 +158,21 @@ size_t mst_mrstft_workspace_bytes(const mst_mrstft_desc* d);
 /* loss: one fp32 on the device. */
 int mst_mrstft_forward(const mst_mrstft_desc* d, const float* pred, const float* target, const void* tables,
                        float* loss, void* workspace, size_t workspace_bytes, void* stream);
+/* Sharded evaluation (the batch rows are split over ranks, one process per GPU; reference: DDP over the batch axis,
+ * configs/config.yaml:34-42).  Every term of the loss is a mean over rows except the batch-global spectral-convergence
+ * ratio (sc_per_example = 0), whose two squared norms must be summed over ALL ranks before the division:
+ *   mst_mrstft_forward_partial   transforms + reductions of this rank's rows; totals (n_res, 4) float64 on the device =
+ *                                {sum (|Y|-|X|)^2, sum |Y|^2, sum |log|X| - log|Y||, sum ||X| - |Y||} per resolution
+ *   (the caller all-reduces `totals` over the ranks - SUM - into global_totals)
+ *   mst_mrstft_forward_finish    loss of this rank = global ratio + this rank's mean terms, so that the MEAN of the rank
+ *                                losses is the single-process loss over the global batch; the backward coefficients carry
+ *                                `world` on the ratio term (the adjoint of the all-reduce), so that gradients averaged over
+ *                                ranks (DDP) equal the single-process gradients.  global_totals = NULL, world = 1: plain
+ *                                local evaluation, identical to mst_mrstft_forward. */
+int mst_mrstft_forward_partial(const mst_mrstft_desc* d, const float* pred, const float* target, const void* tables,
+                               double* totals, void* workspace, size_t workspace_bytes, void* stream);
+int mst_mrstft_forward_finish(const mst_mrstft_desc* d, const double* global_totals, int32_t world, float* loss,
+                              void* workspace, size_t workspace_bytes, void* stream);
 /* grad_loss: one fp32 on the device (dL/dloss); grad_pred (rows, n_samples) is overwritten. */
 int mst_mrstft_backward(const mst_mrstft_desc* d, const float* pred, const float* target, const void* tables,
                         const float* grad_loss, float* grad_pred, void* workspace, size_t workspace_bytes,
