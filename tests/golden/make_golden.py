@@ -192,6 +192,35 @@ def system_case(rsystem, rmodules, rmixing):
     print(f"system_step: loss {loss.item():.6f}  |g_w_track| {model.w_track.grad.abs().max():.3e}")
 
 
+def run_case(rmodules):
+    """The REAL ``mst.utils.run_diffmst`` (mst/utils.py:32-173): LUFS normalisation (stubbed meter = tests/util.py
+    simple_lufs), one parameter estimate, Hann-faded overlap-add of console forwards over 262144-sample windows.  Five tracks,
+    one of them below -80 LUFS (dropped), a last window of 100000 samples."""
+    import pyloudnorm
+    from util import StubModel, simple_lufs
+
+    import mst.utils as rutils
+
+    pyloudnorm.Meter.integrated_loudness = lambda self, x: simple_lufs(x)
+    T, n = 5, 3 * 131072 + 100000
+    torch.manual_seed(51)
+    tracks = (0.05 * torch.randn(1, T, n) * torch.tensor([1.0, 0.3, 2.0, 1e-6, 0.7]).view(1, T, 1)).half().float()
+    ref = 0.2 * torch.randn(1, 2, 300000)
+    model = StubModel(seed=8)
+    with torch.no_grad():
+        pred_mix, tpd, fpd, mpd = rutils.run_diffmst(tracks.clone(), ref, model, rmodules.AdvancedMixConsole(sample_rate=44100),
+                                                     track_start_idx=1000, ref_start_idx=2000)
+    assert pred_mix.shape == (1, 2, n) and tpd["compressor"]["ratio"].shape == (1, 4)
+    np.savez_compressed(
+        os.path.join(HERE, "run_diffmst.npz"), shape=np.array([T, n]), seed_tracks=51, seed_model=8, ref_len=300000,
+        track_start_idx=1000, ref_start_idx=2000, tracks_sub=tracks.numpy()[..., ::4096], ref_sub=ref.numpy()[..., ::4096],
+        pred_mix_sub=pred_mix.numpy()[..., ::8], pred_mix_l2=np.array(pred_mix.double().pow(2).sum().sqrt().item()),
+        seam=pred_mix.numpy()[..., 262144 - 64:262144 + 64],
+        track_ratio=tpd["compressor"]["ratio"].numpy(), master_thr=mpd["compressor"]["threshold_db"].numpy(),
+    )
+    print(f"run_diffmst: mix rms {pred_mix.pow(2).mean().sqrt():.4e}")
+
+
 def main():
     assert os.path.isdir(REF), "golden generation needs /root/reference (build container only)"
     install_stubs()
@@ -205,7 +234,9 @@ def main():
     ref_console = rmodules.AdvancedMixConsole(sample_rate=44100)
     assert ref_console.param_ranges == oc.param_ranges(44100)
     only = set(sys.argv[1:])  # e.g. `make_golden.py system` regenerates one fixture family (default: all)
-    if only and only <= {"system", "fx"}:
+    if only and only <= {"system", "fx", "run"}:
+        if "run" in only:
+            run_case(rmodules)
         if "system" in only:
             system_case(rsystem, rmodules, rmixing)
         if "fx" in only:
@@ -291,6 +322,7 @@ def main():
     assert torch.equal(x / g.clamp(1e-8), oc.batch_stereo_peak_normalize(x))
     system_case(rsystem, rmodules, rmixing)
     fx_case(ref_console)
+    run_case(rmodules)
     print("golden fixtures written to", HERE)
 
 

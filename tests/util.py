@@ -51,3 +51,13 @@ class StubModel(torch.nn.Module):
         # squashed away from 0/1: the estimated parameters stay strictly inside the console's ranges
         sq = lambda z: 0.02 + 0.96 * torch.sigmoid(z)
         return sq(ft @ self.w_track.t()), sq(fm @ self.w_fx.t()), sq(fm @ self.w_master.t())
+
+
+def simple_lufs(x):
+    """Stand-in loudness meter for the inference-driver tests: ``x`` is the ``(n, channels)`` numpy array the reference hands
+    to ``pyloudnorm.Meter.integrated_loudness`` (mst/utils.py:93-95); un-gated, un-weighted mean-square level with the
+    BS.1770 offset.  pyloudnorm is absent from the image; the fixture generator installs THIS function behind the stubbed
+    ``pyloudnorm.Meter`` of the real ``run_diffmst`` and the GPU test injects it as ``loudness_fn``."""
+    import numpy as np
+
+    return float(-0.691 + 10.0 * np.log10(np.mean(np.asarray(x, dtype=np.float64) ** 2) + 1e-12))
