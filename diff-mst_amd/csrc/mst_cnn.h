@@ -1,0 +1,39 @@
+// mst_cnn.h - shared declarations of the spectrogram encoder kernels (mst_cnn.hip: MFMA convolutions, mst_cnn_net.hip: the
+// Cnn14 launch sequences behind mst_cnn14_forward / _backward).  SURVEY 8f rank 2; reference mst/panns.py:27-209,
+// mst/modules.py:740-806.
+//
+// Image convention: the reference's spectrogram is (bs, 1, bins, frames); the STFT kernel emits (frames, bins) rows (bins
+// contiguous: coalesced stores), so the whole network runs on the TRANSPOSED image - H = frames, W = bins, every 3x3 weight
+// transposed (tap (dh, dw) here = torch's [kw][kh]) and every pool size swapped.  Activations are NHWC, T = bf16 (uint16_t
+// storage) or fp32; accumulation, BatchNorm statistics and all parameter gradients are fp32 (partials folded in fp64).
+#pragma once
+#include "mst_common.h"
+
+namespace mst {
+
+using bf16_t = uint16_t;
+
+struct ConvArgs {
+    const void* in;   // (N, H, W, Cin) T
+    const void* w;    // (Cout, 9, Cin) T, tap = (dh + 1) * 3 + (dw + 1)
+    void* out;        // (N, H, W, Cout) T
+    float* part;      // (pixel tiles, Cout, 2) per-tile sum / sum of squares of the fp32 results, or null
+    int N, H, W, Cin, Cout;
+};
+struct WgradArgs {
+    const void* dy;   // (N, H, W, Cout) T
+    const void* x;    // (N, H, W, Cin) T   (first layer: (N, H, W) fp32 spectrogram)
+    float* part;      // (splits, 9, Cout, Cin) fp32 partial sums  (first layer: (splits, Cout, 16))
+    int N, H, W, Cin, Cout;
+    int splits;
+    int steps_per_split;  // K steps (of kWgradPix pixels) per split
+};
+constexpr int kConvPix = 128;   // pixels per workgroup of the implicit-GEMM convolution
+constexpr int kWgradPix = 32;   // pixels per K step of the weight-gradient GEMM
+
+// all launchers: precision 0 = bf16 operands, 1 = fp32 operands (mst_cnn14_desc::precision)
+void launch_conv3x3(int precision, const ConvArgs& a, hipStream_t s);
+void launch_conv_wgrad(int precision, const WgradArgs& a, hipStream_t s);
+int conv_pixel_tiles(int N, int H, int W);
+
+}  // namespace mst

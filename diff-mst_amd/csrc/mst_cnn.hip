@@ -1,0 +1,365 @@
+// mst_cnn.hip - the 3x3 convolutions of the Cnn14 spectrogram encoder on the MI355X matrix cores.
+//
+// Replaces the twelve nn.Conv2d (3x3, stride 1, padding 1, no bias) of the reference's encoder (mst/panns.py:27-85, 126-209;
+// MIOpen in the reference) in forward, data-gradient and weight-gradient form.  gfx950 only:
+//   bf16 operands  v_mfma_f32_16x16x32_bf16  (8 bf16 of K per lane and operand, fp32 accumulate)      - the production path
+//   fp32 operands  v_mfma_f32_16x16x4_f32    (exact fp32 FMA chain at the vector rate)                - the parity path
+//
+// k_conv_igemm   implicit GEMM  D[co][pixel] = sum_(tap, ci) W[co][tap][ci] X[pixel + tap][ci]:
+//                the WEIGHTS are the MFMA's A operand (rows = output channels) and the activations its B operand (columns =
+//                pixels), so that a lane's four accumulator registers are four CONSECUTIVE channels of one pixel - an 8-byte
+//                (bf16) / 16-byte (fp32) NHWC store, no LDS transpose in the epilogue.  Both operands are K-contiguous in
+//                memory (NHWC activations, (co, tap, ci) weights): every fragment is one 16-byte LDS read.  Workgroup tile
+//                BC channels x 128 pixels x 32 of K; four waves as 2 x 2, each (BC/2) x 64.  The per-channel sum / sum of
+//                squares that BatchNorm needs ride in the epilogue (fp32 accumulators, before any rounding).
+//                The data gradient is the same kernel on (dY, W^T rotated by 180 degrees) - see k_prep_weights.
+// k_conv_wgrad   dW[co][tap][ci] = sum_pixel dY[pixel][co] X[pixel + tap][ci]: K = pixels, which is the STRIDED axis of both
+//                NHWC operands; the tiles are staged pixel-major as they lie in memory and the fragments are gathered column
+//                by column (bf16: eight 2-byte LDS reads per fragment on a 260-byte pitch that spreads the four k-groups
+//                over the banks).  Split-K over pixel ranges, partial sums reduced in a fixed order by k_wgrad_reduce.
+// k_conv1 / k_conv1_wgrad   the first layer (one input channel): 9 taps are no GEMM K - direct VALU forward; its weight
+//                gradient (64 x 9 sums over every pixel) does go through the MFMA with the nine shifted spectrogram values of
+//                a pixel as the "channels" of the B operand.
+#include "mst_cnn.h"
+
+namespace mst {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float((uint32_t)v << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {  // round to nearest even
+    uint32_t u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return f2bf(v); }
+template <typename T> __device__ __forceinline__ float to_f32(T v);
+template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) { return bf2f(v); }
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> { static constexpr int EPC = 8, LDK = 32; };  // elements per 16-byte chunk; LDS row pitch of a 32-K tile
+template <> struct Mma<float> { static constexpr int EPC = 4, LDK = 36; };   // 144-byte rows: the 16 rows x 4 k of a fragment read hit 64 banks once
+
+__device__ __forceinline__ void store4(bf16_t* p, f32x4 v) {
+    uint2 u;
+    u.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+    u.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+    *reinterpret_cast<uint2*>(p) = u;
+}
+__device__ __forceinline__ void store4(float* p, f32x4 v) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+
+int conv_pixel_tiles(int N, int H, int W) { return (int)(((int64_t)N * H * W + kConvPix - 1) / kConvPix); }
+
+// =====================================================================================================================
+template <typename T, int BC>
+__global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
+    constexpr int BK = 32, BP = kConvPix, EPC = Mma<T>::EPC, LDK = Mma<T>::LDK, RC = BK / EPC;
+    constexpr int WCH = BC * RC / 256, XCH = BP * RC / 256, MT = BC / 32, NT = 4;
+    __shared__ __attribute__((aligned(16))) T sW[BC * LDK];
+    __shared__ __attribute__((aligned(16))) T sX[BP * LDK];
+    __shared__ float red[2][BC][2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wy = wave >> 1, wx = wave & 1;
+    const int g = lane >> 4, li = lane & 15;
+    const int H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout;
+    const int64_t P = (int64_t)a.N * H * W, p0 = (int64_t)blockIdx.x * BP;
+    const int co0 = blockIdx.y * BC;
+    const T* __restrict__ in = reinterpret_cast<const T*>(a.in);
+    const T* __restrict__ w = reinterpret_cast<const T*>(a.w);
+
+    int xh[XCH], xw[XCH], xoff[XCH];
+    int64_t xbase[XCH];
+    bool xok[XCH];
+#pragma unroll
+    for (int q = 0; q < XCH; ++q) {
+        const int c = tid + q * 256, row = c / RC, kc = c % RC;
+        const int64_t p = p0 + row;
+        xok[q] = p < P;
+        const int64_t pp = xok[q] ? p : 0;
+        const int r = (int)(pp % ((int64_t)H * W));
+        xh[q] = r / W;
+        xw[q] = r % W;
+        xbase[q] = pp * Cin + kc * EPC;
+        xoff[q] = row * LDK + kc * EPC;
+    }
+    int64_t wbase[WCH];
+    int woff[WCH];
+#pragma unroll
+    for (int q = 0; q < WCH; ++q) {
+        const int c = tid + q * 256, row = c / RC, kc = c % RC;
+        wbase[q] = (int64_t)(co0 + row) * 9 * Cin + kc * EPC;
+        woff[q] = row * LDK + kc * EPC;
+    }
+    uint4 rw[WCH], rx[XCH];
+    auto gload = [&](int tap, int c0) {
+        const int dh = tap / 3 - 1, dw = tap % 3 - 1;
+        const int64_t shift = ((int64_t)dh * W + dw) * Cin + c0;
+#pragma unroll
+        for (int q = 0; q < XCH; ++q) {
+            const bool ok = xok[q] && (unsigned)(xh[q] + dh) < (unsigned)H && (unsigned)(xw[q] + dw) < (unsigned)W;
+            rx[q] = ok ? *reinterpret_cast<const uint4*>(in + xbase[q] + shift) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < WCH; ++q) rw[q] = *reinterpret_cast<const uint4*>(w + wbase[q] + (int64_t)tap * Cin + c0);
+    };
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int ksteps = Cin / BK, steps = 9 * ksteps;
+    gload(0, 0);
+    int tap = 0, kq = 0;
+    for (int s = 0; s < steps; ++s) {
+#pragma unroll
+        for (int q = 0; q < XCH; ++q) *reinterpret_cast<uint4*>(&sX[xoff[q]]) = rx[q];
+#pragma unroll
+        for (int q = 0; q < WCH; ++q) *reinterpret_cast<uint4*>(&sW[woff[q]]) = rw[q];
+        __syncthreads();
+        if (++kq == ksteps) { kq = 0; ++tap; }
+        if (s + 1 < steps) gload(tap, kq * BK);  // next tile's global loads fly while this one is multiplied
+        if constexpr (sizeof(T) == 2) {
+            bf16x8 af[MT], bfr[NT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) af[m] = *reinterpret_cast<const bf16x8*>(&sW[(wy * (BC / 2) + m * 16 + li) * LDK + g * 8]);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) bfr[n] = *reinterpret_cast<const bf16x8*>(&sX[(wx * 64 + n * 16 + li) * LDK + g * 8]);
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bfr[n], acc[m][n], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < BK / 4; ++kk) {
+                float af[MT], bfr[NT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) af[m] = sW[(wy * (BC / 2) + m * 16 + li) * LDK + kk * 4 + g];
+#pragma unroll
+                for (int n = 0; n < NT; ++n) bfr[n] = sX[(wx * 64 + n * 16 + li) * LDK + kk * 4 + g];
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m], bfr[n], acc[m][n], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    // ---- epilogue: D row = channel (lane >> 4) * 4 + r, D column = pixel lane & 15
+    T* __restrict__ out = reinterpret_cast<T*>(a.out);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int64_t p = p0 + wx * 64 + n * 16 + li;
+        if (p < P) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) store4(out + p * Cout + co0 + wy * (BC / 2) + m * 16 + g * 4, acc[m][n]);
+        }
+    }
+    if (a.part) {  // rows of pixels beyond P multiplied zeros: they add nothing
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    s1 += acc[m][n][r];
+                    s2 = fmaf(acc[m][n][r], acc[m][n][r], s2);
+                }
+#pragma unroll
+                for (int msk = 1; msk < 16; msk <<= 1) {
+                    s1 += __shfl_xor(s1, msk);
+                    s2 += __shfl_xor(s2, msk);
+                }
+                if (li == 0) {
+                    red[wx][wy * (BC / 2) + m * 16 + g * 4 + r][0] = s1;
+                    red[wx][wy * (BC / 2) + m * 16 + g * 4 + r][1] = s2;
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < BC) {
+            float* o = a.part + ((int64_t)blockIdx.x * Cout + co0 + tid) * 2;
+            o[0] = red[0][tid][0] + red[1][tid][0];
+            o[1] = red[0][tid][1] + red[1][tid][1];
+        }
+    }
+}
+
+void launch_conv3x3(int precision, const ConvArgs& a, hipStream_t s) {
+    const int tiles = conv_pixel_tiles(a.N, a.H, a.W);
+    if (a.Cout % 128 == 0) {
+        const dim3 grid(tiles, a.Cout / 128);
+        if (precision == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_igemm<bf16_t, 128>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_igemm<float, 128>), grid, dim3(256), 0, s, a);
+    } else {
+        const dim3 grid(tiles, a.Cout / 64);
+        if (precision == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_igemm<bf16_t, 64>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_igemm<float, 64>), grid, dim3(256), 0, s, a);
+    }
+}
+
+// =====================================================================================================================
+// Weight gradient.  grid (channel tiles, 9 taps, splits); FIRST: the input is the fp32 spectrogram, "channel" j < 9 of the B
+// operand is its value at tap j (BCI = 16, grid.y = 1).
+template <typename T> struct WgPitch;
+template <> struct WgPitch<bf16_t> { static constexpr int PAD = 2; };   // (C + 2) * 2 bytes = 4 (mod 16): k-groups 8 rows apart land 32 bytes apart
+template <> struct WgPitch<float> { static constexpr int PAD = 16; };   // C * 4 + 64 bytes: consecutive rows fill the two halves of the 32 banks
+
+template <typename T, int BCO, int BCI, bool FIRST>
+__global__ __launch_bounds__(256) void k_conv_wgrad(WgradArgs a) {
+    constexpr int BKP = kWgradPix, EPC = Mma<T>::EPC, PY = BCO + WgPitch<T>::PAD, PX = BCI + WgPitch<T>::PAD;
+    constexpr int YCH = BKP * (BCO / EPC), XCH = FIRST ? 0 : BKP * (BCI / EPC);  // 16-byte chunks per tile
+    constexpr int YQ = (YCH + 255) / 256, XQ = FIRST ? 1 : (XCH + 255) / 256;
+    // waves: 2 x 2 over (co, ci); FIRST: 4 x 1 (every wave all 16 taps)
+    constexpr int WCO = FIRST ? BCO / 4 : BCO / 2, WCI = FIRST ? BCI : BCI / 2, MT = WCO / 16, NT = WCI / 16;
+    __shared__ __attribute__((aligned(16))) T sY[BKP * PY];
+    __shared__ __attribute__((aligned(16))) T sX[BKP * PX];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wy = FIRST ? wave : wave >> 1, wx = FIRST ? 0 : wave & 1;
+    const int g = lane >> 4, li = lane & 15;
+    const int H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout, HW = H * W;
+    const int64_t P = (int64_t)a.N * HW;
+    const int ci_tiles = FIRST ? 1 : Cin / BCI;
+    const int co0 = (blockIdx.x / ci_tiles) * BCO, ci0 = (blockIdx.x % ci_tiles) * BCI;
+    const int tap = blockIdx.y, dh = tap / 3 - 1, dw = tap % 3 - 1;
+    const T* __restrict__ dy = reinterpret_cast<const T*>(a.dy);
+    const int64_t pstart = (int64_t)blockIdx.z * a.steps_per_split * BKP;
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    uint4 ry[YQ], rx[XQ];
+    float rs = 0.f;  // FIRST: one gathered spectrogram value per thread and pass
+    float rs2 = 0.f;
+    auto gload = [&](int64_t pb) {
+#pragma unroll
+        for (int q = 0; q < YQ; ++q) {
+            const int c = tid + q * 256, row = c / (BCO / EPC), col = c % (BCO / EPC);
+            const int64_t p = pb + row;
+            ry[q] = (c < YCH && p < P) ? *reinterpret_cast<const uint4*>(dy + p * Cout + co0 + col * EPC) : make_uint4(0, 0, 0, 0);
+        }
+        if constexpr (FIRST) {
+            const float* __restrict__ sp = reinterpret_cast<const float*>(a.x);
+            // thread -> (pixel row tid % 32, tap tid / 32) and a second pass for tap 8 (threads < 32)
+            auto tapval = [&](int row, int t) -> float {
+                const int64_t p = pb + row;
+                if (p >= P) return 0.f;
+                const int r = (int)(p % HW), h = r / W, ww = r % W, th = t / 3 - 1, tw = t % 3 - 1;
+                if ((unsigned)(h + th) >= (unsigned)H || (unsigned)(ww + tw) >= (unsigned)W) return 0.f;
+                return sp[p + (int64_t)th * W + tw];
+            };
+            rs = tapval(tid & 31, tid >> 5);
+            rs2 = tid < 32 ? tapval(tid, 8) : 0.f;
+        } else {
+            const T* __restrict__ x = reinterpret_cast<const T*>(a.x);
+#pragma unroll
+            for (int q = 0; q < XQ; ++q) {
+                const int c = tid + q * 256, row = c / (BCI / EPC), col = c % (BCI / EPC);
+                const int64_t p = pb + row;
+                bool ok = c < XCH && p < P;
+                if (ok) {
+                    const int r = (int)(p % HW), h = r / W, ww = r % W;
+                    ok = (unsigned)(h + dh) < (unsigned)H && (unsigned)(ww + dw) < (unsigned)W;
+                }
+                rx[q] = ok ? *reinterpret_cast<const uint4*>(x + (p + (int64_t)dh * W + dw) * Cin + ci0 + col * EPC) : make_uint4(0, 0, 0, 0);
+            }
+        }
+    };
+    auto put16 = [&](T* dst, uint4 v) {  // the pitches are multiples of 4 bytes, not of 16
+        uint32_t* d = reinterpret_cast<uint32_t*>(dst);
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    };
+    gload(pstart);
+    for (int s = 0; s < a.steps_per_split; ++s) {
+#pragma unroll
+        for (int q = 0; q < YQ; ++q) {
+            const int c = tid + q * 256, row = c / (BCO / EPC), col = c % (BCO / EPC);
+            if (c < YCH) put16(&sY[row * PY + col * EPC], ry[q]);
+        }
+        if constexpr (FIRST) {
+            sX[(tid & 31) * PX + (tid >> 5)] = from_f32<T>(rs);
+            if (tid < 32) sX[tid * PX + 8] = from_f32<T>(rs2);
+            if (tid >= 32 && tid < 32 + 32 * 7) sX[((tid - 32) & 31) * PX + 9 + ((tid - 32) >> 5)] = from_f32<T>(0.f);
+        } else {
+#pragma unroll
+            for (int q = 0; q < XQ; ++q) {
+                const int c = tid + q * 256, row = c / (BCI / EPC), col = c % (BCI / EPC);
+                if (c < XCH) put16(&sX[row * PX + col * EPC], rx[q]);
+            }
+        }
+        __syncthreads();
+        if (s + 1 < a.steps_per_split) gload(pstart + (int64_t)(s + 1) * BKP);
+        if constexpr (sizeof(T) == 2) {
+            bf16x8 af[MT], bfr[NT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const bf16_t* c = reinterpret_cast<const bf16_t*>(sY) + (8 * g) * PY + wy * WCO + m * 16 + li;
+                union { bf16x8 v; bf16_t e[8]; } u;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) u.e[j] = c[j * PY];
+                af[m] = u.v;
+            }
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const bf16_t* c = reinterpret_cast<const bf16_t*>(sX) + (8 * g) * PX + wx * WCI + n * 16 + li;
+                union { bf16x8 v; bf16_t e[8]; } u;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) u.e[j] = c[j * PX];
+                bfr[n] = u.v;
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bfr[n], acc[m][n], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < BKP / 4; ++kk) {
+                float af[MT], bfr[NT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) af[m] = sY[(kk * 4 + g) * PY + wy * WCO + m * 16 + li];
+#pragma unroll
+                for (int n = 0; n < NT; ++n) bfr[n] = sX[(kk * 4 + g) * PX + wx * WCI + n * 16 + li];
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m], bfr[n], acc[m][n], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    // D row = co (lane >> 4) * 4 + r, D column = ci (or tap) lane & 15
+    const int ncol = FIRST ? 16 : Cin;
+    float* __restrict__ o = a.part + ((int64_t)blockIdx.z * (FIRST ? 1 : 9) + (FIRST ? 0 : tap)) * Cout * ncol;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                o[(int64_t)(co0 + wy * WCO + m * 16 + g * 4 + r) * ncol + ci0 + wx * WCI + n * 16 + li] = acc[m][n][r];
+}
+
+void launch_conv_wgrad(int precision, const WgradArgs& a, hipStream_t s) {
+    if (a.Cin == 1) {
+        const dim3 grid(a.Cout / 64, 1, a.splits);
+        if (precision == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_wgrad<bf16_t, 64, 16, true>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_wgrad<float, 64, 16, true>), grid, dim3(256), 0, s, a);
+    } else if (a.Cin % 128 == 0 && a.Cout % 128 == 0) {
+        const dim3 grid((a.Cout / 128) * (a.Cin / 128), 9, a.splits);
+        if (precision == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_wgrad<bf16_t, 128, 128, false>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_wgrad<float, 128, 128, false>), grid, dim3(256), 0, s, a);
+    } else {
+        const dim3 grid((a.Cout / 64) * (a.Cin / 64), 9, a.splits);
+        if (precision == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_wgrad<bf16_t, 64, 64, false>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_wgrad<float, 64, 64, false>), grid, dim3(256), 0, s, a);
+    }
+}
+
+}  // namespace mst

@@ -23,7 +23,7 @@ import sys
 
 __version__ = "0.2.0"
 
-from . import _cabi, _desc, _hip, filter, loss, mixing, modules, utils  # noqa: E402,F401
+from . import _cabi, _desc, _hip, filter, loss, mixing, modules, panns, utils  # noqa: E402,F401
 from . import system  # noqa: E402,F401
 
 # (module of the reference, attribute, replacement)

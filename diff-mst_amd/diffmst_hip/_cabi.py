@@ -70,6 +70,24 @@ class MrstftDesc(C.Structure):
     ]
 
 
+class Cnn14Desc(C.Structure):  # mirrors mst_cnn14_desc
+    _fields_ = [("n", C.c_int32), ("frames", C.c_int32), ("bins", C.c_int32), ("embed_dim", C.c_int32), ("precision", C.c_int32),
+                ("training", C.c_int32), ("bn_eps", C.c_float)]
+
+
+CNN14_CONVS = 12
+
+
+class Cnn14Params(C.Structure):  # mirrors mst_cnn14_params
+    _fields_ = [("conv_w", C.c_void_p * CNN14_CONVS), ("bn_gamma", C.c_void_p * CNN14_CONVS), ("bn_beta", C.c_void_p * CNN14_CONVS),
+                ("bn_mean", C.c_void_p * CNN14_CONVS), ("bn_var", C.c_void_p * CNN14_CONVS), ("fc_w", C.c_void_p), ("fc_b", C.c_void_p)]
+
+
+class Cnn14Grads(C.Structure):  # mirrors mst_cnn14_grads
+    _fields_ = [("conv_w", C.c_void_p * CNN14_CONVS), ("bn_gamma", C.c_void_p * CNN14_CONVS), ("bn_beta", C.c_void_p * CNN14_CONVS),
+                ("fc_w", C.c_void_p), ("fc_b", C.c_void_p)]
+
+
 _P = C.c_void_p
 
 SIGNATURES = {
@@ -94,6 +112,12 @@ SIGNATURES = {
     "mst_afloss_init_tables": (C.c_int, [_P, _P]),
     "mst_afloss_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int64]),
     "mst_afloss_forward": (C.c_int, [_P, _P, C.c_int32, C.c_int64, C.POINTER(C.c_float), _P, _P, _P, _P, C.c_size_t, _P]),
+    "mst_spectrogram_tables_bytes": (C.c_size_t, []),
+    "mst_spectrogram_init_tables": (C.c_int, [_P, _P]),
+    "mst_spectrogram_forward": (C.c_int, [_P, C.c_int32, C.c_int64, C.c_int32, C.c_int32, _P, _P, _P]),
+    "mst_cnn14_workspace_bytes": (C.c_size_t, [C.POINTER(Cnn14Desc)]),
+    "mst_cnn14_forward": (C.c_int, [C.POINTER(Cnn14Desc), _P, C.POINTER(Cnn14Params), _P, _P, _P, C.c_size_t, _P]),
+    "mst_cnn14_backward": (C.c_int, [C.POINTER(Cnn14Desc), _P, C.POINTER(Cnn14Params), _P, C.POINTER(Cnn14Grads), _P, C.c_size_t, _P]),
     "mst_afloss_backward": (C.c_int, [_P, _P, C.c_int32, C.c_int64, C.POINTER(C.c_float), _P, _P, _P, _P, _P, C.c_size_t, _P]),
 }
 

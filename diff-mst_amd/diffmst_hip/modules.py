@@ -474,3 +474,120 @@ class BasicMixConsole(AdvancedMixConsole):
             use_track_compressor=False, use_track_panner=True, use_master_bus=False, use_fx_bus=False,
             use_output_fader=False,
         )
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# The parameter-estimation model (reference mst/modules.py:17-68, :740-914)
+# ----------------------------------------------------------------------------------------------------------------------
+class SpectrogramEncoder(torch.nn.Module):
+    """Drop-in for reference ``SpectrogramEncoder`` (mst/modules.py:740-806): waveform ``(bs, chs, seq_len)`` ->
+    ``torch.stft(n_fft, hop_length, Hann)`` -> ``(|X| + 1e-8)^0.3`` -> ``Cnn14`` -> ``(bs, embed_dim)``.
+
+    The STFT runs on the register-radix FFT engine of the loss kernels (``mst_spectrogram_forward``), the CNN on the matrix
+    cores (``diffmst_hip.panns.Cnn14``); same constructor keywords, same ``window`` buffer and ``model.*`` parameter names as
+    the reference, so its checkpoints load.  ``precision`` ("bf16" | "fp32") is an extra keyword (see ``Cnn14``)."""
+
+    _TABLES = {}
+
+    def __init__(self, embed_dim: int = 128, n_inputs: int = 1, n_fft: int = 2048, hop_length: int = 512,
+                 input_batchnorm: bool = False, encoder_batchnorm: bool = True, precision: str = "bf16") -> None:
+        super().__init__()
+        from .panns import Cnn14
+
+        if n_fft != 2048:
+            raise NotImplementedError("the STFT front end is built for n_fft = 2048 (every config of the reference)")
+        if input_batchnorm:
+            raise NotImplementedError("input_batchnorm=True builds BatchNorm2d(3) on a 1-channel image in the reference (mst/modules.py:768) "
+                                      "and cannot run there either; its configs keep it off")
+        self.embed_dim, self.n_inputs, self.n_fft, self.hop_length = embed_dim, n_inputs, n_fft, hop_length
+        self.input_batchnorm = input_batchnorm
+        self.register_buffer("window", torch.hann_window(window_length=int(n_fft)))
+        self.model = Cnn14(n_inputs=n_inputs, num_classes=embed_dim, use_batchnorm=encoder_batchnorm, precision=precision)
+        self.bn = torch.nn.Identity()
+
+    def spectrogram(self, x: torch.Tensor) -> torch.Tensor:
+        """(rows, seq_len) on the device -> (rows, frames, bins) fp32 compressed magnitudes (frames-major, see mst_cnn.h)."""
+        _hip.require_cuda(x)
+        lib = _hip.lib()
+        dev = x.device
+        key = str(dev)
+        tables = self._TABLES.get(key)
+        if tables is None:
+            tables = torch.empty(lib.mst_spectrogram_tables_bytes() // 4, dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                _hip.check(lib.mst_spectrogram_init_tables(_cabi.ptr(tables), _hip.current_stream_ptr(dev)), "mst_spectrogram_init_tables")
+            self._TABLES[key] = tables
+        x = x.detach().float().contiguous()
+        rows, n = x.shape
+        spec = torch.empty(rows, 1 + n // self.hop_length, self.n_fft // 2 + 1, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _hip.check(lib.mst_spectrogram_forward(_cabi.ptr(x), rows, n, self.n_fft, self.hop_length, _cabi.ptr(tables), _cabi.ptr(spec),
+                                                   _hip.current_stream_ptr(dev)), "mst_spectrogram_forward")
+        return spec
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        bs, chs, seq_len = x.size()
+        if chs != 1:
+            raise NotImplementedError("n_inputs = 1: the reference feeds (bs * chs, 1, seq_len) (mst/modules.py:40, :57)")
+        return self.model.forward_frames_major(self.spectrogram(x.reshape(bs * chs, seq_len)))
+
+
+class TransformerController(torch.nn.Module):
+    """Reference ``TransformerController`` (mst/modules.py:809-914): learned type embeddings added to the track / mix
+    embeddings, one fx-bus and one master-bus token appended, ``torch.nn.TransformerEncoder`` (dropout 0, batch_first),
+    three sigmoid-bounded projections.  Host-library work (rocBLAS GEMMs + SDPA through torch) - 30 tokens of width 512 are
+    not a kernel-design problem; same parameter names as the reference."""
+
+    def __init__(self, embed_dim: int, num_track_control_params: int, num_fx_bus_control_params: int,
+                 num_master_bus_control_params: int, num_layers: int = 6, nhead: int = 8, use_fx_bus: bool = False,
+                 use_master_bus: bool = False) -> None:
+        super().__init__()
+        self.embed_dim = embed_dim
+        self.num_track_control_params = num_track_control_params
+        self.num_fx_bus_control_params = num_fx_bus_control_params
+        self.num_master_bus_control_params = num_master_bus_control_params
+        self.num_layers, self.nhead = num_layers, nhead
+        self.use_fx_bus, self.use_master_bus = use_fx_bus, use_master_bus
+        self.track_embedding = torch.nn.Parameter(torch.randn(1, 1, embed_dim))
+        self.mix_embedding = torch.nn.Parameter(torch.randn(1, 2, embed_dim))
+        self.fx_bus_embedding = torch.nn.Parameter(torch.randn(1, 1, embed_dim))
+        self.master_bus_embedding = torch.nn.Parameter(torch.randn(1, 1, embed_dim))
+        layer = torch.nn.TransformerEncoderLayer(d_model=embed_dim, nhead=nhead, batch_first=True, dropout=0.0)
+        self.transformer_encoder = torch.nn.TransformerEncoder(layer, num_layers=num_layers)
+        self.track_projection = torch.nn.Linear(embed_dim, num_track_control_params)
+        self.fx_bus_projection = torch.nn.Linear(embed_dim, num_fx_bus_control_params)
+        self.master_bus_projection = torch.nn.Linear(embed_dim, num_master_bus_control_params)
+
+    def forward(self, track_embeds: torch.Tensor, mix_embeds: torch.Tensor, track_padding_mask=None):
+        bs, num_tracks, _ = track_embeds.size()
+        tokens = torch.cat((track_embeds + self.track_embedding, mix_embeds + self.mix_embedding,
+                            self.fx_bus_embedding.expand(bs, -1, -1), self.master_bus_embedding.expand(bs, -1, -1)), dim=1)
+        if track_padding_mask is not None:  # the four appended tokens are always attended to
+            track_padding_mask = torch.cat((track_padding_mask, torch.zeros((bs, 4), dtype=torch.bool).type_as(track_padding_mask)), dim=1)
+        z = self.transformer_encoder(tokens, src_key_padding_mask=track_padding_mask)
+        return (torch.sigmoid(self.track_projection(z[:, :num_tracks, :])), torch.sigmoid(self.fx_bus_projection(z[:, -2, :])),
+                torch.sigmoid(self.master_bus_projection(z[:, -1, :])))
+
+
+class MixStyleTransferModel(torch.nn.Module):
+    """Reference ``MixStyleTransferModel`` (mst/modules.py:17-68): encode every track and both channels of the reference mix
+    (or its mid / side with ``sum_and_diff``), hand the embeddings to the controller."""
+
+    def __init__(self, track_encoder: torch.nn.Module, mix_encoder: torch.nn.Module, controller: torch.nn.Module,
+                 sum_and_diff: bool = False) -> None:
+        super().__init__()
+        self.track_encoder, self.mix_encoder, self.controller = track_encoder, mix_encoder, controller
+        self.sum_and_diff = sum_and_diff
+
+    def forward(self, tracks: torch.Tensor, ref_mix: torch.Tensor, track_padding_mask=None):
+        bs, num_tracks, seq_len = tracks.size()
+        track_embeds = self.track_encoder(tracks.view(bs * num_tracks, 1, -1)).view(bs, num_tracks, -1)
+        if self.sum_and_diff:
+            # reference :44-52 hands (bs, seq_len) / (bs, 1, seq_len) tensors of different rank to the encoder; the intent -
+            # one embedding of the mid and one of the side signal - is what is built here
+            mid = ref_mix.sum(dim=1, keepdim=True)
+            side = ref_mix[..., 0:1, :] - ref_mix[..., 1:2, :]
+            mix_embeds = torch.stack((self.mix_encoder(mid), self.mix_encoder(side)), dim=1)
+        else:
+            mix_embeds = self.mix_encoder(ref_mix.reshape(bs * 2, 1, -1)).view(bs, 2, -1)
+        return self.controller(track_embeds, mix_embeds, track_padding_mask)

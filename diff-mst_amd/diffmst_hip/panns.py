@@ -1,0 +1,178 @@
+"""``diffmst_hip.panns`` (alias ``mst.panns``) - the Cnn14 spectrogram encoder on the MI355X matrix cores.
+
+Same module tree and parameter names as the reference (mst/panns.py:27-85 ``ConvBlock``, :126-209 ``Cnn14``):
+``conv_block{1..6}.{conv1,conv2}.weight``, ``.bn{1,2}.{weight,bias,running_mean,running_var,num_batches_tracked}``,
+``fc.{weight,bias}`` - a reference checkpoint loads with ``load_state_dict`` unchanged.  The modules only HOLD the parameters:
+the twelve 3x3 convolutions (implicit GEMM on MFMA), BatchNorm, ReLU, average pooling, the pooling head and the final Linear
+all run in ``csrc/mst_cnn*.hip`` through ``mst_cnn14_forward`` / ``mst_cnn14_backward`` (include/diffmst_hip.h), forward and
+reverse mode; autograd sees ONE function.
+
+``precision``: ``"bf16"`` (default) - bf16 operands and activations, fp32 accumulation / statistics / gradients;
+``"fp32"`` - fp32 operands on the fp32 MFMA (the parity setting).
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+import torch.nn as nn
+from torch.autograd.function import once_differentiable
+
+from . import _cabi, _hip
+
+_CHANNELS = (64, 128, 256, 512, 1024, 2048)
+# pool sizes over (bins, frames) as the reference passes them (mst/panns.py:186-197)
+POOL_SIZES = ((2, 2), (4, 4), (4, 2), (4, 2), (4, 2), (2, 2))
+
+
+def init_layer(layer):
+    nn.init.xavier_uniform_(layer.weight)
+    if getattr(layer, "bias", None) is not None:
+        layer.bias.data.fill_(0.0)
+
+
+def init_bn(bn):
+    bn.bias.data.fill_(0.0)
+    bn.weight.data.fill_(1.0)
+
+
+class ConvBlock(nn.Module):
+    """Parameter holder of one block (reference mst/panns.py:27-85); evaluated inside the fused Cnn14 call."""
+
+    def __init__(self, in_channels: int, out_channels: int, use_batchnorm: bool = True, pool_type: str = "avg"):
+        super().__init__()
+        if not use_batchnorm or pool_type != "avg":
+            raise NotImplementedError("the MI355X encoder builds the reference's configuration: BatchNorm on, average pooling")
+        self.use_batchnorm = use_batchnorm
+        self.conv1 = nn.Conv2d(in_channels, out_channels, (3, 3), (1, 1), (1, 1), bias=False)
+        self.conv2 = nn.Conv2d(out_channels, out_channels, (3, 3), (1, 1), (1, 1), bias=False)
+        self.bn1 = nn.BatchNorm2d(out_channels)
+        self.bn2 = nn.BatchNorm2d(out_channels)
+        for conv in (self.conv1, self.conv2):
+            init_layer(conv)
+        for bn in (self.bn1, self.bn2):
+            init_bn(bn)
+
+    def forward(self, *_a, **_k):
+        raise RuntimeError("ConvBlock is evaluated by Cnn14's fused kernels; call the Cnn14 module")
+
+
+class _Cnn14Function(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, spec, module, training, *params):
+        """spec (n, frames, bins) fp32; params = 12 conv weights, 12 BN weights, 12 BN biases, fc weight, fc bias."""
+        _hip.require_cuda(spec)
+        lib = _hip.lib()
+        dev = spec.device
+        n, frames, bins = spec.shape
+        desc = _cabi.Cnn14Desc(n, frames, bins, module.fc.out_features, 0 if module.precision == "bf16" else 1, int(training),
+                               float(module.conv_block1.bn1.eps))
+        nbytes = lib.mst_cnn14_workspace_bytes(ctypes.byref(desc))
+        if nbytes == 0:
+            raise ValueError(f"Cnn14: unsupported spectrogram size {(frames, bins)} (six pooling stages need >= 128 frames x 1024 bins)")
+        convs, gammas, betas = params[0:12], params[12:24], params[24:36]
+        fc_w, fc_b = params[36], params[37]
+        bns = module._bns()
+        keep = [t.detach().float().contiguous() for t in (*convs, *gammas, *betas, fc_w, fc_b)]
+        rmean = [bn.running_mean.detach().float().contiguous() for bn in bns]
+        rvar = [bn.running_var.detach().float().contiguous() for bn in bns]
+        prm = _cabi.Cnn14Params()
+        for i in range(12):
+            prm.conv_w[i] = keep[i].data_ptr()
+            prm.bn_gamma[i] = keep[12 + i].data_ptr()
+            prm.bn_beta[i] = keep[24 + i].data_ptr()
+            prm.bn_mean[i] = rmean[i].data_ptr()
+            prm.bn_var[i] = rvar[i].data_ptr()
+        prm.fc_w, prm.fc_b = keep[36].data_ptr(), keep[37].data_ptr()
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        embed = torch.empty(n, module.fc.out_features, dtype=torch.float32, device=dev)
+        stats = torch.empty(12, 2, 2048, dtype=torch.float32, device=dev) if training else None
+        spec = spec.float().contiguous()
+        with torch.cuda.device(dev):
+            _hip.check(lib.mst_cnn14_forward(ctypes.byref(desc), _cabi.ptr(spec), ctypes.byref(prm), _cabi.ptr(embed), _cabi.ptr(stats),
+                                             _cabi.ptr(ws), nbytes, _hip.current_stream_ptr(dev)), "mst_cnn14_forward")
+        ctx.desc, ctx.nbytes, ctx.dev = desc, nbytes, dev
+        # the backward reads mean / invstd from the workspace; the running statistics (updated in place by the module right
+        # after a training-mode call) are only handed over again, never read in training mode
+        ctx.running = (rmean, rvar)
+        ctx.save_for_backward(spec, ws, *keep)
+        ctx.mark_non_differentiable(*([stats] if stats is not None else []))
+        return (embed, stats) if training else (embed, None)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_embed, _g_stats):
+        spec, ws, *rest = ctx.saved_tensors
+        keep = rest[:38]
+        rmean, rvar = ctx.running
+        lib = _hip.lib()
+        dev = ctx.dev
+        prm, gr = _cabi.Cnn14Params(), _cabi.Cnn14Grads()
+        grads = [torch.empty_like(t) for t in keep]
+        for i in range(12):
+            prm.conv_w[i], prm.bn_gamma[i], prm.bn_beta[i] = keep[i].data_ptr(), keep[12 + i].data_ptr(), keep[24 + i].data_ptr()
+            prm.bn_mean[i], prm.bn_var[i] = rmean[i].data_ptr(), rvar[i].data_ptr()
+            gr.conv_w[i], gr.bn_gamma[i], gr.bn_beta[i] = grads[i].data_ptr(), grads[12 + i].data_ptr(), grads[24 + i].data_ptr()
+        prm.fc_w, prm.fc_b = keep[36].data_ptr(), keep[37].data_ptr()
+        gr.fc_w, gr.fc_b = grads[36].data_ptr(), grads[37].data_ptr()
+        g = g_embed.float().contiguous()
+        with torch.cuda.device(dev):
+            _hip.check(lib.mst_cnn14_backward(ctypes.byref(ctx.desc), _cabi.ptr(spec), ctypes.byref(prm), _cabi.ptr(g), ctypes.byref(gr),
+                                              _cabi.ptr(ws), ctx.nbytes, _hip.current_stream_ptr(dev)), "mst_cnn14_backward")
+        return (None, None, None, *grads)
+
+
+class Cnn14(nn.Module):
+    """Drop-in for reference ``mst.panns.Cnn14`` (:126-209): ``(bs, 1, bins, frames)`` spectrogram -> ``(bs, num_classes)``."""
+
+    def __init__(self, num_classes: int, n_inputs: int = 1, use_batchnorm: bool = True, precision: str = "bf16"):
+        super().__init__()
+        if n_inputs != 1:
+            raise NotImplementedError("n_inputs = 1 (the reference's SpectrogramEncoder default) is what the first-layer kernel is built for")
+        if precision not in ("bf16", "fp32"):
+            raise ValueError("precision must be 'bf16' or 'fp32'")
+        self.precision = precision
+        c_in = n_inputs
+        for i, c_out in enumerate(_CHANNELS, start=1):
+            setattr(self, f"conv_block{i}", ConvBlock(c_in, c_out, use_batchnorm=use_batchnorm))
+            c_in = c_out
+        self.fc = nn.Linear(2048, num_classes, bias=True)
+        init_layer(self.fc)
+
+    def _blocks(self):
+        return [getattr(self, f"conv_block{i}") for i in range(1, 7)]
+
+    def _bns(self):
+        return [bn for b in self._blocks() for bn in (b.bn1, b.bn2)]
+
+    def _parameters_in_abi_order(self):
+        blocks = self._blocks()
+        convs = [c.weight for b in blocks for c in (b.conv1, b.conv2)]
+        bns = self._bns()
+        return (*convs, *(bn.weight for bn in bns), *(bn.bias for bn in bns), self.fc.weight, self.fc.bias)
+
+    def forward_frames_major(self, spec: torch.Tensor) -> torch.Tensor:
+        """spec (n, frames, bins): the layout the STFT kernel emits and the kernels consume."""
+        training = self.training
+        embed, stats = _Cnn14Function.apply(spec, self, training, *self._parameters_in_abi_order())
+        if training:  # nn.BatchNorm2d bookkeeping (momentum 0.1, unbiased running variance), on the batch statistics of this call
+            n, frames, bins = spec.shape
+            h, w = frames, bins
+            with torch.no_grad():
+                for i, block in enumerate(self._blocks()):
+                    count = n * h * w
+                    for k, bn in enumerate((block.bn1, block.bn2)):
+                        c = bn.num_features
+                        mean, var = stats[2 * i + k, 0, :c], stats[2 * i + k, 1, :c]
+                        m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked + 1)
+                        bn.running_mean.lerp_(mean, m)
+                        bn.running_var.lerp_(var * (count / max(count - 1, 1)), m)
+                        bn.num_batches_tracked += 1
+                    h, w = h // POOL_SIZES[i][1], w // POOL_SIZES[i][0]
+        return embed
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        bs, chs, bins, frames = x.size()
+        if chs != 1:
+            raise NotImplementedError("n_inputs = 1")
+        return self.forward_frames_major(x.reshape(bs, bins, frames).transpose(1, 2).contiguous())

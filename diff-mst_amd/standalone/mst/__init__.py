@@ -17,10 +17,10 @@ try:
 except ImportError:  # this directory alone was put on sys.path: the implementation package sits two levels up
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
     import diffmst_hip
-from diffmst_hip import _cabi, _desc, _hip, filter, loss, mixing, modules, system, utils  # noqa: F401
+from diffmst_hip import _cabi, _desc, _hip, filter, loss, mixing, modules, panns, system, utils  # noqa: F401
 
 __diffmst_alias__ = True
 __version__ = diffmst_hip.__version__
-for _name in ("_cabi", "_desc", "_hip", "filter", "loss", "mixing", "modules", "system", "utils"):
+for _name in ("_cabi", "_desc", "_hip", "filter", "loss", "mixing", "modules", "panns", "system", "utils"):
     sys.modules[__name__ + "." + _name] = getattr(diffmst_hip, _name)
 del _name

@@ -207,6 +207,56 @@ int mst_afloss_backward(const float* pred, const float* target, int32_t bs, int6
                         const void* tables, const float* filterbank, const float* grad_losses5, float* grad_pred,
                         void* workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Spectrogram encoder: SpectrogramEncoder (reference mst/modules.py:740-806) = STFT front end +
+ * Cnn14 (mst/panns.py:126-209, ConvBlock :27-85).  The 3x3 convolutions run on the matrix cores (MFMA); activations are
+ * NHWC in the workspace; master weights, BatchNorm statistics and every gradient are fp32 in torch's own layouts.
+ *
+ * mst_spectrogram_forward: x (rows, n_samples) -> spec (rows, frames, bins) fp32 = (|STFT| + 1e-8)^0.3 with
+ *   frames = 1 + n_samples / hop, bins = n_fft / 2 + 1 (torch.stft: periodic Hann, centre frames, reflect padding;
+ *   modules.py:789-800).  n_fft = 2048 (the reference's the yaml files under configs/models).  Note the (frames, bins) order: the network
+ *   below runs on the transposed image (its weights are transposed on the fly), nothing of it is user-visible. */
+size_t mst_spectrogram_tables_bytes(void);
+int mst_spectrogram_init_tables(void* tables, void* stream);
+int mst_spectrogram_forward(const float* x, int32_t rows, int64_t n_samples, int32_t n_fft, int32_t hop, const void* tables,
+                            float* spec, void* stream);
+
+#define MST_CNN14_CONVS 12 /* six ConvBlocks x two convolutions, in forward order */
+typedef struct mst_cnn14_desc {
+    int32_t n;          /* signals = batch x channels of the encoder call */
+    int32_t frames, bins;
+    int32_t embed_dim;  /* num_classes of the final Linear(2048, embed_dim) */
+    int32_t precision;  /* 0: bf16 operands, fp32 accumulate (v_mfma_f32_16x16x32_bf16); 1: fp32 operands (v_mfma_f32_16x16x4_f32) */
+    int32_t training;   /* 1: BatchNorm2d with batch statistics (returned in batch_stats); 0: running statistics */
+    float bn_eps;       /* 1e-5 */
+} mst_cnn14_desc;
+typedef struct mst_cnn14_params { /* device pointers, fp32, torch layouts */
+    const float* conv_w[MST_CNN14_CONVS];   /* (co, ci, 3, 3); channels 1-64-64-128-128-...-2048-2048 */
+    const float* bn_gamma[MST_CNN14_CONVS]; /* BatchNorm2d weight */
+    const float* bn_beta[MST_CNN14_CONVS];  /* BatchNorm2d bias */
+    const float* bn_mean[MST_CNN14_CONVS];  /* running_mean (read when training = 0) */
+    const float* bn_var[MST_CNN14_CONVS];   /* running_var */
+    const float* fc_w;                      /* (embed_dim, 2048) */
+    const float* fc_b;                      /* (embed_dim) */
+} mst_cnn14_params;
+typedef struct mst_cnn14_grads { /* device pointers, fp32, same layouts; every array is overwritten */
+    float* conv_w[MST_CNN14_CONVS];
+    float* bn_gamma[MST_CNN14_CONVS];
+    float* bn_beta[MST_CNN14_CONVS];
+    float* fc_w;
+    float* fc_b;
+} mst_cnn14_grads;
+size_t mst_cnn14_workspace_bytes(const mst_cnn14_desc* d);
+/* spec (n, frames, bins) fp32 -> embed (n, embed_dim).  batch_stats (12, 2, 2048) fp32 or NULL: per convolution the batch
+ * mean and the biased batch variance of its output (training = 1) - what nn.BatchNorm2d folds into its running statistics.
+ * The workspace keeps what mst_cnn14_backward needs. */
+int mst_cnn14_forward(const mst_cnn14_desc* d, const float* spec, const mst_cnn14_params* params, float* embed,
+                      float* batch_stats, void* workspace, size_t workspace_bytes, void* stream);
+/* grad_embed (n, embed_dim) -> gradients of every parameter.  The spectrogram gets no gradient (the encoder's inputs are
+ * audio, which the reference never differentiates: mst/system.py:284-300). */
+int mst_cnn14_backward(const mst_cnn14_desc* d, const float* spec, const mst_cnn14_params* params, const float* grad_embed,
+                       const mst_cnn14_grads* grads, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -221,6 +221,73 @@ def run_case(rmodules):
     print(f"run_diffmst: mix rms {pred_mix.pow(2).mean().sqrt():.4e}")
 
 
+def encoder_setup(enc_cls, seed_init=71, seed_bn=72, embed_dim=64):
+    """Seeded SpectrogramEncoder: default (xavier) initialisation under ``seed_init``, then BatchNorm affine parameters moved
+    off their 1 / 0 defaults under ``seed_bn`` so that their gradients and the ReLU masks are generic.  The GPU test builds
+    the HIP encoder with the same two calls (same torch build on the GPU box: same CPU generator stream)."""
+    torch.manual_seed(seed_init)
+    enc = enc_cls(embed_dim=embed_dim)
+    torch.manual_seed(seed_bn)
+    with torch.no_grad():
+        for name, p in sorted(enc.named_parameters()):
+            if ".bn" in name and name.endswith("weight"):
+                p.copy_(0.5 + torch.rand_like(p))
+            elif ".bn" in name and name.endswith("bias"):
+                p.copy_(0.2 * torch.randn_like(p))
+    return enc
+
+
+def encoder_case(rmodules):
+    """The REAL ``mst.modules.SpectrogramEncoder`` + ``mst.panns.Cnn14`` (pure torch, imported unchanged): one training-mode
+    forward + backward and one eval-mode forward on seeded audio.  Also pins oracle/encoder_restated.py."""
+    from oracle import encoder_restated as oe
+
+    enc = encoder_setup(rmodules.SpectrogramEncoder)
+    bs, n = 2, 65536
+    torch.manual_seed(73)
+    wave = (0.1 * torch.randn(bs, 1, n)).half().float()
+    G = torch.randn(bs, 64)
+    sd0 = {k: v.detach().clone() for k, v in enc.state_dict().items()}
+    enc.train()
+    embed = enc(wave)
+    (embed * G).sum().backward()
+    grads = {k: p.grad.detach().clone() for k, p in enc.named_parameters()}
+    sd1 = {k: v.detach().clone() for k, v in enc.state_dict().items()}
+    enc.eval()
+    with torch.no_grad():
+        embed_eval = enc(wave)
+    # the oracle's restatement on the same state_dict: identical torch ops, so identical numbers
+    osd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k and k != "window" else v.clone()) for k, v in sd0.items()}
+    o_embed = oe.spectrogram_encoder(wave, osd, training=True)
+    (o_embed * G).sum().backward()
+    assert torch.equal(o_embed, embed), "oracle encoder != reference"
+    for k, g in grads.items():
+        assert torch.equal(osd[k].grad, g), k
+    for k in sd1:
+        if "running" in k:
+            assert torch.equal(osd[k], sd1[k]), k
+    with torch.no_grad():
+        assert torch.equal(oe.spectrogram_encoder(wave, {k: v for k, v in sd1.items()}, training=False), embed_eval)
+    spec = oe.spectrogram(wave.view(bs, n))
+    out = dict(shape=np.array([bs, n]), seed_init=71, seed_bn=72, seed_wave=73, wave_sub=wave.numpy()[..., ::1024], G=G.numpy(),
+               embed=embed.detach().numpy(), embed_eval=embed_eval.numpy(), spec_sub=spec.numpy()[:, ::41, ::7],
+               spec_l2=np.array(spec.double().pow(2).sum().sqrt().item()))
+    for k, g in grads.items():
+        if g.numel() <= 4096 or k.startswith("model.fc"):
+            out["g." + k] = g.numpy()
+        else:
+            out["gsub." + k] = g.flatten()[::997].numpy()
+            out["gl2." + k] = np.array(g.double().pow(2).sum().sqrt().item())
+    for k, v in sd0.items():
+        if k.endswith("conv1.weight") or k.endswith("conv2.weight"):
+            out["wsum." + k] = np.array([v.double().sum().item(), v.double().abs().sum().item()])
+    for k in ("model.conv_block1.bn1.running_mean", "model.conv_block1.bn2.running_var", "model.conv_block3.bn1.running_var",
+              "model.conv_block6.bn2.running_mean", "model.conv_block6.bn2.running_var"):
+        out["run." + k] = sd1[k].numpy()
+    np.savez_compressed(os.path.join(HERE, "encoder_2x65536.npz"), **out)
+    print(f"encoder: |embed| {embed.abs().max():.4e}  |g conv1| {grads['model.conv_block1.conv1.weight'].abs().max():.3e}")
+
+
 def main():
     assert os.path.isdir(REF), "golden generation needs /root/reference (build container only)"
     install_stubs()
@@ -234,7 +301,9 @@ def main():
     ref_console = rmodules.AdvancedMixConsole(sample_rate=44100)
     assert ref_console.param_ranges == oc.param_ranges(44100)
     only = set(sys.argv[1:])  # e.g. `make_golden.py system` regenerates one fixture family (default: all)
-    if only and only <= {"system", "fx", "run"}:
+    if only and only <= {"system", "fx", "run", "encoder"}:
+        if "encoder" in only:
+            encoder_case(rmodules)
         if "run" in only:
             run_case(rmodules)
         if "system" in only:
@@ -323,6 +392,7 @@ def main():
     system_case(rsystem, rmodules, rmixing)
     fx_case(ref_console)
     run_case(rmodules)
+    encoder_case(rmodules)
     print("golden fixtures written to", HERE)
 
 
