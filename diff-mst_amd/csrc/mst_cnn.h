@@ -19,6 +19,11 @@ struct ConvArgs {
     void* out;        // (N, H, W, Cout) T
     float* part;      // (pixel tiles, Cout, 2) per-tile sum / sum of squares of the fp32 results, or null
     int N, H, W, Cin, Cout;
+    // split K (layers with few pixels and a long K = 9 Cin: 32 workgroups at 16 signals otherwise): workgroup z of
+    // 9 * csplit multiplies tap z / csplit, input channels [(z % csplit) Cin / csplit, +Cin / csplit) and stores its fp32 partial
+    // product to kpart (9 csplit, pixels, Cout); k_conv_splitk_reduce folds them in a fixed order (and makes the statistics)
+    int csplit;       // 0: no split
+    float* kpart;
 };
 struct WgradArgs {
     const void* dy;   // (N, H, W, Cout) T
@@ -32,7 +37,8 @@ constexpr int kConvPix = 128;   // pixels per workgroup of the implicit-GEMM con
 constexpr int kWgradPix = 32;   // pixels per K step of the weight-gradient GEMM
 
 // all launchers: precision 0 = bf16 operands, 1 = fp32 operands (mst_cnn14_desc::precision)
-void launch_conv3x3(int precision, const ConvArgs& a, hipStream_t s);
+void launch_conv3x3(int precision, ConvArgs a, hipStream_t s, float* kpart, size_t kpart_bytes);
+size_t conv_splitk_bytes(int N, int H, int W, int Cin, int Cout);
 void launch_conv_wgrad(int precision, const WgradArgs& a, hipStream_t s);
 int conv_pixel_tiles(int N, int H, int W);
 

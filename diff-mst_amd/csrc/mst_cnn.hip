@@ -111,9 +111,14 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
 #pragma unroll
         for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int ksteps = Cin / BK, steps = 9 * ksteps;
-    gload(0, 0);
-    int tap = 0, kq = 0;
+    int ksteps = Cin / BK, steps = 9 * ksteps, tap = 0, kq = 0, kq0 = 0;
+    if (a.csplit) {  // this workgroup's slice of K
+        tap = blockIdx.z / a.csplit;
+        ksteps /= a.csplit;
+        kq0 = (blockIdx.z % a.csplit) * ksteps;
+        steps = ksteps;
+    }
+    gload(tap, kq0 * BK);
     for (int s = 0; s < steps; ++s) {
 #pragma unroll
         for (int q = 0; q < XCH; ++q) *reinterpret_cast<uint4*>(&sX[xoff[q]]) = rx[q];
@@ -121,7 +126,7 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
         for (int q = 0; q < WCH; ++q) *reinterpret_cast<uint4*>(&sW[woff[q]]) = rw[q];
         __syncthreads();
         if (++kq == ksteps) { kq = 0; ++tap; }
-        if (s + 1 < steps) gload(tap, kq * BK);  // next tile's global loads fly while this one is multiplied
+        if (s + 1 < steps) gload(tap, (kq0 + kq) * BK);  // next tile's global loads fly while this one is multiplied
         if constexpr (sizeof(T) == 2) {
             bf16x8 af[MT], bfr[NT];
 #pragma unroll
@@ -149,6 +154,18 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
         __syncthreads();
     }
     // ---- epilogue: D row = channel (lane >> 4) * 4 + r, D column = pixel lane & 15
+    if (a.csplit) {
+        float* __restrict__ kp = a.kpart + (int64_t)blockIdx.z * P * Cout;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int64_t p = p0 + wx * 64 + n * 16 + li;
+            if (p < P) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m) store4(kp + p * Cout + co0 + wy * (BC / 2) + m * 16 + g * 4, acc[m][n]);
+            }
+        }
+        return;
+    }
     T* __restrict__ out = reinterpret_cast<T*>(a.out);
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
@@ -189,16 +206,73 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
     }
 }
 
-void launch_conv3x3(int precision, const ConvArgs& a, hipStream_t s) {
+// fold the split-K partials: out[p][c] = sum_z kpart[z][p][c] (fixed order), per-tile channel statistics as the unsplit epilogue
+template <typename T>
+__global__ __launch_bounds__(256) void k_conv_splitk_reduce(const float* __restrict__ kpart, T* __restrict__ out, float* __restrict__ part, int64_t P,
+                                                            int Cout, int nz) {
+    // workgroup = (pixel tile, 32 channels): lanes 0..31 walk the channels (128-byte lines), the 8 lane groups share the pixels
+    __shared__ float red[8][32][2];
+    const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5, c = blockIdx.y * 32 + cl;
+    const int64_t p0 = (int64_t)blockIdx.x * kConvPix;
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = pl; i < kConvPix; i += 8) {
+        const int64_t p = p0 + i;
+        if (p >= P) break;
+        float v = 0.f;
+        for (int z = 0; z < nz; ++z) v += kpart[((int64_t)z * P + p) * Cout + c];
+        out[p * Cout + c] = from_f32<T>(v);
+        s1 += v;
+        s2 = fmaf(v, v, s2);
+    }
+    if (part) {
+        red[pl][cl][0] = s1;
+        red[pl][cl][1] = s2;
+        __syncthreads();
+        if (pl == 0) {
+            for (int q = 1; q < 8; ++q) {
+                s1 += red[q][cl][0];
+                s2 += red[q][cl][1];
+            }
+            part[((int64_t)blockIdx.x * Cout + c) * 2] = s1;
+            part[((int64_t)blockIdx.x * Cout + c) * 2 + 1] = s2;
+        }
+    }
+}
+static int conv_csplit(int N, int H, int W, int Cin, int Cout) {
+    const int tiles = conv_pixel_tiles(N, H, W), bc = Cout % 128 == 0 ? 128 : 64, wgs = tiles * (Cout / bc);
+    if (wgs >= 512) return 0;
+    int cs = 1;
+    while (wgs * 9 * cs < 1024 && Cin / (cs * 2) >= 128) cs *= 2;
+    return cs;
+}
+size_t conv_splitk_bytes(int N, int H, int W, int Cin, int Cout) {
+    const int cs = conv_csplit(N, H, W, Cin, Cout);
+    return cs ? (size_t)9 * cs * N * H * W * Cout * sizeof(float) : 0;
+}
+void launch_conv3x3(int precision, ConvArgs a, hipStream_t s, float* kpart, size_t kpart_bytes) {
     const int tiles = conv_pixel_tiles(a.N, a.H, a.W);
+    a.csplit = 0;
+    a.kpart = nullptr;
+    const size_t need = conv_splitk_bytes(a.N, a.H, a.W, a.Cin, a.Cout);
+    if (need && kpart && need <= kpart_bytes) {
+        a.csplit = conv_csplit(a.N, a.H, a.W, a.Cin, a.Cout);
+        a.kpart = kpart;
+    }
+    const unsigned gz = a.csplit ? 9 * a.csplit : 1;
     if (a.Cout % 128 == 0) {
-        const dim3 grid(tiles, a.Cout / 128);
+        const dim3 grid(tiles, a.Cout / 128, gz);
         if (precision == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_igemm<bf16_t, 128>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_igemm<float, 128>), grid, dim3(256), 0, s, a);
     } else {
-        const dim3 grid(tiles, a.Cout / 64);
+        const dim3 grid(tiles, a.Cout / 64, gz);
         if (precision == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_igemm<bf16_t, 64>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_igemm<float, 64>), grid, dim3(256), 0, s, a);
+    }
+    if (a.csplit) {
+        const dim3 grid(tiles, a.Cout / 32);
+        const int64_t P = (int64_t)a.N * a.H * a.W;
+        if (precision == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_splitk_reduce<bf16_t>), grid, dim3(256), 0, s, a.kpart, (bf16_t*)a.out, a.part, P, a.Cout, (int)gz);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_splitk_reduce<float>), grid, dim3(256), 0, s, a.kpart, (float*)a.out, a.part, P, a.Cout, (int)gz);
     }
 }
 

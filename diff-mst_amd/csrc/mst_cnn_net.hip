@@ -211,7 +211,37 @@ __global__ __launch_bounds__(256) void k_conv1(const float* __restrict__ spec, c
 
 // =====================================================================================================================
 // BatchNorm2d (training: batch statistics, biased variance; eval: running statistics).  stat = {mean, invstd, var} x C.
-__global__ void k_bn_finalize(const float* __restrict__ part, int tiles, int C, double count, const float* __restrict__ run_mean,
+// column sums of a (tiles, C, 2) fp32 partial array, first stage: workgroup (channel group of 32, slice s of S) folds its
+// slice of the tiles in fp64, fixed order -> (S, C, 2) doubles.  (One thread per channel walking every tile was 60 % of the
+// encoder step: 65 k tiles per layer at 16 signals, each read 8 bytes out of a 512-byte-strided line.)
+constexpr int kColSlices = 64;
+__global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ part, int tiles, int C, double* __restrict__ out) {
+    __shared__ double red[8][32][2];
+    const int cl = threadIdx.x & 31, tl = threadIdx.x >> 5, c = blockIdx.x * 32 + cl, S = gridDim.y, s = blockIdx.y;
+    const int per = (tiles + S - 1) / S, t0 = s * per, t1 = (t0 + per < tiles) ? t0 + per : tiles;
+    double s1 = 0.0, s2 = 0.0;
+    for (int t = t0 + tl; t < t1; t += 8) {
+        const float2 v = *reinterpret_cast<const float2*>(part + ((int64_t)t * C + c) * 2);
+        s1 += (double)v.x;
+        s2 += (double)v.y;
+    }
+    red[tl][cl][0] = s1;
+    red[tl][cl][1] = s2;
+    __syncthreads();
+    if (tl == 0) {
+        for (int q = 1; q < 8; ++q) {
+            s1 += red[q][cl][0];
+            s2 += red[q][cl][1];
+        }
+        out[((int64_t)s * C + c) * 2] = s1;
+        out[((int64_t)s * C + c) * 2 + 1] = s2;
+    }
+}
+static int colsum_slices(int tiles) {
+    const int s = (tiles + 63) / 64;
+    return s < 1 ? 1 : (s > kColSlices ? kColSlices : s);
+}
+__global__ void k_bn_finalize(const double* __restrict__ part, int tiles, int C, double count, const float* __restrict__ run_mean,
                               const float* __restrict__ run_var, int training, float eps, float* __restrict__ stat, float* __restrict__ batch_stats) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
@@ -219,8 +249,8 @@ __global__ void k_bn_finalize(const float* __restrict__ part, int tiles, int C, 
     if (training) {
         double s1 = 0.0, s2 = 0.0;
         for (int t = 0; t < tiles; ++t) {
-            s1 += (double)part[((int64_t)t * C + c) * 2];
-            s2 += (double)part[((int64_t)t * C + c) * 2 + 1];
+            s1 += part[((int64_t)t * C + c) * 2];
+            s2 += part[((int64_t)t * C + c) * 2 + 1];
         }
         const double m = s1 / count;
         double v = s2 / count - m * m;
@@ -377,15 +407,15 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(BnBwdArgs a) {
         }
     }
 }
-__global__ void k_bn_bwd_finalize(const float* __restrict__ part, int strips, int C, double count, const float* __restrict__ stat,
+__global__ void k_bn_bwd_finalize(const double* __restrict__ part, int strips, int C, double count, const float* __restrict__ stat,
                                   const float* __restrict__ gamma, int training, float* __restrict__ coef, float* __restrict__ g_gamma,
                                   float* __restrict__ g_beta) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     double s1 = 0.0, s2 = 0.0;
     for (int t = 0; t < strips; ++t) {
-        s1 += (double)part[((int64_t)t * C + c) * 2];
-        s2 += (double)part[((int64_t)t * C + c) * 2 + 1];
+        s1 += part[((int64_t)t * C + c) * 2];
+        s2 += part[((int64_t)t * C + c) * 2 + 1];
     }
     g_beta[c] = (float)s1;
     g_gamma[c] = (float)s2;
@@ -500,8 +530,8 @@ struct CnnPlan {
     int H[kBlocks + 1], W[kBlocks + 1];
     size_t raw1[kBlocks], a1[kBlocks], raw2[kBlocks], out[kBlocks];
     size_t wf[2 * kBlocks], wd[2 * kBlocks], stat[2 * kBlocks];
-    size_t w1, bnpart, coef, feat, arg, gfeat, ga, gb, wgpart;
-    size_t bnpart_bytes, wgpart_bytes;
+    size_t w1, bnpart, colsum, coef, feat, arg, gfeat, ga, gb, wgpart;
+    size_t bnpart_bytes, wgpart_bytes, kpart, kpart_bytes;
     size_t total;
 };
 static int64_t wgrad_part_floats(int layer, int64_t P, int Cin, int Cout, int* splits, int* steps) {
@@ -539,7 +569,7 @@ static CnnPlan cnn_plan(const mst_cnn14_desc* d) {
         o += (bytes + 255) / 256 * 256;
         return at;
     };
-    size_t gmax = 0, bnmax = 0, wgmax = 0;
+    size_t gmax = 0, bnmax = 0, wgmax = 0, kmax = 0;
     for (int b = 0; b < kBlocks; ++b) {
         const int64_t P = (int64_t)p.n * p.H[b] * p.W[b];
         const size_t full = (size_t)P * kChan[b + 1] * p.esz;
@@ -562,11 +592,17 @@ static CnnPlan cnn_plan(const mst_cnn14_desc* d) {
             int sp, st;
             const size_t wg = (size_t)wgrad_part_floats(2 * b + k, P, Cin, Cout, &sp, &st) * 4;
             wgmax = wg > wgmax ? wg : wgmax;
+            if (Cin > 1) {  // split-K scratch of the forward convolution and of its data gradient (channel roles swapped)
+                const size_t k1 = conv_splitk_bytes(p.n, p.H[b], p.W[b], Cin, Cout), k2 = conv_splitk_bytes(p.n, p.H[b], p.W[b], Cout, Cin);
+                kmax = k1 > kmax ? k1 : kmax;
+                kmax = k2 > kmax ? k2 : kmax;
+            }
         }
     }
     p.w1 = take(64 * 9 * 4);
     p.bnpart_bytes = bnmax;
     p.bnpart = take(bnmax);
+    p.colsum = take((size_t)kColSlices * 2048 * 2 * 8);
     p.coef = take((size_t)2048 * 3 * 4);
     p.feat = take((size_t)p.n * 2048 * 4);
     p.arg = take((size_t)p.n * 2048 * 4);
@@ -575,6 +611,8 @@ static CnnPlan cnn_plan(const mst_cnn14_desc* d) {
     p.gb = take(gmax);
     p.wgpart_bytes = wgmax;
     p.wgpart = take(wgmax);
+    p.kpart_bytes = kmax;
+    p.kpart = take(kmax);
     p.total = o;
     p.ok = true;
     return p;
@@ -610,11 +648,14 @@ static int cnn_forward_t(const mst_cnn14_desc* d, const CnnPlan& p, const float*
                                    d->training ? part : nullptr, p.n, H, W);
             } else {
                 tiles = conv_pixel_tiles(p.n, H, W);
-                ConvArgs ca{x_in, ws + p.wf[l], raw, d->training ? part : nullptr, p.n, H, W, Cin, C};
-                launch_conv3x3(prec, ca, s);
+                ConvArgs ca{x_in, ws + p.wf[l], raw, d->training ? part : nullptr, p.n, H, W, Cin, C, 0, nullptr};
+                launch_conv3x3(prec, ca, s, (float*)(ws + p.kpart), p.kpart_bytes);
             }
             float* stat = (float*)(ws + p.stat[l]);
-            hipLaunchKernelGGL(k_bn_finalize, dim3((C + 255) / 256), dim3(256), 0, s, part, tiles, C, (double)P, prm->bn_mean[l], prm->bn_var[l],
+            double* cs = (double*)(ws + p.colsum);
+            const int slices = colsum_slices(tiles);
+            if (d->training) hipLaunchKernelGGL(k_colsum, dim3(C / 32, slices), dim3(256), 0, s, part, tiles, C, cs);
+            hipLaunchKernelGGL(k_bn_finalize, dim3((C + 255) / 256), dim3(256), 0, s, cs, slices, C, (double)P, prm->bn_mean[l], prm->bn_var[l],
                                d->training, d->bn_eps, stat, batch_stats ? batch_stats + (size_t)l * 2 * 2048 : nullptr);
             if (k == 0) {
                 T* a1 = (T*)(ws + p.a1[b]);
@@ -668,7 +709,10 @@ static int cnn_backward_t(const mst_cnn14_desc* d, const CnnPlan& p, const float
             const dim3 rgrid((unsigned)strips, cg / cgw);
             if (k == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bn_bwd_reduce<T, true>), rgrid, dim3(256), 0, s, ba);
             else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bn_bwd_reduce<T, false>), rgrid, dim3(256), 0, s, ba);
-            hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((C + 255) / 256), dim3(256), 0, s, part, (int)strips, C, (double)P, (const float*)(ws + p.stat[l]),
+            double* cs = (double*)(ws + p.colsum);
+            const int slices = colsum_slices((int)strips);
+            hipLaunchKernelGGL(k_colsum, dim3(C / 32, slices), dim3(256), 0, s, part, (int)strips, C, cs);
+            hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((C + 255) / 256), dim3(256), 0, s, cs, slices, C, (double)P, (const float*)(ws + p.stat[l]),
                                prm->bn_gamma[l], d->training, coef, gr->bn_gamma[l], gr->bn_beta[l]);
             if (k == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bn_bwd_apply<T, true>), dim3(ew_grid(P * cg)), dim3(256), 0, s, ba);
             else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bn_bwd_apply<T, false>), dim3(ew_grid(P * cg)), dim3(256), 0, s, ba);
@@ -681,8 +725,8 @@ static int cnn_backward_t(const mst_cnn14_desc* d, const CnnPlan& p, const float
             hipLaunchKernelGGL(k_wgrad_reduce, dim3(ew_grid((int64_t)9 * Cin * C)), dim3(256), 0, s, wgpart, gr->conv_w[l], Cin, C, splits, Cin == 1 ? 1 : 0);
             // data gradient (not for the spectrogram itself)
             if (Cin > 1) {
-                ConvArgs ca{GA, ws + p.wd[l], GB, nullptr, p.n, H, W, C, Cin};
-                launch_conv3x3(prec, ca, s);
+                ConvArgs ca{GA, ws + p.wd[l], GB, nullptr, p.n, H, W, C, Cin, 0, nullptr};
+                launch_conv3x3(prec, ca, s, (float*)(ws + p.kpart), p.kpart_bytes);
             }
         }
     }
