@@ -52,13 +52,15 @@ def test_struct_layout_matches_the_header():
     src = r'''
     #include <stdio.h>
     #include "%s"
-    int main(void) { printf("%%zu %%zu\n", sizeof(mst_console_desc), sizeof(mst_mrstft_desc)); return 0; }
+    int main(void) { printf("%%zu %%zu %%zu %%zu %%zu\n", sizeof(mst_console_desc), sizeof(mst_mrstft_desc), sizeof(mst_cnn14_desc),
+                            sizeof(mst_cnn14_params), sizeof(mst_cnn14_grads)); return 0; }
     ''' % HEADER
     exe = "/tmp/mst_sizeof_test"
     subprocess.run(["gcc", "-x", "c", "-", "-o", exe], input=src.encode(), check=True)
-    a, b = (int(v) for v in subprocess.run([exe], capture_output=True, check=True).stdout.split())
+    a, b, c, d, e = (int(v) for v in subprocess.run([exe], capture_output=True, check=True).stdout.split())
     assert ctypes.sizeof(_cabi.ConsoleDesc) == a
     assert ctypes.sizeof(_cabi.MrstftDesc) == b
+    assert (ctypes.sizeof(_cabi.Cnn14Desc), ctypes.sizeof(_cabi.Cnn14Params), ctypes.sizeof(_cabi.Cnn14Grads)) == (c, d, e)
 
 
 def test_workspace_sizes_and_validation(lib):
@@ -91,3 +93,10 @@ def test_workspace_sizes_and_validation(lib):
     assert lib.mst_afloss_workspace_bytes(8, 262144) > 0
     assert lib.mst_afloss_workspace_bytes(8, 16384) == 0  # reflect padding needs n > 16384
     assert lib.mst_peak_normalize_workspace_bytes(8, 262144) > 0
+    # spectrogram encoder: 513 x 1025 images (262144 samples), 16 signals - a few GB of bf16 activations; too few frames for six pools -> 0
+    e = _cabi.Cnn14Desc(16, 513, 1025, 512, 0, 1, 1e-5)
+    assert 2e9 < lib.mst_cnn14_workspace_bytes(ctypes.byref(e)) < 2e10
+    e32 = _cabi.Cnn14Desc(16, 513, 1025, 512, 1, 1, 1e-5)
+    assert lib.mst_cnn14_workspace_bytes(ctypes.byref(e32)) > lib.mst_cnn14_workspace_bytes(ctypes.byref(e))
+    assert lib.mst_cnn14_workspace_bytes(ctypes.byref(_cabi.Cnn14Desc(1, 100, 1025, 512, 0, 1, 1e-5))) == 0
+    assert lib.mst_spectrogram_tables_bytes() == 3 * 2048 * 4
