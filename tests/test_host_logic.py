@@ -173,3 +173,41 @@ def test_shard_batch():
     assert [bench.shard_batch(64, r, 8) for r in (0, 3, 7)] == [(0, 8), (24, 32), (56, 64)]
     with pytest.raises(AssertionError):
         bench.shard_batch(10, 0, 4)
+
+
+def test_load_diffmst_splits_a_lightning_checkpoint(tmp_path):
+    """``load_diffmst`` (reference mst/utils.py:176-258): classes named by the training YAML, ``state_dict`` split by the
+    ``model.<part>.`` prefixes, model returned in eval mode.  The YAML below has the structure of the reference's
+    configs/models/naive.yaml (smaller controller)."""
+    import yaml
+
+    from mst.modules import AdvancedMixConsole, MixStyleTransferModel, SpectrogramEncoder, TransformerController
+    from mst.utils import load_diffmst
+
+    enc = dict(class_path="mst.modules.SpectrogramEncoder", init_args=dict(embed_dim=32, n_fft=2048, hop_length=512, input_batchnorm=False))
+    ctl = dict(class_path="mst.modules.TransformerController",
+               init_args=dict(embed_dim=32, num_track_control_params=27, num_fx_bus_control_params=25, num_master_bus_control_params=26,
+                              num_layers=2, nhead=4))
+    cfg = dict(model=dict(class_path="mst.system.System", init_args=dict(
+        model=dict(class_path="mst.modules.MixStyleTransferModel", init_args=dict(track_encoder=enc, mix_encoder=enc, controller=ctl)),
+        mix_console=dict(class_path="mst.modules.AdvancedMixConsole", init_args=dict(sample_rate=44100, input_min_gain_db=-48.0)))))
+    # load_diffmst instantiates the core class from its init_args too (reference :183-185): give it constructible arguments
+    cfg["model"]["init_args"]["model"]["init_args"] = dict(track_encoder=enc, mix_encoder=enc, controller=ctl)
+    torch.manual_seed(0)
+    src = MixStyleTransferModel(SpectrogramEncoder(embed_dim=32), SpectrogramEncoder(embed_dim=32),
+                                TransformerController(32, 27, 25, 26, num_layers=2, nhead=4))
+    with torch.no_grad():
+        src.track_encoder.model.conv_block3.bn1.running_mean.normal_()
+        src.mix_encoder.model.fc.bias.normal_()
+    sd = {"model." + k: v for k, v in src.state_dict().items()}
+    sd["loss.unrelated"] = torch.zeros(3)
+    cfg_path, ckpt_path = tmp_path / "config.yaml", tmp_path / "last.ckpt"
+    cfg_path.write_text(yaml.safe_dump(cfg))
+    torch.save({"state_dict": sd, "epoch": 3}, ckpt_path)
+    model, console = load_diffmst(str(cfg_path), str(ckpt_path))
+    assert isinstance(model, MixStyleTransferModel) and not model.training and isinstance(console, AdvancedMixConsole)
+    got = model.state_dict()
+    assert set(got) == set(src.state_dict())
+    for k, v in src.state_dict().items():
+        assert torch.equal(got[k], v), k
+    assert console.param_ranges["input_fader"]["gain_db"] == (-48.0, 48.0)

@@ -99,3 +99,57 @@ def test_common_step_against_the_oracle_in_the_same_order(dev, record):
     print("\n[common_step vs oracle]", rep)
     record(**rep)
     assert rep["loss"] < 1e-4 and rep["g_w_track"] < 1e-2 and rep["g_w_master"] < 1e-2
+
+
+def test_cfg5_step_with_the_encoder_model(dev, record):
+    """BASELINE cfg #5 on one GPU at batch 1: the full training step - naive_random_mix reference, the REAL model structure
+    (SpectrogramEncoder + Cnn14 on MFMA for 32 tracks + 2 mix channels, TransformerController), AdvancedMixConsole with 32 tracks,
+    AudioFeatureLoss (weights of configs/models/unpaired+feat.yaml:55-60) - forward and backward through every part.
+    Parity of the new link (audio -> estimated parameters) against the oracle's encoder + the same controller on the host; the
+    console and the loss are pinned by their own tests."""
+    from mst.loss import AudioFeatureLoss
+    from mst.mixing import naive_random_mix
+    from mst.modules import AdvancedMixConsole, MixStyleTransferModel, SpectrogramEncoder, TransformerController
+    from mst.system import CommonStep
+    from oracle import encoder_restated as oe
+
+    bs, T, n = 1, 32, 262144
+    torch.manual_seed(100)
+    model = MixStyleTransferModel(SpectrogramEncoder(embed_dim=64, precision="fp32"), SpectrogramEncoder(embed_dim=64, precision="fp32"),
+                                  TransformerController(64, 27, 25, 26, num_layers=2, nhead=4))
+    sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.to(dev).train()
+    step = CommonStep(model, AdvancedMixConsole(44100), naive_random_mix, AudioFeatureLoss([0.1, 0.001, 1.0, 1.0, 0.1], 44100), generate_mix=True,
+                      active_eq_epoch=0, active_compressor_epoch=0, active_fx_bus_epoch=1000, active_master_bus_epoch=0)
+    torch.manual_seed(101)
+    tracks = 0.05 * torch.randn(bs, T, n)
+    batch = (tracks.to(dev), None, None, torch.zeros(bs, T, dtype=torch.bool, device=dev), None, ["a"])
+    torch.manual_seed(102)
+    loss, data = step(batch, train=True, collect=True)
+    loss.backward()
+    assert torch.isfinite(loss) and set(data["loss_terms"]) == {"mix-rms", "mix-crest_factor", "mix-stereo_width", "mix-stereo_imbalance", "mix-barkspectrum"}
+    missing = [k for k, p in model.named_parameters() if p.grad is None and "fx_bus_projection" not in k]
+    assert not missing, missing  # fx bus off: its projection gets no gradient, everything else does
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+    assert float(model.track_encoder.model.conv_block1.conv1.weight.grad.abs().max()) > 0
+    assert data["pred_track_param_dict"]["stereo_panner"]["pan"].shape == (bs, T)
+
+    # audio -> parameters: the oracle's encoders (fp32, training mode: batch statistics over the 32 / 2 signals) + the same controller
+    mid = n // 2
+    ref_mix_a = data["ref_mix_a"]
+    host = MixStyleTransferModel(torch.nn.Identity(), torch.nn.Identity(), TransformerController(64, 27, 25, 26, num_layers=2, nhead=4)).train()
+    host.controller.load_state_dict({k[len("controller."):]: v for k, v in sd0.items() if k.startswith("controller.")})
+    with torch.no_grad():
+        te = oe.spectrogram_encoder(tracks[..., mid:].reshape(bs * T, 1, -1), {k[len("track_encoder."):]: v.clone() for k, v in sd0.items()
+                                                                               if k.startswith("track_encoder.")}, training=True)
+        me = oe.spectrogram_encoder(ref_mix_a.reshape(bs * 2, 1, -1), {k[len("mix_encoder."):]: v.clone() for k, v in sd0.items()
+                                                                       if k.startswith("mix_encoder.")}, training=True)
+        o_tp, o_fp, o_mp = host.controller(te.view(bs, T, -1), me.view(bs, 2, -1), torch.zeros(bs, T, dtype=torch.bool))
+    model.load_state_dict(sd0)  # the step above moved the running statistics
+    model.train()
+    with torch.no_grad():
+        h_tp, h_fp, h_mp = model(tracks.to(dev)[..., mid:], ref_mix_a.to(dev), track_padding_mask=torch.zeros(bs, T, dtype=torch.bool, device=dev))
+    rep = dict(track_params=rel(h_tp, o_tp), fx_params=rel(h_fp, o_fp), master_params=rel(h_mp, o_mp), loss=float(loss.detach()))
+    print("\n[cfg #5 step, batch 1] estimated parameters vs oracle encoder + controller:", rep)
+    record(**rep)
+    assert rep["track_params"] < 1e-3 and rep["fx_params"] < 1e-3 and rep["master_params"] < 1e-3
