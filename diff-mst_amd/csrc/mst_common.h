@@ -23,6 +23,7 @@ constexpr int kTile = kEqWG * kEqChunk;  // samples one single-wave workgroup of
 constexpr int kPow1 = 12;              // in-wave scans use M^(2^j), j = 0..5 (lanes of a tile) and 6..11 (tiles of a row)
 constexpr int kTri2 = 2 * 592;         // ... stored as two block-triangular table sets per row (mst_mat.h: kTriFloats each)
 constexpr int kFxDhChunks = 4;          // fx bus backward: frame chunks of the dH product (partials summed by the inverse transform)
+constexpr int kWz = kEqChunk * 16;      // floats of one zero-state map: 64 samples x (12 states + 4 pad)
 constexpr int kMaxTiles1 = 64;         // rows of up to 64 tiles (262144 samples) scan in-wave (no carry-scan kernel)
 
 // ---- per-filter-row constants ("rc"), written by k_prep, floats -------------------------------
@@ -207,6 +208,7 @@ struct Layout {
     int64_t cp_t, cp_m, ep_t, ep_m;      // partial sums
     int64_t pow1F_t, pow1F_m, pow1A_t, pow1A_m;  // in-wave scan tables rows x kTri2
     int64_t aggF_t, aggF_m, aggA_t, aggA_m;      // tile aggregates sigrows x 12 x kMaxTiles1 (forward / adjoint cascade)
+    int64_t wzF_t, wzF_m, wzA_t, wzA_m;          // zero-state maps rows x 64 x 16: chunk end state = W^T chunk (mst_eq.hip, k_eq_zs_mfma)
     // fx bus (only laid out when MST_USE_FX_BUS is set)
     int fxS, fxTaps, fxK, fxBlk, fxBlkIr;         // impulse-response samples, band-pass taps, partitions, signal blocks, ir-bwd blocks
     int64_t fx_rc, fx_in, fx_wnf, fx_ir, fx_Xs, fx_Hs, fx_Ys, fx_dXs, fx_dHs, fx_dir, fx_din, fx_part, fx_Hf, fx_mix, fx_dry;
@@ -287,6 +289,10 @@ inline Layout make_layout(const mst_console_desc* d) {
     L.aggF_m = L.aggF_t + R * kStates * kMaxTiles1;
     L.aggA_t = take((R + 2 * B) * kStates * kMaxTiles1);
     L.aggA_m = L.aggA_t + R * kStates * kMaxTiles1;
+    L.wzF_t = take((R + B) * kWz);
+    L.wzF_m = L.wzF_t + R * kWz;
+    L.wzA_t = take((R + B) * kWz);
+    L.wzA_m = L.wzA_t + R * kWz;
     if (d->flags & MST_USE_FX_BUS) {
         L.fxS = d->fx_ir_samples;
         L.fxTaps = d->fx_bandpass_taps;

@@ -29,6 +29,15 @@ static constexpr bool fuse_allpole() {
 #endif
 }
 
+// build-time A/B switch (-DMST_EQ_ZS_VALU): zero-state EQ passes on the vector ALU (round-2 kernels) instead of the matrix pipe
+static constexpr bool mfma_zs() {
+#ifdef MST_EQ_ZS_VALU
+    return false;
+#else
+    return true;
+#endif
+}
+
 extern "C" int mst_abi_version(void) { return 4; }
 
 extern "C" size_t mst_console_fx_tables_bytes(void) { return (size_t)8192 * 2 * sizeof(float); }
@@ -79,7 +88,7 @@ extern "C" int mst_console_forward(const mst_console_desc* d, const float* track
 
     PrepArgs pa{track_params, fx_bus_params, master_bus_params, ws + L.rc_t, ws + L.rc_m,
                 ws + L.powF_t, ws + L.powF_m, ws + L.powA_t, ws + L.powA_m, ws + L.powP_t, ws + L.powP_m,
-                ws + L.pow1F_t, ws + L.pow1F_m, ws + L.pow1A_t, ws + L.pow1A_m, fx_on ? ws + L.fx_rc : nullptr, fx_on ? ws + L.fx_mix : nullptr, status, L.R, L.bs, L.KE,
+                ws + L.pow1F_t, ws + L.pow1F_m, ws + L.pow1A_t, ws + L.pow1A_m, ws + L.wzF_t, ws + L.wzF_m, ws + L.wzA_t, ws + L.wzA_m, fx_on ? ws + L.fx_rc : nullptr, fx_on ? ws + L.fx_mix : nullptr, status, L.R, L.bs, L.KE,
                 L.eq1, *d};
     launch_prep(pa, stream);
 
@@ -92,7 +101,8 @@ extern "C" int mst_console_forward(const mst_console_desc* d, const float* track
     // a call that saves for backward also leaves the all-pole zero-state ends of the coefficient-gradient pass
     float* zP_t = (save && fuse_allpole()) ? ws + L.zP_t : nullptr;
     float* zP_m = (save && fuse_allpole()) ? ws + L.zP_m : nullptr;
-    launch_cascade(EQ_FWD, false, tracks, d->track_row_stride, nullptr, 0, ws + L.rc_t, L.R, nullptr, ws + L.zE_t, L.ncE_pad, n, L.R, stream, p1F_t, L.ntE, ws + L.aggF_t);
+    if (L.eq1 && mfma_zs()) launch_eq_zs_mfma(EQ_FWD, tracks, d->track_row_stride, ws + L.wzF_t, L.R, ws + L.zE_t, L.ncE_pad, n, L.R, stream, p1F_t, L.ntE, ws + L.aggF_t);
+    else launch_cascade(EQ_FWD, false, tracks, d->track_row_stride, nullptr, 0, ws + L.rc_t, L.R, nullptr, ws + L.zE_t, L.ncE_pad, n, L.R, stream, p1F_t, L.ntE, ws + L.aggF_t);
     if (!L.eq1) launch_scan12(false, ws + L.zE_t, ws + L.sE_t, ws + L.powF_t, L.R, L.ncE, L.ncE_pad, L.KE, L.R, stream);
     if (t_comp)  // EQ run fused with the gain computer + per-block envelope aggregates
         launch_cascade_run_gc(tracks, d->track_row_stride, ws + L.u_t, Ns, ws + L.rc_t, L.R, sE_t, L.ncE_pad, n, L.R,
@@ -111,7 +121,8 @@ extern "C" int mst_console_forward(const mst_console_desc* d, const float* track
 
     // ---- master bus
     if (m_on) {
-        launch_cascade(EQ_FWD, false, ws + L.bus, Ns, nullptr, 0, ws + L.rc_m, 0, nullptr, ws + L.zE_m, L.ncE_pad, n, 2 * L.bs, stream, p1F_m, L.ntE, ws + L.aggF_m);
+        if (L.eq1 && mfma_zs()) launch_eq_zs_mfma(EQ_FWD, ws + L.bus, Ns, ws + L.wzF_m, 0, ws + L.zE_m, L.ncE_pad, n, 2 * L.bs, stream, p1F_m, L.ntE, ws + L.aggF_m);
+        else launch_cascade(EQ_FWD, false, ws + L.bus, Ns, nullptr, 0, ws + L.rc_m, 0, nullptr, ws + L.zE_m, L.ncE_pad, n, 2 * L.bs, stream, p1F_m, L.ntE, ws + L.aggF_m);
         if (!L.eq1) launch_scan12(false, ws + L.zE_m, ws + L.sE_m, ws + L.powF_m, 0, L.ncE, L.ncE_pad, L.KE, 2 * L.bs, stream);
         launch_cascade(EQ_FWD, true, ws + L.bus, Ns, ws + L.v_m, Ns, ws + L.rc_m, 0, sE_m, nullptr, L.ncE_pad, n, 2 * L.bs, stream, p1F_m, L.ntE, ws + L.aggF_m, zP_m);
         launch_comp_zs(2, ws + L.v_m, Ns, ws + L.rc_m, ws + L.zS_m, L.ncC_pad, n, L.bs, stream);
@@ -162,7 +173,8 @@ extern "C" int mst_console_backward(const mst_console_desc* d, const float* trac
         ca.s0 = ws + L.zQ_m;
         launch_comp_bwd(true, true, ca, L.bs, stream);
         const float* p1A_m = L.eq1 ? ws + L.pow1A_m : nullptr;
-        launch_cascade(EQ_ADJ, false, ws + L.du_m, Ns, nullptr, 0, ws + L.rc_m, 0, nullptr, ws + L.zA_m, L.ncE_pad, n, 2 * L.bs, stream, p1A_m, L.ntE, ws + L.aggA_m);
+        if (L.eq1 && mfma_zs()) launch_eq_zs_mfma(EQ_ADJ, ws + L.du_m, Ns, ws + L.wzA_m, 0, ws + L.zA_m, L.ncE_pad, n, 2 * L.bs, stream, p1A_m, L.ntE, ws + L.aggA_m);
+        else launch_cascade(EQ_ADJ, false, ws + L.du_m, Ns, nullptr, 0, ws + L.rc_m, 0, nullptr, ws + L.zA_m, L.ncE_pad, n, 2 * L.bs, stream, p1A_m, L.ntE, ws + L.aggA_m);
         if (!L.eq1) launch_scan12(true, ws + L.zA_m, ws + L.sA_m, ws + L.powA_m, 0, L.ncE, L.ncE_pad, L.KE, 2 * L.bs, stream);
         launch_cascade(EQ_ADJ, true, ws + L.du_m, Ns, ws + L.dbus, Ns, ws + L.rc_m, 0, L.eq1 ? ws + L.zA_m : ws + L.sA_m, nullptr, L.ncE_pad, n,
                        2 * L.bs, stream, p1A_m, L.ntE, ws + L.aggA_m);
@@ -195,7 +207,8 @@ extern "C" int mst_console_backward(const mst_console_desc* d, const float* trac
         launch_coefgrad(ws + L.u_t, Ns, ws + L.du_t, Ns, ws + L.rc_t, L.R, ws + L.sP_t, L.ncE_pad, ws + L.ep_t, n, nsig_all, stream);
         if (grad_tracks) {
             const float* p1A_t = L.eq1 ? ws + L.pow1A_t : nullptr;
-            launch_cascade(EQ_ADJ, false, ws + L.du_t, Ns, nullptr, 0, ws + L.rc_t, L.R, nullptr, ws + L.zA_t, L.ncE_pad, n, L.R, stream, p1A_t, L.ntE, ws + L.aggA_t);
+            if (L.eq1 && mfma_zs()) launch_eq_zs_mfma(EQ_ADJ, ws + L.du_t, Ns, ws + L.wzA_t, L.R, ws + L.zA_t, L.ncE_pad, n, L.R, stream, p1A_t, L.ntE, ws + L.aggA_t);
+            else launch_cascade(EQ_ADJ, false, ws + L.du_t, Ns, nullptr, 0, ws + L.rc_t, L.R, nullptr, ws + L.zA_t, L.ncE_pad, n, L.R, stream, p1A_t, L.ntE, ws + L.aggA_t);
             if (!L.eq1) launch_scan12(true, ws + L.zA_t, ws + L.sA_t, ws + L.powA_t, L.R, L.ncE, L.ncE_pad, L.KE, L.R, stream);
             launch_cascade(EQ_ADJ, true, ws + L.du_t, Ns, grad_tracks, n, ws + L.rc_t, L.R, L.eq1 ? ws + L.zA_t : ws + L.sA_t, nullptr, L.ncE_pad,
                            n, L.R, stream, p1A_t, L.ntE, ws + L.aggA_t);

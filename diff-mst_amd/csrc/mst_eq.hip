@@ -315,6 +315,86 @@ __global__ __launch_bounds__(kEqWG, (MODE_RUN && FUSE_GC && FUSE_AP) ? MST_EQ_RU
     else cascade_body<DIR, MODE_RUN, FUSE_GC, SCAN1, false, FUSE_AP>(in, in_stride, out, out_stride, rc, split, s0, z, nc_pad, n, zs_comp, nblk_comp, pw1, ntiles, agg, tile, zp);
 }
 
+// ---- zero-state pass on the matrix pipe ------------------------------------------------------------------------------
+// The end state of a chunk run from zero state is a fixed linear map of its 64 samples: z = W^T x with W (64 x 12) the row's
+// impulse-to-end-state responses (k_prep, fp64).  For the 64 chunks of a tile that is Z (64 x 12) = X (64 x 64) W - a GEMM the
+// otherwise idle matrix pipe runs as 64 v_mfma_f32_16x16x4_f32 (exact fp32 FMA chains, k-ordered) instead of 64 x 30
+// DEPENDENT vector FMAs per lane: the tile goes straight from HBM into A fragments (lane (i, g) of the MFMA takes four
+// 16-byte pieces of row 16 m + i; the K order - sample 16 s + 4 g + e at step (s, e) - is the W fragments' order too, so no
+// LDS staging and no shuffles), the results are written out in the chunk-state layout the run kernel reads, transposed
+// through LDS to one chunk per lane, and scanned across the tile like before for the tile aggregate.
+typedef float f32x4_t __attribute__((vector_size(16)));
+template <int DIR>
+__global__ __launch_bounds__(kEqWG) void k_eq_zs_mfma(const float* __restrict__ in, int64_t in_stride, const float* __restrict__ wz, int split,
+                                                     float* __restrict__ z, int nc_pad, int64_t n, const float* __restrict__ pw1, int ntiles,
+                                                     float* __restrict__ agg) {
+    constexpr int kPitch = kStates + 1;
+    __shared__ __attribute__((aligned(16))) float tile[kEqWG * kPitch > kTriFloats ? kEqWG * kPitch : kTriFloats];
+    const int lane = threadIdx.x, sig = blockIdx.y, li = lane & 15, g = lane >> 4;
+    const int64_t tile_base = (int64_t)blockIdx.x * kTile;
+    const float* row = in + (int64_t)sig * in_stride;
+    const int frow = filter_row(sig, split);
+    const bool fast = tile_fast(row, tile_base, n);
+    float4 x[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int64_t at = tile_base + (int64_t)(16 * m + li) * kEqChunk + 16 * s + 4 * g;
+            x[m][s] = fast ? *reinterpret_cast<const float4*>(row + at) : load4(row, at, n);
+        }
+    const float* w = wz + (int64_t)frow * kWz;
+    float wb[16];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) wb[4 * s + e] = w[(16 * s + 4 * g + e) * 16 + li];
+    TabRegs tlo;
+    tab_fetch(tlo, pw1 + (int64_t)frow * kTri2, lane);
+    f32x4_t acc[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        acc[m] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const float xs[4] = {x[m][s].x, x[m][s].y, x[m][s].z, x[m][s].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(xs[e], wb[4 * s + e], acc[m], 0, 0, 0);
+        }
+    }
+    // D: column = state (lane & 15), row = chunk 16 m + 4 g + r
+    const int chunk0 = blockIdx.x * kEqWG;
+    if (li < kStates) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            *reinterpret_cast<float4*>(&z[((int64_t)sig * kStates + li) * nc_pad + chunk0 + 16 * m + 4 * g]) =
+                make_float4(acc[m][0], acc[m][1], acc[m][2], acc[m][3]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tile[(16 * m + 4 * g + r) * kPitch + li] = acc[m][r];
+        }
+    }
+    wave_lds_sync();
+    float st[kStates];
+#pragma unroll
+    for (int dd = 0; dd < kStates; ++dd) st[dd] = tile[lane * kPitch + dd];
+    wave_lds_sync();
+    tab_stash(tlo, tile, lane);
+    wave_lds_sync();
+    const int pos = DIR == EQ_FWD ? lane : kEqWG - 1 - lane;
+    wave_scan_tri<DIR == EQ_ADJ>(st, tile, pos);
+    if (pos == kEqWG - 1) {
+        const int wt = DIR == EQ_FWD ? (int)blockIdx.x : ntiles - 1 - (int)blockIdx.x;
+#pragma unroll
+        for (int dd = 0; dd < kStates; ++dd) agg[((int64_t)sig * kStates + dd) * kMaxTiles1 + wt] = st[dd];
+    }
+}
+void launch_eq_zs_mfma(int dir, const float* in, int64_t in_stride, const float* wz, int split, float* z, int nc_pad, int64_t n, int nsig,
+                       hipStream_t stream, const float* pw1, int ntiles, float* agg) {
+    const dim3 grid(ntiles, nsig), block(kEqWG);
+    if (dir == EQ_FWD) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_eq_zs_mfma<EQ_FWD>), grid, block, 0, stream, in, in_stride, wz, split, z, nc_pad, n, pw1, ntiles, agg);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_eq_zs_mfma<EQ_ADJ>), grid, block, 0, stream, in, in_stride, wz, split, z, nc_pad, n, pw1, ntiles, agg);
+}
+
 // ---- all-pole bank for the coefficient gradients ------------------------------------------------
 // filter f = 2k : w = u - a1 w1 - a2 w2 (1/A_k);  f = 2k+1 : w = u - (b1/b0) w1 - (b2/b0) w2 (b0/B_k: the 1/b0 of 1/B_k is
 // applied once, to the finished inner products - one multiply per sample and section less in all three kernels)

@@ -21,6 +21,8 @@ struct PrepArgs {
     float* powP_t; float* powP_m;  // all-pole scan tables
     float* pow1F_t; float* pow1F_m;  // in-wave scan tables (forward / adjoint cascade)
     float* pow1A_t; float* pow1A_m;
+    float* wzF_t; float* wzF_m;      // zero-state maps of the forward / adjoint cascade (eq1 only)
+    float* wzA_t; float* wzA_m;
     float* rc_fx;   // (bs, 24): reverberation band gains (times the wet/dry mix) and decay rates 10 d + 1 (fx bus), or nullptr
     float* fx_mix;  // (bs): wet/dry mix - 1 (reference mst/modules.py:420) unless MST_NO_RANGE_CHECK hands a value over
     int32_t* status;
@@ -63,6 +65,9 @@ void launch_cascade(int dir, bool run, const float* in, int64_t in_stride, float
 void launch_cascade_run_gc(const float* in, int64_t in_stride, float* out, int64_t out_stride, const float* rc, int split,
                            const float* s0, int nc_pad, int64_t n, int nsig, float* zs_comp, int nblk_comp, hipStream_t stream,
                            const float* pw1 = nullptr, int ntiles = 0, float* agg = nullptr, float* zp = nullptr);
+// zero-state pass of the SCAN1 path on the matrix pipe: chunk end states = W^T chunk (wz: filter rows x 64 x 16, made by k_prep)
+void launch_eq_zs_mfma(int dir, const float* in, int64_t in_stride, const float* wz, int split, float* z, int nc_pad, int64_t n, int nsig,
+                       hipStream_t stream, const float* pw1, int ntiles, float* agg);
 void launch_allpole_zs(const float* u, int64_t u_stride, const float* rc, int split, float* z, int nc_pad, int64_t n, int nsig,
                        hipStream_t stream);
 void launch_coefgrad(const float* u, int64_t u_stride, const float* g, int64_t g_stride, const float* rc, int split,

@@ -145,6 +145,7 @@ __device__ __forceinline__ void mat12_mul(const double* A, const double* B, doub
 // all-pole tables - two serial fp64 chains that would otherwise run back to back.
 __global__ __launch_bounds__(320) void k_prep(PrepArgs a) {
     __shared__ double mats[2][3][144];  // [fwd|adj][cur, tmp, acc]
+    __shared__ double wv[2][kEqChunk][12];  // A^t b, t < 64: response of the chunk's end state to an impulse t samples before its end
     __shared__ double dblk[2][2][kSections][4];  // diagonal 2x2 blocks of M and M^64, [set][fwd|adj][section]
     __shared__ float coef[32];
     const int row = blockIdx.x, tid = threadIdx.x;
@@ -266,6 +267,14 @@ __global__ __launch_bounds__(320) void k_prep(PrepArgs a) {
         else cascade_adj_step<double>(0.0, c64, st);
         for (int i = 0; i < 12; ++i) mats[which][0][i * 12 + col] = st[i];
     }
+    if (tid >= 32 && tid < 34) {  // b = the state one unit input sample leaves behind
+        const int which = tid - 32;
+        double st[12];
+        for (int i = 0; i < 12; ++i) st[i] = 0.0;
+        if (which == 0) cascade_step<double>(1.0, c64, st);
+        else cascade_adj_step<double>(1.0, c64, st);
+        for (int i = 0; i < 12; ++i) wv[which][0][i] = st[i];
+    }
     __syncthreads();
 
     const int grp = tid / 144, e = tid % 144;  // lanes 0..287 own one matrix element each
@@ -276,11 +285,31 @@ __global__ __launch_bounds__(320) void k_prep(PrepArgs a) {
     // cur = A^(kEqChunk) by log2(kEqChunk) squarings
     int cur = 0;
     for (int s = 1; s < kEqChunk; s <<= 1) {
+        // zero-state map by doubling: cur = A^s, so A^(t+s) b = cur (A^t b) for every t < s already made
+        if (a.eq1) {
+            for (int item = tid; item < 2 * s * 12; item += 320) {
+                const int g2 = item / (s * 12), t = (item / 12) % s, dd = item % 12;
+                double acc = 0.0;
+#pragma unroll
+                for (int q = 0; q < 12; ++q) acc = fma(mats[g2][cur][dd * 12 + q], wv[g2][t][q], acc);
+                wv[g2][t + s][dd] = acc;
+            }
+        }
         if (mat_lane) mat12_mul(mats[grp][cur], mats[grp][cur], mats[grp][cur ^ 1], e);
         __syncthreads();
         cur ^= 1;
     }
     if (mat_lane) pw[0 * 144 + e] = (float)mats[grp][cur][e];
+    if (a.eq1) {
+        // forward: an impulse at sample j of the chunk is 63 - j steps from its end; adjoint (reverse time): j steps
+        float* wzF = is_master ? a.wzF_m + (int64_t)mrow * kWz : a.wzF_t + (int64_t)row * kWz;
+        float* wzA = is_master ? a.wzA_m + (int64_t)mrow * kWz : a.wzA_t + (int64_t)row * kWz;
+        for (int item = tid; item < 2 * kWz; item += 320) {
+            const int g2 = item / kWz, j = (item % kWz) / 16, dd = item % 16;
+            const float v = dd < 12 ? (float)wv[g2][g2 == 0 ? kEqChunk - 1 - j : j][dd] : 0.0f;
+            (g2 == 0 ? wzF : wzA)[j * 16 + dd] = v;
+        }
+    }
     if (a.eq1) {
         // in-wave scans: M^(2^j), j = 0..kPow1-1 (M = one-chunk transition), by repeated squaring; what is kept of each power is
         // its six diagonal 2x2 blocks (the diagonal blocks of a power of a block-triangular matrix are the powers of its diagonal

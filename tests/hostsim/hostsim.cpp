@@ -5,3 +5,15 @@ thread_local dim3 t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
 thread_local BlockCtx* t_ctx = nullptr;
 thread_local unsigned t_tid = 0;
 }  // namespace hostsim
+
+// The spectrogram encoder (mst_cnn*.hip: bf16 MFMA kernels) is not built into the simulator library; its C-ABI entry points
+// exist so that the binding (which insists on every symbol of include/diffmst_hip.h) loads, and refuse to run.
+#include "../../include/diffmst_hip.h"
+extern "C" {
+size_t mst_spectrogram_tables_bytes(void) { return 0; }
+int mst_spectrogram_init_tables(void*, void*) { return 801; /* hipErrorNotSupported */ }
+int mst_spectrogram_forward(const float*, int32_t, int64_t, int32_t, int32_t, const void*, float*, void*) { return 801; }
+size_t mst_cnn14_workspace_bytes(const mst_cnn14_desc*) { return 0; }
+int mst_cnn14_forward(const mst_cnn14_desc*, const float*, const mst_cnn14_params*, float*, float*, void*, size_t, void*) { return 801; }
+int mst_cnn14_backward(const mst_cnn14_desc*, const float*, const mst_cnn14_params*, const float*, const mst_cnn14_grads*, void*, size_t, void*) { return 801; }
+}

@@ -219,6 +219,18 @@ static inline void __builtin_amdgcn_s_sleep(int) { std::this_thread::yield(); }
 static inline void __builtin_amdgcn_sched_barrier(int) {}
 
 // raw gfx950 transcendental builtins used by the kernels
+// v_mfma_f32_16x16x4_f32: D = A B + C for one wave; lane l supplies A[l & 15][l >> 4] and B[l >> 4][l & 15] and holds
+// D[(l >> 4) * 4 + r][l & 15], r < 4; a k-ordered fp32 FMA chain (cdna_hip_programming.md)
+typedef float hostsim_f32x4 __attribute__((vector_size(16)));
+static inline hostsim_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, hostsim_f32x4 c, int, int, int) {
+    const unsigned lane = hostsim::t_tid & 63u;
+    for (unsigned r = 0; r < 4; ++r)
+        for (unsigned k = 0; k < 4; ++k) {
+            const float av = hostsim::shfl_idx(a, k * 16u + (lane >> 4) * 4u + r), bv = hostsim::shfl_idx(b, k * 16u + (lane & 15u));
+            c[r] = fmaf(av, bv, c[r]);
+        }
+    return c;
+}
 static inline float __builtin_amdgcn_logf(float x) { return log2f(x); }
 static inline float __builtin_amdgcn_exp2f(float x) { return exp2f(x); }
 static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }

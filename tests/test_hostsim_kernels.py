@@ -55,7 +55,7 @@ def test_console_inwave_scan_eq_matches_three_kernel_eq(ranges):
     b = harness.console(ranges, tracks, tp, fp, mp, FULL, grad_mix=gmix, want_mixed=False, want_grad_tracks=True,
                         multipass_eq=True)
     assert a["status"] == 0 and b["status"] == 0
-    assert rel(a["mix"], b["mix"]) < 2e-6
+    assert rel(a["mix"], b["mix"]) < 5e-6  # round 3: the in-wave path takes its zero-state ends from the MFMA map (a 64-term dot product, not the recursion)
     assert rel(a["grad_tracks"], b["grad_tracks"]) < 5e-5  # two fp32 scan orders; each sits 1.6e-4 from float64
     assert rel(a["grad_tp"], b["grad_tp"]) < 1e-4
     assert rel(a["grad_mp"], b["grad_mp"]) < 1e-4
