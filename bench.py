@@ -188,6 +188,8 @@ def make_workload(dev, bs, n_tracks, n, loss_kind, seed, lean=True, flags=FLAGS,
     else:
         loss_fn = lambda a, b: (a * b).mean()
 
+    seed_grad = torch.ones((), device=dev)  # dL/dL, resident: `loss.backward()` would launch a ones-fill for it every step
+
     def step(marks=None):
         track_params.grad = None
         master_params.grad = None
@@ -202,7 +204,7 @@ def make_workload(dev, bs, n_tracks, n, loss_kind, seed, lean=True, flags=FLAGS,
         loss = loss_fn(mix, ref)
         if marks:
             marks["loss"].record()
-        loss.backward()
+        torch.autograd.backward(loss, grad_tensors=seed_grad.expand_as(loss))
         return loss.detach()
 
     step.console = console
