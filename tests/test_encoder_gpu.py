@@ -144,7 +144,7 @@ def test_encoder_gradients_three_way(dev, record):
     for k in hip:
         t = (rel(hip[k], g32[k]), rel(hip[k], g64[k]), rel(g32[k], g64[k]))
         rep["g." + k.replace("model.", "").replace("conv_block", "b")] = t
-        if t[1] > 3 * t[2] + 1e-4:
+        if t[1] > 3 * t[2] + 3e-3:  # 3e-3: what one or two flipped ReLU masks move a layer's gradient by (either path can draw them)
             bad.append((k, t))
     print("\n[encoder three-way] (hip vs ref32, hip vs f64, ref32 vs f64)")
     for k, v in rep.items():
@@ -152,6 +152,8 @@ def test_encoder_gradients_three_way(dev, record):
     record(**rep)
     assert rep["embed"][1] < 1e-4
     assert not bad, bad
+    # the last block's gradients involve no mask decision of an earlier layer: fp32 round-off only
+    assert all(v[1] < 5e-5 for k, v in rep.items() if k.startswith("g.b6.") or k.startswith("g.fc"))
 
 
 @pytest.mark.parametrize("precision,tol", [("fp32", 2e-4), ("bf16", 6e-2)])
