@@ -227,6 +227,74 @@ def time_steps(step, steps, warmup):
     return statistics.median(per), sum(per) / steps
 
 
+def conv_flops(frames, bins):
+    """Forward multiply-add flops of Cnn14's twelve 3x3 convolutions for ONE signal (reference mst/panns.py:135-198): 124.5 GF
+    at 513 x 1025 (262144 samples, STFT 2048 / 512)."""
+    ch = (1, 64, 128, 256, 512, 1024, 2048)
+    pools = ((2, 2), (4, 4), (2, 4), (2, 4), (2, 4), (2, 2))  # (frames, bins)
+    h, w, f = frames, bins, 0
+    for b in range(6):
+        f += 2 * 9 * h * w * (ch[b] * ch[b + 1] + ch[b + 1] * ch[b + 1])
+        h, w = h // pools[b][0], w // pools[b][1]
+    return f
+
+
+MFMA_PEAK_BF16_TF = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak
+
+
+def encoder_lines(dev):
+    """the spectrogram encoder (STFT front end + Cnn14 on MFMA), forward + backward, and the cfg #5 step."""
+    from mst.loss import AudioFeatureLoss
+    from mst.mixing import naive_random_mix
+    from mst.modules import AdvancedMixConsole, MixStyleTransferModel, SpectrogramEncoder, TransformerController
+    from mst.system import CommonStep
+
+    out = []
+    torch.manual_seed(3000)
+    ns = 34  # the 32 tracks + 2 reference-mix channels one cfg #5 mix sends through the encoders
+    enc = SpectrogramEncoder(embed_dim=512).to(dev).train()
+    x = (0.1 * torch.randn(ns, 1, N)).to(dev)
+    g = torch.randn(ns, 512, device=dev)
+
+    def enc_step():
+        enc.zero_grad(set_to_none=True)
+        enc(x).backward(g)
+
+    med, mean = time_steps(enc_step, 5, 2)
+    fl = 3.0 * ns * conv_flops(1 + N // 512, 1025)
+    out.append({"workload": f"SpectrogramEncoder + Cnn14 (embed 512) fwd+bwd, {ns} signals x {N} samples, bf16 MFMA operands / fp32 accumulate "
+                            "(reference mst/modules.py:740-806, mst/panns.py:126-209)",
+                "ms_per_step_median": med, "ms_per_step_mean": mean, "steps": 5, "signals_per_s": ns / (med * 1e-3),
+                "conv_TFLOPs_per_s": fl / (med * 1e-3) / 1e12, "frac_of_dense_bf16_mfma_peak": fl / (med * 1e-3) / 1e12 / MFMA_PEAK_BF16_TF,
+                "note": "flops = 3 x forward multiply-adds x 2 of the twelve convolutions; time = whole encoder step incl. STFT, BatchNorm, pooling, "
+                        "weight re-layout; per-kernel MFMA counters: profiles/round3_encoder_counters.md"})
+    del enc, x, g
+    torch.cuda.empty_cache()
+    # cfg #5 on one GPU, one mix per step: full step with the real model structure (configs/models/naive+feat.yaml sizes)
+    torch.manual_seed(3001)
+    model = MixStyleTransferModel(SpectrogramEncoder(embed_dim=512), SpectrogramEncoder(embed_dim=512),
+                                  TransformerController(512, 27, 25, 26, num_layers=12, nhead=8)).to(dev).train()
+    step = CommonStep(model, AdvancedMixConsole(SR, materialize_mixed_tracks=False, validate="deferred", param_dicts="lazy"), naive_random_mix,
+                      AudioFeatureLoss(AF_WEIGHTS, SR), generate_mix=True, active_eq_epoch=0, active_compressor_epoch=0,
+                      active_fx_bus_epoch=1000, active_master_bus_epoch=0)
+    tracks = (0.05 * torch.randn(1, 32, N)).to(dev)
+    batch = (tracks, None, None, torch.zeros(1, 32, dtype=torch.bool, device=dev), None, ["a"])
+
+    def sys_step():
+        model.zero_grad(set_to_none=True)
+        loss, _ = step(batch, train=True)
+        loss.backward()
+
+    med, mean = time_steps(sys_step, 5, 2)
+    out.append({"workload": "cfg #5 step on ONE GPU, batch 1: System.common_step order (two naive_random_mix reference mixes, peak normalise, "
+                            "A/B split) + MixStyleTransferModel (2 x SpectrogramEncoder/Cnn14 on MFMA for 32 tracks + 2 mix channels of 131072 "
+                            "samples, 12-layer TransformerController) + AdvancedMixConsole 32 tracks + AudioFeatureLoss, fwd+bwd to every weight",
+                "ms_per_step_median": med, "ms_per_step_mean": mean, "steps": 5, "mixes_per_s": 1.0 / (med * 1e-3)})
+    del model, step, tracks
+    torch.cuda.empty_cache()
+    return out
+
+
 def secondary_lines(dev):
     out = []
     specs = [
@@ -240,6 +308,7 @@ def secondary_lines(dev):
         ("cfg #1: BasicMixConsole (gain + pan + bus sum) 4 tracks x 65536, batch 2, fwd+bwd",
          dict(bs=2, n_tracks=4, n=65536, loss_kind="none", lean=True, basic=True), False, 50, 10),
     ]
+    out.extend(encoder_lines(dev))
     for name, kw, materialised, steps, warm in specs:
         step = make_workload(dev, seed=2000, **kw)
         med, mean = time_steps(step, steps, warm)
