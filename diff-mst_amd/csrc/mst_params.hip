@@ -7,6 +7,9 @@
 // :353-460; biquad design + compressor constants + pan law = dasp-pytorch 0.0.1.
 #include "mst_kernels.h"
 
+#ifndef MST_PREP_STOP
+#define MST_PREP_STOP 0  // timing diagnostics only (wrong results): k_prep returns after stage 1 / 2 / 3
+#endif
 namespace mst {
 
 // ---------------------------------------------------------------------------------------------
@@ -254,6 +257,9 @@ __global__ __launch_bounds__(320) void k_prep(PrepArgs a) {
         rc[RC_AP + 3 * tid + 2] = 1.0f / b0;
     }
 
+#if MST_PREP_STOP == 1
+    return;
+#endif
     // ---- one-sample transition matrices of the forward and the adjoint cascade (zero input)
     double c64[30];
     for (int i = 0; i < 30; ++i) c64[i] = (double)coef[i];
@@ -300,6 +306,9 @@ __global__ __launch_bounds__(320) void k_prep(PrepArgs a) {
         cur ^= 1;
     }
     if (mat_lane) pw[0 * 144 + e] = (float)mats[grp][cur][e];
+#if MST_PREP_STOP == 2
+    return;
+#endif
     if (a.eq1) {
         // forward: an impulse at sample j of the chunk is 63 - j steps from its end; adjoint (reverse time): j steps
         float* wzF = is_master ? a.wzF_m + (int64_t)mrow * kWz : a.wzF_t + (int64_t)row * kWz;
@@ -339,6 +348,9 @@ __global__ __launch_bounds__(320) void k_prep(PrepArgs a) {
                 cur ^= 1;
             }
         }
+#if MST_PREP_STOP == 3
+        return;
+#endif
         // Dp[k][q] = D_k^(q+1), q < 16 (the in-row fix-up of the scans): 24 (set, cascade, section) blocks x 16 powers, one
         // (block, power) per lane and pass, by binary exponentiation in fp64 (at most 7 products of 2x2 matrices)
         __syncthreads();
