@@ -647,9 +647,8 @@ static int cnn_forward_t(const mst_cnn14_desc* d, const CnnPlan& p, const float*
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv1<T>), dim3(tiles), dim3(256), 0, s, (const float*)x_in, (const float*)(ws + p.w1), raw,
                                    d->training ? part : nullptr, p.n, H, W);
             } else {
-                tiles = conv_pixel_tiles(p.n, H, W);
                 ConvArgs ca{x_in, ws + p.wf[l], raw, d->training ? part : nullptr, p.n, H, W, Cin, C, 0, nullptr};
-                launch_conv3x3(prec, ca, s, (float*)(ws + p.kpart), p.kpart_bytes);
+                tiles = launch_conv3x3(prec, ca, s, (float*)(ws + p.kpart), p.kpart_bytes);
             }
             float* stat = (float*)(ws + p.stat[l]);
             double* cs = (double*)(ws + p.colsum);
