@@ -6,3 +6,6 @@ timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -4
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
 bash tools/pmc_passes.sh ${1:-r3} > gpurun_out/${1:-r3}_passes.log 2>&1; tail -3 gpurun_out/${1:-r3}_passes.log
 cd $R && timeout 900 python bench.py > gpurun_out/${1:-r3}_bench.log 2>&1; tail -c 300 gpurun_out/${1:-r3}_bench.log
+# the spectrogram encoder: per-kernel table and MFMA / LDS counters (16 signals x 262144, bf16)
+cd $R && bash tools/encoder_prof.sh 16 262144 bf16 > gpurun_out/${1:-r3}_encoder_prof.txt 2>&1
+cd $R && bash tools/encoder_pmc.sh > gpurun_out/${1:-r3}_encoder_pmc.txt 2>&1; tail -3 gpurun_out/${1:-r3}_encoder_pmc.txt
