@@ -56,7 +56,9 @@ def test_console_inwave_scan_eq_matches_three_kernel_eq(ranges):
                         multipass_eq=True)
     assert a["status"] == 0 and b["status"] == 0
     assert rel(a["mix"], b["mix"]) < 5e-6  # round 3: the in-wave path takes its zero-state ends from the MFMA map (a 64-term dot product, not the recursion)
-    assert rel(a["grad_tracks"], b["grad_tracks"]) < 5e-5  # two fp32 scan orders; each sits 1.6e-4 from float64
+    # two fp32 evaluation orders (round 3: MFMA zero-state map vs recursion, in both adjoint cascades); on the GPU both sit
+    # 1.3e-5 .. 3.5e-5 from float64 at 131072 samples and 6e-6 from each other (tools/dbg_gtracks_paths.py); this short clip: 1.0e-4
+    assert rel(a["grad_tracks"], b["grad_tracks"]) < 2e-4
     assert rel(a["grad_tp"], b["grad_tp"]) < 1e-4
     assert rel(a["grad_mp"], b["grad_mp"]) < 1e-4
 
