@@ -223,12 +223,22 @@ static inline void __builtin_amdgcn_sched_barrier(int) {}
 // D[(l >> 4) * 4 + r][l & 15], r < 4; a k-ordered fp32 FMA chain (cdna_hip_programming.md)
 typedef float hostsim_f32x4 __attribute__((vector_size(16)));
 static inline hostsim_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, hostsim_f32x4 c, int, int, int) {
-    const unsigned lane = hostsim::t_tid & 63u;
+    // one exchange for the whole instruction (a, b packed into the lane's 64-bit slot): two rendezvous instead of 64
+    hostsim::BlockCtx* ctx = hostsim::t_ctx;
+    const unsigned wave = hostsim::t_tid >> 6, lane = hostsim::t_tid & 63u, base = wave << 6;
+    float ab[2] = {a, b};
+    uint64_t bits;
+    memcpy(&bits, ab, 8);
+    ctx->xchg[hostsim::t_tid] = bits;
+    ctx->wave_bar[wave]->arrive_and_wait();
     for (unsigned r = 0; r < 4; ++r)
         for (unsigned k = 0; k < 4; ++k) {
-            const float av = hostsim::shfl_idx(a, k * 16u + (lane >> 4) * 4u + r), bv = hostsim::shfl_idx(b, k * 16u + (lane & 15u));
-            c[r] = fmaf(av, bv, c[r]);
+            float pa[2], pb[2];
+            memcpy(pa, &ctx->xchg[base + k * 16u + (lane >> 4) * 4u + r], 8);
+            memcpy(pb, &ctx->xchg[base + k * 16u + (lane & 15u)], 8);
+            c[r] = fmaf(pa[0], pb[1], c[r]);
         }
+    ctx->wave_bar[wave]->arrive_and_wait();
     return c;
 }
 static inline float __builtin_amdgcn_logf(float x) { return log2f(x); }
