@@ -613,9 +613,17 @@ __global__ __launch_bounds__(64) void k_mrstft_rowsums(LossArgs a) {
     const int tid = threadIdx.x, row = blockIdx.x, res = blockIdx.y;
     const float* p = a.part + a.part_off[res] + (int64_t)row * a.n_groups[res] * 4;
     double s[4] = {0, 0, 0, 0};
-    for (int g = tid; g < a.n_groups[res]; g += 64) {
-        const float4 v = *reinterpret_cast<const float4*>(p + (int64_t)g * 4);
-        s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+    const int ng = a.n_groups[res];
+    for (int g0 = tid; g0 < ng; g0 += 256) {  // four strips in flight per lane, folded in ascending order
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int g = g0 + 64 * u;
+            v[u] = g < ng ? *reinterpret_cast<const float4*>(p + (int64_t)g * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (g0 + 64 * u < ng) { s[0] += v[u].x; s[1] += v[u].y; s[2] += v[u].z; s[3] += v[u].w; }
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q)
@@ -635,17 +643,43 @@ __global__ __launch_bounds__(64) void k_mrstft_totals(LossArgs a) {
         a.totals[tid] = t;
     }
 }
+__device__ __forceinline__ void write_coef(const LossArgs& a, int i, int res, double c_sc) {
+    float* c = a.coef + (int64_t)i * 4;
+    c[0] = (float)(c_sc / a.n_res);
+    c[1] = (float)(a.w_log / a.count[res] / a.n_res);
+    c[2] = (float)(a.w_lin / a.count[res] / a.n_res);
+    c[3] = 0.f;
+}
 // stage 2: loss scalar + per-row backward coefficients (without dL/dloss, applied by k_scale_coef)
 __global__ __launch_bounds__(64) void k_mrstft_final(LossArgs a) {
     __shared__ double rs[kMaxRes][4];
+    __shared__ double ratio[kMaxRes * 64];  // per (resolution, row): sqrt(sum |d|^2) / sqrt(sum |Y|^2)
+    __shared__ float4 srow[kMaxRes * 64];   // the row sums, fetched by all lanes at once
     const int tid = threadIdx.x;
+    // A lane per resolution walking its rows paid one L2 round trip per row plus a ~150-instruction fp64 sqrt / sqrt / divide chain
+    // (7.2 us for 16 rows).  One lane per (resolution, row) fetches and takes the roots side by side; the fold over the rows below
+    // reads LDS and keeps its fixed order (bitwise the same loss).
+    const bool staged = a.n_res * a.rows <= kMaxRes * 64;
+    for (int i = tid; i < a.n_res * a.rows; i += 64) {
+        const float4 sm = *reinterpret_cast<const float4*>(a.sums + (int64_t)i * 4);
+        if (staged) srow[i] = sm;
+        if (a.sc_per_example) {
+            const double s0 = sqrt((double)sm.x), s1 = sqrt((double)sm.y);
+            if (staged) ratio[i] = s0 / s1;
+            double c_sc = a.w_sc / ((double)a.rows * s0 * s1);
+            if (!(c_sc == c_sc) || c_sc > 1e30) c_sc = 0.0;  // identical signals: 0/0 -> no SC gradient
+            write_coef(a, i, i / a.rows, c_sc);
+        }
+    }
+    __syncthreads();
     if (tid < a.n_res) {
         const int res = tid;
         double tot[4] = {0, 0, 0, 0}, sc_acc = 0.0;
         for (int row = 0; row < a.rows; ++row) {
-            const float* sm = a.sums + ((int64_t)res * a.rows + row) * 4;
-            for (int q = 0; q < 4; ++q) tot[q] += (double)sm[q];
-            sc_acc += sqrt((double)sm[0]) / sqrt((double)sm[1]);
+            const int i = res * a.rows + row;
+            const float4 sm = staged ? srow[i] : *reinterpret_cast<const float4*>(a.sums + (int64_t)i * 4);
+            tot[0] += (double)sm.x; tot[1] += (double)sm.y; tot[2] += (double)sm.z; tot[3] += (double)sm.w;
+            if (a.sc_per_example) sc_acc += staged ? ratio[i] : sqrt((double)sm.x) / sqrt((double)sm.y);  // same roots, same quotient
         }
         for (int q = 0; q < 4; ++q) rs[res][q] = tot[q];
         if (a.gtotals) {  // batch-global ratio over the rows of every rank
@@ -661,18 +695,12 @@ __global__ __launch_bounds__(64) void k_mrstft_final(LossArgs a) {
         for (int res = 0; res < a.n_res; ++res) total += rs[res][3];
         a.loss[0] = (float)(total / a.n_res);
     }
+    if (a.sc_per_example) return;  // coefficients written in the staging loop
     for (int i = tid; i < a.n_res * a.rows; i += 64) {
         const int res = i / a.rows;
-        const float* sm = a.sums + (int64_t)i * 4;
-        double c_sc;
-        if (a.sc_per_example) c_sc = a.w_sc / ((double)a.rows * sqrt((double)sm[0]) * sqrt((double)sm[1]));
-        else c_sc = a.w_sc * (double)a.world / (sqrt(rs[res][0]) * sqrt(rs[res][1]));  // world: see mst_mrstft_forward_finish
+        double c_sc = a.w_sc * (double)a.world / (sqrt(rs[res][0]) * sqrt(rs[res][1]));  // world: see mst_mrstft_forward_finish
         if (!(c_sc == c_sc) || c_sc > 1e30) c_sc = 0.0;  // identical signals: 0/0 -> no SC gradient
-        float* c = a.coef + (int64_t)i * 4;
-        c[0] = (float)(c_sc / a.n_res);
-        c[1] = (float)(a.w_log / a.count[res] / a.n_res);
-        c[2] = (float)(a.w_lin / a.count[res] / a.n_res);
-        c[3] = 0.f;
+        write_coef(a, i, res, c_sc);
     }
 }
 }  // namespace mst

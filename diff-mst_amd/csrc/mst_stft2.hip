@@ -63,6 +63,14 @@ struct FrameLoader {
     }
 };
 
+// |X| and 1 / |X| of the loss epilogues: the hardware's 1-ulp v_sqrt_f32 / v_rcp_f32 instead of the correctly rounded library
+// sequences (10 and 11 instructions each; the arguments are clamped to >= eps, far from the denormal range those sequences guard)
+#ifndef MST_STFT2_PRECISE_MAG
+#define MST_STFT2_PRECISE_MAG 0
+#endif
+__device__ __forceinline__ float mag_sqrt(float v) { return MST_STFT2_PRECISE_MAG ? sqrtf(v) : __builtin_amdgcn_sqrtf(v); }
+__device__ __forceinline__ float mag_rcp(float v) { return MST_STFT2_PRECISE_MAG ? 1.0f / v : __builtin_amdgcn_rcpf(v); }
+
 // periodic Hann window value of element lane + LG t.  n_fft <= 2048: from the table (same fp32 values as torch.hann_window);
 // 8192: 0.5 - 0.5 cos(2 pi i / N) with the cosine taken from the product W_N^lane W_32^t that the radix-2 split needs anyway
 template <int N>
@@ -136,8 +144,8 @@ __global__ __launch_bounds__(FftPlan<N>::LG, (N == 8192 ? MST_STFT2_W8192 : 1)) 
         for (int k = lane; k <= ((MST_STFT2_ABLATE & 1) ? lane : N / 2); k += LG) {
             float2 X, Y;
             L::split(buf, k, X, Y);
-            const float xm = sqrtf(fmaxf(X.x * X.x + X.y * X.y, a.eps));
-            const float ym = sqrtf(fmaxf(Y.x * Y.x + Y.y * Y.y, a.eps));
+            const float xm = mag_sqrt(fmaxf(X.x * X.x + X.y * X.y, a.eps));
+            const float ym = mag_sqrt(fmaxf(Y.x * Y.x + Y.y * Y.y, a.eps));
             const float d = ym - xm;
             s1 = fmaf(d, d, s1);
             s2 = fmaf(ym, ym, s2);
@@ -185,13 +193,14 @@ __device__ __forceinline__ float2 cotangent(const float2 (*buf)[FftShape<N>::SLO
     float2 X, Y;
     FrameLoader<N>::split(buf, k, X, Y);
     const float p2 = X.x * X.x + X.y * X.y;
-    const float xm = sqrtf(fmaxf(p2, eps));
-    const float ym = sqrtf(fmaxf(Y.x * Y.x + Y.y * Y.y, eps));
+    const float xm = mag_sqrt(fmaxf(p2, eps));
+    const float ym = mag_sqrt(fmaxf(Y.x * Y.x + Y.y * Y.y, eps));
     float g = coef[0] * (xm - ym);
     const float dl = __builtin_amdgcn_logf(xm) - __builtin_amdgcn_logf(ym);
-    g += coef[1] * ((dl > 0.f) - (dl < 0.f)) / xm;
+    const float rx = mag_rcp(xm);
+    g += coef[1] * ((dl > 0.f) - (dl < 0.f)) * rx;
     g += coef[2] * ((xm > ym) - (xm < ym));
-    const float s = (p2 >= eps) ? g / xm : 0.0f;  // through sqrt(clamp(|X|^2, eps)): zero below the clamp
+    const float s = (p2 >= eps) ? g * rx : 0.0f;  // through sqrt(clamp(|X|^2, eps)): zero below the clamp
     return make_float2(s * X.x, s * X.y);
 }
 
