@@ -266,6 +266,198 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs a) {  // 2: up t
 }
 
 // =====================================================================================================================
+// k_conv_igemm3 (bf16): k_conv_igemm's GEMM with its tiles brought in by LDS-direct loads (global_load_lds_dwordx4: 1 KiB per wave
+// instruction, no staging registers, no ds_write pass) into a ring of NS stages, so that NS - 2 whole K tiles stay in flight
+// ACROSS the barrier of the tile being multiplied (k_conv_igemm: one tile, parked in 32 registers; the ablation that showed the
+// load path - not the matrix pipe - binding it is in DESIGN 9.3).
+//   * The LDS image of such a load is lane-linear (wave-uniform base + 16 lane): a tile is rows of 32 of K = four 16-byte slots,
+//     lane l of a wave instruction fills slot l & 3 of row base + (l >> 2).  The XOR swizzle of the fragment reads therefore sits on
+//     the SOURCE address: slot s of a row receives K chunk s ^ ((row >> 1) & 3), the involution Mma<bf16_t, 32>::off() reads with.
+//   * Taps outside the image fetch from a 64-byte zero page instead of the activations.
+//   * hipcc orders every ds_read it can see behind ALL outstanding LDS-direct loads (s_waitcnt vmcnt(0)), which would empty the ring
+//     each step; the fragment reads are therefore asm statements with the counted waits written out: vmcnt((NS - 2) G) (G loads per
+//     lane and tile: this wave's share of tile s has landed) -> s_barrier (everyone's share has; everyone is done reading tile
+//     s - 1) -> issue tile s + NS - 1 into the slot of tile s - 1 -> read fragments -> lgkmcnt(0) -> MFMAs.  One barrier per K tile.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void glb_void_t;
+__device__ uint4 g_conv_zero[4];  // never written
+
+template <int OFF> __device__ __forceinline__ u32x4 lds_read16(uint32_t addr) {
+    u32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+template <int N, int STRIDE, int I = 0> __device__ __forceinline__ void lds_read_frags(u32x4 (&r)[N], uint32_t addr) {
+    r[I] = lds_read16<I * STRIDE>(addr);
+    if constexpr (I + 1 < N) lds_read_frags<N, STRIDE, I + 1>(r, addr);
+}
+// after the s_waitcnt statement: the consumers of r must not be scheduled above it (volatile asm statements keep their order)
+template <int N> __device__ __forceinline__ void lds_frags_landed(u32x4 (&r)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) asm volatile("" : "+v"(r[i]));
+}
+#ifndef MST_CONV_GLDS_STAGES
+#define MST_CONV_GLDS_STAGES 3
+#endif
+#ifndef MST_CONV_XCD_REMAP
+#define MST_CONV_XCD_REMAP 1  // pixel tiles in eight contiguous ranges, one per XCD (neighbouring image rows share an L2)
+#endif
+template <int BC, int BP, int NS>
+__global__ __launch_bounds__(256, 2) void k_conv_igemm3(ConvArgs a) {
+    constexpr int BK = 32, MT = BC / 32, NT = BP / 32;
+    constexpr int XG = BP * 4 / 256, WG = BC * 4 / 256, G = XG + WG;  // 1 KiB wave instructions per lane and tile
+    constexpr int SW = BC * BK, SX = BP * BK;                           // elements per stage
+    static_assert(NS >= 3 && NS <= 6, "ring depth");
+    __shared__ __attribute__((aligned(1024))) bf16_t sW[NS * SW];
+    __shared__ __attribute__((aligned(1024))) bf16_t sX[NS * SX];
+    __shared__ float red[2][BC][2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wy = wave >> 1, wx = wave & 1;
+    const int g = lane >> 4, li = lane & 15;
+    const int H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout;
+    int bx = blockIdx.x;
+    if (MST_CONV_XCD_REMAP) {  // workgroup ids go round-robin over the 8 XCDs: give XCD j the j-th contiguous range of tiles
+        const int gx = gridDim.x, q = gx >> 3, r = gx & 7, xcd = bx & 7, idx = bx >> 3;
+        bx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int64_t P = (int64_t)a.N * H * W, p0 = (int64_t)bx * BP;
+    const int co0 = blockIdx.y * BC;
+    const bf16_t* __restrict__ in = reinterpret_cast<const bf16_t*>(a.in);
+    const bf16_t* __restrict__ w = reinterpret_cast<const bf16_t*>(a.w);
+    const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_conv_zero);
+
+    // loader: wave instruction (q, wave) fills rows [(4 q + wave) 16, +16) of the tile
+    unsigned xmask[XG];
+    int64_t xbase[XG], wbase[WG];
+#pragma unroll
+    for (int q = 0; q < XG; ++q) {
+        const int row = (q * 4 + wave) * 16 + (lane >> 2), kc = (lane & 3) ^ ((row >> 1) & 3);
+        const int64_t p = p0 + row;
+        const bool ok = p < P;
+        const int64_t pp = ok ? p : 0;
+        const int r = (int)(pp % ((int64_t)H * W)), xh = r / W, xw = r % W;
+        unsigned m = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+            if (ok && (unsigned)(xh + t / 3 - 1) < (unsigned)H && (unsigned)(xw + t % 3 - 1) < (unsigned)W) m |= 1u << t;
+        xmask[q] = m;
+        xbase[q] = pp * Cin + kc * 8;
+    }
+#pragma unroll
+    for (int q = 0; q < WG; ++q) {
+        const int row = (q * 4 + wave) * 16 + (lane >> 2), kc = (lane & 3) ^ ((row >> 1) & 3);
+        wbase[q] = (int64_t)(co0 + row) * 9 * Cin + kc * 8;
+    }
+    int ksteps = Cin / BK, steps = 9 * ksteps, itap = 0, ikq = 0, kq0 = 0;
+    if (a.csplit) {  // this workgroup's slice of K
+        itap = blockIdx.z / a.csplit;
+        ksteps /= a.csplit;
+        kq0 = (blockIdx.z % a.csplit) * ksteps;
+        steps = ksteps;
+    }
+    auto issue = [&](int stage) {  // tile (itap, ikq) -> ring slot `stage`; advances the issue cursor
+        const int c0 = (kq0 + ikq) * BK;
+        const int64_t shift = ((int64_t)(itap / 3 - 1) * W + (itap % 3 - 1)) * Cin + c0;
+#pragma unroll
+        for (int q = 0; q < XG; ++q) {
+            const bf16_t* src = (xmask[q] >> itap) & 1u ? in + xbase[q] + shift : zero;
+            __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)(uintptr_t)(sX + stage * SX + (q * 4 + wave) * 512), 16, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < WG; ++q) {
+            const bf16_t* src = w + wbase[q] + (int64_t)itap * Cin + c0;
+            __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)(uintptr_t)(sW + stage * SW + (q * 4 + wave) * 512), 16, 0, 0);
+        }
+        if (++ikq == ksteps) { ikq = 0; ++itap; }
+    };
+    // fragment addresses (bytes): row = wy BC/2 + 16 m + li resp. wx 64 + 16 n + li; (row >> 1) & 3 = (li >> 1) & 3 for every m, n
+    const uint32_t fsw = (uint32_t)(((g ^ ((li >> 1) & 3)) << 3) * 2);
+    const uint32_t aaddr0 = (uint32_t)(uintptr_t)sW + (uint32_t)((wy * (BC / 2) + li) * BK * 2) + fsw;
+    const uint32_t baddr0 = (uint32_t)(uintptr_t)sX + (uint32_t)((wx * (BP / 2) + li) * BK * 2) + fsw;
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (s < steps) issue(s);
+    int cur = 0;
+    for (int s = 0; s < steps; ++s) {
+        // tiles issued beyond s: min(NS - 2, steps - 1 - s); the short tail drains everything
+        if (steps - 1 - s >= NS - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * G) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (s + NS - 1 < steps) issue(cur == 0 ? NS - 1 : cur - 1);
+        const uint32_t aaddr = aaddr0 + (uint32_t)(cur * SW * 2), baddr = baddr0 + (uint32_t)(cur * SX * 2);
+        u32x4 rb[NT], ra[MT];
+        lds_read_frags<NT, 16 * BK * 2>(rb, baddr);
+        lds_read_frags<MT, 16 * BK * 2>(ra, aaddr);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        lds_frags_landed(rb);
+        lds_frags_landed(ra);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ra[m]), __builtin_bit_cast(bf16x8, rb[n]), acc[m][n], 0, 0, 0);
+        cur = cur + 1 == NS ? 0 : cur + 1;
+    }
+    // ---- epilogue (as k_conv_igemm): D row = channel (lane >> 4) * 4 + r, D column = pixel lane & 15
+    if (a.csplit) {
+        float* __restrict__ kp = a.kpart + (int64_t)blockIdx.z * P * Cout;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int64_t p = p0 + wx * (BP / 2) + n * 16 + li;
+            if (p < P) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m) store4(kp + p * Cout + co0 + wy * (BC / 2) + m * 16 + g * 4, acc[m][n]);
+            }
+        }
+        return;
+    }
+    bf16_t* __restrict__ out = reinterpret_cast<bf16_t*>(a.out);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int64_t p = p0 + wx * (BP / 2) + n * 16 + li;
+        if (p < P) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) store4(out + p * Cout + co0 + wy * (BC / 2) + m * 16 + g * 4, acc[m][n]);
+        }
+    }
+    if (a.part) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    s1 += acc[m][n][r];
+                    s2 = fmaf(acc[m][n][r], acc[m][n][r], s2);
+                }
+#pragma unroll
+                for (int msk = 1; msk < 16; msk <<= 1) {
+                    s1 += __shfl_xor(s1, msk);
+                    s2 += __shfl_xor(s2, msk);
+                }
+                if (li == 0) {
+                    red[wx][wy * (BC / 2) + m * 16 + g * 4 + r][0] = s1;
+                    red[wx][wy * (BC / 2) + m * 16 + g * 4 + r][1] = s2;
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < BC) {
+            float* o = a.part + ((int64_t)bx * Cout + co0 + tid) * 2;
+            o[0] = red[0][tid][0] + red[1][tid][0];
+            o[1] = red[0][tid][1] + red[1][tid][1];
+        }
+    }
+}
+
+// =====================================================================================================================
 // k_conv_igemm2 (bf16, Cout % 128 == 0, Cin % 64 == 0): the same GEMM with the L1 traffic cut to 0.44x.  Ablations of k_conv_igemm
 // (-DMST_CONV_ABLATE) showed what binds it: with the MFMAs and LDS reads removed it still takes 337 of its 367 us, without its
 // global loads 211 - every K step pulls 32 KB through a 64 B/clk L1 for 512 MFMA cycles.  Here
@@ -463,6 +655,13 @@ static constexpr bool conv2_enabled() {
     return true;
 #endif
 }
+static constexpr bool conv3_enabled() {
+#ifdef MST_CONV_NO_GLDS
+    return false;  // A/B switch: register-staged k_conv_igemm
+#else
+    return true;
+#endif
+}
 static int conv_csplit(int N, int H, int W, int Cin, int Cout) {
     const int tiles = conv_pixel_tiles(N, H, W), bc = Cout % 128 == 0 ? 128 : 64, wgs = tiles * (Cout / bc);
     if (wgs >= 512) return 0;
@@ -485,18 +684,28 @@ int launch_conv3x3(int precision, ConvArgs a, hipStream_t s, float* kpart, size_
     }
     const unsigned gz = a.csplit ? 9 * a.csplit : 1;
     const int tiles2 = (int)(((int64_t)a.N * a.H * a.W + kConvPix2 - 1) / kConvPix2);
-    // the fat-tile kernel pays where it fills the chip twice over (measured at 16 signals: 1024+ workgroups -11..-16 %, 256: +35 %)
-    if (precision == 0 && !a.csplit && a.Cout % 128 == 0 && a.Cin % 64 == 0 && conv2_enabled() && (int64_t)tiles2 * (a.Cout / 128) >= 1024) {
+#ifndef MST_CONV_FAT_MIN
+#define MST_CONV_FAT_MIN 1024  // workgroups from which the 256-pixel tile is used
+#endif
+    const bool fat_ok = precision == 0 && !a.csplit && a.Cout % 128 == 0 && (int64_t)tiles2 * (a.Cout / 128) >= MST_CONV_FAT_MIN;
+    if (fat_ok && conv3_enabled()) {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_igemm3<128, 256, MST_CONV_GLDS_STAGES>), dim3(tiles2, a.Cout / 128), dim3(256), 0, s, a);
+        return tiles2;
+    }
+    // (register-staged predecessor of the above: measured at 16 signals 1024+ workgroups -11..-16 % against k_conv_igemm, 256: +35 %)
+    if (fat_ok && a.Cin % 64 == 0 && conv2_enabled() && !conv3_enabled()) {
         hipLaunchKernelGGL(k_conv_igemm2, dim3(tiles2, a.Cout / 128), dim3(256), 0, s, a);
         return tiles2;
     }
     if (a.Cout % 128 == 0) {
         const dim3 grid(tiles, a.Cout / 128, gz);
-        if (precision == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_igemm<bf16_t, 128, 64>), grid, dim3(256), 0, s, a);
+        if (precision == 0 && conv3_enabled()) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_igemm3<128, 128, MST_CONV_GLDS_STAGES>), grid, dim3(256), 0, s, a);
+        else if (precision == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_igemm<bf16_t, 128, 64>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_igemm<float, 128, 32>), grid, dim3(256), 0, s, a);
     } else {
         const dim3 grid(tiles, a.Cout / 64, gz);
-        if (precision == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_igemm<bf16_t, 64, 32>), grid, dim3(256), 0, s, a);
+        if (precision == 0 && conv3_enabled()) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_igemm3<64, 128, MST_CONV_GLDS_STAGES>), grid, dim3(256), 0, s, a);
+        else if (precision == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_igemm<bf16_t, 64, 32>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_igemm<float, 64, 32>), grid, dim3(256), 0, s, a);
     }
     if (a.csplit) {
