@@ -861,6 +861,138 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(WgradArgs a) {
                 o[(int64_t)(co0 + wy * WCO + m * 16 + g * 4 + r) * ncol + ci0 + wx * WCI + n * 16 + li] = acc[m][n][r];
 }
 
+// =====================================================================================================================
+// k_conv_wgrad3 (bf16, Cin > 1): the weight-gradient GEMM on the loader of k_conv_igemm3 and gfx950's transposing LDS read.
+// K = pixels is the strided axis of both NHWC operands.  A stage holds 32 pixels of dY and of the (tap-shifted) X as they lie in
+// memory, cut into [32 pixels][16 channels] subtiles of 1 KiB - one LDS-direct wave instruction each (lane l brings half a row:
+// pixel l >> 1, channels 8 (l & 1) .. +7).  ds_read_b64_tr_b16 then hands lane (i, kg) of a fragment the four pixels 4 kg .. 4 kg + 3
+// of channel i (each lane of a 16-lane group addresses one 8-byte piece of a [4][16] block, the hardware transposes:
+// tools/ubench/tr_read.hip); a second read 16 pixels further on fills K slots 4 .. 7.  Which pixel sits in which K slot is free as
+// long as both operands agree - with (4 kg + j, 16 + 4 kg + j) every read sweeps a contiguous 512 bytes.  Two 8-byte reads per
+// fragment instead of eight 2-byte gathers and their packing; ring, waits and barrier as in k_conv_igemm3.
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+template <int OFF> __device__ __forceinline__ u32x2 lds_read_tr8(uint32_t addr) {
+    u32x2 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+template <int N, int I = 0> __device__ __forceinline__ void lds_read_tr_frags(u32x2 (&lo)[N], u32x2 (&hi)[N], uint32_t addr) {
+    lo[I] = lds_read_tr8<I * 1024>(addr);
+    hi[I] = lds_read_tr8<I * 1024 + 512>(addr);
+    if constexpr (I + 1 < N) lds_read_tr_frags<N, I + 1>(lo, hi, addr);
+}
+template <int N> __device__ __forceinline__ void lds_frags_landed(u32x2 (&r)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) asm volatile("" : "+v"(r[i]));
+}
+template <int BCO, int BCI, int NS>
+__global__ __launch_bounds__(256, 2) void k_conv_wgrad3(WgradArgs a) {
+    constexpr int BKP = kWgradPix, WCO = BCO / 2, WCI = BCI / 2, MT = WCO / 16, NT = WCI / 16;
+    constexpr int YG = BCO / 64, XG = BCI / 64, G = YG + XG;  // 1 KiB subtiles per lane and stage
+    constexpr int SY = BCO * BKP, SX = BCI * BKP;             // elements per stage
+    static_assert(BKP == 32 && NS >= 3 && NS <= 6, "stage shape");
+    __shared__ __attribute__((aligned(1024))) bf16_t sY[NS * SY];
+    __shared__ __attribute__((aligned(1024))) bf16_t sX[NS * SX];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wy = wave >> 1, wx = wave & 1;
+    const int g = lane >> 4, li = lane & 15;
+    const int H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout, HW = H * W;
+    const int64_t P = (int64_t)a.N * HW;
+    // 1-D grid, decoded so that the nine taps (and the channel tiles) of one pixel range run on ONE XCD at about the same time
+    // (workgroup ids go round-robin over the 8 XCDs): with (tiles, 9, splits) grids the nine readers of a range of dY sat on nine
+    // different L2s and the 64 -> 64 layer pulled 19 GB through HBM at 7 TB/s
+    const int ci_tiles = Cin / BCI, tiles = ci_tiles * (Cout / BCO);
+    const int xcd = blockIdx.x & 7, kseq = blockIdx.x >> 3;
+    const int tap = kseq % 9, tile = (kseq / 9) % tiles, split = (kseq / (9 * tiles)) * 8 + xcd;
+    if (split >= a.splits) return;
+    const int co0 = (tile / ci_tiles) * BCO, ci0 = (tile % ci_tiles) * BCI;
+    const int dh = tap / 3 - 1, dw = tap % 3 - 1;
+    const bf16_t* __restrict__ dy = reinterpret_cast<const bf16_t*>(a.dy);
+    const bf16_t* __restrict__ x = reinterpret_cast<const bf16_t*>(a.x);
+    const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_conv_zero);
+    const int64_t pstart = (int64_t)split * a.steps_per_split * BKP;
+
+    // loader: this lane's pixel of the stage being issued; its position inside the image and its two source pointers are kept
+    // incrementally (selects between two ready pointers: hipcc turns a select over a 64-bit multiply into divergent branches
+    // with one exec-masked load each - harmless for the counted waits, which only need >= G loads per stage, but slower)
+    int64_t ip = pstart + (lane >> 1);
+    int ir = (int)(ip % HW);
+    const bf16_t* pdy = dy + ip * Cout + co0 + 8 * (lane & 1);
+    const bf16_t* px = x + (ip + (int64_t)dh * W + dw) * Cin + ci0 + 8 * (lane & 1);
+    const int64_t dy_step = (int64_t)BKP * Cout, x_step = (int64_t)BKP * Cin;
+    auto issue = [&](int stage) {
+        const bool live = ip < P;
+        const int h = ir / W, ww = ir - h * W;
+        const bool xok = live && (unsigned)(h + dh) < (unsigned)H && (unsigned)(ww + dw) < (unsigned)W;
+        const bf16_t* sdy = live ? pdy : zero;
+        const bf16_t* sx = xok ? px : zero;
+        const int dsub = live ? 16 : 0, xsub = xok ? 16 : 0;
+#pragma unroll
+        for (int q = 0; q < YG; ++q) {
+            const int sub = q * 4 + wave;
+            __builtin_amdgcn_global_load_lds((glb_void_t*)(sdy + dsub * sub), (lds_void_t*)(uintptr_t)(sY + stage * SY + sub * 512), 16, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < XG; ++q) {
+            const int sub = q * 4 + wave;
+            __builtin_amdgcn_global_load_lds((glb_void_t*)(sx + xsub * sub), (lds_void_t*)(uintptr_t)(sX + stage * SX + sub * 512), 16, 0, 0);
+        }
+        ip += BKP;
+        pdy += dy_step;
+        px += x_step;
+        ir += BKP;
+        while (ir >= HW) ir -= HW;
+    };
+    // fragment piece of lane (kg = g, t = li): row 4 g + (t >> 2), columns 4 (t & 3) .. +3 of its subtile (32-byte rows)
+    const uint32_t piece = (uint32_t)((4 * g + (li >> 2)) * 32 + 8 * (li & 3));
+    const uint32_t aaddr0 = (uint32_t)(uintptr_t)sY + (uint32_t)(wy * (WCO / 16) * 1024) + piece;
+    const uint32_t baddr0 = (uint32_t)(uintptr_t)sX + (uint32_t)(wx * (WCI / 16) * 1024) + piece;
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int steps = a.steps_per_split;
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (s < steps) issue(s);
+    int cur = 0;
+    for (int s = 0; s < steps; ++s) {
+        if (steps - 1 - s >= NS - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * G) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (s + NS - 1 < steps) issue(cur == 0 ? NS - 1 : cur - 1);
+        const uint32_t aaddr = aaddr0 + (uint32_t)(cur * SY * 2), baddr = baddr0 + (uint32_t)(cur * SX * 2);
+        u32x2 alo[MT], ahi[MT], blo[NT], bhi[NT];
+        lds_read_tr_frags<NT>(blo, bhi, baddr);
+        lds_read_tr_frags<MT>(alo, ahi, aaddr);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        lds_frags_landed(blo);
+        lds_frags_landed(bhi);
+        lds_frags_landed(alo);
+        lds_frags_landed(ahi);
+        bf16x8 af[MT], bfr[NT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) af[m] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(alo[m], ahi[m], 0, 1, 2, 3));
+#pragma unroll
+        for (int n = 0; n < NT; ++n) bfr[n] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(blo[n], bhi[n], 0, 1, 2, 3));
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bfr[n], acc[m][n], 0, 0, 0);
+        cur = cur + 1 == NS ? 0 : cur + 1;
+    }
+    // D row = co (lane >> 4) * 4 + r, D column = ci lane & 15
+    float* __restrict__ o = a.part + ((int64_t)split * 9 + tap) * Cout * Cin;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                o[(int64_t)(co0 + wy * WCO + m * 16 + g * 4 + r) * Cin + ci0 + wx * WCI + n * 16 + li] = acc[m][n][r];
+}
+
 void launch_conv_wgrad(int precision, const WgradArgs& a, hipStream_t s) {
     if (a.Cin == 1) {
         const dim3 grid(a.Cout / 64, 1, a.splits);
@@ -868,11 +1000,15 @@ void launch_conv_wgrad(int precision, const WgradArgs& a, hipStream_t s) {
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_wgrad<float, 64, 16, true>), grid, dim3(256), 0, s, a);
     } else if (a.Cin % 128 == 0 && a.Cout % 128 == 0) {
         const dim3 grid((a.Cout / 128) * (a.Cin / 128), 9, a.splits);
-        if (precision == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_wgrad<bf16_t, 128, 128, false>), grid, dim3(256), 0, s, a);
+        const dim3 grid3((a.Cout / 128) * (a.Cin / 128) * 9 * ((a.splits + 7) / 8) * 8);
+        if (precision == 0 && conv3_enabled()) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_wgrad3<128, 128, MST_CONV_GLDS_STAGES>), grid3, dim3(256), 0, s, a);
+        else if (precision == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_wgrad<bf16_t, 128, 128, false>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_wgrad<float, 128, 128, false>), grid, dim3(256), 0, s, a);
     } else {
         const dim3 grid((a.Cout / 64) * (a.Cin / 64), 9, a.splits);
-        if (precision == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_wgrad<bf16_t, 64, 64, false>), grid, dim3(256), 0, s, a);
+        const dim3 grid3((a.Cout / 64) * (a.Cin / 64) * 9 * ((a.splits + 7) / 8) * 8);
+        if (precision == 0 && conv3_enabled()) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_wgrad3<64, 64, MST_CONV_GLDS_STAGES>), grid3, dim3(256), 0, s, a);
+        else if (precision == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_wgrad<bf16_t, 64, 64, false>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_wgrad<float, 64, 64, false>), grid, dim3(256), 0, s, a);
     }
 }
