@@ -132,73 +132,113 @@ __global__ void k_prep_weights(const float* __restrict__ w, T* __restrict__ wf, 
         if (wd) wd[((int64_t)ci * 9 + (8 - tap)) * Cout + co] = cvt_out<T>(v);
     }
 }
-// partial sums (splits, 9, Cout, Cin) [first layer: (splits, Cout, 16)] -> torch layout (co, ci, kh, kw), fixed order
-__global__ void k_wgrad_reduce(const float* __restrict__ part, float* __restrict__ gw, int Cin, int Cout, int splits, int first) {
+// the same for Cin, Cout multiples of 32, through a (32 co x 32 ci x 9) LDS tile: 1152-byte runs in, 32-element rows out in
+// both layouts (the element-wise kernel scatters the data-gradient layout in 2-byte writes: 1.4 ms per step for 80 M weights)
+template <typename T>
+__global__ __launch_bounds__(256) void k_prep_weights_tiled(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wd, int Cin, int Cout) {
+    constexpr int ROW = 32 * 9 + 2;  // odd dword pitch for T = bf16 and for T = float
+    __shared__ T tile[32 * ROW];
+    const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32, tid = threadIdx.x;
+    for (int i = tid; i < 32 * 288; i += 256) {
+        const int co = i / 288, j = i % 288;  // j = ci * 9 + kh * 3 + kw
+        tile[co * ROW + j] = cvt_out<T>(w[((int64_t)(co0 + co) * Cin + ci0) * 9 + j]);
+    }
+    __syncthreads();
+    const int l32 = tid & 31;
+    for (int r = tid >> 5; r < 32 * 9; r += 8) {
+        const int o = r / 9, tap = r % 9, inner = (tap % 3) * 3 + tap / 3;  // source index kh * 3 + kw of tap = kw * 3 + kh
+        wf[((int64_t)(co0 + o) * 9 + tap) * Cin + ci0 + l32] = tile[o * ROW + l32 * 9 + inner];
+        wd[((int64_t)(ci0 + o) * 9 + (8 - tap)) * Cout + co0 + l32] = tile[l32 * ROW + o * 9 + inner];
+    }
+}
+// partial sums (splits, 9, Cout, Cin) -> torch layout (co, ci, kh, kw), fixed order
+__global__ void k_wgrad_reduce(const float* __restrict__ part, float* __restrict__ gw, int Cin, int Cout, int splits) {
     const int64_t total = (int64_t)Cout * Cin * 9;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         const int ci = (int)(e % Cin), tap = (int)((e / Cin) % 9), co = (int)(e / ((int64_t)Cin * 9));
         float acc = 0.f;
-        if (first) {
-            for (int s = 0; s < splits; ++s) acc += part[((int64_t)s * Cout + co) * 16 + tap];
-        } else {
-            for (int s = 0; s < splits; ++s) acc += part[(((int64_t)s * 9 + tap) * Cout + co) * Cin + ci];
-        }
+        for (int s = 0; s < splits; ++s) acc += part[(((int64_t)s * 9 + tap) * Cout + co) * Cin + ci];
         const int a_ = tap / 3, b_ = tap % 3;
         gw[(((int64_t)co * Cin + ci) * 3 + b_) * 3 + a_] = acc;
     }
 }
+// first layer (Cin = 1, partial sums (splits, Cout, 16)): 576 sums over ~2000 pixel splits each - one workgroup per output channel,
+// 16 lanes per tap take every 16th split, folded in a fixed order (one thread per output walking all splits: 520 us)
+__global__ __launch_bounds__(256) void k_wgrad_reduce_first(const float* __restrict__ part, float* __restrict__ gw, int Cout, int splits) {
+    __shared__ float red[16][16];
+    const int co = blockIdx.x, tap = threadIdx.x & 15, lane16 = threadIdx.x >> 4;
+    float acc = 0.f;
+    for (int s = lane16; s < splits; s += 16) acc += part[((int64_t)s * Cout + co) * 16 + tap];
+    red[lane16][tap] = acc;
+    __syncthreads();
+    if (threadIdx.x < 9) {
+        float v = 0.f;
+        for (int j = 0; j < 16; ++j) v += red[j][threadIdx.x];
+        const int a_ = threadIdx.x / 3, b_ = threadIdx.x % 3;
+        gw[((int64_t)co * 3 + b_) * 3 + a_] = v;
+    }
+}
 
 // =====================================================================================================================
-// first layer: one input channel (the fp32 spectrogram), 64 outputs; direct form.  256 lanes x 8 pixels per workgroup.
+// first layer: one input channel (the fp32 spectrogram), 64 outputs; direct form.  Eight lanes per pixel, eight channels per lane:
+// a wave instruction stores eight whole 128-byte pixels (one pixel x 64 channels per lane strode the stores by 128 bytes - 64
+// separate 16-byte segments per instruction, 780 us for 1.08 GB); the nine taps are fetched by all eight lanes of a pixel (L1 hits).
 constexpr int kConv1Pix = 2048;
 template <typename T>
 __global__ __launch_bounds__(256) void k_conv1(const float* __restrict__ spec, const float* __restrict__ w /* (64, tap) */, T* __restrict__ out,
                                                float* __restrict__ part, int N, int H, int W) {
-    __shared__ float sw[64 * 9];
     __shared__ float red[4][64][2];
-    const int tid = threadIdx.x;
-    for (int i = tid; i < 64 * 9; i += 256) sw[i] = w[i];
-    __syncthreads();
-    const int64_t P = (int64_t)N * H * W;
-    float s1[64], s2[64];
+    const int tid = threadIdx.x, oct = tid & 7, pl = tid >> 3;
+    float wr[8][9];
 #pragma unroll
-    for (int c = 0; c < 64; ++c) s1[c] = s2[c] = 0.f;
-    for (int it = 0; it < kConv1Pix / 256; ++it) {
-        const int64_t p = (int64_t)blockIdx.x * kConv1Pix + it * 256 + tid;
-        if (p >= P) break;
-        const int r = (int)(p % ((int64_t)H * W)), h = r / W, ww = r % W;
-        float x[9];
+    for (int j = 0; j < 8; ++j)
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int dh = t / 3 - 1, dw = t % 3 - 1;
-            const bool ok = (unsigned)(h + dh) < (unsigned)H && (unsigned)(ww + dw) < (unsigned)W;
-            x[t] = ok ? spec[p + (int64_t)dh * W + dw] : 0.f;
-        }
-        T* o = out + p * 64;
+        for (int t = 0; t < 9; ++t) wr[j][t] = w[(oct * 8 + j) * 9 + t];
+    const int HW = H * W;
+    const int64_t P = (int64_t)N * HW;
+    float s1[8], s2[8];
 #pragma unroll
-        for (int c8 = 0; c8 < 8; ++c8) {
+    for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
+    int64_t p = (int64_t)blockIdx.x * kConv1Pix + pl;
+    int r = (int)(p % HW);
+    for (int it = 0; it < kConv1Pix / 32; ++it, p += 32) {
+        if (p < P) {
+            const int h = r / W, ww = r - h * W;
+            float x[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int dh = t / 3 - 1, dw = t % 3 - 1;
+                const bool ok = (unsigned)(h + dh) < (unsigned)H && (unsigned)(ww + dw) < (unsigned)W;
+                x[t] = ok ? spec[p + (int64_t)dh * W + dw] : 0.f;
+            }
             float v[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int c = c8 * 8 + j;
                 float acc = 0.f;
 #pragma unroll
-                for (int t = 0; t < 9; ++t) acc = fmaf(sw[c * 9 + t], x[t], acc);
+                for (int t = 0; t < 9; ++t) acc = fmaf(wr[j][t], x[t], acc);
                 v[j] = acc;
-                s1[c] += acc;
-                s2[c] = fmaf(acc, acc, s2[c]);
+                s1[j] += acc;
+                s2[j] = fmaf(acc, acc, s2[j]);
             }
-            store8(o + c8 * 8, v);
+            store8(out + p * 64 + oct * 8, v);
         }
+        r += 32;
+        while (r >= HW) r -= HW;
     }
     if (part) {
         const int wave = tid >> 6, lane = tid & 63;
 #pragma unroll
-        for (int c = 0; c < 64; ++c) {
-            const float a = wave_sum(s1[c]), b = wave_sum(s2[c]);
-            if (lane == 0) {
-                red[wave][c][0] = a;
-                red[wave][c][1] = b;
+        for (int j = 0; j < 8; ++j) {
+            float a = s1[j], b = s2[j];
+#pragma unroll
+            for (int m = 8; m < 64; m <<= 1) {
+                a += __shfl_xor(a, m);
+                b += __shfl_xor(b, m);
+            }
+            if (lane < 8) {
+                red[wave][oct * 8 + j][0] = a;
+                red[wave][oct * 8 + j][1] = b;
             }
         }
         __syncthreads();
@@ -630,7 +670,7 @@ static int cnn_forward_t(const mst_cnn14_desc* d, const CnnPlan& p, const float*
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_prep_weights<float>), dim3(3), dim3(256), 0, s, prm->conv_w[0], (float*)(ws + p.w1), (float*)nullptr, 1, 64);
     for (int l = 1; l < 2 * kBlocks; ++l) {
         const int b = l / 2, Cin = (l & 1) ? kChan[b + 1] : kChan[b], Cout = kChan[b + 1];
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_prep_weights<T>), dim3(ew_grid((int64_t)9 * Cin * Cout)), dim3(256), 0, s, prm->conv_w[l],
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_prep_weights_tiled<T>), dim3(Cin / 32, Cout / 32), dim3(256), 0, s, prm->conv_w[l],
                            (T*)(ws + p.wf[l]), (T*)(ws + p.wd[l]), Cin, Cout);
     }
     const void* x_in = spec;
@@ -721,7 +761,8 @@ static int cnn_backward_t(const mst_cnn14_desc* d, const CnnPlan& p, const float
             wgrad_part_floats(l, P, Cin, C, &splits, &steps);
             WgradArgs wa{GA, x_in, wgpart, p.n, H, W, Cin, C, splits, steps};
             launch_conv_wgrad(prec, wa, s);
-            hipLaunchKernelGGL(k_wgrad_reduce, dim3(ew_grid((int64_t)9 * Cin * C)), dim3(256), 0, s, wgpart, gr->conv_w[l], Cin, C, splits, Cin == 1 ? 1 : 0);
+            if (Cin == 1) hipLaunchKernelGGL(k_wgrad_reduce_first, dim3(C), dim3(256), 0, s, wgpart, gr->conv_w[l], C, splits);
+            else hipLaunchKernelGGL(k_wgrad_reduce, dim3(ew_grid((int64_t)9 * Cin * C)), dim3(256), 0, s, wgpart, gr->conv_w[l], Cin, C, splits);
             // data gradient (not for the spectrogram itself)
             if (Cin > 1) {
                 ConvArgs ca{GA, ws + p.wd[l], GB, nullptr, p.n, H, W, C, Cin, 0, nullptr};
