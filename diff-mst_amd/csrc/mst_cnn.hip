@@ -458,6 +458,202 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm3(ConvArgs a) {
 }
 
 // =====================================================================================================================
+// k_conv_igemm4 (bf16, no split K): k_conv_igemm3 with the activation bytes cut to a third.  k_conv_igemm3 fills LDS at ~20 bytes per
+// clock and CU (13 TB/s over the chip) and that, not the matrix pipe, is its limit on the large layers.  Here the three taps of an
+// image row share ONE activation segment: rows j = 0 .. BP + 1 of the segment hold input pixels p0 - 1 + j (+ dh W), staged once per
+// (dh, channel block) into a double buffer, and tap dw reads its B fragments from rows shifted by dw + 1 (the slot swizzle
+// (row >> 1) & 3 is conflict-free for all three shifts: tools/lds_conflicts.py).  What a shift drags in across a row end, an image
+// border or the end of the batch is zeroed per lane (a lane's B fragment is eight channels of ONE pixel).  Weight tiles (one tap x 32
+// channels) run through a three-slot ring; a step = one tap = MT x NT MFMAs per wave between two barriers.  Counted waits: at step
+// t only what step t - 1 issued may still be in flight (the next weight tile, plus the next segment when t - 1 opened a tap row).
+template <int BC, int BP>
+__global__ __launch_bounds__(256, 2) void k_conv_igemm4(ConvArgs a) {
+    constexpr int BK = 32, MT = BC / 32, NT = BP / 32;
+    constexpr int XR = BP + 16, XI = XR / 16;              // segment rows (BP + 2 used), 1 KiB wave instructions per segment
+    constexpr int XG0 = (XI + 3) / 4, XG1 = XI / 4;        // of which wave 0 / waves 1-3 issue
+    constexpr int WGc = BC / 64;                           // weight instructions per wave and tap
+    constexpr int SW = BC * BK, SX = XR * BK;              // elements per weight slot / segment buffer
+    static_assert(XI % 4 == 1, "wave 0 takes the odd segment instruction");
+    __shared__ __attribute__((aligned(1024))) bf16_t sW[3 * SW];
+    __shared__ __attribute__((aligned(1024))) bf16_t sX[2 * SX];
+    __shared__ float red[2][BC][2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wy = wave >> 1, wx = wave & 1;
+    const int g = lane >> 4, li = lane & 15;
+    const int H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout, HW = H * W;
+    int bx = blockIdx.x;
+    if (MST_CONV_XCD_REMAP) {
+        const int gx = gridDim.x, q = gx >> 3, r = gx & 7, xcd = bx & 7, idx = bx >> 3;
+        bx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int64_t P = (int64_t)a.N * HW, p0 = (int64_t)bx * BP;
+    const int co0 = blockIdx.y * BC;
+    const bf16_t* __restrict__ in = reinterpret_cast<const bf16_t*>(a.in);
+    const bf16_t* __restrict__ w = reinterpret_cast<const bf16_t*>(a.w);
+    const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_conv_zero);
+
+    // segment loader: instruction i = wave + 4 q fills rows [16 i, +16); row j <-> centre pixel c = p0 - 1 + j
+    // (the K chunk of a lane, (lane & 3) ^ ((row >> 1) & 3), is the same for all its instructions: rows differ by multiples of 64)
+    const int kc = (lane & 3) ^ ((lane >> 3) & 3);
+    unsigned xmask = 0;  // bit 3 q + d: row h + d - 1 of the image of instruction q's centre pixel exists
+#pragma unroll
+    for (int q = 0; q < XG0; ++q) {
+        const int row = (wave + 4 * q) * 16 + (lane >> 2);
+        const int64_t c = p0 - 1 + row;
+        if (c >= 0 && c < P && row < BP + 2) {
+            const int h = (int)(c % HW) / W;
+#pragma unroll
+            for (int d = 0; d < 3; ++d)
+                if ((unsigned)(h + d - 1) < (unsigned)H) xmask |= 1u << (3 * q + d);
+        }
+    }
+    const bf16_t* xsrc0 = in + (p0 - 1 + wave * 16 + (lane >> 2)) * Cin + kc * 8;  // + 64 q Cin per instruction; dereferenced only where xmask allows
+    const bf16_t* wsrc0 = w + (int64_t)(co0 + wave * 16 + (lane >> 2)) * 9 * Cin + kc * 8;
+    // horizontal validity of this lane's output pixels: bit n = the left neighbour exists, bit 8 + n = the right one does
+    unsigned hmask = 0;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int64_t p = p0 + wx * (BP / 2) + n * 16 + li;
+        if (p < P) {
+            const int ww = (int)(p % HW) % W;
+            if (ww > 0) hmask |= 1u << n;
+            if (ww < W - 1) hmask |= 1u << (8 + n);
+        }
+    }
+    constexpr unsigned kAll = (1u << NT) - 1u;
+    const bool edgeL = __builtin_amdgcn_ballot_w64((hmask & kAll) != kAll) != 0;          // wave-uniform: some lane needs zeroing
+    const bool edgeR = __builtin_amdgcn_ballot_w64(((hmask >> 8) & kAll) != kAll) != 0;
+
+    const int chunks = Cin / BK, K = 3 * chunks;  // tap-row groups k = dh_idx * chunks + chunk; steps t = 3 k + dw_idx
+    int wk_dh = 0, wk_ch = 0, wk_d = 0, wslot = 0;  // weight issue cursor
+    auto issue_w = [&]() {
+        const int tap = wk_dh * 3 + wk_d, c0 = wk_ch * BK;
+#pragma unroll
+        for (int q = 0; q < WGc; ++q) {
+            const bf16_t* src = wsrc0 + ((int64_t)q * 64 * 9 + tap) * Cin + c0;
+            __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)(uintptr_t)(sW + wslot * SW + (q * 4 + wave) * 512), 16, 0, 0);
+        }
+        wslot = wslot == 2 ? 0 : wslot + 1;
+        if (++wk_d == 3) { wk_d = 0; if (++wk_ch == chunks) { wk_ch = 0; ++wk_dh; } }
+    };
+    int xk_dh = 0, xk_ch = 0, xbuf = 0;  // segment issue cursor
+    auto issue_x = [&]() {
+        const int64_t shift = (int64_t)(xk_dh - 1) * W * Cin + xk_ch * BK;
+#pragma unroll
+        for (int q = 0; q < XG0; ++q) {
+            if (q < XG1 || wave == 0) {
+                const bf16_t* src = (xmask >> (3 * q + xk_dh)) & 1u ? xsrc0 + (int64_t)q * 64 * Cin + shift : zero;
+                __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)(uintptr_t)(sX + xbuf * SX + (wave + 4 * q) * 512), 16, 0, 0);
+            }
+        }
+        xbuf ^= 1;
+        if (++xk_ch == chunks) { xk_ch = 0; ++xk_dh; }
+    };
+    const uint32_t fsw = (uint32_t)(((li >> 1) & 3));
+    const uint32_t aaddr0 = (uint32_t)(uintptr_t)sW + (uint32_t)((wy * (BC / 2) + li) * BK * 2) + (((uint32_t)g ^ fsw) << 4);
+    // B rows are shifted by d = 0, 1, 2: the slot swizzle follows the row, (row >> 1) & 3 with row = li + d (the 16 n and wx BP/2 terms vanish)
+    uint32_t baddr0[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+        baddr0[d] = (uint32_t)(uintptr_t)sX + (uint32_t)((wx * (BP / 2) + li + d) * BK * 2) + (((uint32_t)g ^ (uint32_t)(((li + d) >> 1) & 3)) << 4);
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    issue_x();
+    issue_w();
+    issue_w();
+    int rslot = 0;  // weight slot of the current step
+    for (int k = 0; k < K; ++k) {
+        const bool last = k == K - 1;
+        const uint32_t xoff = (uint32_t)((k & 1) * SX * 2);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            // in flight may stay: what the previous step issued
+            if (d == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WGc) : "memory");
+            else if (d == 1) {
+                if (last) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WGc) : "memory");
+                else if (wave == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WGc + XG0) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WGc + XG1) : "memory");
+            } else {
+                if (last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WGc) : "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            if (!(last && d >= 1)) issue_w();          // tile t + 2 into the slot of tile t - 1
+            if (d == 0 && !last) issue_x();            // next segment into the buffer the previous tap row used
+            const uint32_t aaddr = aaddr0 + (uint32_t)(rslot * SW * 2), baddr = baddr0[d] + xoff;
+            u32x4 ra[MT];
+            lds_read_frags<MT, 16 * BK * 2>(ra, aaddr);
+#pragma unroll
+            for (int nh = 0; nh < NT / 4; ++nh) {  // four pixel columns at a time (all eight: 32 more registers, spills)
+                u32x4 rb[4];
+                lds_read_frags<4, 16 * BK * 2>(rb, baddr + (uint32_t)(nh * 64 * BK * 2));
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                lds_frags_landed(rb);
+                if (nh == 0) lds_frags_landed(ra);
+                if (d == 0 && edgeL) {
+#pragma unroll
+                    for (int n = 0; n < 4; ++n)
+                        if (!((hmask >> (nh * 4 + n)) & 1u)) rb[n] = u32x4{0u, 0u, 0u, 0u};
+                }
+                if (d == 2 && edgeR) {
+#pragma unroll
+                    for (int n = 0; n < 4; ++n)
+                        if (!((hmask >> (8 + nh * 4 + n)) & 1u)) rb[n] = u32x4{0u, 0u, 0u, 0u};
+                }
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n)
+                        acc[m][nh * 4 + n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ra[m]), __builtin_bit_cast(bf16x8, rb[n]), acc[m][nh * 4 + n], 0, 0, 0);
+            }
+            rslot = rslot == 2 ? 0 : rslot + 1;
+        }
+    }
+    // ---- epilogue (as k_conv_igemm3)
+    bf16_t* __restrict__ out = reinterpret_cast<bf16_t*>(a.out);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int64_t p = p0 + wx * (BP / 2) + n * 16 + li;
+        if (p < P) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) store4(out + p * Cout + co0 + wy * (BC / 2) + m * 16 + g * 4, acc[m][n]);
+        }
+    }
+    if (a.part) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    s1 += acc[m][n][r];
+                    s2 = fmaf(acc[m][n][r], acc[m][n][r], s2);
+                }
+#pragma unroll
+                for (int msk = 1; msk < 16; msk <<= 1) {
+                    s1 += __shfl_xor(s1, msk);
+                    s2 += __shfl_xor(s2, msk);
+                }
+                if (li == 0) {
+                    red[wx][wy * (BC / 2) + m * 16 + g * 4 + r][0] = s1;
+                    red[wx][wy * (BC / 2) + m * 16 + g * 4 + r][1] = s2;
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < BC) {
+            float* o = a.part + ((int64_t)bx * Cout + co0 + tid) * 2;
+            o[0] = red[0][tid][0] + red[1][tid][0];
+            o[1] = red[0][tid][1] + red[1][tid][1];
+        }
+    }
+}
+
+// =====================================================================================================================
 // k_conv_igemm2 (bf16, Cout % 128 == 0, Cin % 64 == 0): the same GEMM with the L1 traffic cut to 0.44x.  Ablations of k_conv_igemm
 // (-DMST_CONV_ABLATE) showed what binds it: with the MFMAs and LDS reads removed it still takes 337 of its 367 us, without its
 // global loads 211 - every K step pulls 32 KB through a 64 B/clk L1 for 512 MFMA cycles.  Here
@@ -620,31 +816,46 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm2(ConvArgs a) {
 template <typename T>
 __global__ __launch_bounds__(256) void k_conv_splitk_reduce(const float* __restrict__ kpart, T* __restrict__ out, float* __restrict__ part, int64_t P,
                                                             int Cout, int nz) {
-    // workgroup = (pixel tile, 32 channels): lanes 0..31 walk the channels (128-byte lines), the 8 lane groups share the pixels
-    __shared__ float red[8][32][2];
-    const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5, c = blockIdx.y * 32 + cl;
+    // workgroup = (pixel tile, 32 channels): 8 lanes x 4 channels cover a 128-byte line, the 32 lane groups share the pixels; eight
+    // slabs are requested before the first is added (one 4-byte load per slab and a dependent add was 0.45 TB/s on 75 MB)
+    __shared__ float red[32][32][2];
+    const int c4 = threadIdx.x & 7, pl = threadIdx.x >> 3, c = blockIdx.y * 32 + c4 * 4;
     const int64_t p0 = (int64_t)blockIdx.x * kConvPix;
-    float s1 = 0.f, s2 = 0.f;
-    for (int i = pl; i < kConvPix; i += 8) {
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i = pl; i < kConvPix; i += 32) {
         const int64_t p = p0 + i;
         if (p >= P) break;
-        float v = 0.f;
-        for (int z = 0; z < nz; ++z) v += kpart[((int64_t)z * P + p) * Cout + c];
-        out[p * Cout + c] = from_f32<T>(v);
-        s1 += v;
-        s2 = fmaf(v, v, s2);
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        const float* src = kpart + p * Cout + c;
+        const int64_t zs = P * Cout;
+        for (int z0 = 0; z0 < nz; z0 += 8) {
+            float4 t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = z0 + u < nz ? *reinterpret_cast<const float4*>(src + (z0 + u) * zs) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {  // slabs in ascending order (fixed summation order)
+                if (z0 + u < nz) { v[0] += t[u].x; v[1] += t[u].y; v[2] += t[u].z; v[3] += t[u].w; }
+            }
+        }
+        store4(out + p * Cout + c, f32x4{v[0], v[1], v[2], v[3]});
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            s1[q] += v[q];
+            s2[q] = fmaf(v[q], v[q], s2[q]);
+        }
     }
     if (part) {
-        red[pl][cl][0] = s1;
-        red[pl][cl][1] = s2;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            red[pl][c4 * 4 + q][0] = s1[q];
+            red[pl][c4 * 4 + q][1] = s2[q];
+        }
         __syncthreads();
-        if (pl == 0) {
-            for (int q = 1; q < 8; ++q) {
-                s1 += red[q][cl][0];
-                s2 += red[q][cl][1];
-            }
-            part[((int64_t)blockIdx.x * Cout + c) * 2] = s1;
-            part[((int64_t)blockIdx.x * Cout + c) * 2 + 1] = s2;
+        if (threadIdx.x < 64) {
+            const int cl = threadIdx.x >> 1, w = threadIdx.x & 1;
+            float acc = 0.f;
+            for (int q = 0; q < 32; ++q) acc += red[q][cl][w];
+            part[((int64_t)blockIdx.x * Cout + blockIdx.y * 32 + cl) * 2 + w] = acc;
         }
     }
 }
@@ -688,6 +899,14 @@ int launch_conv3x3(int precision, ConvArgs a, hipStream_t s, float* kpart, size_
 #define MST_CONV_FAT_MIN 1024  // workgroups from which the 256-pixel tile is used
 #endif
     const bool fat_ok = precision == 0 && !a.csplit && a.Cout % 128 == 0 && (int64_t)tiles2 * (a.Cout / 128) >= MST_CONV_FAT_MIN;
+#ifndef MST_CONV_TAPROW
+#define MST_CONV_TAPROW 1  // A/B switch: 0 = k_conv_igemm3 everywhere
+#endif
+    if (MST_CONV_TAPROW && conv3_enabled() && precision == 0 && !a.csplit && (int64_t)tiles2 * (a.Cout / (a.Cout % 128 == 0 ? 128 : 64)) >= MST_CONV_FAT_MIN) {
+        if (a.Cout % 128 == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_igemm4<128, 256>), dim3(tiles2, a.Cout / 128), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_igemm4<64, 256>), dim3(tiles2, a.Cout / 64), dim3(256), 0, s, a);
+        return tiles2;
+    }
     if (fat_ok && conv3_enabled()) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_igemm3<128, 256, MST_CONV_GLDS_STAGES>), dim3(tiles2, a.Cout / 128), dim3(256), 0, s, a);
         return tiles2;
