@@ -41,6 +41,8 @@ constexpr int kWgradPix = 32;   // pixels per K step of the weight-gradient GEMM
 int launch_conv3x3(int precision, ConvArgs a, hipStream_t s, float* kpart, size_t kpart_bytes);
 size_t conv_splitk_bytes(int N, int H, int W, int Cin, int Cout);
 void launch_conv_wgrad(int precision, const WgradArgs& a, hipStream_t s);
+// true: launch_conv_wgrad runs all nine taps in one workgroup (k_conv_wgrad4) - the split policy counts a ninth of the workgroups
+bool conv_wgrad_nine_taps(int precision, int W, int Cin, int Cout);
 int conv_pixel_tiles(int N, int H, int W);
 
 }  // namespace mst

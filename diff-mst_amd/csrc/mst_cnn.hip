@@ -1212,7 +1212,183 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad3(WgradArgs a) {
                 o[(int64_t)(co0 + wy * WCO + m * 16 + g * 4 + r) * Cin + ci0 + wx * WCI + n * 16 + li] = acc[m][n][r];
 }
 
+// =====================================================================================================================
+// k_conv_wgrad4 (bf16, 64 x 64 channel tiles, W >= 64): ALL NINE taps of a pixel range in one workgroup.  k_conv_wgrad3 runs one
+// tap per workgroup, so every 32-pixel slab of dY and X crosses the L2 -> LDS path nine times (19 GB for the 64 -> 64 layer at
+// ~12 TB/s: that path, not the matrix pipe, is its limit).  Here a stage holds the 32 pixels of dY once and, per vertical offset dh,
+// one segment of X: rows j = 0 .. 33 <-> pixels pb - 1 + j (+ dh W).  Tap (dh, dw) reads its B fragments from segment dh shifted
+// by dw + 1 rows (32 bytes: the transposing read's pieces stay 8-byte aligned and sweep a contiguous 512 bytes); nine accumulator
+// sets of 2 x 2 MFMA tiles per wave.  17.5 KB per stage for 36 MFMAs per wave instead of 72 KB.
+//   * vertical validity (row h + dh of the centre pixel's image) acts at load time (zero page);
+//   * horizontal validity is per PIXEL = per K slot of a fragment: in the stages that contain a row end (wave-uniform test on the
+//     column of pb; every 32nd stage at W = 1025) the fragments of the dw = -1 / +1 taps are ANDed with a per-lane mask.
+// Segment subtiles are [34 rows][16 channels] on a 1152-byte pitch: one full LDS-direct instruction (rows 0 .. 31) and one with four
+// active lanes (rows 32, 33).  Seven instructions per wave and stage, the same for every wave: counted waits as in k_conv_wgrad3.
+constexpr int kWg4Sub = 1152;  // bytes per segment subtile
+template <int NS>
+__global__ __launch_bounds__(256, 2) void k_conv_wgrad4(WgradArgs a) {
+    constexpr int BKP = kWgradPix, G = 7;
+    constexpr int SYB = 4 * 1024, SEGB = 4 * kWg4Sub, SXB = 3 * SEGB;  // bytes per stage: dY, one segment, three segments
+    static_assert(BKP == 32 && NS >= 3 && NS <= 4, "stage shape");
+    __shared__ __attribute__((aligned(1024))) char sY[NS * SYB];
+    __shared__ __attribute__((aligned(1024))) char sX[NS * SXB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wy = wave >> 1, wx = wave & 1;
+    const int g = lane >> 4, li = lane & 15;
+    const int H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout, HW = H * W;
+    const int64_t P = (int64_t)a.N * HW;
+    const int ci_tiles = Cin / 64, tiles = ci_tiles * (Cout / 64);
+    const int xcd = blockIdx.x & 7, kseq = blockIdx.x >> 3;
+    const int tile = kseq % tiles, split = (kseq / tiles) * 8 + xcd;
+    if (split >= a.splits) return;
+    const int co0 = (tile / ci_tiles) * 64, ci0 = (tile % ci_tiles) * 64;
+    const bf16_t* __restrict__ dy = reinterpret_cast<const bf16_t*>(a.dy);
+    const bf16_t* __restrict__ x = reinterpret_cast<const bf16_t*>(a.x);
+    const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_conv_zero);
+    const int64_t pstart = (int64_t)split * a.steps_per_split * BKP;
+
+    // loader: wave w owns channel subtile w of dY and of every segment; lane l brings half a row (pixel row l >> 1, channels 8 (l & 1) ..)
+    int64_t ip = pstart + (lane >> 1);                 // dY pixel of the stage being issued; segment row l >> 1 is pixel ip - 1
+    int irc = (int)((ip - 1 + HW) % HW);               // position of pixel ip - 1 inside its image
+    const bf16_t* pdy = dy + ip * Cout + co0 + 16 * wave + 8 * (lane & 1);
+    const bf16_t* px = x + (ip - 1) * Cin + ci0 + 16 * wave + 8 * (lane & 1);
+    const int64_t dy_step = (int64_t)BKP * Cout, x_step = (int64_t)BKP * Cin, x_tail = (int64_t)32 * Cin, x_row = (int64_t)W * Cin;
+    auto issue = [&](int stage) {
+        const bool live = ip < P;
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(live ? pdy : zero), (lds_void_t*)(uintptr_t)(sY + stage * SYB + wave * 1024), 16, 0, 0);
+        // centre pixels: c = ip - 1 (rows 0 .. 31) and c + 32 (rows 32, 33: lanes 0 .. 3)
+        const int64_t c = ip - 1;
+        const bool okc = c >= 0 && c < P, okt = c + 32 < P;  // c + 32 >= 31
+        const int h = irc / W;
+        int irt = irc + 32;
+        while (irt >= HW) irt -= HW;
+        const int ht = irt / W;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const bool v = okc && (unsigned)(h + d - 1) < (unsigned)H;
+            const bf16_t* src = v ? px + (d - 1) * x_row : zero;
+            __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)(uintptr_t)(sX + stage * SXB + d * SEGB + wave * kWg4Sub), 16, 0, 0);
+        }
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const bool v = okt && (unsigned)(ht + d - 1) < (unsigned)H;
+            const bf16_t* src = v ? px + x_tail + (d - 1) * x_row : zero;
+            if (lane < 4)
+                __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)(uintptr_t)(sX + stage * SXB + d * SEGB + wave * kWg4Sub + 1024), 16, 0, 0);
+        }
+        ip += BKP;
+        pdy += dy_step;
+        px += x_step;
+        irc += BKP;
+        while (irc >= HW) irc -= HW;
+    };
+    // fragment piece of lane (kg = g, t = li): row 4 g + (t >> 2), columns 4 (t & 3) .. +3 of its subtile (32-byte rows)
+    const uint32_t piece = (uint32_t)((4 * g + (li >> 2)) * 32 + 8 * (li & 3));
+    const uint32_t aaddr0 = (uint32_t)(uintptr_t)sY + (uint32_t)(wy * 2 * 1024) + piece;
+    const uint32_t baddr0 = (uint32_t)(uintptr_t)sX + (uint32_t)(wx * 2 * kWg4Sub) + piece;
+    f32x4 acc[9][2][2];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) acc[t][m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int steps = a.steps_per_split;
+    int wp = (int)(pstart % HW) % W;  // column of the stage's first pixel (wave-uniform)
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (s < steps) issue(s);
+    int cur = 0;
+    for (int s = 0; s < steps; ++s) {
+        if (steps - 1 - s >= NS - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * G) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (s + NS - 1 < steps) issue(cur == 0 ? NS - 1 : cur - 1);
+        const uint32_t aaddr = aaddr0 + (uint32_t)(cur * SYB), baddr = baddr0 + (uint32_t)(cur * SXB);
+        // K slot s of this lane's fragments <-> pixel offset 4 g + (s & 3) + 16 (s >> 2); masks of the slots whose left / right
+        // neighbour lies in another image row (only in stages that contain a row end)
+        const bool edge = wp == 0 || wp + 31 >= W - 1;
+        uint32_t mL[4] = {~0u, ~0u, ~0u, ~0u}, mR[4] = {~0u, ~0u, ~0u, ~0u};
+        if (edge) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                int col = wp + 4 * g + (q & 3) + 16 * (q >> 2);
+                if (col >= W) col -= W;
+                const uint32_t keep = (q & 1) ? 0x0000ffffu : 0xffff0000u;  // what stays of the dword when slot q goes
+                if (col == 0) mL[q >> 1] &= keep;
+                if (col == W - 1) mR[q >> 1] &= keep;
+            }
+        }
+        u32x2 alo[2], ahi[2];
+        lds_read_tr_frags<2>(alo, ahi, aaddr);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {       // vertical offset dh = d - 1: one segment
+            u32x2 blo[3][2], bhi[3][2];
+#pragma unroll
+            for (int e = 0; e < 3; ++e) {   // horizontal offset dw = e - 1: rows shifted by e
+                blo[e][0] = lds_read_tr8<0>(baddr + (uint32_t)(d * SEGB + e * 32));
+                bhi[e][0] = lds_read_tr8<512>(baddr + (uint32_t)(d * SEGB + e * 32));
+                blo[e][1] = lds_read_tr8<kWg4Sub>(baddr + (uint32_t)(d * SEGB + e * 32));
+                bhi[e][1] = lds_read_tr8<kWg4Sub + 512>(baddr + (uint32_t)(d * SEGB + e * 32));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (d == 0) {
+                lds_frags_landed(alo);
+                lds_frags_landed(ahi);
+            }
+#pragma unroll
+            for (int e = 0; e < 3; ++e) {
+                lds_frags_landed(blo[e]);
+                lds_frags_landed(bhi[e]);
+            }
+            if (edge) {
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    blo[0][n][0] &= mL[0]; blo[0][n][1] &= mL[1]; bhi[0][n][0] &= mL[2]; bhi[0][n][1] &= mL[3];
+                    blo[2][n][0] &= mR[0]; blo[2][n][1] &= mR[1]; bhi[2][n][0] &= mR[2]; bhi[2][n][1] &= mR[3];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 3; ++e)
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)
+                        acc[d * 3 + e][m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(bf16x8, __builtin_shufflevector(alo[m], ahi[m], 0, 1, 2, 3)),
+                            __builtin_bit_cast(bf16x8, __builtin_shufflevector(blo[e][n], bhi[e][n], 0, 1, 2, 3)), acc[d * 3 + e][m][n], 0, 0, 0);
+        }
+        cur = cur + 1 == NS ? 0 : cur + 1;
+        wp += BKP;
+        if (wp >= W) wp -= W;
+    }
+    // D row = co (lane >> 4) * 4 + r, D column = ci lane & 15
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        float* __restrict__ o = a.part + ((int64_t)split * 9 + t) * Cout * Cin;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    o[(int64_t)(co0 + wy * 32 + m * 16 + g * 4 + r) * Cin + ci0 + wx * 32 + n * 16 + li] = acc[t][m][n][r];
+    }
+}
+bool conv_wgrad_nine_taps(int precision, int W, int Cin, int Cout) {
+#ifdef MST_CONV_NO_WGRAD4
+    return false;  // A/B switch
+#else
+    return precision == 0 && conv3_enabled() && W >= 64 && Cin % 64 == 0 && Cout % 64 == 0;
+#endif
+}
+
 void launch_conv_wgrad(int precision, const WgradArgs& a, hipStream_t s) {
+    if (conv_wgrad_nine_taps(precision, a.W, a.Cin, a.Cout)) {
+        const dim3 grid4((a.Cout / 64) * (a.Cin / 64) * ((a.splits + 7) / 8) * 8);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_wgrad4<3>), grid4, dim3(256), 0, s, a);
+        return;
+    }
     if (a.Cin == 1) {
         const dim3 grid(a.Cout / 64, 1, a.splits);
         if (precision == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_wgrad<bf16_t, 64, 16, true>), grid, dim3(256), 0, s, a);

@@ -574,10 +574,11 @@ struct CnnPlan {
     size_t bnpart_bytes, wgpart_bytes, kpart, kpart_bytes;
     size_t total;
 };
-static int64_t wgrad_part_floats(int layer, int64_t P, int Cin, int Cout, int* splits, int* steps) {
+static int64_t wgrad_part_floats(int precision, int W, int64_t P, int Cin, int Cout, int* splits, int* steps) {
     const int64_t ksteps = (P + kWgradPix - 1) / kWgradPix;
     int tiles;
-    if (Cin == 1) tiles = 1;
+    if (conv_wgrad_nine_taps(precision, W, Cin, Cout)) tiles = 2 * (Cout / 64) * (Cin / 64);  // ~1024 workgroups: two per CU, two rounds
+    else if (Cin == 1) tiles = 1;
     else if (Cin % 128 == 0 && Cout % 128 == 0) tiles = (Cout / 128) * (Cin / 128) * 9;
     else tiles = (Cout / 64) * (Cin / 64) * 9;
     int64_t s = (2048 + tiles - 1) / tiles;
@@ -588,7 +589,6 @@ static int64_t wgrad_part_floats(int layer, int64_t P, int Cin, int Cout, int* s
     s = (ksteps + per - 1) / per;
     *splits = (int)s;
     *steps = (int)per;
-    (void)layer;
     return Cin == 1 ? s * Cout * 16 : s * 9 * (int64_t)Cout * Cin;
 }
 static CnnPlan cnn_plan(const mst_cnn14_desc* d) {
@@ -630,7 +630,7 @@ static CnnPlan cnn_plan(const mst_cnn14_desc* d) {
             size_t bn = (tiles > strips ? tiles : strips) * Cout * 2 * 4;
             bnmax = bn > bnmax ? bn : bnmax;
             int sp, st;
-            const size_t wg = (size_t)wgrad_part_floats(2 * b + k, P, Cin, Cout, &sp, &st) * 4;
+            const size_t wg = (size_t)wgrad_part_floats(p.esz == 2 ? 0 : 1, p.W[b], P, Cin, Cout, &sp, &st) * 4;
             wgmax = wg > wgmax ? wg : wgmax;
             if (Cin > 1) {  // split-K scratch of the forward convolution and of its data gradient (channel roles swapped)
                 const size_t k1 = conv_splitk_bytes(p.n, p.H[b], p.W[b], Cin, Cout), k2 = conv_splitk_bytes(p.n, p.H[b], p.W[b], Cout, Cin);
@@ -758,7 +758,7 @@ static int cnn_backward_t(const mst_cnn14_desc* d, const CnnPlan& p, const float
             // weight gradient
             const void* x_in = k == 1 ? (const void*)(ws + p.a1[b]) : (b == 0 ? (const void*)spec : (const void*)(ws + p.out[b - 1]));
             int splits, steps;
-            wgrad_part_floats(l, P, Cin, C, &splits, &steps);
+            wgrad_part_floats(prec, W, P, Cin, C, &splits, &steps);
             WgradArgs wa{GA, x_in, wgpart, p.n, H, W, Cin, C, splits, steps};
             launch_conv_wgrad(prec, wa, s);
             if (Cin == 1) hipLaunchKernelGGL(k_wgrad_reduce_first, dim3(C), dim3(256), 0, s, wgpart, gr->conv_w[l], C, splits);
