@@ -151,15 +151,32 @@ __global__ __launch_bounds__(256) void k_prep_weights_tiled(const float* __restr
         wd[((int64_t)(ci0 + o) * 9 + (8 - tap)) * Cout + co0 + l32] = tile[l32 * ROW + o * 9 + inner];
     }
 }
-// partial sums (splits, 9, Cout, Cin) -> torch layout (co, ci, kh, kw), fixed order
-__global__ void k_wgrad_reduce(const float* __restrict__ part, float* __restrict__ gw, int Cin, int Cout, int splits) {
+// partial sums (splits, 9, Cout, Cin) -> torch layout (co, ci, kh, kw), fixed order.  A workgroup folds 64 consecutive sums (256-byte
+// rows of the slabs); its four 64-lane groups take every fourth slab, four loads in flight each, and meet in LDS (one thread per sum
+// walking all slabs: 360 us for the 64 -> 64 layer's 1024 slabs)
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ part, float* __restrict__ gw, int Cin, int Cout, int splits) {
+    __shared__ float red[4][64];
     const int64_t total = (int64_t)Cout * Cin * 9;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        const int ci = (int)(e % Cin), tap = (int)((e / Cin) % 9), co = (int)(e / ((int64_t)Cin * 9));
+    const int l = threadIdx.x & 63, sg = threadIdx.x >> 6;
+    for (int64_t e0 = (int64_t)blockIdx.x * 64; e0 < total; e0 += (int64_t)gridDim.x * 64) {  // e = (tap Cout + co) Cin + ci: the order of a slab
+        const int64_t e = e0 + l;
         float acc = 0.f;
-        for (int s = 0; s < splits; ++s) acc += part[(((int64_t)s * 9 + tap) * Cout + co) * Cin + ci];
-        const int a_ = tap / 3, b_ = tap % 3;
-        gw[(((int64_t)co * Cin + ci) * 3 + b_) * 3 + a_] = acc;
+        for (int s0 = sg; s0 < splits; s0 += 16) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = s0 + 4 * u < splits ? part[(int64_t)(s0 + 4 * u) * total + e] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc += v[u];
+        }
+        red[sg][l] = acc;
+        __syncthreads();
+        if (sg == 0) {
+            const float v = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+            const int ci = (int)(e % Cin), co = (int)((e / Cin) % Cout), tap = (int)(e / ((int64_t)Cin * Cout));  // slab order (tap, co, ci)
+            const int a_ = tap / 3, b_ = tap % 3;
+            gw[(((int64_t)co * Cin + ci) * 3 + b_) * 3 + a_] = v;
+        }
+        __syncthreads();
     }
 }
 // first layer (Cin = 1, partial sums (splits, Cout, 16)): 576 sums over ~2000 pixel splits each - one workgroup per output channel,
@@ -762,7 +779,7 @@ static int cnn_backward_t(const mst_cnn14_desc* d, const CnnPlan& p, const float
             WgradArgs wa{GA, x_in, wgpart, p.n, H, W, Cin, C, splits, steps};
             launch_conv_wgrad(prec, wa, s);
             if (Cin == 1) hipLaunchKernelGGL(k_wgrad_reduce_first, dim3(C), dim3(256), 0, s, wgpart, gr->conv_w[l], C, splits);
-            else hipLaunchKernelGGL(k_wgrad_reduce, dim3(ew_grid((int64_t)9 * Cin * C)), dim3(256), 0, s, wgpart, gr->conv_w[l], Cin, C, splits);
+            else hipLaunchKernelGGL(k_wgrad_reduce, dim3(ew_grid((int64_t)9 * Cin * C * 4)), dim3(256), 0, s, wgpart, gr->conv_w[l], Cin, C, splits);
             // data gradient (not for the spectrogram itself)
             if (Cin > 1) {
                 ConvArgs ca{GA, ws + p.wd[l], GB, nullptr, p.n, H, W, C, Cin, 0, nullptr};
