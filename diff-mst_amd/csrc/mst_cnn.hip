@@ -13,6 +13,11 @@
 //                BC channels x 128 pixels x 32 of K; four waves as 2 x 2, each (BC/2) x 64.  The per-channel sum / sum of
 //                squares that BatchNorm needs ride in the epilogue (fp32 accumulators, before any rounding).
 //                The data gradient is the same kernel on (dY, W^T rotated by 180 degrees) - see k_prep_weights.
+// k_conv_igemm3 / k_conv_igemm4   the bf16 production form of that GEMM: tiles fetched by LDS-direct loads into a ring with counted
+//                waits (3), the three taps of an image row sharing one activation segment (4).  k_conv_igemm stays for fp32 operands
+//                and as the register-staged A/B baseline (-DMST_CONV_NO_GLDS).
+// k_conv_wgrad3 / k_conv_wgrad4   bf16 weight gradient on the same loader + ds_read_b64_tr_b16 fragments; one tap (3) or all nine (4)
+//                per workgroup.
 // k_conv_wgrad   dW[co][tap][ci] = sum_pixel dY[pixel][co] X[pixel + tap][ci]: K = pixels, which is the STRIDED axis of both
 //                NHWC operands; the tiles are staged pixel-major as they lie in memory and the fragments are gathered column
 //                by column (bf16: eight 2-byte LDS reads per fragment on a 260-byte pitch that spreads the four k-groups
@@ -654,165 +659,6 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm4(ConvArgs a) {
 }
 
 // =====================================================================================================================
-// k_conv_igemm2 (bf16, Cout % 128 == 0, Cin % 64 == 0): the same GEMM with the L1 traffic cut to 0.44x.  Ablations of k_conv_igemm
-// (-DMST_CONV_ABLATE) showed what binds it: with the MFMAs and LDS reads removed it still takes 337 of its 367 us, without its
-// global loads 211 - every K step pulls 32 KB through a 64 B/clk L1 for 512 MFMA cycles.  Here
-//   * the three taps of an image row share ONE activation tile: pixels p0 - 1 .. p0 + 256 of row h + dh are staged once per
-//     (dh, channel block) and tap dw reads its B fragments from LDS rows shifted by dw + 1 (the slot swizzle `row & 6` keeps
-//     shifted reads conflict-free); what the shift drags in across a row end or an image border is zeroed per lane from a
-//     nine-bit validity mask of the lane's pixel;
-//   * a workgroup covers 256 pixels, so every weight tile feeds twice the MFMAs (wave tile 64 channels x 128 pixels: also
-//     0.75x the LDS bytes per MFMA).
-// 21 16-byte loads per thread per 192 MFMAs instead of 48.  Weight tiles are double-buffered in LDS (one barrier per tap).
-// Measured (16 signals): 128 -> 128 at 256 x 512: 1.79 -> 1.50 ms, 256 -> 256 at 64 x 128: 448 -> 378 us - 16 %, not the 1.3x the
-// ablation promised: at 256 registers (28 spilled) and 68 KB of LDS two workgroups share a CU, and grids under 1024 workgroups
-// lose more to the half-empty chip than they gain (launch_conv3x3 keeps those on k_conv_igemm).
-constexpr int kConvPix2 = 256;
-__global__ __launch_bounds__(256, 2) void k_conv_igemm2(ConvArgs a) {
-    using T = bf16_t;
-    constexpr int BC = 128, BP = kConvPix2, BK = 64, XROWS = BP + 2, XQ = (XROWS * 8 + 255) / 256, WQ = BC * 8 / 256, MT = 4, NT = 8;
-    __shared__ __attribute__((aligned(16))) T sX[(XROWS + 6) * BK];
-    __shared__ __attribute__((aligned(16))) T sW[2][BC * BK];
-    __shared__ float red[2][BC][2];
-    auto off = [](int row, int kc) { return row * BK + ((kc ^ (row & 6)) << 3); };
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wy = wave >> 1, wx = wave & 1;
-    const int g = lane >> 4, li = lane & 15;
-    const int H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout, HW = H * W;
-    const int64_t P = (int64_t)a.N * HW, p0 = (int64_t)blockIdx.x * BP;
-    const int co0 = blockIdx.y * BC;
-    const T* __restrict__ in = reinterpret_cast<const T*>(a.in);
-    const T* __restrict__ w = reinterpret_cast<const T*>(a.w);
-
-    unsigned vm[NT];  // bit t: tap t of pixel (wx 128 + n 16 + li) lies inside the image
-#pragma unroll
-    for (int n = 0; n < NT; ++n) {
-        const int64_t p = p0 + wx * 128 + n * 16 + li;
-        unsigned m = 0;
-        if (p < P) {
-            const int r = (int)(p % HW), h = r / W, ww = r % W;
-#pragma unroll
-            for (int t = 0; t < 9; ++t)
-                if ((unsigned)(h + t / 3 - 1) < (unsigned)H && (unsigned)(ww + t % 3 - 1) < (unsigned)W) m |= 1u << t;
-        }
-        vm[n] = m;
-    }
-    uint4 rx[XQ], rw[WQ];
-    auto xload = [&](int dh, int c0) {  // LDS row j <- linear pixel p0 - 1 + j + dh W (zeros outside [0, P))
-#pragma unroll
-        for (int q = 0; q < XQ; ++q) {
-            const int c = tid + q * 256, row = c >> 3, kc = c & 7;
-            const int64_t L = p0 - 1 + row + (int64_t)dh * W;
-            rx[q] = (row < XROWS && L >= 0 && L < P) ? *reinterpret_cast<const uint4*>(in + L * Cin + c0 + kc * 8) : make_uint4(0, 0, 0, 0);
-        }
-    };
-    auto xstore = [&]() {
-#pragma unroll
-        for (int q = 0; q < XQ; ++q) {
-            const int c = tid + q * 256, row = c >> 3, kc = c & 7;
-            if (row < XROWS) *reinterpret_cast<uint4*>(&sX[off(row, kc)]) = rx[q];
-        }
-    };
-    auto wload = [&](int tap, int c0) {
-#pragma unroll
-        for (int q = 0; q < WQ; ++q) {
-            const int c = tid + q * 256, row = c >> 3, kc = c & 7;
-            rw[q] = *reinterpret_cast<const uint4*>(w + (int64_t)(co0 + row) * 9 * Cin + (int64_t)tap * Cin + c0 + kc * 8);
-        }
-    };
-    auto wstore = [&](T* dst) {
-#pragma unroll
-        for (int q = 0; q < WQ; ++q) {
-            const int c = tid + q * 256, row = c >> 3, kc = c & 7;
-            *reinterpret_cast<uint4*>(&dst[off(row, kc)]) = rw[q];
-        }
-    };
-    f32x4 acc[MT][NT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-    auto multiply = [&](const T* sWc, int tap) {
-        const int sh = tap % 3;  // dw + 1: LDS row of pixel i at this tap = i + sh
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 af[MT];
-#pragma unroll
-            for (int m = 0; m < MT; ++m) af[m] = *reinterpret_cast<const bf16x8*>(&sWc[off(wy * 64 + m * 16 + li, ks * 4 + g)]);
-#pragma unroll
-            for (int n = 0; n < NT; ++n) {
-                uint4 u = *reinterpret_cast<const uint4*>(&sX[off(wx * 128 + n * 16 + li + sh, ks * 4 + g)]);
-                const unsigned keep = (vm[n] >> tap) & 1u ? 0xffffffffu : 0u;
-                u.x &= keep; u.y &= keep; u.z &= keep; u.w &= keep;
-                const bf16x8 bfr = __builtin_bit_cast(bf16x8, u);
-#pragma unroll
-                for (int m = 0; m < MT; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bfr, acc[m][n], 0, 0, 0);
-            }
-        }
-    };
-    // sub-step t = (dh, channel block, dw), dw fastest; weight tile t sits in sW[t & 1]
-    const int ksteps = Cin / BK, nsub = 9 * ksteps;
-    auto sub_tap = [&](int t) { return ((t / 3) / ksteps) * 3 + t % 3; };
-    auto sub_c0 = [&](int t) { return ((t / 3) % ksteps) * BK; };
-    xload(-1, 0);
-    wload(sub_tap(0), 0);
-    xstore();
-    wstore(sW[0]);
-    if (nsub > 1) wload(sub_tap(1), sub_c0(1));
-    __syncthreads();
-    for (int t = 0; t < nsub; ++t) {
-        const bool last_dw = t % 3 == 2, more = t + 1 < nsub;
-        if (t % 3 == 0 && t + 3 < nsub) xload((t + 3) / 3 / ksteps - 1, sub_c0(t + 3));  // the next activation tile flies during three taps
-        multiply(sW[t & 1], sub_tap(t));
-        if (more) wstore(sW[(t + 1) & 1]);
-        if (t + 2 < nsub) wload(sub_tap(t + 2), sub_c0(t + 2));
-        if (last_dw && more) {
-            __syncthreads();  // every wave is done with the activation tile
-            xstore();
-        }
-        __syncthreads();
-    }
-    // ---- epilogue (as k_conv_igemm): D row = channel (lane >> 4) * 4 + r, D column = pixel lane & 15
-    T* __restrict__ out = reinterpret_cast<T*>(a.out);
-#pragma unroll
-    for (int n = 0; n < NT; ++n) {
-        const int64_t p = p0 + wx * 128 + n * 16 + li;
-        if (p < P) {
-#pragma unroll
-            for (int m = 0; m < MT; ++m) store4(out + p * Cout + co0 + wy * 64 + m * 16 + g * 4, acc[m][n]);
-        }
-    }
-    if (a.part) {
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-                for (int n = 0; n < NT; ++n) {
-                    s1 += acc[m][n][r];
-                    s2 = fmaf(acc[m][n][r], acc[m][n][r], s2);
-                }
-#pragma unroll
-                for (int msk = 1; msk < 16; msk <<= 1) {
-                    s1 += __shfl_xor(s1, msk);
-                    s2 += __shfl_xor(s2, msk);
-                }
-                if (li == 0) {
-                    red[wx][wy * 64 + m * 16 + g * 4 + r][0] = s1;
-                    red[wx][wy * 64 + m * 16 + g * 4 + r][1] = s2;
-                }
-            }
-        }
-        __syncthreads();
-        if (tid < BC) {
-            float* o = a.part + ((int64_t)blockIdx.x * Cout + co0 + tid) * 2;
-            o[0] = red[0][tid][0] + red[1][tid][0];
-            o[1] = red[0][tid][1] + red[1][tid][1];
-        }
-    }
-}
-
-// fold the split-K partials: out[p][c] = sum_z kpart[z][p][c] (fixed order), per-tile channel statistics as the unsplit epilogue
 template <typename T>
 __global__ __launch_bounds__(256) void k_conv_splitk_reduce(const float* __restrict__ kpart, T* __restrict__ out, float* __restrict__ part, int64_t P,
                                                             int Cout, int nz) {
@@ -859,13 +705,6 @@ __global__ __launch_bounds__(256) void k_conv_splitk_reduce(const float* __restr
         }
     }
 }
-static constexpr bool conv2_enabled() {
-#ifdef MST_CONV_NO_IGEMM2
-    return false;  // A/B switch: every layer on k_conv_igemm
-#else
-    return true;
-#endif
-}
 static constexpr bool conv3_enabled() {
 #ifdef MST_CONV_NO_GLDS
     return false;  // A/B switch: register-staged k_conv_igemm
@@ -894,6 +733,7 @@ int launch_conv3x3(int precision, ConvArgs a, hipStream_t s, float* kpart, size_
         a.kpart = kpart;
     }
     const unsigned gz = a.csplit ? 9 * a.csplit : 1;
+    constexpr int kConvPix2 = 256;  // pixels per workgroup of the fat tiles
     const int tiles2 = (int)(((int64_t)a.N * a.H * a.W + kConvPix2 - 1) / kConvPix2);
 #ifndef MST_CONV_FAT_MIN
 #define MST_CONV_FAT_MIN 1024  // workgroups from which the 256-pixel tile is used
@@ -909,11 +749,6 @@ int launch_conv3x3(int precision, ConvArgs a, hipStream_t s, float* kpart, size_
     }
     if (fat_ok && conv3_enabled()) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_igemm3<128, 256, MST_CONV_GLDS_STAGES>), dim3(tiles2, a.Cout / 128), dim3(256), 0, s, a);
-        return tiles2;
-    }
-    // (register-staged predecessor of the above: measured at 16 signals 1024+ workgroups -11..-16 % against k_conv_igemm, 256: +35 %)
-    if (fat_ok && a.Cin % 64 == 0 && conv2_enabled() && !conv3_enabled()) {
-        hipLaunchKernelGGL(k_conv_igemm2, dim3(tiles2, a.Cout / 128), dim3(256), 0, s, a);
         return tiles2;
     }
     if (a.Cout % 128 == 0) {
