@@ -330,16 +330,20 @@ __global__ void k_bn_finalize(const double* __restrict__ part, int tiles, int C,
 template <typename T>
 __global__ void k_bn_relu(const T* __restrict__ raw, T* __restrict__ out, const float* __restrict__ stat, const float* __restrict__ gamma,
                           const float* __restrict__ beta, int64_t chunks, int C) {
-    const int cg = C / 8;
+    // the grid stride (a multiple of 256) is a multiple of C / 8 <= 256: a thread stays on ONE channel group - its constants are loaded once
+    const int cg = C / 8, c0 = (int)((blockIdx.x * blockDim.x + threadIdx.x) % cg) * 8;
+    float sc[8], mu[8], be[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        sc[j] = gamma[c0 + j] * stat[C + c0 + j];
+        mu[j] = stat[c0 + j];
+        be[j] = beta[c0 + j];
+    }
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < chunks; e += (int64_t)gridDim.x * blockDim.x) {
-        const int c0 = (int)(e % cg) * 8;
         float v[8];
         load8(raw + e * 8, v);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float sc = gamma[c0 + j] * stat[C + c0 + j];
-            v[j] = fmaxf(fmaf(v[j] - stat[c0 + j], sc, beta[c0 + j]), 0.f);
-        }
+        for (int j = 0; j < 8; ++j) v[j] = fmaxf(fmaf(v[j] - mu[j], sc[j], be[j]), 0.f);
         store8(out + e * 8, v);
     }
 }
@@ -349,20 +353,30 @@ __global__ void k_bn_relu_pool(const T* __restrict__ raw, T* __restrict__ out, c
     const int cg = C / 8, Ho = H / ph, Wo = W / pw;
     const int64_t chunks = (int64_t)N * Ho * Wo * cg;
     const float inv = 1.0f / (float)(ph * pw);
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < chunks; e += (int64_t)gridDim.x * blockDim.x) {
-        const int c0 = (int)(e % cg) * 8;
-        int64_t r = e / cg;
-        const int wo = (int)(r % Wo);
-        r /= Wo;
-        const int ho = (int)(r % Ho), n = (int)(r / Ho);
-        float sc[8], mu[8], be[8], acc[8];
+    const int c0 = (int)((blockIdx.x * blockDim.x + threadIdx.x) % cg) * 8;  // constant per thread (see k_bn_relu)
+    float sc[8], mu[8], be[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            sc[j] = gamma[c0 + j] * stat[C + c0 + j];
-            mu[j] = stat[c0 + j];
-            be[j] = beta[c0 + j];
-            acc[j] = 0.f;
+    for (int j = 0; j < 8; ++j) {
+        sc[j] = gamma[c0 + j] * stat[C + c0 + j];
+        mu[j] = stat[c0 + j];
+        be[j] = beta[c0 + j];
+    }
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < chunks; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = e / cg;  // pooled pixel (n, ho, wo); cg is a power of two
+        int n, ho, wo;
+        if (r < 0x7fffffff) {  // 32-bit divisions (a 64-bit one is ~100 instructions)
+            const unsigned ru = (unsigned)r, q = ru / (unsigned)Wo;
+            wo = (int)(ru - q * (unsigned)Wo);
+            n = (int)(q / (unsigned)Ho);
+            ho = (int)(q - (unsigned)n * (unsigned)Ho);
+        } else {
+            wo = (int)(r % Wo);
+            ho = (int)((r / Wo) % Ho);
+            n = (int)(r / Wo / Ho);
         }
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
         for (int i = 0; i < ph; ++i)
             for (int k = 0; k < pw; ++k) {
                 float v[8];
@@ -376,8 +390,6 @@ __global__ void k_bn_relu_pool(const T* __restrict__ raw, T* __restrict__ out, c
     }
 }
 
-// ---- backward of (pool) - ReLU - BatchNorm.  g_up: cotangent of the ReLU output - at full resolution (POOL = false) or of the
-// pooled output (POOL = true: spread evenly over its ph x pw window, pixels beyond the pooled region get none).
 struct BnBwdArgs {
     const void* raw;   // (N, H, W, C) conv output
     const void* g_up;
@@ -401,9 +413,16 @@ __device__ __forceinline__ void bn_bwd_pixel(const BnBwdArgs& a, int64_t p, int 
     float scale = 1.0f;
     int64_t gp = p;
     if (POOL) {
-        const int Ho = a.H / a.ph, Wo = a.W / a.pw;
-        const int r = (int)(p % ((int64_t)a.H * a.W)), n = (int)(p / ((int64_t)a.H * a.W));
-        const int ho = (r / a.W) / a.ph, wo = (r % a.W) / a.pw;
+        const int Ho = a.H / a.ph, Wo = a.W / a.pw, HW = a.H * a.W;
+        int r, n;
+        if (p < 0x7fffffff) {  // 32-bit divisions (a 64-bit one is ~100 instructions, and every 16-byte chunk pays it)
+            n = (int)((unsigned)p / (unsigned)HW);
+            r = (int)((unsigned)p - (unsigned)n * (unsigned)HW);
+        } else {
+            n = (int)(p / HW);
+            r = (int)(p - (int64_t)n * HW);
+        }
+        const int h = r / a.W, ho = h / a.ph, wo = (r - h * a.W) / a.pw;
         inside = ho < Ho && wo < Wo;
         gp = ((int64_t)n * Ho + ho) * Wo + wo;
         scale = 1.0f / (float)(a.ph * a.pw);
@@ -485,20 +504,24 @@ __global__ void k_bn_bwd_apply(BnBwdArgs a) {
     const int cg = a.C / 8;
     const int64_t chunks = (int64_t)a.N * a.H * a.W * cg;
     T* d = reinterpret_cast<T*>(a.d_raw);
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < chunks; e += (int64_t)gridDim.x * blockDim.x) {
-        const int c0 = (int)(e % cg) * 8;
-        const int64_t p = e / cg;
-        float mu[8], is[8], ga[8], be[8], g[8], xh[8];
+    const int c0 = (int)((blockIdx.x * blockDim.x + threadIdx.x) % cg) * 8;  // constant per thread (see k_bn_relu)
+    float mu[8], is[8], ga[8], be[8], k0[8], k1[8], k2[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            mu[j] = a.stat[c0 + j];
-            is[j] = a.stat[a.C + c0 + j];
-            ga[j] = a.gamma[c0 + j];
-            be[j] = a.beta[c0 + j];
-        }
+    for (int j = 0; j < 8; ++j) {
+        mu[j] = a.stat[c0 + j];
+        is[j] = a.stat[a.C + c0 + j];
+        ga[j] = a.gamma[c0 + j];
+        be[j] = a.beta[c0 + j];
+        k0[j] = a.coef[(c0 + j) * 3];
+        k1[j] = a.coef[(c0 + j) * 3 + 1];
+        k2[j] = a.coef[(c0 + j) * 3 + 2];
+    }
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < chunks; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = e / cg;
+        float g[8], xh[8];
         bn_bwd_pixel<T, POOL>(a, p, c0, mu, is, ga, be, g, xh);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) g[j] = a.coef[(c0 + j) * 3] * (g[j] - a.coef[(c0 + j) * 3 + 1] - xh[j] * a.coef[(c0 + j) * 3 + 2]);
+        for (int j = 0; j < 8; ++j) g[j] = k0[j] * (g[j] - k1[j] - xh[j] * k2[j]);
         store8(d + e * 8, g);
     }
 }
@@ -594,7 +617,10 @@ struct CnnPlan {
 static int64_t wgrad_part_floats(int precision, int W, int64_t P, int Cin, int Cout, int* splits, int* steps) {
     const int64_t ksteps = (P + kWgradPix - 1) / kWgradPix;
     int tiles;
-    if (conv_wgrad_nine_taps(precision, W, Cin, Cout)) tiles = 2 * (Cout / 64) * (Cin / 64);  // ~1024 workgroups: two per CU, two rounds
+#ifndef MST_WGRAD4_WGS
+#define MST_WGRAD4_WGS 512  // workgroups of the nine-tap kernel (two per CU, one round; 1024: +4 % kernel time and twice the slabs): its 9 x Cout x Cin fp32 slab per split is written and re-read
+#endif
+    if (conv_wgrad_nine_taps(precision, W, Cin, Cout)) tiles = (2048 / MST_WGRAD4_WGS) * (Cout / 64) * (Cin / 64);
     else if (Cin == 1) tiles = 1;
     else if (Cin % 128 == 0 && Cout % 128 == 0) tiles = (Cout / 128) * (Cin / 128) * 9;
     else tiles = (Cout / 64) * (Cin / 64) * 9;
