@@ -25,6 +25,24 @@ constexpr int kAf2Lanes = 512;
 #define MST_AF2_W_BWD 4  // one half per launch: 121-124 registers, two workgroups per CU
 #endif
 
+// |X| and g / |X| on the hardware's 1-ulp v_sqrt_f32 / v_rsq_f32 (the correctly rounded sqrtf and '/' are 10 + 11 instructions per bin
+// with a denormal guard; -DMST_AF_PRECISE_MAG=1 restores them).  |X|^2 below 1e-30 - |X| < 1e-15, far under fp32 round-off of any
+// audible frame - counts as zero in the gradient, as |X| = 0 did.
+#ifndef MST_AF_PRECISE_MAG
+#define MST_AF_PRECISE_MAG 0
+#endif
+__device__ __forceinline__ float af_mag(float2 X) {
+    const float p2 = X.x * X.x + X.y * X.y;
+    return MST_AF_PRECISE_MAG ? sqrtf(p2) : __builtin_amdgcn_sqrtf(p2);
+}
+__device__ __forceinline__ float af_over_mag(float g, float2 X) {
+    const float p2 = X.x * X.x + X.y * X.y;
+    if (MST_AF_PRECISE_MAG) {
+        const float m = sqrtf(p2);
+        return m > 0.f ? g / m : 0.f;
+    }
+    return p2 > 1e-30f ? g * __builtin_amdgcn_rsqf(p2) : 0.f;
+}
 // W_32^t = (cos, -sin)(2 pi t / 32), t < 16: W_16384^(lane + 512 t) = W_16384^lane W_32^t
 __device__ __forceinline__ float2 w32(int t) {
     constexpr float c[16] = {1.0f, 0.98078528040323043f, 0.92387953251128674f, 0.83146961230254524f, 0.70710678118654752f,
@@ -128,14 +146,14 @@ __device__ __forceinline__ void af2_fwd_body(const AfArgs& a, float2 (*buf)[AfS:
             const int qm = HALF == 0 ? ((kAfHalf - q) & (kAfHalf - 1)) : kAfHalf - 1 - q;
             float2 Xk, Xm;
             af2_untangle(af2_at(buf, q), af2_at(buf, qm), twN[2 * q + HALF], Xk, Xm);
-            acc_lo[j] += sqrtf(Xk.x * Xk.x + Xk.y * Xk.y);
-            acc_hi[j] += sqrtf(Xm.x * Xm.x + Xm.y * Xm.y);  // k = 0 -> bin M (Nyquist)
+            acc_lo[j] += af_mag(Xk);
+            acc_hi[j] += af_mag(Xm);  // k = 0 -> bin M (Nyquist)
         }
         if (HALF == 0 && lane == 0) {
             const float2 z = af2_at(buf, kAfHalf / 2);  // k = M/2 pairs with itself
             float2 Xk, Xm;
             af2_untangle(z, z, twN[kAfM / 2], Xk, Xm);
-            acc_mid += sqrtf(Xk.x * Xk.x + Xk.y * Xk.y);
+            acc_mid += af_mag(Xk);
         }
     }
     float* out = a.magpart + ((int64_t)s * a.n_groups + grp) * kAfBins;
@@ -169,8 +187,7 @@ __device__ __forceinline__ void af2_cotangent(const AfArgs& a, float2 (*buf)[AfS
         const float2 w = twN[k];  // W^k ; W^(M-k) = -conj(W^k)
         float2 Xk, Xm;
         af2_untangle(af2_at(buf, q), af2_at(buf, qm), w, Xk, Xm);
-        const float ak = sqrtf(Xk.x * Xk.x + Xk.y * Xk.y), am = sqrtf(Xm.x * Xm.x + Xm.y * Xm.y);
-        const float gk = ak > 0.f ? dM[k] / ak : 0.f, gm = am > 0.f ? dM[kAfM - k] / am : 0.f;
+        const float gk = af_over_mag(dM[k], Xk), gm = af_over_mag(dM[kAfM - k], Xm);
         float2 Hk = make_float2(gk * Xk.x, gk * Xk.y), Hm = make_float2(gm * Xm.x, gm * Xm.y);  // G[k], G[M-k]
         if (HALF == 0 && k == 0) {
             // slot 0 combines H[0] = Re G[0] and H[M] = Re G[M]: A[0] = H[0] + H[M], Bq[0] = H[0] - H[M] (both real)
