@@ -218,7 +218,6 @@ __global__ __launch_bounds__(256) void k_conv1(const float* __restrict__ spec, c
     for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
     int64_t p = (int64_t)blockIdx.x * kConv1Pix + pl;
     int r = (int)(p % HW);
-#pragma unroll 2  // two pixels in flight per thread: the nine tap loads of the second hide behind the FMAs of the first
     for (int it = 0; it < kConv1Pix / 32; ++it, p += 32) {
         if (p < P) {
             const int h = r / W, ww = r - h * W;
