@@ -9,6 +9,9 @@
 
 namespace mst {
 
+#ifndef MST_FUSE_COEFGRAD
+#define MST_FUSE_COEFGRAD 1  // the track rows' coefficient-gradient sums are made inside k_comp_bwd_run (A/B switch: 0 = k_coefgrad for every row)
+#endif
 constexpr int kSections = 6;           // low shelf, 4 peaking, high shelf (reference mst/modules.py:125-143)
 constexpr int kStates = 2 * kSections; // DF2T state of the whole cascade
 constexpr int kWG = 256;               // lanes per workgroup in the compressor kernels
@@ -190,6 +193,7 @@ struct Layout {
     int ncE, ncE_pad;        // EQ lane-chunks per signal row (pad to kWG)
     int ncC, ncC_pad;        // compressor lane-chunks per row
     int nblkE, nblkC;        // workgroups per row in EQ / compressor kernels
+    int nblkEt;              // coefficient-gradient partial rows per TRACK row: nblkC when k_comp_bwd_run makes them (MST_FUSE_COEFGRAD), else nblkE
     int KE, KC;              // chunks per scan thread
     int ntE;                 // 4096-sample EQ tiles per row
     int eq1;                 // 1: EQ carries scanned inside the zs / run kernels, 0: separate carry-scan kernel
@@ -227,6 +231,7 @@ inline Layout make_layout(const mst_console_desc* d) {
     L.ncC_pad = (int)round_up(L.ncC, kWG);
     L.nblkE = L.ncE_pad / kEqWG;
     L.nblkC = L.ncC_pad / kWG;
+    L.nblkEt = MST_FUSE_COEFGRAD ? L.nblkC : L.nblkE;
     L.KE = (L.ncE + kScanThreads - 1) / kScanThreads;
     if (L.KE > 8) L.KE = (int)round_up(L.KE, 8);  // whole 8-chunk sub-spans: aligned 16-byte state accesses in k_scan
     L.KC = (L.ncC + kScanThreads - 1) / kScanThreads;
@@ -279,8 +284,8 @@ inline Layout make_layout(const mst_console_desc* d) {
     L.sP_m = L.sP_t + R * 24 * L.ncE_pad;
     L.cp_t = take(R * L.nblkC * CP_COUNT);
     L.cp_m = take(B * L.nblkC * CP_COUNT);
-    L.ep_t = take((R + 2 * B) * L.nblkE * EP_COUNT);
-    L.ep_m = L.ep_t + R * L.nblkE * EP_COUNT;
+    L.ep_t = take((R * L.nblkEt + 2 * B * L.nblkE) * EP_COUNT);
+    L.ep_m = L.ep_t + R * L.nblkEt * EP_COUNT;
     L.pow1F_t = take((R + B) * kTri2);
     L.pow1F_m = L.pow1F_t + R * kTri2;
     L.pow1A_t = take((R + B) * kTri2);

@@ -344,9 +344,80 @@ __global__ __launch_bounds__(kWG) void k_comp_bwd_zs(CompBwdArgs a) {
     else comp_bwd_zs_body<MASTER, false>(a);
 }
 
+// ---- coefficient-gradient sums of the block, formed where du and u are in registers (MST_FUSE_COEFGRAD) ----------------------
+// k_coefgrad's arithmetic (all-pole bank 1/A_k, b0/B_k on u from the saved chunk-entry states, five inner products with the
+// cotangent per section) on this workgroup's 2048 samples = 32 chunks of 64: the block's du and u go to LDS in the chunk-per-row
+// layout, lane (section s = tid >> 5, chunk c = tid & 31) walks its chunk with ONE section (k_coefgrad: three per lane), the 32
+// chunk lanes of a section meet in a half-wave shuffle sum.  192 of the 256 lanes work; the cotangent du crosses HBM only if
+// someone downstream wants it, u is not fetched a second time.
+constexpr int kCgPitch = kEqChunk + 4, kCgChunks = kWG * CC / kEqChunk, kCgTile = kCgChunks * kCgPitch;
+static_assert(kCgChunks == 32 && kSections * 32 <= kWG, "one section x 32 chunks per 32 lanes");
+template <bool FAST>
+__device__ __forceinline__ void coefgrad_fused(const CompBwdArgs& a, int row, const float* __restrict__ rc, int64_t i0, const float* xu,
+                                               const float* du, float* __restrict__ cg_u, float* __restrict__ cg_g) {
+    const int tid = threadIdx.x;
+    {
+        const int c = tid >> 3, off = (tid & 7) * CC;  // 8 lanes x 8 samples = one chunk
+        float g[CC];
+#pragma unroll
+        for (int i = 0; i < CC; ++i) g[i] = (FAST || i0 + i < a.n) ? du[i] : 0.0f;
+        float* pu = &cg_u[c * kCgPitch + off];
+        float* pg = &cg_g[c * kCgPitch + off];
+        *reinterpret_cast<float4*>(pu) = make_float4(xu[0], xu[1], xu[2], xu[3]);
+        *reinterpret_cast<float4*>(pu + 4) = make_float4(xu[4], xu[5], xu[6], xu[7]);
+        *reinterpret_cast<float4*>(pg) = make_float4(g[0], g[1], g[2], g[3]);
+        *reinterpret_cast<float4*>(pg + 4) = make_float4(g[4], g[5], g[6], g[7]);
+    }
+    lds_barrier();
+    const int s = tid >> 5, c = tid & 31;
+    if (s < kSections) {
+        const float ka1 = rc[RC_SOS + 5 * s + 3], ka2 = rc[RC_SOS + 5 * s + 4];
+        const float kc1 = rc[RC_AP + 3 * s], kc2 = rc[RC_AP + 3 * s + 1], kib0 = rc[RC_AP + 3 * s + 2];
+        const int64_t base = ((int64_t)row * 24 + 4 * s) * a.ap_nc_pad + (int64_t)blockIdx.x * kCgChunks + c;
+        float wa1 = a.ap_s0[base], wa2 = a.ap_s0[base + a.ap_nc_pad], wb1 = a.ap_s0[base + 2 * (int64_t)a.ap_nc_pad],
+              wb2 = a.ap_s0[base + 3 * (int64_t)a.ap_nc_pad];
+        float db0 = 0.f, db1 = 0.f, db2 = 0.f, da1 = 0.f, da2 = 0.f;
+        const float* mu = &cg_u[c * kCgPitch];
+        const float* mg = &cg_g[c * kCgPitch];
+#pragma unroll 2
+        for (int i4 = 0; i4 < kEqChunk; i4 += 4) {
+            const float4 xv = *reinterpret_cast<const float4*>(&mu[i4]);
+            const float4 gv = *reinterpret_cast<const float4*>(&mg[i4]);
+            const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, gs[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float x = xs[t], gp = gs[t], gm = -gs[t];
+                const float wa = fmaf(-ka2, wa2, fmaf(-ka1, wa1, x));
+                const float wb = fmaf(-kc2, wb2, fmaf(-kc1, wb1, x));
+                db0 = fmaf(gp, wb, db0);
+                db1 = fmaf(gp, wb1, db1);
+                db2 = fmaf(gp, wb2, db2);
+                da1 = fmaf(gm, wa1, da1);
+                da2 = fmaf(gm, wa2, da2);
+                wa2 = wa1;
+                wa1 = wa;
+                wb2 = wb1;
+                wb1 = wb;
+            }
+        }
+        float acc[5] = {db0 * kib0, db1 * kib0, db2 * kib0, da1, da2};
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+#pragma unroll
+            for (int m = 16; m >= 1; m >>= 1) acc[i] += __shfl_xor(acc[i], m);  // the 32 chunk lanes of the section (one half wave), fixed order
+        }
+        if (c == 0) {
+            float* o = a.ep + ((int64_t)row * gridDim.x + blockIdx.x) * EP_COUNT + 5 * s;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) o[i] = acc[i];
+        }
+    }
+    lds_barrier();  // red[] below and the next use of the tiles
+}
+
 // FXS: the fx send bus is on (tracks only) - its cotangent rows are read and the send-gain sum is formed
 template <bool MASTER, bool FAST, bool FXS>
-__device__ __forceinline__ void comp_bwd_run_body(const CompBwdArgs& a) {
+__device__ __forceinline__ void comp_bwd_run_body(const CompBwdArgs& a, float* __restrict__ cg_u, float* __restrict__ cg_g) {
     constexpr int NCH = MASTER ? 2 : 1;
     __shared__ float red[4][CP_COUNT];  // red[0] doubles as the 8-float scan scratch
     const int tid = threadIdx.x, row = blockIdx.y, chunk = blockIdx.x * kWG + tid;
@@ -358,6 +429,7 @@ __device__ __forceinline__ void comp_bwd_run_body(const CompBwdArgs& a) {
 #pragma unroll
     for (int i = 0; i < CP_COUNT; ++i) p[i] = 0.0f;
     float gl[CC], gr[CC], du0[CC], du1[CC];
+    float xu[MASTER ? 1 : CC];  // tracks: the compressor input of this lane's samples, kept for the fused coefficient-gradient pass
     load_gy<MASTER, FAST>(a, row, rc, i0, gl, gr);
     const float pl = rc[RC_PANL], pr = rc[RC_PANR];  // master: both = output-fader gain
     // cotangent of the fx send gain: sum_n (pl fL + pr fR)[n] y[n]  (fL, fR = cotangent of the send bus)
@@ -390,6 +462,10 @@ __device__ __forceinline__ void comp_bwd_run_body(const CompBwdArgs& a) {
             }
         }
         LD8<FAST>(u0, i0, a.n, x0);
+        if (!MASTER) {
+#pragma unroll
+            for (int i = 0; i < CC; ++i) xu[i] = x0[i];
+        }
         LD8S<FAST>(u0, i0 - a.lookahead, a.n, xd0);
         if (MASTER) {
             LD8<FAST>(u1, i0, a.n, x1);
@@ -456,6 +532,10 @@ __device__ __forceinline__ void comp_bwd_run_body(const CompBwdArgs& a) {
         float x0[CC], x1[CC];
         LD8<FAST>(u0, i0, a.n, x0);
         if (MASTER) LD8<FAST>(u1, i0, a.n, x1);
+        if (!MASTER) {
+#pragma unroll
+            for (int i = 0; i < CC; ++i) xu[i] = x0[i];
+        }
 #pragma unroll
         for (int i = 0; i < CC; ++i) {
             du0[i] = MASTER ? pl * gl[i] : pl * gl[i] + pr * gr[i];
@@ -470,8 +550,11 @@ __device__ __forceinline__ void comp_bwd_run_body(const CompBwdArgs& a) {
             }
         }
     }
-    ST8<FAST>(a.du + (int64_t)(row * NCH) * a.stride, i0, a.n, du0);
-    if (MASTER) ST8<FAST>(a.du + (int64_t)(row * NCH + 1) * a.stride, i0, a.n, du1);
+    if (a.du) {
+        ST8<FAST>(a.du + (int64_t)(row * NCH) * a.stride, i0, a.n, du0);
+        if (MASTER) ST8<FAST>(a.du + (int64_t)(row * NCH + 1) * a.stride, i0, a.n, du1);
+    }
+    if (!MASTER && a.ep) coefgrad_fused<FAST>(a, row, rc, i0, xu, du0, cg_u, cg_g);
 
     const int wave = tid >> 6, lane = tid & 63;
 #pragma unroll
@@ -488,8 +571,9 @@ __device__ __forceinline__ void comp_bwd_run_body(const CompBwdArgs& a) {
 #endif
 template <bool MASTER, bool FXS = false>
 __global__ __launch_bounds__(kWG, (!MASTER && !FXS) ? 4 : MST_COMP_BWD_W) void k_comp_bwd_run(CompBwdArgs a) {  // tracks without fx: 130 registers uncapped, two short of four waves per SIMD
-    if (block_interior(a.n, a.lookahead, a.aligned)) comp_bwd_run_body<MASTER, true, FXS>(a);
-    else comp_bwd_run_body<MASTER, false, FXS>(a);
+    __shared__ __attribute__((aligned(16))) float cg_u[MASTER ? 4 : kCgTile], cg_g[MASTER ? 4 : kCgTile];  // one copy for both bodies
+    if (block_interior(a.n, a.lookahead, a.aligned)) comp_bwd_run_body<MASTER, true, FXS>(a, cg_u, cg_g);
+    else comp_bwd_run_body<MASTER, false, FXS>(a, cg_u, cg_g);
 }
 
 // ---- launch helpers ---------------------------------------------------------------------------------

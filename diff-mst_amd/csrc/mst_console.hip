@@ -202,9 +202,18 @@ extern "C" int mst_console_backward(const mst_console_desc* d, const float* trac
             launch_comp_bwd(false, false, ca, L.R, stream);
             ca.s0 = ws + L.zQ_t;
         }
+        if (MST_FUSE_COEFGRAD) {
+            // the run pass forms the tracks' coefficient-gradient sums from the du and u it holds in registers: du crosses HBM only
+            // when the EQ adjoint below needs it (grad_tracks), u is not read a second time
+            ca.ap_s0 = ws + L.sP_t;
+            ca.ap_nc_pad = L.ncE_pad;
+            ca.ep = ws + L.ep_t;
+            if (!grad_tracks) ca.du = nullptr;
+        }
         launch_comp_bwd(false, true, ca, L.R, stream);
-        // coefficient-gradient sums for the track rows and (same launch) the master rows
-        launch_coefgrad(ws + L.u_t, Ns, ws + L.du_t, Ns, ws + L.rc_t, L.R, ws + L.sP_t, L.ncE_pad, ws + L.ep_t, n, nsig_all, stream);
+        // coefficient-gradient sums: master rows (all rows without the fusion: the master rows follow the tracks in the same arrays)
+        if (!MST_FUSE_COEFGRAD) launch_coefgrad(ws + L.u_t, Ns, ws + L.du_t, Ns, ws + L.rc_t, L.R, ws + L.sP_t, L.ncE_pad, ws + L.ep_t, n, nsig_all, stream);
+        else if (m_on) launch_coefgrad(ws + L.v_m, Ns, ws + L.du_m, Ns, ws + L.rc_m, 0, ws + L.sP_m, L.ncE_pad, ws + L.ep_m, n, 2 * L.bs, stream);
         if (grad_tracks) {
             const float* p1A_t = L.eq1 ? ws + L.pow1A_t : nullptr;
             if (L.eq1 && mfma_zs()) launch_eq_zs_mfma(EQ_ADJ, ws + L.du_t, Ns, ws + L.wzA_t, L.R, ws + L.zA_t, L.ncE_pad, n, L.R, stream, p1A_t, L.ntE, ws + L.aggA_t);
@@ -216,7 +225,7 @@ extern "C" int mst_console_backward(const mst_console_desc* d, const float* trac
     }
     PrepBwdArgs pb{track_params, master_bus_params, ws + L.rc_t, ws + L.rc_m, ws + L.cp_t, ws + L.cp_m, ws + L.ep_t, ws + L.ep_m,
                    grad_track_params, grad_master_params, fx_bus_params, fx_on ? ws + L.fx_part : nullptr,
-                   fx_on ? grad_fx_params : nullptr, L.fxBlkIr, fx_on ? ws + L.fx_mix : nullptr, fx_on ? ws + L.fx_dry : nullptr, L.fxBlk, L.R, L.bs, L.nblkC, L.nblkE, *d};
+                   fx_on ? grad_fx_params : nullptr, L.fxBlkIr, fx_on ? ws + L.fx_mix : nullptr, fx_on ? ws + L.fx_dry : nullptr, L.fxBlk, L.R, L.bs, L.nblkC, L.nblkE, L.nblkEt, *d};
     launch_prep_bwd(pb, stream);
     return (int)hipGetLastError();
 }

@@ -48,6 +48,7 @@ struct PrepBwdArgs {
     const float* fx_dry;                   // (bs, nblkX) partial sums <dbus, fx_in>
     int nblkX;
     int R, bs, nblkC, nblkE;
+    int nblkEt;                            // partial rows per track row (Layout::nblkEt)
     mst_console_desc d;
 };
 void launch_prep(const PrepArgs& a, hipStream_t stream);
@@ -123,6 +124,10 @@ struct CompBwdArgs {
     int T, nc_pad, lookahead, comp_on;
     int64_t n;
     int aligned;
+    // tracks, MST_FUSE_COEFGRAD: the run pass also forms the coefficient-gradient sums of its 2048 samples (else ep = null)
+    const float* ap_s0;   // all-pole states entering every 64-sample chunk (rows, 24, ap_nc_pad)
+    int ap_nc_pad;
+    float* ep;            // (rows, nblkC, EP_COUNT)
 };
 void launch_comp_zs(int nch, const float* u, int64_t stride, const float* rc, float* zs, int nc_pad, int64_t n, int rows,
                     hipStream_t stream);
