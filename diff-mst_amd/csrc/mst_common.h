@@ -193,7 +193,7 @@ struct Layout {
     int ncE, ncE_pad;        // EQ lane-chunks per signal row (pad to kWG)
     int ncC, ncC_pad;        // compressor lane-chunks per row
     int nblkE, nblkC;        // workgroups per row in EQ / compressor kernels
-    int nblkEt;              // coefficient-gradient partial rows per TRACK row: nblkC when k_comp_bwd_run makes them (MST_FUSE_COEFGRAD), else nblkE
+    int nblkEt;              // coefficient-gradient partial rows per signal row: nblkC when k_comp_bwd_run makes them (MST_FUSE_COEFGRAD), else nblkE
     int KE, KC;              // chunks per scan thread
     int ntE;                 // 4096-sample EQ tiles per row
     int eq1;                 // 1: EQ carries scanned inside the zs / run kernels, 0: separate carry-scan kernel
@@ -284,7 +284,7 @@ inline Layout make_layout(const mst_console_desc* d) {
     L.sP_m = L.sP_t + R * 24 * L.ncE_pad;
     L.cp_t = take(R * L.nblkC * CP_COUNT);
     L.cp_m = take(B * L.nblkC * CP_COUNT);
-    L.ep_t = take((R * L.nblkEt + 2 * B * L.nblkE) * EP_COUNT);
+    L.ep_t = take((R + 2 * B) * L.nblkEt * EP_COUNT);
     L.ep_m = L.ep_t + R * L.nblkEt * EP_COUNT;
     L.pow1F_t = take((R + B) * kTri2);
     L.pow1F_m = L.pow1F_t + R * kTri2;

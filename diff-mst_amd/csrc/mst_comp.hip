@@ -353,7 +353,7 @@ __global__ __launch_bounds__(kWG) void k_comp_bwd_zs(CompBwdArgs a) {
 constexpr int kCgPitch = kEqChunk + 4, kCgChunks = kWG * CC / kEqChunk, kCgTile = kCgChunks * kCgPitch;
 static_assert(kCgChunks == 32 && kSections * 32 <= kWG, "one section x 32 chunks per 32 lanes");
 template <bool FAST>
-__device__ __forceinline__ void coefgrad_fused(const CompBwdArgs& a, int row, const float* __restrict__ rc, int64_t i0, const float* xu,
+__device__ __forceinline__ void coefgrad_fused(const CompBwdArgs& a, int sig, const float* __restrict__ rc, int64_t i0, const float* xu,
                                                const float* du, float* __restrict__ cg_u, float* __restrict__ cg_g) {
     const int tid = threadIdx.x;
     {
@@ -373,7 +373,7 @@ __device__ __forceinline__ void coefgrad_fused(const CompBwdArgs& a, int row, co
     if (s < kSections) {
         const float ka1 = rc[RC_SOS + 5 * s + 3], ka2 = rc[RC_SOS + 5 * s + 4];
         const float kc1 = rc[RC_AP + 3 * s], kc2 = rc[RC_AP + 3 * s + 1], kib0 = rc[RC_AP + 3 * s + 2];
-        const int64_t base = ((int64_t)row * 24 + 4 * s) * a.ap_nc_pad + (int64_t)blockIdx.x * kCgChunks + c;
+        const int64_t base = ((int64_t)sig * 24 + 4 * s) * a.ap_nc_pad + (int64_t)blockIdx.x * kCgChunks + c;
         float wa1 = a.ap_s0[base], wa2 = a.ap_s0[base + a.ap_nc_pad], wb1 = a.ap_s0[base + 2 * (int64_t)a.ap_nc_pad],
               wb2 = a.ap_s0[base + 3 * (int64_t)a.ap_nc_pad];
         float db0 = 0.f, db1 = 0.f, db2 = 0.f, da1 = 0.f, da2 = 0.f;
@@ -407,7 +407,7 @@ __device__ __forceinline__ void coefgrad_fused(const CompBwdArgs& a, int row, co
             for (int m = 16; m >= 1; m >>= 1) acc[i] += __shfl_xor(acc[i], m);  // the 32 chunk lanes of the section (one half wave), fixed order
         }
         if (c == 0) {
-            float* o = a.ep + ((int64_t)row * gridDim.x + blockIdx.x) * EP_COUNT + 5 * s;
+            float* o = a.ep + ((int64_t)sig * gridDim.x + blockIdx.x) * EP_COUNT + 5 * s;
 #pragma unroll
             for (int i = 0; i < 5; ++i) o[i] = acc[i];
         }
@@ -429,7 +429,7 @@ __device__ __forceinline__ void comp_bwd_run_body(const CompBwdArgs& a, float* _
 #pragma unroll
     for (int i = 0; i < CP_COUNT; ++i) p[i] = 0.0f;
     float gl[CC], gr[CC], du0[CC], du1[CC];
-    float xu[MASTER ? 1 : CC];  // tracks: the compressor input of this lane's samples, kept for the fused coefficient-gradient pass
+    float xu[CC], xu1[MASTER ? CC : 1];  // the compressor input of this lane's samples, kept for the fused coefficient-gradient pass
     load_gy<MASTER, FAST>(a, row, rc, i0, gl, gr);
     const float pl = rc[RC_PANL], pr = rc[RC_PANR];  // master: both = output-fader gain
     // cotangent of the fx send gain: sum_n (pl fL + pr fR)[n] y[n]  (fL, fR = cotangent of the send bus)
@@ -462,13 +462,13 @@ __device__ __forceinline__ void comp_bwd_run_body(const CompBwdArgs& a, float* _
             }
         }
         LD8<FAST>(u0, i0, a.n, x0);
-        if (!MASTER) {
 #pragma unroll
-            for (int i = 0; i < CC; ++i) xu[i] = x0[i];
-        }
+        for (int i = 0; i < CC; ++i) xu[i] = x0[i];
         LD8S<FAST>(u0, i0 - a.lookahead, a.n, xd0);
         if (MASTER) {
             LD8<FAST>(u1, i0, a.n, x1);
+#pragma unroll
+            for (int i = 0; i < CC; ++i) xu1[i] = x1[i];
             LD8S<FAST>(u1, i0 - a.lookahead, a.n, xd1);
         }
         LD8<FAST>(a.gs + (int64_t)row * a.stride, i0, a.n, g);
@@ -532,9 +532,10 @@ __device__ __forceinline__ void comp_bwd_run_body(const CompBwdArgs& a, float* _
         float x0[CC], x1[CC];
         LD8<FAST>(u0, i0, a.n, x0);
         if (MASTER) LD8<FAST>(u1, i0, a.n, x1);
-        if (!MASTER) {
 #pragma unroll
-            for (int i = 0; i < CC; ++i) xu[i] = x0[i];
+        for (int i = 0; i < CC; ++i) {
+            xu[i] = x0[i];
+            if (MASTER) xu1[i] = x1[i];
         }
 #pragma unroll
         for (int i = 0; i < CC; ++i) {
@@ -554,7 +555,10 @@ __device__ __forceinline__ void comp_bwd_run_body(const CompBwdArgs& a, float* _
         ST8<FAST>(a.du + (int64_t)(row * NCH) * a.stride, i0, a.n, du0);
         if (MASTER) ST8<FAST>(a.du + (int64_t)(row * NCH + 1) * a.stride, i0, a.n, du1);
     }
-    if (!MASTER && a.ep) coefgrad_fused<FAST>(a, row, rc, i0, xu, du0, cg_u, cg_g);
+    if (a.ep) {  // signal rows: tracks = row, master = 2 row + channel
+        coefgrad_fused<FAST>(a, row * NCH, rc, i0, xu, du0, cg_u, cg_g);
+        if (MASTER) coefgrad_fused<FAST>(a, row * NCH + 1, rc, i0, xu1, du1, cg_u, cg_g);
+    }
 
     const int wave = tid >> 6, lane = tid & 63;
 #pragma unroll
@@ -571,7 +575,7 @@ __device__ __forceinline__ void comp_bwd_run_body(const CompBwdArgs& a, float* _
 #endif
 template <bool MASTER, bool FXS = false>
 __global__ __launch_bounds__(kWG, (!MASTER && !FXS) ? 4 : MST_COMP_BWD_W) void k_comp_bwd_run(CompBwdArgs a) {  // tracks without fx: 130 registers uncapped, two short of four waves per SIMD
-    __shared__ __attribute__((aligned(16))) float cg_u[MASTER ? 4 : kCgTile], cg_g[MASTER ? 4 : kCgTile];  // one copy for both bodies
+    __shared__ __attribute__((aligned(16))) float cg_u[kCgTile], cg_g[kCgTile];  // one copy for both bodies
     if (block_interior(a.n, a.lookahead, a.aligned)) comp_bwd_run_body<MASTER, true, FXS>(a, cg_u, cg_g);
     else comp_bwd_run_body<MASTER, false, FXS>(a, cg_u, cg_g);
 }

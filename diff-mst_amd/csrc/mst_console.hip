@@ -171,6 +171,11 @@ extern "C" int mst_console_backward(const mst_console_desc* d, const float* trac
                        grad_mix, n, nullptr, nullptr, 0, 1, L.ncC_pad, d->master_lookahead, 1, n, aligned};
         launch_comp_bwd(true, false, ca, L.bs, stream);
         ca.s0 = ws + L.zQ_m;
+        if (MST_FUSE_COEFGRAD) {  // coefficient-gradient sums of the two bus channels in the run pass (see the tracks below)
+            ca.ap_s0 = ws + L.sP_m;
+            ca.ap_nc_pad = L.ncE_pad;
+            ca.ep = ws + L.ep_m;
+        }
         launch_comp_bwd(true, true, ca, L.bs, stream);
         const float* p1A_m = L.eq1 ? ws + L.pow1A_m : nullptr;
         if (L.eq1 && mfma_zs()) launch_eq_zs_mfma(EQ_ADJ, ws + L.du_m, Ns, ws + L.wzA_m, 0, ws + L.zA_m, L.ncE_pad, n, 2 * L.bs, stream, p1A_m, L.ntE, ws + L.aggA_m);
@@ -211,9 +216,8 @@ extern "C" int mst_console_backward(const mst_console_desc* d, const float* trac
             if (!grad_tracks) ca.du = nullptr;
         }
         launch_comp_bwd(false, true, ca, L.R, stream);
-        // coefficient-gradient sums: master rows (all rows without the fusion: the master rows follow the tracks in the same arrays)
+        // without the fusion: one k_coefgrad launch for the track rows and the master rows (which follow the tracks in the same arrays)
         if (!MST_FUSE_COEFGRAD) launch_coefgrad(ws + L.u_t, Ns, ws + L.du_t, Ns, ws + L.rc_t, L.R, ws + L.sP_t, L.ncE_pad, ws + L.ep_t, n, nsig_all, stream);
-        else if (m_on) launch_coefgrad(ws + L.v_m, Ns, ws + L.du_m, Ns, ws + L.rc_m, 0, ws + L.sP_m, L.ncE_pad, ws + L.ep_m, n, 2 * L.bs, stream);
         if (grad_tracks) {
             const float* p1A_t = L.eq1 ? ws + L.pow1A_t : nullptr;
             if (L.eq1 && mfma_zs()) launch_eq_zs_mfma(EQ_ADJ, ws + L.du_t, Ns, ws + L.wzA_t, L.R, ws + L.zA_t, L.ncE_pad, n, L.R, stream, p1A_t, L.ntE, ws + L.aggA_t);

@@ -481,9 +481,9 @@ __global__ __launch_bounds__(256) void k_prep_bwd(PrepBwdArgs a) {
     // dual-number biquad design (exp2, sincos) whose Jacobian the chain rule below needs - it used to wait for the reduction.
     if (tid < 64) {
         const int nsig = is_master ? 2 : 1;
-        const float* ep = is_master ? a.ep_m + ((int64_t)(mrow * 2) * a.nblkE) * EP_COUNT
+        const float* ep = is_master ? a.ep_m + ((int64_t)(mrow * 2) * a.nblkEt) * EP_COUNT
                                     : a.ep_t + ((int64_t)row * a.nblkEt) * EP_COUNT;
-        const int nE = chain_on ? (is_master ? nsig * a.nblkE : a.nblkEt) : 0;  // the two channels of a master row are adjacent
+        const int nE = chain_on ? nsig * a.nblkEt : 0;  // the two channels of a master row are adjacent
         double se[EP_COUNT];
 #pragma unroll
         for (int q = 0; q < EP_COUNT; ++q) se[q] = 0.0;
