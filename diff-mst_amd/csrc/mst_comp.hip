@@ -350,6 +350,9 @@ __global__ __launch_bounds__(kWG) void k_comp_bwd_zs(CompBwdArgs a) {
 // layout, lane (section s = tid >> 5, chunk c = tid & 31) walks its chunk with ONE section (k_coefgrad: three per lane), the 32
 // chunk lanes of a section meet in a half-wave shuffle sum.  192 of the 256 lanes work; the cotangent du crosses HBM only if
 // someone downstream wants it, u is not fetched a second time.
+#ifndef MST_CG_ABLATE
+#define MST_CG_ABLATE 0  // timing diagnostics only (wrong results): 1 = no state loads, 2 = four samples instead of 64
+#endif
 constexpr int kCgPitch = kEqChunk + 4, kCgChunks = kWG * CC / kEqChunk, kCgTile = kCgChunks * kCgPitch;
 static_assert(kCgChunks == 32 && kSections * 32 <= kWG, "one section x 32 chunks per 32 lanes");
 template <bool FAST>
@@ -376,11 +379,12 @@ __device__ __forceinline__ void coefgrad_fused(const CompBwdArgs& a, int sig, co
         const int64_t base = ((int64_t)sig * 24 + 4 * s) * a.ap_nc_pad + (int64_t)blockIdx.x * kCgChunks + c;
         float wa1 = a.ap_s0[base], wa2 = a.ap_s0[base + a.ap_nc_pad], wb1 = a.ap_s0[base + 2 * (int64_t)a.ap_nc_pad],
               wb2 = a.ap_s0[base + 3 * (int64_t)a.ap_nc_pad];
+        if (MST_CG_ABLATE & 1) wa1 = wa2 = wb1 = wb2 = (float)c;
         float db0 = 0.f, db1 = 0.f, db2 = 0.f, da1 = 0.f, da2 = 0.f;
         const float* mu = &cg_u[c * kCgPitch];
         const float* mg = &cg_g[c * kCgPitch];
 #pragma unroll 2
-        for (int i4 = 0; i4 < kEqChunk; i4 += 4) {
+        for (int i4 = 0; i4 < ((MST_CG_ABLATE & 2) ? 4 : kEqChunk); i4 += 4) {
             const float4 xv = *reinterpret_cast<const float4*>(&mu[i4]);
             const float4 gv = *reinterpret_cast<const float4*>(&mg[i4]);
             const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, gs[4] = {gv.x, gv.y, gv.z, gv.w};
