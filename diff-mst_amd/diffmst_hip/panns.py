@@ -159,16 +159,31 @@ class Cnn14(nn.Module):
             n, frames, bins = spec.shape
             h, w = frames, bins
             with torch.no_grad():
+                # all twelve layers in four multi-tensor launches (48 one-tensor kernels otherwise); same arithmetic as
+                # nn.BatchNorm2d: running.lerp_(batch, momentum) with the unbiased batch variance
+                rmeans, rvars, means, vars_, scales, counters, moms = [], [], [], [], [], [], []
                 for i, block in enumerate(self._blocks()):
                     count = n * h * w
                     for k, bn in enumerate((block.bn1, block.bn2)):
                         c = bn.num_features
-                        mean, var = stats[2 * i + k, 0, :c], stats[2 * i + k, 1, :c]
-                        m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked + 1)
-                        bn.running_mean.lerp_(mean, m)
-                        bn.running_var.lerp_(var * (count / max(count - 1, 1)), m)
-                        bn.num_batches_tracked += 1
+                        rmeans.append(bn.running_mean)
+                        rvars.append(bn.running_var)
+                        means.append(stats[2 * i + k, 0, :c])
+                        vars_.append(stats[2 * i + k, 1, :c])
+                        scales.append(count / max(count - 1, 1))
+                        counters.append(bn.num_batches_tracked)
+                        moms.append(bn.momentum)
                     h, w = h // POOL_SIZES[i][1], w // POOL_SIZES[i][0]
+                if all(m is not None and m == moms[0] for m in moms):
+                    torch._foreach_lerp_(rmeans, means, moms[0])
+                    torch._foreach_lerp_(rvars, torch._foreach_mul(vars_, scales), moms[0])
+                    torch._foreach_add_(counters, 1)
+                else:  # cumulative averages (momentum None) or per-layer momenta: one layer at a time
+                    for rm, rv, mean, var, sc, nb, mom in zip(rmeans, rvars, means, vars_, scales, counters, moms):
+                        m = mom if mom is not None else 1.0 / float(nb + 1)
+                        rm.lerp_(mean, m)
+                        rv.lerp_(var * sc, m)
+                        nb += 1
         return embed
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
