@@ -155,27 +155,35 @@ __global__ __launch_bounds__(256) void k_prep_weights_tiled(const float* __restr
 // rows of the slabs); its four 64-lane groups take every fourth slab, four loads in flight each, and meet in LDS (one thread per sum
 // walking all slabs: 360 us for the 64 -> 64 layer's 1024 slabs)
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ part, float* __restrict__ gw, int Cin, int Cout, int splits) {
-    __shared__ float red[4][64];
+    // workgroup = (output channel co, 64 input channels): nine 256-byte rows of every slab in, 576 CONSECUTIVE floats of the torch layout
+    // out (one thread per sum wrote 4 bytes every 36: the re-layout of the deep layers' single slab was a 150 MB scatter)
+    __shared__ float red[4][9][64];
+    __shared__ float outv[9 * 64];
     const int64_t total = (int64_t)Cout * Cin * 9;
-    const int l = threadIdx.x & 63, sg = threadIdx.x >> 6;
-    for (int64_t e0 = (int64_t)blockIdx.x * 64; e0 < total; e0 += (int64_t)gridDim.x * 64) {  // e = (tap Cout + co) Cin + ci: the order of a slab
-        const int64_t e = e0 + l;
-        float acc = 0.f;
-        for (int s0 = sg; s0 < splits; s0 += 16) {
-            float v[4];
+    const int l = threadIdx.x & 63, sg = threadIdx.x >> 6, cib = Cin / 64;
+    for (int64_t blk = blockIdx.x; blk < (int64_t)Cout * cib; blk += gridDim.x) {
+        const int co = (int)(blk / cib), ci0 = (int)(blk % cib) * 64;
+        float acc[9];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = s0 + 4 * u < splits ? part[(int64_t)(s0 + 4 * u) * total + e] : 0.f;
+        for (int t = 0; t < 9; ++t) acc[t] = 0.f;
+        for (int s = sg; s < splits; s += 4) {  // the four lane groups take every fourth slab; nine loads in flight per lane
+            const float* p = part + (int64_t)s * total + (int64_t)co * Cin + ci0 + l;
+            float v[9];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) acc += v[u];
+            for (int t = 0; t < 9; ++t) v[t] = p[(int64_t)t * Cout * Cin];  // slab order (tap, co, ci)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc[t] += v[t];
         }
-        red[sg][l] = acc;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) red[sg][t][l] = acc[t];
         __syncthreads();
-        if (sg == 0) {
-            const float v = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
-            const int ci = (int)(e % Cin), co = (int)((e / Cin) % Cout), tap = (int)(e / ((int64_t)Cin * Cout));  // slab order (tap, co, ci)
-            const int a_ = tap / 3, b_ = tap % 3;
-            gw[(((int64_t)co * Cin + ci) * 3 + b_) * 3 + a_] = v;
+        for (int i = threadIdx.x; i < 9 * 64; i += 256) {
+            const int t = i / 64, c = i % 64, a_ = t / 3, b_ = t % 3;  // tap = a_ * 3 + b_  ->  torch index kh * 3 + kw = b_ * 3 + a_
+            outv[c * 9 + b_ * 3 + a_] = (red[0][t][c] + red[1][t][c]) + (red[2][t][c] + red[3][t][c]);
         }
+        __syncthreads();
+        float* o = gw + ((int64_t)co * Cin + ci0) * 9;
+        for (int i = threadIdx.x; i < 9 * 64; i += 256) o[i] = outv[i];
         __syncthreads();
     }
 }
@@ -830,7 +838,7 @@ static int cnn_backward_t(const mst_cnn14_desc* d, const CnnPlan& p, const float
             WgradArgs wa{GA, x_in, wgpart, p.n, H, W, Cin, C, splits, steps};
             launch_conv_wgrad(prec, wa, s);
             if (Cin == 1) hipLaunchKernelGGL(k_wgrad_reduce_first, dim3(C), dim3(256), 0, s, wgpart, gr->conv_w[l], C, splits);
-            else hipLaunchKernelGGL(k_wgrad_reduce, dim3(ew_grid((int64_t)9 * Cin * C * 4)), dim3(256), 0, s, wgpart, gr->conv_w[l], Cin, C, splits);
+            else hipLaunchKernelGGL(k_wgrad_reduce, dim3(ew_grid((int64_t)C * (Cin / 64) * 256)), dim3(256), 0, s, wgpart, gr->conv_w[l], Cin, C, splits);
             // data gradient (not for the spectrogram itself)
             if (Cin > 1) {
                 ConvArgs ca{GA, ws + p.wd[l], GB, nullptr, p.n, H, W, C, Cin, 0, nullptr};
