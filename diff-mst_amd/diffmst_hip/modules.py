@@ -535,13 +535,23 @@ class SpectrogramEncoder(torch.nn.Module):
 class TransformerController(torch.nn.Module):
     """Reference ``TransformerController`` (mst/modules.py:809-914): learned type embeddings added to the track / mix
     embeddings, one fx-bus and one master-bus token appended, ``torch.nn.TransformerEncoder`` (dropout 0, batch_first),
-    three sigmoid-bounded projections.  Host-library work (rocBLAS GEMMs + SDPA through torch) - 30 tokens of width 512 are
-    not a kernel-design problem; same parameter names as the reference."""
+    three sigmoid-bounded projections.  Host-library work (rocBLAS GEMMs + SDPA through torch); same parameter names as the
+    reference.
+
+    ``graphed`` (extra keyword, default False = the reference's eager behaviour): 12 layers over ~36 tokens are ~580 kernels of
+    a few microseconds each per training step, and at batch 1 the HOST cannot issue them as fast as the GPU retires them
+    (cfg #5: 7.6 ms of the 29.6 ms step were idle gaps in front of these kernels).  With ``graphed=True`` the
+    training-mode forward and backward are captured once per (batch, tracks, mask?) shape into two hipGraphs
+    (``torch.cuda.make_graphed_callables``) and replayed: same kernels, same arithmetic, one launch each.  The returned
+    tensors live in the graph's static buffers until the next call of the same shape; parameters must keep their storage
+    (in-place optimizer steps do)."""
 
     def __init__(self, embed_dim: int, num_track_control_params: int, num_fx_bus_control_params: int,
                  num_master_bus_control_params: int, num_layers: int = 6, nhead: int = 8, use_fx_bus: bool = False,
-                 use_master_bus: bool = False) -> None:
+                 use_master_bus: bool = False, graphed: bool = False) -> None:
         super().__init__()
+        self.graphed = bool(graphed)
+        object.__setattr__(self, "_graphs", {})  # shape key -> graphed callable (not a submodule: state_dict stays the reference's)
         self.embed_dim = embed_dim
         self.num_track_control_params = num_track_control_params
         self.num_fx_bus_control_params = num_fx_bus_control_params
@@ -559,14 +569,52 @@ class TransformerController(torch.nn.Module):
         self.master_bus_projection = torch.nn.Linear(embed_dim, num_master_bus_control_params)
 
     def forward(self, track_embeds: torch.Tensor, mix_embeds: torch.Tensor, track_padding_mask=None):
+        if self.graphed and self.training and torch.is_grad_enabled() and track_embeds.is_cuda:
+            return self._graphed_forward(track_embeds, mix_embeds, track_padding_mask)
+        return self._eager_forward(track_embeds, mix_embeds, track_padding_mask)
+
+    def _graphed_forward(self, track_embeds, mix_embeds, track_padding_mask):
+        key = (tuple(track_embeds.shape), tuple(mix_embeds.shape), track_padding_mask is not None, str(track_embeds.device))
+        fn = self._graphs.get(key)
+        if fn is None:
+            core = _ControllerCore(self, track_padding_mask is not None)
+            sample = [torch.randn_like(track_embeds).requires_grad_(True), torch.randn_like(mix_embeds).requires_grad_(True)]
+            if track_padding_mask is not None:
+                sample.append(torch.zeros_like(track_padding_mask))
+            fn = torch.cuda.make_graphed_callables(core, tuple(sample))
+            self._graphs[key] = fn
+        args = (track_embeds.contiguous(), mix_embeds.contiguous())
+        if track_padding_mask is not None:
+            args += (track_padding_mask.contiguous(),)
+        return fn(*args)
+
+    def _eager_forward(self, track_embeds: torch.Tensor, mix_embeds: torch.Tensor, track_padding_mask=None):
         bs, num_tracks, _ = track_embeds.size()
         tokens = torch.cat((track_embeds + self.track_embedding, mix_embeds + self.mix_embedding,
                             self.fx_bus_embedding.expand(bs, -1, -1), self.master_bus_embedding.expand(bs, -1, -1)), dim=1)
         if track_padding_mask is not None:  # the four appended tokens are always attended to
-            track_padding_mask = torch.cat((track_padding_mask, torch.zeros((bs, 4), dtype=torch.bool).type_as(track_padding_mask)), dim=1)
+            track_padding_mask = torch.cat((track_padding_mask, track_padding_mask.new_zeros((bs, 4))), dim=1)  # made on the device: no host copy
         z = self.transformer_encoder(tokens, src_key_padding_mask=track_padding_mask)
         return (torch.sigmoid(self.track_projection(z[:, :num_tracks, :])), torch.sigmoid(self.fx_bus_projection(z[:, -2, :])),
                 torch.sigmoid(self.master_bus_projection(z[:, -1, :])))
+
+
+class _ControllerCore(torch.nn.Module):
+    """What ``make_graphed_callables`` captures for a ``TransformerController``: the controller's own parameters and
+    submodules registered a second time (the same objects), so that the graphed backward hands their gradients out."""
+
+    def __init__(self, controller: "TransformerController", with_mask: bool):
+        super().__init__()
+        for name, p in controller._parameters.items():
+            self.register_parameter(name, p)
+        for name, m in controller._modules.items():
+            self.add_module(name, m)
+        object.__setattr__(self, "_controller", controller)
+        self.with_mask = with_mask
+        self.train(controller.training)
+
+    def forward(self, track_embeds, mix_embeds, mask=None):
+        return self._controller._eager_forward(track_embeds, mix_embeds, mask if self.with_mask else None)
 
 
 class MixStyleTransferModel(torch.nn.Module):

@@ -13,7 +13,8 @@ iters = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 dev = torch.device("cuda:0")
 torch.manual_seed(3001)
 model = MixStyleTransferModel(SpectrogramEncoder(embed_dim=512), SpectrogramEncoder(embed_dim=512),
-                              TransformerController(512, 27, 25, 26, num_layers=12, nhead=8)).to(dev).train()
+                              TransformerController(512, 27, 25, 26, num_layers=12, nhead=8,
+                                                    graphed=os.environ.get("MST_GRAPHED", "1") == "1")).to(dev).train()
 step = CommonStep(model, AdvancedMixConsole(bench.SR, materialize_mixed_tracks=False, validate="deferred", param_dicts="lazy"), naive_random_mix,
                   AudioFeatureLoss(bench.AF_WEIGHTS, bench.SR), generate_mix=True, active_eq_epoch=0, active_compressor_epoch=0,
                   active_fx_bus_epoch=1000, active_master_bus_epoch=0)
