@@ -38,7 +38,7 @@ static constexpr bool mfma_zs() {
 #endif
 }
 
-extern "C" int mst_abi_version(void) { return 4; }
+extern "C" int mst_abi_version(void) { return 5; }
 
 extern "C" size_t mst_console_fx_tables_bytes(void) { return (size_t)8192 * 2 * sizeof(float); }
 extern "C" int mst_console_fx_init_tables(void* tables, void* stream) {

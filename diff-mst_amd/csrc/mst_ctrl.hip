@@ -1,0 +1,568 @@
+// mst_ctrl.hip - the TransformerController's encoder stack (reference mst/modules.py:809-914: torch.nn.TransformerEncoder of
+// post-norm TransformerEncoderLayer(d_model, nhead, dim_feedforward = 2048, relu, dropout 0, batch_first), forward and backward.
+//
+// Why it exists: at the reference's sizes (one mix of 32 tracks = 36 tokens of width 512, 12 layers) the stack is ~580 library
+// kernels of a few microseconds each per training step; on torch (rocBLAS + SDPA) it took 5.3 ms of the 25.6 ms cfg #5 step,
+// hipGraph replay included.  M = bs x tokens is tiny, so every GEMM is a WEIGHT-STREAMING problem: 12.6 MB of fp32
+// weights per layer are read once by the forward, once by the data gradient, and 12.6 MB of weight gradient are written.  The
+// kernels are therefore organised around "every weight element crosses the memory system once, 16 bytes per lane":
+//   k_lin_nt  C = act(A W^T + b) (+ R)   one workgroup per 16 output columns, its 4 waves split K, fragments straight from
+//                                        global memory (both operands K-contiguous: float4 per lane, the K order inside a
+//                                        16-step is permuted identically for A and W, which a dot product does not see)
+//   k_lin_nn  C = (A W) (.) mask (+ R)   data gradient: one workgroup per 16 output columns, 8 waves split the reduction
+//   k_lin_tn  dW = dY^T X, db            one wave per 64 x 64 tile of the weight gradient (row and column permutations
+//                                        make both operand loads and the stores 16 bytes per lane), bias gradient on the way
+// all on v_mfma_f32_16x16x4_f32 (fp32 operands, exact fp32 FMA chains: parity with the reference's fp32 stack is rounding-level).
+// Attention (<= 128 tokens, head width <= 64) and LayerNorm are small vector-ALU kernels.  No atomics: run-to-run deterministic.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/diffmst_hip.h"
+
+namespace mst {
+namespace ctrl {
+
+typedef float f32x4 __attribute__((vector_size(16)));
+#define MFMA4(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float comp(const float4& v, int j) { return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w)); }
+
+// ---- C[m][n] = act(sum_k A[m][k] W[n][k] + bias[n]) (+ R[m][n]);  grid (N / 16, ceil(M / 64)), 256 lanes -------------------
+template <bool RELU>
+__global__ __launch_bounds__(256) void k_lin_nt(const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw,
+                                                const float* __restrict__ bias, const float* __restrict__ R, int ldr,
+                                                float* __restrict__ C, int ldc, int M, int K) {
+    __shared__ float red[4][4][4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
+    const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 64;
+    const int nmt = min(4, (M - m0 + 15) >> 4);
+    const int kq = K >> 2, kb = wave * kq;
+    f32x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* wp = W + (int64_t)(n0 + i) * ldw + kb + 4 * g;
+    const float* ap[4];
+    bool ok[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int row = m0 + 16 * t + i;
+        ok[t] = t < nmt && row < M;
+        ap[t] = A + (int64_t)(ok[t] ? row : m0) * lda + kb + 4 * g;
+    }
+
+    for (int k = 0; k < kq; k += 16) {
+        const float4 b4 = ld4(wp + k);
+        float4 a4[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) a4[t] = ok[t] ? ld4(ap[t] + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (t < nmt) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[t] = MFMA4(comp(a4[t], j), comp(b4, j), acc[t]);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][t][r][lane] = acc[t][r];
+    __syncthreads();
+    const int t = wave;  // wave w finishes row tile w
+    if (t < nmt) {
+        const float bv = bias ? bias[n0 + i] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = m0 + 16 * t + 4 * g + r;
+            if (row < M) {
+                float v = ((red[0][t][r][lane] + red[1][t][r][lane]) + (red[2][t][r][lane] + red[3][t][r][lane])) + bv;
+                if (RELU) v = fmaxf(v, 0.f);
+                if (R) v += R[(int64_t)row * ldr + n0 + i];
+                C[(int64_t)row * ldc + n0 + i] = v;
+            }
+        }
+    }
+}
+
+// ---- C[m][c] = (sum_n A[m][n] W[n][c]) (. [Hm[m][c] > 0]) (+ R[m][c]);  grid (cols / 16, ceil(M / 64)), 512 lanes ------------
+__global__ __launch_bounds__(512) void k_lin_nn(const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw,
+                                                const float* __restrict__ Hm, int ldh, const float* __restrict__ R, int ldr,
+                                                float* __restrict__ C, int ldc, int M, int N) {
+    __shared__ float red[8][4][4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
+    const int c0 = blockIdx.x * 16, m0 = blockIdx.y * 64;
+    const int nmt = min(4, (M - m0 + 15) >> 4);
+    const int nq = N >> 3, nb = wave * nq;
+    f32x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* wp = W + (int64_t)(nb + 4 * g) * ldw + c0 + i;
+    const float* ap[4];
+    bool ok[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int row = m0 + 16 * t + i;
+        ok[t] = t < nmt && row < M;
+        ap[t] = A + (int64_t)(ok[t] ? row : m0) * lda + nb + 4 * g;
+    }
+
+    for (int n = 0; n < nq; n += 16) {
+        float b[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = wp[(int64_t)(n + j) * ldw];
+        float4 a4[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) a4[t] = ok[t] ? ld4(ap[t] + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (t < nmt) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[t] = MFMA4(comp(a4[t], j), b[j], acc[t]);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][t][r][lane] = acc[t][r];
+    __syncthreads();
+    const int t = wave >> 1;
+    if (t < nmt) {
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int r = 2 * (wave & 1) + rr;
+            const int row = m0 + 16 * t + 4 * g + r;
+            if (row < M) {
+                float v = 0.f;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) v += red[w][t][r][lane];
+                if (Hm && !(Hm[(int64_t)row * ldh + c0 + i] > 0.f)) v = 0.f;
+                if (R) v += R[(int64_t)row * ldr + c0 + i];
+                C[(int64_t)row * ldc + c0 + i] = v;
+            }
+        }
+    }
+}
+
+// ---- dW[n][k] = sum_m dY[m][n] X[m][k],  db[n] = sum_m dY[m][n];  grid (Kd / 64, N / 64), one wave --------------------------
+// Row tile ii of the wave holds the rows n0 + 4 r + ii (r = 0..15), column tile t the columns k0 + 4 c + t: a lane's float4 of
+// dY is one element of each of the four row tiles, its float4 of X one element of each column tile.
+__global__ __launch_bounds__(64) void k_lin_tn(const float* __restrict__ dY, int ldy, const float* __restrict__ X, int ldx,
+                                               float* __restrict__ dW, int ldw, float* __restrict__ db, int M) {
+    const int lane = threadIdx.x, c = lane & 15, g = lane >> 4;
+    const int k0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[ii][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int m = 0; m < M; m += 4) {
+        const int row = m + g;
+        float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f), b4 = a4;
+        if (row < M) {
+            a4 = ld4(dY + (int64_t)row * ldy + n0 + 4 * c);
+            b4 = ld4(X + (int64_t)row * ldx + k0 + 4 * c);
+        }
+        bsum.x += a4.x; bsum.y += a4.y; bsum.z += a4.z; bsum.w += a4.w;
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[ii][t] = MFMA4(comp(a4, ii), comp(b4, t), acc[ii][t]);
+    }
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int n = n0 + 4 * (4 * g + q) + ii;
+            *reinterpret_cast<float4*>(dW + (int64_t)n * ldw + k0 + 4 * c) =
+                make_float4(acc[ii][0][q], acc[ii][1][q], acc[ii][2][q], acc[ii][3][q]);
+        }
+    if (db && blockIdx.x == 0) {
+        float v[4] = {bsum.x, bsum.y, bsum.z, bsum.w};
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            v[ii] += __shfl_xor(v[ii], 16);
+            v[ii] += __shfl_xor(v[ii], 32);
+        }
+        if (g == 0) *reinterpret_cast<float4*>(db + n0 + 4 * c) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+// ---- attention ----------------------------------------------------------------------------------------------------------
+constexpr int kMaxS = 128, kMaxDh = 64, kPitch = kMaxDh + 1;
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// qkv (bs S, 3 d) -> P (bs, H, S, S) softmax probabilities, ctx (bs S, d).  grid (H, bs), 256 lanes; a wave per query row.
+__global__ __launch_bounds__(256) void k_attn_fwd(const float* __restrict__ qkv, const uint8_t* __restrict__ mask, float* __restrict__ P,
+                                                  float* __restrict__ ctx, int S, int d, int dh, float scale) {
+    extern __shared__ float sm[];
+    float* q = sm;
+    float* k = q + S * kPitch;
+    float* v = k + S * kPitch;
+    float* pw = v + S * kPitch;  // [4][kMaxS]
+    const int h = blockIdx.x, b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* base = qkv + (int64_t)b * S * 3 * d + h * dh;
+    for (int e = threadIdx.x; e < S * dh; e += 256) {
+        const int r = e / dh, c = e - r * dh;
+        const float* p = base + (int64_t)r * 3 * d + c;
+        q[r * kPitch + c] = p[0] * scale;  // torch scales q before the product
+        k[r * kPitch + c] = p[d];
+        v[r * kPitch + c] = p[2 * d];
+    }
+    __syncthreads();
+    const uint8_t* mk = mask ? mask + (int64_t)b * S : nullptr;
+    for (int r = wave; r < S; r += 4) {
+        float s[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int j = lane + 64 * u;
+            float a = -INFINITY;
+            if (j < S && !(mk && mk[j])) {
+                a = 0.f;
+                for (int c = 0; c < dh; ++c) a = fmaf(q[r * kPitch + c], k[j * kPitch + c], a);
+            }
+            s[u] = a;
+        }
+        const float mx = wave_max(fmaxf(s[0], s[1]));
+        const float e0 = s[0] == -INFINITY ? 0.f : __expf(s[0] - mx), e1 = s[1] == -INFINITY ? 0.f : __expf(s[1] - mx);
+        const float inv = 1.0f / wave_sum(e0 + e1);
+        float* prow = P + (((int64_t)b * gridDim.x + h) * S + r) * S;
+        if (lane < S) { pw[wave * kMaxS + lane] = e0 * inv; prow[lane] = e0 * inv; }
+        if (lane + 64 < S) { pw[wave * kMaxS + lane + 64] = e1 * inv; prow[lane + 64] = e1 * inv; }
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own LDS writes have landed (wave-local data, no barrier)
+        __builtin_amdgcn_wave_barrier();
+        if (lane < dh) {
+            float o = 0.f;
+            for (int j = 0; j < S; ++j) o = fmaf(pw[wave * kMaxS + j], v[j * kPitch + lane], o);
+            ctx[((int64_t)b * S + r) * d + h * dh + lane] = o;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// dS = P (.) (dP - rowsum(dP (.) P)) with dP = dO V^T, written unscaled.  grid (H, bs), 256 lanes
+__global__ __launch_bounds__(256) void k_attn_bwd1(const float* __restrict__ qkv, const float* __restrict__ dctx, const float* __restrict__ P,
+                                                   float* __restrict__ dS, int S, int d, int dh) {
+    extern __shared__ float sm[];
+    float* v = sm;
+    float* go = v + S * kPitch;
+    const int h = blockIdx.x, b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int e = threadIdx.x; e < S * dh; e += 256) {
+        const int r = e / dh, c = e - r * dh;
+        v[r * kPitch + c] = qkv[((int64_t)b * S + r) * 3 * d + 2 * d + h * dh + c];
+        go[r * kPitch + c] = dctx[((int64_t)b * S + r) * d + h * dh + c];
+    }
+    __syncthreads();
+    for (int r = wave; r < S; r += 4) {
+        const int64_t off = (((int64_t)b * gridDim.x + h) * S + r) * S;
+        float dp[2], p[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int j = lane + 64 * u;
+            dp[u] = 0.f;
+            p[u] = 0.f;
+            if (j < S) {
+                p[u] = P[off + j];
+                float a = 0.f;
+                for (int c = 0; c < dh; ++c) a = fmaf(go[r * kPitch + c], v[j * kPitch + c], a);
+                dp[u] = a;
+            }
+        }
+        const float delta = wave_sum(dp[0] * p[0] + dp[1] * p[1]);
+        if (lane < S) dS[off + lane] = p[0] * (dp[0] - delta);
+        if (lane + 64 < S) dS[off + lane + 64] = p[1] * (dp[1] - delta);
+    }
+}
+
+// dQ = scale dS K, dK = scale dS^T Q, dV = P^T dO -> dqkv (bs S, 3 d).  grid (H, bs), 256 lanes; lane = head column
+__global__ __launch_bounds__(256) void k_attn_bwd2(const float* __restrict__ qkv, const float* __restrict__ dctx, const float* __restrict__ P,
+                                                   const float* __restrict__ dS, float* __restrict__ dqkv, int S, int d, int dh, float scale) {
+    extern __shared__ float sm[];
+    float* q = sm;
+    float* k = q + S * kPitch;
+    float* go = k + S * kPitch;
+    float* pw = go + S * kPitch;  // [4][2][kMaxS]
+    const int h = blockIdx.x, b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* base = qkv + (int64_t)b * S * 3 * d + h * dh;
+    for (int e = threadIdx.x; e < S * dh; e += 256) {
+        const int r = e / dh, c = e - r * dh;
+        q[r * kPitch + c] = base[(int64_t)r * 3 * d + c];
+        k[r * kPitch + c] = base[(int64_t)r * 3 * d + d + c];
+        go[r * kPitch + c] = dctx[((int64_t)b * S + r) * d + h * dh + c];
+    }
+    __syncthreads();
+    const int64_t hb = ((int64_t)b * gridDim.x + h) * S * S;
+    float* w0 = pw + wave * 2 * kMaxS;
+    float* w1 = w0 + kMaxS;
+    for (int r = wave; r < S; r += 4) {
+        // row r of dS -> dQ[r]; column r of dS -> dK[r]; column r of P -> dV[r]
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int j = lane + 64 * u;
+            if (j < S) w0[j] = dS[hb + (int64_t)r * S + j];
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        float dq = 0.f;
+        if (lane < dh)
+            for (int j = 0; j < S; ++j) dq = fmaf(w0[j], k[j * kPitch + lane], dq);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int j = lane + 64 * u;
+            if (j < S) {
+                w0[j] = dS[hb + (int64_t)j * S + r];
+                w1[j] = P[hb + (int64_t)j * S + r];
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        if (lane < dh) {
+            float dk = 0.f, dv = 0.f;
+            for (int j = 0; j < S; ++j) {
+                dk = fmaf(w0[j], q[j * kPitch + lane], dk);
+                dv = fmaf(w1[j], go[j * kPitch + lane], dv);
+            }
+            float* o = dqkv + ((int64_t)b * S + r) * 3 * d + h * dh + lane;
+            o[0] = dq * scale;
+            o[d] = dk * scale;
+            o[2 * d] = dv;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ---- LayerNorm (rows of width d <= 1024, one wave per row) --------------------------------------------------------------
+constexpr int kLnMax = 16;  // columns per lane
+
+__global__ __launch_bounds__(256) void k_ln_fwd(const float* __restrict__ s, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                float* __restrict__ y, float* __restrict__ stats, int M, int d, float eps) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* x = s + (int64_t)row * d;
+    float v[kLnMax];
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < kLnMax; ++t) {
+        const int c = lane + 64 * t;
+        v[t] = c < d ? x[c] : 0.f;
+        sum += v[t];
+    }
+    const float mean = wave_sum(sum) / (float)d;
+    float sq = 0.f;
+#pragma unroll
+    for (int t = 0; t < kLnMax; ++t) {
+        const int c = lane + 64 * t;
+        const float u = c < d ? v[t] - mean : 0.f;
+        sq = fmaf(u, u, sq);
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)d + eps);
+#pragma unroll
+    for (int t = 0; t < kLnMax; ++t) {
+        const int c = lane + 64 * t;
+        if (c < d) y[(int64_t)row * d + c] = (v[t] - mean) * rstd * gamma[c] + beta[c];
+    }
+    if (lane == 0) {
+        stats[2 * row] = mean;
+        stats[2 * row + 1] = rstd;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ln_bwd_dx(const float* __restrict__ dy, const float* __restrict__ s, const float* __restrict__ stats,
+                                                   const float* __restrict__ gamma, float* __restrict__ dx, int M, int d) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+    float xh[kLnMax], gh[kLnMax];
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < kLnMax; ++t) {
+        const int c = lane + 64 * t;
+        xh[t] = gh[t] = 0.f;
+        if (c < d) {
+            xh[t] = (s[(int64_t)row * d + c] - mean) * rstd;
+            gh[t] = dy[(int64_t)row * d + c] * gamma[c];
+        }
+        c1 += gh[t];
+        c2 = fmaf(gh[t], xh[t], c2);
+    }
+    c1 = wave_sum(c1) / (float)d;
+    c2 = wave_sum(c2) / (float)d;
+#pragma unroll
+    for (int t = 0; t < kLnMax; ++t) {
+        const int c = lane + 64 * t;
+        if (c < d) dx[(int64_t)row * d + c] = rstd * (gh[t] - c1 - xh[t] * c2);
+    }
+}
+
+// dgamma[c] = sum_rows dy xhat, dbeta[c] = sum_rows dy: 64 columns per workgroup, 4 row groups folded through LDS in a fixed order
+__global__ __launch_bounds__(256) void k_ln_bwd_gb(const float* __restrict__ dy, const float* __restrict__ s, const float* __restrict__ stats,
+                                                   float* __restrict__ dgamma, float* __restrict__ dbeta, int M, int d) {
+    __shared__ float part[2][4][64];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6, c = blockIdx.x * 64 + lane;
+    float a = 0.f, b = 0.f;
+    if (c < d)
+        for (int row = grp; row < M; row += 4) {
+            const float g = dy[(int64_t)row * d + c];
+            a = fmaf(g, (s[(int64_t)row * d + c] - stats[2 * row]) * stats[2 * row + 1], a);
+            b += g;
+        }
+    part[0][grp][lane] = a;
+    part[1][grp][lane] = b;
+    __syncthreads();
+    if (grp == 0 && c < d) {
+        dgamma[c] = (part[0][0][lane] + part[0][1][lane]) + (part[0][2][lane] + part[0][3][lane]);
+        dbeta[c] = (part[1][0][lane] + part[1][1][lane]) + (part[1][2][lane] + part[1][3][lane]);
+    }
+}
+
+// ---- host side ------------------------------------------------------------------------------------------------------------
+struct Plan {
+    int M, S, d, H, dh, ff, L;
+    size_t qkv, P, ctx, s1, st1, x1, h, s2, st2, x2, per_layer;  // float offsets inside one layer's slab
+    size_t t_g0, t_g1, t_ds, t_dh, t_dx1, t_dctx, t_dqkv, t_dS, total;  // backward temporaries (floats, after the slabs)
+};
+
+static bool make_plan(const mst_ctrl_desc* d, Plan& p) {
+    if (!d || d->bs < 1 || d->seq < 1 || d->seq > kMaxS || d->n_layers < 1 || d->nhead < 1) return false;
+    if (d->d_model % 128 || d->d_ff % 128 || d->d_model > 64 * kLnMax || d->d_model % d->nhead) return false;
+    p.dh = d->d_model / d->nhead;
+    if (p.dh > kMaxDh) return false;
+    p.M = d->bs * d->seq; p.S = d->seq; p.d = d->d_model; p.H = d->nhead; p.ff = d->d_ff; p.L = d->n_layers;
+    auto up = [](size_t v) { return (v + 63) & ~(size_t)63; };
+    size_t o = 0;
+    const size_t M = p.M, dm = p.d;
+    p.qkv = o; o += up(M * 3 * dm);
+    p.P = o; o += up((size_t)d->bs * p.H * p.S * p.S);
+    p.ctx = o; o += up(M * dm);
+    p.s1 = o; o += up(M * dm);
+    p.st1 = o; o += up(2 * M);
+    p.x1 = o; o += up(M * dm);
+    p.h = o; o += up(M * p.ff);
+    p.s2 = o; o += up(M * dm);
+    p.st2 = o; o += up(2 * M);
+    p.x2 = o; o += up(M * dm);
+    p.per_layer = o;
+    o = p.per_layer * p.L;
+    p.t_g0 = o; o += up(M * dm);
+    p.t_g1 = o; o += up(M * dm);
+    p.t_ds = o; o += up(M * dm);
+    p.t_dh = o; o += up(M * p.ff);
+    p.t_dx1 = o; o += up(M * dm);
+    p.t_dctx = o; o += up(M * dm);
+    p.t_dqkv = o; o += up(M * 3 * dm);
+    p.t_dS = o; o += up((size_t)d->bs * p.H * p.S * p.S);
+    p.total = o;
+    return true;
+}
+
+static void lin_nt(bool relu, const float* A, int lda, const float* W, int ldw, const float* bias, const float* R, int ldr, float* C, int ldc,
+                   int M, int N, int K, hipStream_t st) {
+    const dim3 grid(N / 16, (M + 63) / 64);
+    if (relu) hipLaunchKernelGGL(k_lin_nt<true>, grid, dim3(256), 0, st, A, lda, W, ldw, bias, R, ldr, C, ldc, M, K);
+    else hipLaunchKernelGGL(k_lin_nt<false>, grid, dim3(256), 0, st, A, lda, W, ldw, bias, R, ldr, C, ldc, M, K);
+}
+static void lin_nn(const float* A, int lda, const float* W, int ldw, const float* Hm, int ldh, const float* R, int ldr, float* C, int ldc, int M,
+                   int N, int cols, hipStream_t st) {
+    hipLaunchKernelGGL(k_lin_nn, dim3(cols / 16, (M + 63) / 64), dim3(512), 0, st, A, lda, W, ldw, Hm, ldh, R, ldr, C, ldc, M, N);
+}
+static void lin_tn(const float* dY, int ldy, const float* X, int ldx, float* dW, int ldw, float* db, int M, int N, int Kd, hipStream_t st) {
+    hipLaunchKernelGGL(k_lin_tn, dim3(Kd / 64, N / 64), dim3(64), 0, st, dY, ldy, X, ldx, dW, ldw, db, M);
+}
+
+}  // namespace ctrl
+}  // namespace mst
+
+using namespace mst::ctrl;
+
+extern "C" size_t mst_ctrl_workspace_bytes(const mst_ctrl_desc* d) {
+    Plan p;
+    return make_plan(d, p) ? p.total * sizeof(float) : 0;
+}
+
+extern "C" int mst_ctrl_forward(const mst_ctrl_desc* d, const float* tokens, const uint8_t* key_padding_mask, const mst_ctrl_layer* layers,
+                                float* out, void* workspace, size_t workspace_bytes, void* stream_) {
+    Plan p;
+    if (!make_plan(d, p) || !tokens || !layers || !out || !workspace) return hipErrorInvalidValue;
+    if (workspace_bytes < p.total * sizeof(float)) return hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream_;
+    float* ws = (float*)workspace;
+    const int M = p.M, dm = p.d, ff = p.ff;
+    const float scale = 1.0f / sqrtf((float)p.dh);
+    const size_t lds_attn = ((size_t)3 * p.S * kPitch + 4 * kMaxS) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)k_attn_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (3 * kMaxS * kPitch + 4 * kMaxS) * 4);
+        (void)hipFuncSetAttribute((const void*)k_attn_bwd1, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kMaxS * kPitch * 4);
+        (void)hipFuncSetAttribute((const void*)k_attn_bwd2, hipFuncAttributeMaxDynamicSharedMemorySize, (3 * kMaxS * kPitch + 8 * kMaxS) * 4);
+        attr_set = true;
+    }
+    const float* x = tokens;
+    for (int l = 0; l < p.L; ++l) {
+        float* L = ws + p.per_layer * l;
+        const mst_ctrl_layer& w = layers[l];
+        float* x2 = l == p.L - 1 ? out : L + p.x2;
+        lin_nt(false, x, dm, w.in_proj_weight, dm, w.in_proj_bias, nullptr, 0, L + p.qkv, 3 * dm, M, 3 * dm, dm, st);
+        hipLaunchKernelGGL(k_attn_fwd, dim3(p.H, d->bs), dim3(256), lds_attn, st, L + p.qkv, key_padding_mask, L + p.P, L + p.ctx, p.S, dm, p.dh, scale);
+        lin_nt(false, L + p.ctx, dm, w.out_proj_weight, dm, w.out_proj_bias, x, dm, L + p.s1, dm, M, dm, dm, st);
+        hipLaunchKernelGGL(k_ln_fwd, dim3((M + 3) / 4), dim3(256), 0, st, L + p.s1, w.norm1_weight, w.norm1_bias, L + p.x1, L + p.st1, M, dm, d->ln_eps);
+        lin_nt(true, L + p.x1, dm, w.linear1_weight, dm, w.linear1_bias, nullptr, 0, L + p.h, ff, M, ff, dm, st);
+        lin_nt(false, L + p.h, ff, w.linear2_weight, ff, w.linear2_bias, L + p.x1, dm, L + p.s2, dm, M, dm, ff, st);
+        hipLaunchKernelGGL(k_ln_fwd, dim3((M + 3) / 4), dim3(256), 0, st, L + p.s2, w.norm2_weight, w.norm2_bias, x2, L + p.st2, M, dm, d->ln_eps);
+        x = x2;
+    }
+    return (int)hipGetLastError();
+}
+
+extern "C" int mst_ctrl_backward(const mst_ctrl_desc* d, const float* tokens, const mst_ctrl_layer* layers, const float* grad_out,
+                                 const mst_ctrl_layer_grads* grads, float* grad_tokens, void* workspace, size_t workspace_bytes, void* stream_) {
+    Plan p;
+    if (!make_plan(d, p) || !tokens || !layers || !grad_out || !grads || !grad_tokens || !workspace) return hipErrorInvalidValue;
+    if (workspace_bytes < p.total * sizeof(float)) return hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream_;
+    float* ws = (float*)workspace;
+    const int M = p.M, dm = p.d, ff = p.ff;
+    const float scale = 1.0f / sqrtf((float)p.dh);
+    const size_t lds1 = (size_t)2 * p.S * kPitch * sizeof(float), lds2 = ((size_t)3 * p.S * kPitch + 8 * kMaxS) * sizeof(float);
+    const dim3 rows((M + 3) / 4), cols((dm + 63) / 64);
+    const float* g = grad_out;
+    for (int l = p.L - 1; l >= 0; --l) {
+        float* L = ws + p.per_layer * l;
+        const mst_ctrl_layer& w = layers[l];
+        const mst_ctrl_layer_grads& gw = grads[l];
+        const float* x = l == 0 ? tokens : ws + p.per_layer * (l - 1) + p.x2;
+        float* gout = l == 0 ? grad_tokens : ws + ((l & 1) ? p.t_g1 : p.t_g0);
+        float *ds = ws + p.t_ds, *dh = ws + p.t_dh, *dx1 = ws + p.t_dx1, *dctx = ws + p.t_dctx, *dqkv = ws + p.t_dqkv, *dS = ws + p.t_dS;
+        // LayerNorm 2 (input s2 = x1 + ffn)
+        hipLaunchKernelGGL(k_ln_bwd_gb, cols, dim3(256), 0, st, g, L + p.s2, L + p.st2, gw.norm2_weight, gw.norm2_bias, M, dm);
+        hipLaunchKernelGGL(k_ln_bwd_dx, rows, dim3(256), 0, st, g, L + p.s2, L + p.st2, w.norm2_weight, ds, M, dm);
+        // feed-forward
+        lin_tn(ds, dm, L + p.h, ff, gw.linear2_weight, ff, gw.linear2_bias, M, dm, ff, st);
+        lin_nn(ds, dm, w.linear2_weight, ff, L + p.h, ff, nullptr, 0, dh, ff, M, dm, ff, st);
+        lin_tn(dh, ff, L + p.x1, dm, gw.linear1_weight, dm, gw.linear1_bias, M, ff, dm, st);
+        lin_nn(dh, ff, w.linear1_weight, dm, nullptr, 0, ds, dm, dx1, dm, M, ff, dm, st);
+        // LayerNorm 1 (input s1 = x + attention); `ds` is free again
+        hipLaunchKernelGGL(k_ln_bwd_gb, cols, dim3(256), 0, st, dx1, L + p.s1, L + p.st1, gw.norm1_weight, gw.norm1_bias, M, dm);
+        hipLaunchKernelGGL(k_ln_bwd_dx, rows, dim3(256), 0, st, dx1, L + p.s1, L + p.st1, w.norm1_weight, ds, M, dm);
+        // attention
+        lin_tn(ds, dm, L + p.ctx, dm, gw.out_proj_weight, dm, gw.out_proj_bias, M, dm, dm, st);
+        lin_nn(ds, dm, w.out_proj_weight, dm, nullptr, 0, nullptr, 0, dctx, dm, M, dm, dm, st);
+        hipLaunchKernelGGL(k_attn_bwd1, dim3(p.H, d->bs), dim3(256), lds1, st, L + p.qkv, dctx, L + p.P, dS, p.S, dm, p.dh);
+        hipLaunchKernelGGL(k_attn_bwd2, dim3(p.H, d->bs), dim3(256), lds2, st, L + p.qkv, dctx, L + p.P, dS, dqkv, p.S, dm, p.dh, scale);
+        lin_tn(dqkv, 3 * dm, x, dm, gw.in_proj_weight, dm, gw.in_proj_bias, M, 3 * dm, dm, st);
+        lin_nn(dqkv, 3 * dm, w.in_proj_weight, dm, nullptr, 0, ds, dm, gout, dm, M, 3 * dm, dm, st);
+        g = gout;
+    }
+    return (int)hipGetLastError();
+}

@@ -23,7 +23,7 @@ SAVE_FOR_BACKWARD = 0x100
 DEV_MULTIPASS_EQ = 0x200
 NO_RANGE_CHECK = 0x400
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class ConsoleDesc(C.Structure):
@@ -88,6 +88,19 @@ class Cnn14Grads(C.Structure):  # mirrors mst_cnn14_grads
                 ("fc_w", C.c_void_p), ("fc_b", C.c_void_p)]
 
 
+CTRL_FIELDS = ("in_proj_weight", "in_proj_bias", "out_proj_weight", "out_proj_bias", "linear1_weight", "linear1_bias",
+               "linear2_weight", "linear2_bias", "norm1_weight", "norm1_bias", "norm2_weight", "norm2_bias")
+
+
+class CtrlDesc(C.Structure):  # mirrors mst_ctrl_desc
+    _fields_ = [("bs", C.c_int32), ("seq", C.c_int32), ("d_model", C.c_int32), ("nhead", C.c_int32), ("d_ff", C.c_int32),
+                ("n_layers", C.c_int32), ("ln_eps", C.c_float)]
+
+
+class CtrlLayer(C.Structure):  # mirrors mst_ctrl_layer and mst_ctrl_layer_grads (same twelve pointers)
+    _fields_ = [(name, C.c_void_p) for name in CTRL_FIELDS]
+
+
 _P = C.c_void_p
 
 SIGNATURES = {
@@ -119,6 +132,9 @@ SIGNATURES = {
     "mst_cnn14_forward": (C.c_int, [C.POINTER(Cnn14Desc), _P, C.POINTER(Cnn14Params), _P, _P, _P, C.c_size_t, _P]),
     "mst_cnn14_backward": (C.c_int, [C.POINTER(Cnn14Desc), _P, C.POINTER(Cnn14Params), _P, C.POINTER(Cnn14Grads), _P, C.c_size_t, _P]),
     "mst_afloss_backward": (C.c_int, [_P, _P, C.c_int32, C.c_int64, C.POINTER(C.c_float), _P, _P, _P, _P, _P, C.c_size_t, _P]),
+    "mst_ctrl_workspace_bytes": (C.c_size_t, [C.POINTER(CtrlDesc)]),
+    "mst_ctrl_forward": (C.c_int, [C.POINTER(CtrlDesc), _P, _P, C.POINTER(CtrlLayer), _P, _P, C.c_size_t, _P]),
+    "mst_ctrl_backward": (C.c_int, [C.POINTER(CtrlDesc), _P, C.POINTER(CtrlLayer), _P, C.POINTER(CtrlLayer), _P, _P, C.c_size_t, _P]),
 }
 
 

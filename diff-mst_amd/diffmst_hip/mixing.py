@@ -19,12 +19,19 @@ def naive_random_mix(
     The misspelt ``use_ouput_fader`` keyword and the ``**kwargs`` sink are part of the reference's
     interface (mixing.py:44; ``System`` passes ``use_output_fader`` which lands in kwargs, SURVEY
     App. C.2) and are kept.  Parameters are drawn with the CPU generator in the same order as the
-    reference (mixing.py:61-69) so seeded runs agree, then moved to ``tracks``' device.
+    reference (mixing.py:61-69) so seeded runs agree, then moved to ``tracks``' device (asynchronously, from pinned memory).
     """
     bs, num_tracks, _ = tracks.size()
-    mix_params = torch.rand(bs, num_tracks, mix_console.num_track_control_params).type_as(tracks)
-    fx_bus_params = torch.rand(bs, mix_console.num_fx_bus_control_params).type_as(tracks)
-    master_bus_params = torch.rand(bs, mix_console.num_master_bus_control_params).type_as(tracks)
+    def draw(*shape):
+        # same CPU-generator stream as the reference; drawn into pinned memory and copied asynchronously: `.type_as` on a
+        # pageable tensor is a copy + stream synchronize, i.e. three host stalls per mix with the GPU drained behind them
+        if tracks.is_cuda:
+            return torch.rand(*shape, pin_memory=True).to(tracks.device, non_blocking=True).type_as(tracks)
+        return torch.rand(*shape).type_as(tracks)
+
+    mix_params = draw(bs, num_tracks, mix_console.num_track_control_params)
+    fx_bus_params = draw(bs, mix_console.num_fx_bus_control_params)
+    master_bus_params = draw(bs, mix_console.num_master_bus_control_params)
     with torch.no_grad():
         mixed_tracks, mix, track_param_dict, fx_bus_param_dict, master_bus_param_dict = mix_console(
             tracks, mix_params, fx_bus_params, master_bus_params,

@@ -548,9 +548,10 @@ class TransformerController(torch.nn.Module):
 
     def __init__(self, embed_dim: int, num_track_control_params: int, num_fx_bus_control_params: int,
                  num_master_bus_control_params: int, num_layers: int = 6, nhead: int = 8, use_fx_bus: bool = False,
-                 use_master_bus: bool = False, graphed: bool = False) -> None:
+                 use_master_bus: bool = False, graphed: bool = False, native: bool = False) -> None:
         super().__init__()
         self.graphed = bool(graphed)
+        self.native = bool(native)  # encoder stack on csrc/mst_ctrl.hip (fp32 MFMA) instead of torch's layers; see controller.py
         object.__setattr__(self, "_graphs", {})  # shape key -> graphed callable (not a submodule: state_dict stays the reference's)
         self.embed_dim = embed_dim
         self.num_track_control_params = num_track_control_params
@@ -569,7 +570,7 @@ class TransformerController(torch.nn.Module):
         self.master_bus_projection = torch.nn.Linear(embed_dim, num_master_bus_control_params)
 
     def forward(self, track_embeds: torch.Tensor, mix_embeds: torch.Tensor, track_padding_mask=None):
-        if self.graphed and self.training and torch.is_grad_enabled() and track_embeds.is_cuda:
+        if self.graphed and not self.native and self.training and torch.is_grad_enabled() and track_embeds.is_cuda:
             return self._graphed_forward(track_embeds, mix_embeds, track_padding_mask)
         return self._eager_forward(track_embeds, mix_embeds, track_padding_mask)
 
@@ -594,7 +595,15 @@ class TransformerController(torch.nn.Module):
                             self.fx_bus_embedding.expand(bs, -1, -1), self.master_bus_embedding.expand(bs, -1, -1)), dim=1)
         if track_padding_mask is not None:  # the four appended tokens are always attended to
             track_padding_mask = torch.cat((track_padding_mask, track_padding_mask.new_zeros((bs, 4))), dim=1)  # made on the device: no host copy
-        z = self.transformer_encoder(tokens, src_key_padding_mask=track_padding_mask)
+        if self.native and tokens.is_cuda:
+            from . import controller
+
+            if not controller.supported(self.transformer_encoder, bs, tokens.shape[1]):
+                raise ValueError("TransformerController(native=True): encoder stack outside the kernels' limits "
+                                 "(<= 128 tokens, d_model % 128 == 0, head width <= 64, post-norm relu layers, dropout 0)")
+            z = controller.encoder_stack(self.transformer_encoder, tokens, track_padding_mask)
+        else:
+            z = self.transformer_encoder(tokens, src_key_padding_mask=track_padding_mask)
         return (torch.sigmoid(self.track_projection(z[:, :num_tracks, :])), torch.sigmoid(self.fx_bus_projection(z[:, -2, :])),
                 torch.sigmoid(self.master_bus_projection(z[:, -1, :])))
 

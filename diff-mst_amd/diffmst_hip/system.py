@@ -37,8 +37,17 @@ class CommonStep(torch.nn.Module):
         active_master_bus_epoch: int = 0,
         max_epochs: int = 500,
         repeat_reference_mix: bool = True,
+        nan_check: str = "sync",
     ) -> None:
         super().__init__()
+        if nan_check not in ("sync", "deferred"):
+            raise ValueError("nan_check is 'sync' or 'deferred'")
+        # "sync" = the reference's `if torch.isnan(ref_mix).any(): raise` (:178-180): one device -> host readback in the middle
+        # of every step, after which the GPU idles until the host has issued the encoder's first kernels.  "deferred" keeps the
+        # flag on the device: `check_finite()` - called at the top of the NEXT step, when the flag has long been written -
+        # raises the same ValueError one step later and the host never waits (cfg #5: DESIGN 9.6).
+        self.nan_check = nan_check
+        self._nan_flag = None
         self.model = model
         self.mix_console = mix_console
         self.mix_fn = mix_fn
@@ -86,8 +95,15 @@ class CommonStep(torch.nn.Module):
             ke_dict=None,
         )
 
+    def check_finite(self):
+        """Deferred NaN guard: raise the reference's ValueError if a reference mix of an earlier step held a NaN."""
+        flag, self._nan_flag = self._nan_flag, None
+        if flag is not None and bool(flag):
+            raise ValueError("Found nan in ref_mix")
+
     def forward(self, batch: tuple, train: bool = False, collect: bool = False):
         tracks, instrument_id, stereo_info, track_padding, ref_mix, song_name = batch
+        self.check_finite()
         middle_idx = tracks.shape[-1] // 2
         if self.current_epoch >= self.active_eq_epoch:
             self.use_track_eq = True
@@ -104,7 +120,10 @@ class CommonStep(torch.nn.Module):
                 (_, ref_mix, ref_track_param_dict, ref_fx_bus_param_dict, ref_master_bus_param_dict,
                  _, _, _) = self._reference_mix(tracks, instrument_id, stereo_info)
                 ref_mix = batch_stereo_peak_normalize(ref_mix)
-                if torch.isnan(ref_mix).any():
+                found = torch.isnan(ref_mix).any()
+                if self.nan_check == "deferred":
+                    self._nan_flag = found if self._nan_flag is None else self._nan_flag | found
+                elif found:
                     raise ValueError("Found nan in ref_mix")
             ref_mix_a = ref_mix[..., :middle_idx]
             ref_mix_b = ref_mix[..., middle_idx:]

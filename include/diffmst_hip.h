@@ -257,6 +257,51 @@ int mst_cnn14_forward(const mst_cnn14_desc* d, const float* spec, const mst_cnn1
 int mst_cnn14_backward(const mst_cnn14_desc* d, const float* spec, const mst_cnn14_params* params, const float* grad_embed,
                        const mst_cnn14_grads* grads, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- TransformerController encoder stack (reference mst/modules.py:848-854, :893-895: torch.nn.TransformerEncoder of
+ * post-norm TransformerEncoderLayer(d_model, nhead, dim_feedforward, relu, dropout 0, batch_first) over the (bs, seq, d_model)
+ * token sequence, with the key-padding mask of :880-890).  fp32 operands on v_mfma_f32_16x16x4_f32.  Limits: seq <= 128,
+ * d_model % 128 == 0, d_model <= 1024, d_model / nhead <= 64, d_ff % 128 == 0 (workspace_bytes returns 0 otherwise). */
+typedef struct mst_ctrl_desc {
+    int32_t bs, seq, d_model, nhead, d_ff, n_layers;
+    float ln_eps; /* 1e-5 */
+} mst_ctrl_desc;
+typedef struct mst_ctrl_layer { /* device pointers, fp32, torch layouts (the state_dict entries of one layer) */
+    const float* in_proj_weight;  /* self_attn.in_proj_weight (3 d_model, d_model) */
+    const float* in_proj_bias;    /* (3 d_model) */
+    const float* out_proj_weight; /* self_attn.out_proj.weight (d_model, d_model) */
+    const float* out_proj_bias;
+    const float* linear1_weight;  /* (d_ff, d_model) */
+    const float* linear1_bias;
+    const float* linear2_weight;  /* (d_model, d_ff) */
+    const float* linear2_bias;
+    const float* norm1_weight;
+    const float* norm1_bias;
+    const float* norm2_weight;
+    const float* norm2_bias;
+} mst_ctrl_layer;
+typedef struct mst_ctrl_layer_grads { /* same entries; every array is overwritten */
+    float* in_proj_weight;
+    float* in_proj_bias;
+    float* out_proj_weight;
+    float* out_proj_bias;
+    float* linear1_weight;
+    float* linear1_bias;
+    float* linear2_weight;
+    float* linear2_bias;
+    float* norm1_weight;
+    float* norm1_bias;
+    float* norm2_weight;
+    float* norm2_bias;
+} mst_ctrl_layer_grads;
+size_t mst_ctrl_workspace_bytes(const mst_ctrl_desc* d);
+/* tokens (bs, seq, d_model) -> out (bs, seq, d_model).  key_padding_mask (bs, seq) bytes, non-zero = ignore that key, or NULL.
+ * layers: HOST array of n_layers entries.  The workspace keeps what mst_ctrl_backward needs. */
+int mst_ctrl_forward(const mst_ctrl_desc* d, const float* tokens, const uint8_t* key_padding_mask, const mst_ctrl_layer* layers,
+                     float* out, void* workspace, size_t workspace_bytes, void* stream);
+/* grad_out (bs, seq, d_model) -> gradients of every layer parameter (grads: HOST array of n_layers entries) and of the tokens. */
+int mst_ctrl_backward(const mst_ctrl_desc* d, const float* tokens, const mst_ctrl_layer* layers, const float* grad_out,
+                      const mst_ctrl_layer_grads* grads, float* grad_tokens, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

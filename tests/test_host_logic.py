@@ -211,3 +211,48 @@ def test_load_diffmst_splits_a_lightning_checkpoint(tmp_path):
     for k, v in src.state_dict().items():
         assert torch.equal(got[k], v), k
     assert console.param_ranges["input_fader"]["gain_db"] == (-48.0, 48.0)
+
+
+def test_common_step_deferred_nan_guard(monkeypatch):
+    """nan_check='deferred' raises the reference's error (mst/system.py:178-180) at the top of the next step; 'sync' at once."""
+    import mst.system
+    from mst.system import CommonStep
+
+    monkeypatch.setattr(mst.system, "batch_stereo_peak_normalize", lambda x: x)  # the HIP op has no CPU path; not under test here
+
+    class Console(torch.nn.Module):
+        supports_fx_bus = True
+
+        def forward(self, tracks, tp, fp, mp, **kw):
+            mix = tracks.sum(1, keepdim=True).repeat(1, 2, 1) * tp.mean()
+            return None, mix, {}, {}, {}
+
+    class Model(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.ones(1))
+
+        def forward(self, tracks, ref, track_padding_mask=None):
+            bs, T, _ = tracks.shape
+            return self.w * torch.ones(bs, T, 27), torch.ones(bs, 25), torch.ones(bs, 26)
+
+    poison = {"on": True}
+
+    def mix_fn(tracks, console, **kw):
+        mix = tracks.sum(1, keepdim=True).repeat(1, 2, 1)
+        if poison["on"]:
+            mix = mix.clone()
+            mix[0, 0, 3] = float("nan")
+        return None, mix, {}, {}, {}, None, None, None
+
+    batch = (torch.randn(1, 3, 64), None, None, None, None, ["s"])
+    loss_fn = lambda a, b: (a - b).abs().mean()
+    with pytest.raises(ValueError, match="Found nan in ref_mix"):
+        CommonStep(Model(), Console(), mix_fn, loss_fn)(batch)
+    step = CommonStep(Model(), Console(), mix_fn, loss_fn, nan_check="deferred")
+    step(batch)  # the poisoned step itself goes through
+    poison["on"] = False
+    with pytest.raises(ValueError, match="Found nan in ref_mix"):
+        step(batch)
+    step(batch)  # the flag was consumed
+    step.check_finite()
