@@ -6,7 +6,7 @@
 // hipGraph replay included.  M = bs x tokens is tiny, so every GEMM is a WEIGHT-STREAMING problem: 12.6 MB of fp32
 // weights per layer are read once by the forward, once by the data gradient, and 12.6 MB of weight gradient are written.  The
 // kernels are therefore organised around "every weight element crosses the memory system once, 16 bytes per lane":
-//   k_lin_nt  C = act(A W^T + b) (+ R)   one workgroup per 16 output columns, its 4 waves split K, fragments straight from
+//   k_lin_nt  C = act(A W^T + b) (+ R)   one workgroup per 16 output columns, its 8 waves split K, fragments straight from
 //                                        global memory (both operands K-contiguous: float4 per lane, the K order inside a
 //                                        16-step is permuted identically for A and W, which a dot product does not see)
 //   k_lin_nn  C = (A W) (.) mask (+ R)   data gradient: one workgroup per 16 output columns, 8 waves split the reduction
@@ -27,16 +27,16 @@ typedef float f32x4 __attribute__((vector_size(16)));
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ float comp(const float4& v, int j) { return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w)); }
 
-// ---- C[m][n] = act(sum_k A[m][k] W[n][k] + bias[n]) (+ R[m][n]);  grid (N / 16, ceil(M / 64)), 256 lanes -------------------
+// ---- C[m][n] = act(sum_k A[m][k] W[n][k] + bias[n]) (+ R[m][n]);  grid (N / 16, ceil(M / 64)), 512 lanes -------------------
 template <bool RELU>
-__global__ __launch_bounds__(256) void k_lin_nt(const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw,
+__global__ __launch_bounds__(512) void k_lin_nt(const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw,
                                                 const float* __restrict__ bias, const float* __restrict__ R, int ldr,
                                                 float* __restrict__ C, int ldc, int M, int K) {
-    __shared__ float red[4][4][4][64];
+    __shared__ float red[8][4][4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
     const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 64;
     const int nmt = min(4, (M - m0 + 15) >> 4);
-    const int kq = K >> 2, kb = wave * kq;
+    const int kq = K >> 3, kb = wave * kq;  // K % 128 == 0: every wave owns a multiple of 16
     f32x4 acc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -49,33 +49,43 @@ __global__ __launch_bounds__(256) void k_lin_nt(const float* __restrict__ A, int
         ok[t] = t < nmt && row < M;
         ap[t] = A + (int64_t)(ok[t] ? row : m0) * lda + kb + 4 * g;
     }
-
-    for (int k = 0; k < kq; k += 16) {
-        const float4 b4 = ld4(wp + k);
-        float4 a4[4];
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < kq; k += 64) {  // four 16-steps per trip, every load of the trip issued before the first product
+        float4 b4[4], a4[4][4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) a4[t] = ok[t] ? ld4(ap[t] + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int u = 0; u < 4; ++u) {
+            const bool in = k + 16 * u < kq;
+            b4[u] = in ? ld4(wp + k + 16 * u) : zero4;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            if (t < nmt) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[t] = MFMA4(comp(a4[t], j), comp(b4, j), acc[t]);
-            }
+            for (int t = 0; t < 4; ++t) a4[u][t] = (in && ok[t]) ? ld4(ap[t] + k + 16 * u) : zero4;
         }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (t < nmt) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[t] = MFMA4(comp(a4[u][t], j), comp(b4[u], j), acc[t]);
+                }
+            }
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) red[wave][t][r][lane] = acc[t][r];
     __syncthreads();
-    const int t = wave;  // wave w finishes row tile w
+    const int t = wave >> 1;  // waves 2 t, 2 t + 1 finish row tile t (two accumulator rows each)
     if (t < nmt) {
         const float bv = bias ? bias[n0 + i] : 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int rr = 0; rr < 2; ++rr) {
+            const int r = 2 * (wave & 1) + rr;
             const int row = m0 + 16 * t + 4 * g + r;
             if (row < M) {
-                float v = ((red[0][t][r][lane] + red[1][t][r][lane]) + (red[2][t][r][lane] + red[3][t][r][lane])) + bv;
+                float v = 0.f;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) v += red[w][t][r][lane];
+                v += bv;
                 if (RELU) v = fmaxf(v, 0.f);
                 if (R) v += R[(int64_t)row * ldr + n0 + i];
                 C[(int64_t)row * ldc + n0 + i] = v;
@@ -106,20 +116,27 @@ __global__ __launch_bounds__(512) void k_lin_nn(const float* __restrict__ A, int
         ap[t] = A + (int64_t)(ok[t] ? row : m0) * lda + nb + 4 * g;
     }
 
-    for (int n = 0; n < nq; n += 16) {
-        float b[4];
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int n = 0; n < nq; n += 64) {
+        float b[4][4];
+        float4 a4[4][4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) b[j] = wp[(int64_t)(n + j) * ldw];
-        float4 a4[4];
+        for (int u = 0; u < 4; ++u) {
+            const bool in = n + 16 * u < nq;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) a4[t] = ok[t] ? ld4(ap[t] + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int j = 0; j < 4; ++j) b[u][j] = in ? wp[(int64_t)(n + 16 * u + j) * ldw] : 0.f;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            if (t < nmt) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[t] = MFMA4(comp(a4[t], j), b[j], acc[t]);
-            }
+            for (int t = 0; t < 4; ++t) a4[u][t] = (in && ok[t]) ? ld4(ap[t] + n + 16 * u) : zero4;
         }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (t < nmt) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[t] = MFMA4(comp(a4[u][t], j), b[u][j], acc[t]);
+                }
+            }
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t)
@@ -157,18 +174,25 @@ __global__ __launch_bounds__(64) void k_lin_tn(const float* __restrict__ dY, int
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[ii][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int m = 0; m < M; m += 4) {
-        const int row = m + g;
-        float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f), b4 = a4;
-        if (row < M) {
-            a4 = ld4(dY + (int64_t)row * ldy + n0 + 4 * c);
-            b4 = ld4(X + (int64_t)row * ldx + k0 + 4 * c);
+    for (int m = 0; m < M; m += 16) {  // four 4-row steps per trip, loads first
+        float4 a4[4], b4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int row = m + 4 * u + g;
+            a4[u] = b4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < M) {
+                a4[u] = ld4(dY + (int64_t)row * ldy + n0 + 4 * c);
+                b4[u] = ld4(X + (int64_t)row * ldx + k0 + 4 * c);
+            }
         }
-        bsum.x += a4.x; bsum.y += a4.y; bsum.z += a4.z; bsum.w += a4.w;
 #pragma unroll
-        for (int ii = 0; ii < 4; ++ii)
+        for (int u = 0; u < 4; ++u) {
+            bsum.x += a4[u].x; bsum.y += a4[u].y; bsum.z += a4[u].z; bsum.w += a4[u].w;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) acc[ii][t] = MFMA4(comp(a4, ii), comp(b4, t), acc[ii][t]);
+            for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[ii][t] = MFMA4(comp(a4[u], ii), comp(b4[u], t), acc[ii][t]);
+        }
     }
 #pragma unroll
     for (int ii = 0; ii < 4; ++ii)
@@ -191,6 +215,7 @@ __global__ __launch_bounds__(64) void k_lin_tn(const float* __restrict__ dY, int
 
 // ---- attention ----------------------------------------------------------------------------------------------------------
 constexpr int kMaxS = 128, kMaxDh = 64, kPitch = kMaxDh + 1;
+constexpr int kRowsPerWg = 8;  // query rows (key rows in k_attn_bwd2) of one workgroup: grid.z = ceil(S / 8)
 
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
@@ -203,7 +228,7 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-// qkv (bs S, 3 d) -> P (bs, H, S, S) softmax probabilities, ctx (bs S, d).  grid (H, bs), 256 lanes; a wave per query row.
+// qkv (bs S, 3 d) -> P (bs, H, S, S) softmax probabilities, ctx (bs S, d).  grid (H, bs, ceil(S / 8)), 256 lanes; a wave per query row.
 __global__ __launch_bounds__(256) void k_attn_fwd(const float* __restrict__ qkv, const uint8_t* __restrict__ mask, float* __restrict__ P,
                                                   float* __restrict__ ctx, int S, int d, int dh, float scale) {
     extern __shared__ float sm[];
@@ -222,7 +247,7 @@ __global__ __launch_bounds__(256) void k_attn_fwd(const float* __restrict__ qkv,
     }
     __syncthreads();
     const uint8_t* mk = mask ? mask + (int64_t)b * S : nullptr;
-    for (int r = wave; r < S; r += 4) {
+    for (int r = blockIdx.z * kRowsPerWg + wave; r < min(S, (int)(blockIdx.z + 1) * kRowsPerWg); r += 4) {
         float s[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -251,7 +276,7 @@ __global__ __launch_bounds__(256) void k_attn_fwd(const float* __restrict__ qkv,
     }
 }
 
-// dS = P (.) (dP - rowsum(dP (.) P)) with dP = dO V^T, written unscaled.  grid (H, bs), 256 lanes
+// dS = P (.) (dP - rowsum(dP (.) P)) with dP = dO V^T, written unscaled.  grid (H, bs, ceil(S / 8)), 256 lanes
 __global__ __launch_bounds__(256) void k_attn_bwd1(const float* __restrict__ qkv, const float* __restrict__ dctx, const float* __restrict__ P,
                                                    float* __restrict__ dS, int S, int d, int dh) {
     extern __shared__ float sm[];
@@ -264,7 +289,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd1(const float* __restrict__ qkv
         go[r * kPitch + c] = dctx[((int64_t)b * S + r) * d + h * dh + c];
     }
     __syncthreads();
-    for (int r = wave; r < S; r += 4) {
+    for (int r = blockIdx.z * kRowsPerWg + wave; r < min(S, (int)(blockIdx.z + 1) * kRowsPerWg); r += 4) {
         const int64_t off = (((int64_t)b * gridDim.x + h) * S + r) * S;
         float dp[2], p[2];
 #pragma unroll
@@ -285,7 +310,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd1(const float* __restrict__ qkv
     }
 }
 
-// dQ = scale dS K, dK = scale dS^T Q, dV = P^T dO -> dqkv (bs S, 3 d).  grid (H, bs), 256 lanes; lane = head column
+// dQ = scale dS K, dK = scale dS^T Q, dV = P^T dO -> dqkv (bs S, 3 d).  grid (H, bs, ceil(S / 8)), 256 lanes; lane = head column
 __global__ __launch_bounds__(256) void k_attn_bwd2(const float* __restrict__ qkv, const float* __restrict__ dctx, const float* __restrict__ P,
                                                    const float* __restrict__ dS, float* __restrict__ dqkv, int S, int d, int dh, float scale) {
     extern __shared__ float sm[];
@@ -305,7 +330,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd2(const float* __restrict__ qkv
     const int64_t hb = ((int64_t)b * gridDim.x + h) * S * S;
     float* w0 = pw + wave * 2 * kMaxS;
     float* w1 = w0 + kMaxS;
-    for (int r = wave; r < S; r += 4) {
+    for (int r = blockIdx.z * kRowsPerWg + wave; r < min(S, (int)(blockIdx.z + 1) * kRowsPerWg); r += 4) {
         // row r of dS -> dQ[r]; column r of dS -> dK[r]; column r of P -> dV[r]
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -379,9 +404,9 @@ __global__ __launch_bounds__(256) void k_ln_fwd(const float* __restrict__ s, con
     }
 }
 
-__global__ __launch_bounds__(256) void k_ln_bwd_dx(const float* __restrict__ dy, const float* __restrict__ s, const float* __restrict__ stats,
-                                                   const float* __restrict__ gamma, float* __restrict__ dx, int M, int d) {
-    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+__device__ __forceinline__ void ln_bwd_dx(const float* __restrict__ dy, const float* __restrict__ s, const float* __restrict__ stats,
+                                          const float* __restrict__ gamma, float* __restrict__ dx, int M, int d, int blk) {
+    const int lane = threadIdx.x & 63, row = blk * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
     const float mean = stats[2 * row], rstd = stats[2 * row + 1];
     float xh[kLnMax], gh[kLnMax];
@@ -407,10 +432,10 @@ __global__ __launch_bounds__(256) void k_ln_bwd_dx(const float* __restrict__ dy,
 }
 
 // dgamma[c] = sum_rows dy xhat, dbeta[c] = sum_rows dy: 64 columns per workgroup, 4 row groups folded through LDS in a fixed order
-__global__ __launch_bounds__(256) void k_ln_bwd_gb(const float* __restrict__ dy, const float* __restrict__ s, const float* __restrict__ stats,
-                                                   float* __restrict__ dgamma, float* __restrict__ dbeta, int M, int d) {
+__device__ __forceinline__ void ln_bwd_gb(const float* __restrict__ dy, const float* __restrict__ s, const float* __restrict__ stats,
+                                          float* __restrict__ dgamma, float* __restrict__ dbeta, int M, int d, int blk) {
     __shared__ float part[2][4][64];
-    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6, c = blockIdx.x * 64 + lane;
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6, c = blk * 64 + lane;
     float a = 0.f, b = 0.f;
     if (c < d)
         for (int row = grp; row < M; row += 4) {
@@ -425,6 +450,15 @@ __global__ __launch_bounds__(256) void k_ln_bwd_gb(const float* __restrict__ dy,
         dgamma[c] = (part[0][0][lane] + part[0][1][lane]) + (part[0][2][lane] + part[0][3][lane]);
         dbeta[c] = (part[1][0][lane] + part[1][1][lane]) + (part[1][2][lane] + part[1][3][lane]);
     }
+}
+
+// one launch: workgroups [0, ceil(M / 4)) form dx (a wave per row), the next ceil(d / 64) the column sums
+__global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ dy, const float* __restrict__ s, const float* __restrict__ stats,
+                                                const float* __restrict__ gamma, float* __restrict__ dx, float* __restrict__ dgamma,
+                                                float* __restrict__ dbeta, int M, int d) {
+    const int nrow = (M + 3) >> 2;
+    if ((int)blockIdx.x < nrow) ln_bwd_dx(dy, s, stats, gamma, dx, M, d, blockIdx.x);
+    else ln_bwd_gb(dy, s, stats, dgamma, dbeta, M, d, blockIdx.x - nrow);
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------------
@@ -470,8 +504,8 @@ static bool make_plan(const mst_ctrl_desc* d, Plan& p) {
 static void lin_nt(bool relu, const float* A, int lda, const float* W, int ldw, const float* bias, const float* R, int ldr, float* C, int ldc,
                    int M, int N, int K, hipStream_t st) {
     const dim3 grid(N / 16, (M + 63) / 64);
-    if (relu) hipLaunchKernelGGL(k_lin_nt<true>, grid, dim3(256), 0, st, A, lda, W, ldw, bias, R, ldr, C, ldc, M, K);
-    else hipLaunchKernelGGL(k_lin_nt<false>, grid, dim3(256), 0, st, A, lda, W, ldw, bias, R, ldr, C, ldc, M, K);
+    if (relu) hipLaunchKernelGGL(k_lin_nt<true>, grid, dim3(512), 0, st, A, lda, W, ldw, bias, R, ldr, C, ldc, M, K);
+    else hipLaunchKernelGGL(k_lin_nt<false>, grid, dim3(512), 0, st, A, lda, W, ldw, bias, R, ldr, C, ldc, M, K);
 }
 static void lin_nn(const float* A, int lda, const float* W, int ldw, const float* Hm, int ldh, const float* R, int ldr, float* C, int ldc, int M,
                    int N, int cols, hipStream_t st) {
@@ -514,7 +548,7 @@ extern "C" int mst_ctrl_forward(const mst_ctrl_desc* d, const float* tokens, con
         const mst_ctrl_layer& w = layers[l];
         float* x2 = l == p.L - 1 ? out : L + p.x2;
         lin_nt(false, x, dm, w.in_proj_weight, dm, w.in_proj_bias, nullptr, 0, L + p.qkv, 3 * dm, M, 3 * dm, dm, st);
-        hipLaunchKernelGGL(k_attn_fwd, dim3(p.H, d->bs), dim3(256), lds_attn, st, L + p.qkv, key_padding_mask, L + p.P, L + p.ctx, p.S, dm, p.dh, scale);
+        hipLaunchKernelGGL(k_attn_fwd, dim3(p.H, d->bs, (p.S + kRowsPerWg - 1) / kRowsPerWg), dim3(256), lds_attn, st, L + p.qkv, key_padding_mask, L + p.P, L + p.ctx, p.S, dm, p.dh, scale);
         lin_nt(false, L + p.ctx, dm, w.out_proj_weight, dm, w.out_proj_bias, x, dm, L + p.s1, dm, M, dm, dm, st);
         hipLaunchKernelGGL(k_ln_fwd, dim3((M + 3) / 4), dim3(256), 0, st, L + p.s1, w.norm1_weight, w.norm1_bias, L + p.x1, L + p.st1, M, dm, d->ln_eps);
         lin_nt(true, L + p.x1, dm, w.linear1_weight, dm, w.linear1_bias, nullptr, 0, L + p.h, ff, M, ff, dm, st);
@@ -535,7 +569,7 @@ extern "C" int mst_ctrl_backward(const mst_ctrl_desc* d, const float* tokens, co
     const int M = p.M, dm = p.d, ff = p.ff;
     const float scale = 1.0f / sqrtf((float)p.dh);
     const size_t lds1 = (size_t)2 * p.S * kPitch * sizeof(float), lds2 = ((size_t)3 * p.S * kPitch + 8 * kMaxS) * sizeof(float);
-    const dim3 rows((M + 3) / 4), cols((dm + 63) / 64);
+    const dim3 lnb((M + 3) / 4 + (dm + 63) / 64);
     const float* g = grad_out;
     for (int l = p.L - 1; l >= 0; --l) {
         float* L = ws + p.per_layer * l;
@@ -545,21 +579,19 @@ extern "C" int mst_ctrl_backward(const mst_ctrl_desc* d, const float* tokens, co
         float* gout = l == 0 ? grad_tokens : ws + ((l & 1) ? p.t_g1 : p.t_g0);
         float *ds = ws + p.t_ds, *dh = ws + p.t_dh, *dx1 = ws + p.t_dx1, *dctx = ws + p.t_dctx, *dqkv = ws + p.t_dqkv, *dS = ws + p.t_dS;
         // LayerNorm 2 (input s2 = x1 + ffn)
-        hipLaunchKernelGGL(k_ln_bwd_gb, cols, dim3(256), 0, st, g, L + p.s2, L + p.st2, gw.norm2_weight, gw.norm2_bias, M, dm);
-        hipLaunchKernelGGL(k_ln_bwd_dx, rows, dim3(256), 0, st, g, L + p.s2, L + p.st2, w.norm2_weight, ds, M, dm);
+        hipLaunchKernelGGL(k_ln_bwd, lnb, dim3(256), 0, st, g, L + p.s2, L + p.st2, w.norm2_weight, ds, gw.norm2_weight, gw.norm2_bias, M, dm);
         // feed-forward
         lin_tn(ds, dm, L + p.h, ff, gw.linear2_weight, ff, gw.linear2_bias, M, dm, ff, st);
         lin_nn(ds, dm, w.linear2_weight, ff, L + p.h, ff, nullptr, 0, dh, ff, M, dm, ff, st);
         lin_tn(dh, ff, L + p.x1, dm, gw.linear1_weight, dm, gw.linear1_bias, M, ff, dm, st);
         lin_nn(dh, ff, w.linear1_weight, dm, nullptr, 0, ds, dm, dx1, dm, M, ff, dm, st);
         // LayerNorm 1 (input s1 = x + attention); `ds` is free again
-        hipLaunchKernelGGL(k_ln_bwd_gb, cols, dim3(256), 0, st, dx1, L + p.s1, L + p.st1, gw.norm1_weight, gw.norm1_bias, M, dm);
-        hipLaunchKernelGGL(k_ln_bwd_dx, rows, dim3(256), 0, st, dx1, L + p.s1, L + p.st1, w.norm1_weight, ds, M, dm);
+        hipLaunchKernelGGL(k_ln_bwd, lnb, dim3(256), 0, st, dx1, L + p.s1, L + p.st1, w.norm1_weight, ds, gw.norm1_weight, gw.norm1_bias, M, dm);
         // attention
         lin_tn(ds, dm, L + p.ctx, dm, gw.out_proj_weight, dm, gw.out_proj_bias, M, dm, dm, st);
         lin_nn(ds, dm, w.out_proj_weight, dm, nullptr, 0, nullptr, 0, dctx, dm, M, dm, dm, st);
-        hipLaunchKernelGGL(k_attn_bwd1, dim3(p.H, d->bs), dim3(256), lds1, st, L + p.qkv, dctx, L + p.P, dS, p.S, dm, p.dh);
-        hipLaunchKernelGGL(k_attn_bwd2, dim3(p.H, d->bs), dim3(256), lds2, st, L + p.qkv, dctx, L + p.P, dS, dqkv, p.S, dm, p.dh, scale);
+        hipLaunchKernelGGL(k_attn_bwd1, dim3(p.H, d->bs, (p.S + kRowsPerWg - 1) / kRowsPerWg), dim3(256), lds1, st, L + p.qkv, dctx, L + p.P, dS, p.S, dm, p.dh);
+        hipLaunchKernelGGL(k_attn_bwd2, dim3(p.H, d->bs, (p.S + kRowsPerWg - 1) / kRowsPerWg), dim3(256), lds2, st, L + p.qkv, dctx, L + p.P, dS, dqkv, p.S, dm, p.dh, scale);
         lin_tn(dqkv, 3 * dm, x, dm, gw.in_proj_weight, dm, gw.in_proj_bias, M, 3 * dm, dm, st);
         lin_nn(dqkv, 3 * dm, w.in_proj_weight, dm, nullptr, 0, ds, dm, gout, dm, M, 3 * dm, dm, st);
         g = gout;
