@@ -273,7 +273,7 @@ def encoder_lines(dev):
     # cfg #5 on one GPU, one mix per step: full step with the real model structure (configs/models/naive+feat.yaml sizes)
     torch.manual_seed(3001)
     model = MixStyleTransferModel(SpectrogramEncoder(embed_dim=512), SpectrogramEncoder(embed_dim=512),
-                                  TransformerController(512, 27, 25, 26, num_layers=12, nhead=8, graphed=True)).to(dev).train()
+                                  TransformerController(512, 27, 25, 26, num_layers=12, nhead=8, native=True)).to(dev).train()
     step = CommonStep(model, AdvancedMixConsole(SR, materialize_mixed_tracks=False, validate="deferred", param_dicts="lazy"), naive_random_mix,
                       AudioFeatureLoss(AF_WEIGHTS, SR), generate_mix=True, active_eq_epoch=0, active_compressor_epoch=0,
                       active_fx_bus_epoch=1000, active_master_bus_epoch=0, nan_check="deferred")
@@ -288,7 +288,7 @@ def encoder_lines(dev):
     med, mean = time_steps(sys_step, 5, 2)
     out.append({"workload": "cfg #5 step on ONE GPU, batch 1: System.common_step order (two naive_random_mix reference mixes, peak normalise, "
                             "A/B split) + MixStyleTransferModel (2 x SpectrogramEncoder/Cnn14 on MFMA for 32 tracks + 2 mix channels of 131072 "
-                            "samples, 12-layer TransformerController replayed as two hipGraphs) + AdvancedMixConsole 32 tracks + AudioFeatureLoss, fwd+bwd "
+                            "samples, 12-layer TransformerController on csrc/mst_ctrl.hip) + AdvancedMixConsole 32 tracks + AudioFeatureLoss, fwd+bwd "
                             "to every weight; no host readback inside the step (deferred range / NaN checks)",
                 "ms_per_step_median": med, "ms_per_step_mean": mean, "steps": 5, "mixes_per_s": 1.0 / (med * 1e-3)})
     del model, step, tracks

@@ -3,7 +3,7 @@
 //
 // Why it exists: at the reference's sizes (one mix of 32 tracks = 36 tokens of width 512, 12 layers) the stack is ~580 library
 // kernels of a few microseconds each per training step; on torch (rocBLAS + SDPA) it took 5.3 ms of the 25.6 ms cfg #5 step,
-// hipGraph replay included (DESIGN 9.6).  M = bs x tokens is tiny, so every GEMM is a WEIGHT-STREAMING problem: 12.6 MB of fp32
+// hipGraph replay included (DESIGN 9.5).  M = bs x tokens is tiny, so every GEMM is a WEIGHT-STREAMING problem: 12.6 MB of fp32
 // weights per layer are read once by the forward, once by the data gradient, and 12.6 MB of weight gradient are written.  The
 // kernels are therefore organised around "every weight element crosses the memory system once, 16 bytes per lane":
 //   k_lin_nt  C = act(A W^T + b) (+ R)   one workgroup per 16 output columns, its 8 waves split K, fragments straight from

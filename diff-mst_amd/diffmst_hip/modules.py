@@ -540,7 +540,7 @@ class TransformerController(torch.nn.Module):
 
     ``graphed`` (extra keyword, default False = the reference's eager behaviour): 12 layers over ~36 tokens are ~580 kernels of
     a few microseconds each per training step, and at batch 1 the HOST cannot issue them as fast as the GPU retires them
-    (cfg #5: 7.6 ms of the 29.6 ms step were idle gaps in front of these kernels, DESIGN 9.6).  With ``graphed=True`` the
+    (cfg #5: 7.6 ms of the 29.6 ms step were idle gaps in front of these kernels, DESIGN 9.5).  With ``graphed=True`` the
     training-mode forward and backward are captured once per (batch, tracks, mask?) shape into two hipGraphs
     (``torch.cuda.make_graphed_callables``) and replayed: same kernels, same arithmetic, one launch each.  The returned
     tensors live in the graph's static buffers until the next call of the same shape; parameters must keep their storage

@@ -45,7 +45,7 @@ class CommonStep(torch.nn.Module):
         # "sync" = the reference's `if torch.isnan(ref_mix).any(): raise` (:178-180): one device -> host readback in the middle
         # of every step, after which the GPU idles until the host has issued the encoder's first kernels.  "deferred" keeps the
         # flag on the device: `check_finite()` - called at the top of the NEXT step, when the flag has long been written -
-        # raises the same ValueError one step later and the host never waits (cfg #5: DESIGN 9.6).
+        # raises the same ValueError one step later and the host never waits (cfg #5: DESIGN 9.5).
         self.nan_check = nan_check
         self._nan_flag = None
         self.model = model
