@@ -288,6 +288,56 @@ def encoder_case(rmodules):
     print(f"encoder: |embed| {embed.abs().max():.4e}  |g conv1| {grads['model.conv_block1.conv1.weight'].abs().max():.3e}")
 
 
+def controller_setup(ctrl_cls, seed_init=81, seed_pert=82, embed_dim=512, num_layers=3, nhead=8):
+    """Seeded TransformerController: default initialisation under ``seed_init``, then LayerNorm parameters and every bias moved off
+    their 1 / 0 defaults under ``seed_pert``.  The GPU test builds the HIP-backed controller with the same two calls (same torch
+    build on the GPU box: same CPU generator stream, same construction order = same weights; the generator asserts that)."""
+    torch.manual_seed(seed_init)
+    ctrl = ctrl_cls(embed_dim, 27, 25, 26, num_layers=num_layers, nhead=nhead)
+    torch.manual_seed(seed_pert)
+    with torch.no_grad():
+        for name, p in sorted(ctrl.named_parameters()):
+            if "norm" in name or name.endswith("bias"):
+                p.add_(0.1 * torch.randn_like(p))
+    return ctrl
+
+
+def controller_case(rmodules):
+    """The REAL ``mst.modules.TransformerController`` (mst/modules.py:809-914, pure torch, imported unchanged): training-mode forward
+    + backward on seeded embeddings with a padding mask; every output, the input gradients and every parameter gradient
+    (small ones whole, large ones as a strided sample + L2 norm)."""
+    sys.path[:0] = [os.path.join(ROOT, "diff-mst_amd")]
+    from diffmst_hip.modules import TransformerController as Ours
+
+    ctrl = controller_setup(rmodules.TransformerController).train()
+    ours = controller_setup(Ours)
+    sd, sd_ours = ctrl.state_dict(), ours.state_dict()
+    assert list(sd) == list(sd_ours) and all(torch.equal(sd[k], sd_ours[k]) for k in sd), "seeded construction differs from the reference's"
+    bs, T = 2, 10
+    torch.manual_seed(83)
+    te = torch.randn(bs, T, 512)
+    me = torch.randn(bs, 2, 512)
+    mask = torch.zeros(bs, T, dtype=torch.bool)
+    mask[0, 6:] = True
+    mask[1, 2] = True
+    w_t, w_f, w_m = torch.randn(bs, T, 27), torch.randn(bs, 25), torch.randn(bs, 26)
+    a, b = te.clone().requires_grad_(True), me.clone().requires_grad_(True)
+    tp, fp, mp = ctrl(a.clone(), b.clone(), mask)  # the reference adds the type embeddings IN PLACE (:871-872): hand it copies
+    ((tp * w_t).sum() + (fp * w_f).sum() + (mp * w_m).sum()).backward()
+    out = dict(seed_init=81, seed_pert=82, track_embeds=te.numpy(), mix_embeds=me.numpy(), mask=mask.numpy(), w_t=w_t.numpy(), w_f=w_f.numpy(),
+               w_m=w_m.numpy(), track_params=tp.detach().numpy(), fx_params=fp.detach().numpy(), master_params=mp.detach().numpy(),
+               g_track_embeds=a.grad.numpy(), g_mix_embeds=b.grad.numpy())
+    for k, p in ctrl.named_parameters():
+        g = p.grad
+        if g.numel() <= 4096:
+            out["g." + k] = g.numpy()
+        else:
+            out["gsub." + k] = g.flatten()[::499].numpy()
+            out["gl2." + k] = np.array(g.double().pow(2).sum().sqrt().item())
+    np.savez_compressed(os.path.join(HERE, "controller_2x10.npz"), **out)
+    print("controller fixture:", sum(v.nbytes for v in out.values() if hasattr(v, "nbytes")) // 1024, "KiB before compression")
+
+
 def main():
     assert os.path.isdir(REF), "golden generation needs /root/reference (build container only)"
     install_stubs()
@@ -301,9 +351,11 @@ def main():
     ref_console = rmodules.AdvancedMixConsole(sample_rate=44100)
     assert ref_console.param_ranges == oc.param_ranges(44100)
     only = set(sys.argv[1:])  # e.g. `make_golden.py system` regenerates one fixture family (default: all)
-    if only and only <= {"system", "fx", "run", "encoder"}:
+    if only and only <= {"system", "fx", "run", "encoder", "controller"}:
         if "encoder" in only:
             encoder_case(rmodules)
+        if "controller" in only:
+            controller_case(rmodules)
         if "run" in only:
             run_case(rmodules)
         if "system" in only:
@@ -393,6 +445,7 @@ def main():
     fx_case(ref_console)
     run_case(rmodules)
     encoder_case(rmodules)
+    controller_case(rmodules)
     print("golden fixtures written to", HERE)
 
 

@@ -95,3 +95,37 @@ def test_native_encoder_stack_against_torch(bs, T, layers, with_mask, record):
     assert worst_out <= 1e-4, worst_out
     assert worst_gin <= 1e-4, worst_gin
     assert worst_gp <= 1e-4, (worst_name, worst_gp)
+
+
+def test_native_controller_against_the_real_class(golden_dir, record):
+    """Fixture from the REAL ``mst.modules.TransformerController`` (tests/golden/make_golden.py controller: seeded weights that the
+    generator asserts equal to ours, padding mask, all three outputs weighted): outputs, input gradients, every parameter
+    gradient of the HIP encoder stack within the reference's 1e-4."""
+    import os
+
+    import numpy as np
+    from mst.modules import TransformerController
+    from util import seeded_controller as _seeded_controller
+
+    g = np.load(os.path.join(golden_dir, "controller_2x10.npz"))
+    dev = torch.device("cuda:0")
+    ctrl = _seeded_controller(TransformerController, int(g["seed_init"]), int(g["seed_pert"]), native=True).to(dev).train()
+    t = lambda k: torch.from_numpy(g[k]).to(dev)
+    te, me = t("track_embeds").requires_grad_(True), t("mix_embeds").requires_grad_(True)
+    tp, fp, mp = ctrl(te, me, t("mask"))
+    ((tp * t("w_t")).sum() + (fp * t("w_f")).sum() + (mp * t("w_m")).sum()).backward()
+    rel = lambda a, b: float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+    e_out = max(rel(tp.detach(), t("track_params")), rel(fp.detach(), t("fx_params")), rel(mp.detach(), t("master_params")))
+    e_in = max(rel(te.grad, t("g_track_embeds")), rel(me.grad, t("g_mix_embeds")))
+    e_par, worst = 0.0, ""
+    for k, p in ctrl.named_parameters():
+        if "g." + k in g.files:
+            e = rel(p.grad, t("g." + k))
+        else:
+            e = max(rel(p.grad.flatten()[::499], t("gsub." + k)),
+                    abs(float(p.grad.double().pow(2).sum().sqrt()) - float(g["gl2." + k])) / float(g["gl2." + k]))
+        if e > e_par:
+            e_par, worst = e, k
+    record(out=e_out, grad_in=e_in, grad_param=e_par)
+    assert e_out <= 1e-4 and e_in <= 1e-4, (e_out, e_in)
+    assert e_par <= 1e-4, (worst, e_par)

@@ -256,3 +256,26 @@ def test_common_step_deferred_nan_guard(monkeypatch):
         step(batch)
     step(batch)  # the flag was consumed
     step.check_finite()
+
+
+def test_controller_torch_path_reproduces_the_reference_fixture(golden_dir):
+    """``diffmst_hip.modules.TransformerController`` on its torch path (CPU) against the fixture from the REAL class
+    (tests/golden/make_golden.py controller): same seeded weights, same outputs and gradients - what the HIP encoder stack
+    (tests/test_controller_gpu.py) is then held to on the GPU."""
+    import numpy as np
+    from mst.modules import TransformerController
+    from util import seeded_controller
+
+    g = np.load(os.path.join(golden_dir, "controller_2x10.npz"))
+    ctrl = seeded_controller(TransformerController, int(g["seed_init"]), int(g["seed_pert"])).train()
+    t = lambda k: torch.from_numpy(g[k])
+    te, me = t("track_embeds").requires_grad_(True), t("mix_embeds").requires_grad_(True)
+    tp, fp, mp = ctrl(te, me, t("mask"))
+    ((tp * t("w_t")).sum() + (fp * t("w_f")).sum() + (mp * t("w_m")).sum()).backward()
+    for a, k in ((tp, "track_params"), (fp, "fx_params"), (mp, "master_params"), (te.grad, "g_track_embeds"), (me.grad, "g_mix_embeds")):
+        assert torch.allclose(a.detach(), t(k), rtol=1e-5, atol=1e-6), k
+    for k, p in ctrl.named_parameters():
+        if "g." + k in g.files:
+            assert torch.allclose(p.grad, t("g." + k), rtol=1e-4, atol=1e-6), k
+        else:
+            assert abs(float(p.grad.double().pow(2).sum().sqrt()) - float(g["gl2." + k])) <= 1e-5 * float(g["gl2." + k]), k

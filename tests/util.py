@@ -61,3 +61,15 @@ def simple_lufs(x):
     import numpy as np
 
     return float(-0.691 + 10.0 * np.log10(np.mean(np.asarray(x, dtype=np.float64) ** 2) + 1e-12))
+
+
+def seeded_controller(cls, seed_init, seed_pert, **kw):
+    """tests/golden/make_golden.py controller_setup, call for call (same torch build: same CPU generator stream)."""
+    torch.manual_seed(seed_init)
+    ctrl = cls(512, 27, 25, 26, num_layers=3, nhead=8, **kw)
+    torch.manual_seed(seed_pert)
+    with torch.no_grad():
+        for name, p in sorted(ctrl.named_parameters()):
+            if "norm" in name or name.endswith("bias"):
+                p.add_(0.1 * torch.randn_like(p))
+    return ctrl
