@@ -10,7 +10,7 @@
 //                                        global memory (both operands K-contiguous: float4 per lane, the K order inside a
 //                                        16-step is permuted identically for A and W, which a dot product does not see)
 //   k_lin_nn  C = (A W) (.) mask (+ R)   data gradient: one workgroup per 16 output columns, 8 waves split the reduction
-//   k_lin_tn  dW = dY^T X, db            one wave per 64 x 64 tile of the weight gradient (row and column permutations
+//   k_lin_tn_batch  dW = dY^T X, db      (every weight gradient of a backward call in one launch) one wave per 64 x 64 tile (row and column permutations
 //                                        make both operand loads and the stores 16 bytes per lane), bias gradient on the way
 // all on v_mfma_f32_16x16x4_f32 (fp32 operands, exact fp32 FMA chains: parity with the reference's fp32 stack is rounding-level).
 // Attention (<= 128 tokens, head width <= 64) and LayerNorm are small vector-ALU kernels.  No atomics: run-to-run deterministic.
@@ -164,10 +164,10 @@ __global__ __launch_bounds__(512) void k_lin_nn(const float* __restrict__ A, int
 // ---- dW[n][k] = sum_m dY[m][n] X[m][k],  db[n] = sum_m dY[m][n];  grid (Kd / 64, N / 64), one wave --------------------------
 // Row tile ii of the wave holds the rows n0 + 4 r + ii (r = 0..15), column tile t the columns k0 + 4 c + t: a lane's float4 of
 // dY is one element of each of the four row tiles, its float4 of X one element of each column tile.
-__global__ __launch_bounds__(64) void k_lin_tn(const float* __restrict__ dY, int ldy, const float* __restrict__ X, int ldx,
-                                               float* __restrict__ dW, int ldw, float* __restrict__ db, int M) {
+__device__ __forceinline__ void lin_tn_tile(const float* __restrict__ dY, int ldy, const float* __restrict__ X, int ldx,
+                                            float* __restrict__ dW, int ldw, float* __restrict__ db, int M, int bx, int by) {
     const int lane = threadIdx.x, c = lane & 15, g = lane >> 4;
-    const int k0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+    const int k0 = bx * 64, n0 = by * 64;
     f32x4 acc[4][4];
 #pragma unroll
     for (int ii = 0; ii < 4; ++ii)
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(64) void k_lin_tn(const float* __restrict__ dY, int
             *reinterpret_cast<float4*>(dW + (int64_t)n * ldw + k0 + 4 * c) =
                 make_float4(acc[ii][0][q], acc[ii][1][q], acc[ii][2][q], acc[ii][3][q]);
         }
-    if (db && blockIdx.x == 0) {
+    if (db && bx == 0) {
         float v[4] = {bsum.x, bsum.y, bsum.z, bsum.w};
 #pragma unroll
         for (int ii = 0; ii < 4; ++ii) {
@@ -211,6 +211,29 @@ __global__ __launch_bounds__(64) void k_lin_tn(const float* __restrict__ dY, int
         }
         if (g == 0) *reinterpret_cast<float4*>(db + n0 + 4 * c) = make_float4(v[0], v[1], v[2], v[3]);
     }
+}
+
+// Every weight gradient of a backward call in ONE launch: the 4 x n_layers products are off the critical path (nothing in the
+// backward reads a weight gradient), so they wait until every dY has been formed and then fill the chip together
+// (12 layers: 9216 tiles) instead of 48 launches of 64-256 tiles.  Jobs ride in the kernel arguments.
+constexpr int kMaxTnJobs = 64;
+struct TnJob {
+    const float* dY;
+    const float* X;
+    float* dW;
+    float* db;
+    int ldy, ldx, ldw, tiles_x, tile0;  // tile0 = first workgroup of the job
+};
+struct TnBatch {
+    TnJob job[kMaxTnJobs];
+    int n_jobs, M;
+};
+__global__ __launch_bounds__(64) void k_lin_tn_batch(const TnBatch b) {
+    int j = 0;
+    while (j + 1 < b.n_jobs && (int)blockIdx.x >= b.job[j + 1].tile0) ++j;  // wave-uniform walk over <= 64 entries in SGPRs
+    const TnJob& J = b.job[j];
+    const int t = blockIdx.x - J.tile0;
+    lin_tn_tile(J.dY, J.ldy, J.X, J.ldx, J.dW, J.ldw, J.db, b.M, t % J.tiles_x, t / J.tiles_x);
 }
 
 // ---- attention ----------------------------------------------------------------------------------------------------------
@@ -464,12 +487,13 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ dy, co
 // ---- host side ------------------------------------------------------------------------------------------------------------
 struct Plan {
     int M, S, d, H, dh, ff, L;
-    size_t qkv, P, ctx, s1, st1, x1, h, s2, st2, x2, per_layer;  // float offsets inside one layer's slab
-    size_t t_g0, t_g1, t_ds, t_dh, t_dx1, t_dctx, t_dqkv, t_dS, total;  // backward temporaries (floats, after the slabs)
+    size_t qkv, P, ctx, s1, st1, x1, h, s2, st2, x2, b_ds2, b_dh, b_ds1, b_dqkv, per_layer;  // float offsets inside one layer's slab
+                                                                                  // (b_*: the backward's dY operands, kept for the batched weight gradient)
+    size_t t_g0, t_g1, t_dx1, t_dctx, t_dS, total;  // backward temporaries (floats, after the slabs)
 };
 
 static bool make_plan(const mst_ctrl_desc* d, Plan& p) {
-    if (!d || d->bs < 1 || d->seq < 1 || d->seq > kMaxS || d->n_layers < 1 || d->nhead < 1) return false;
+    if (!d || d->bs < 1 || d->seq < 1 || d->seq > kMaxS || d->n_layers < 1 || 4 * d->n_layers > kMaxTnJobs || d->nhead < 1) return false;
     if (d->d_model % 128 || d->d_ff % 128 || d->d_model > 64 * kLnMax || d->d_model % d->nhead) return false;
     p.dh = d->d_model / d->nhead;
     if (p.dh > kMaxDh) return false;
@@ -487,15 +511,16 @@ static bool make_plan(const mst_ctrl_desc* d, Plan& p) {
     p.s2 = o; o += up(M * dm);
     p.st2 = o; o += up(2 * M);
     p.x2 = o; o += up(M * dm);
+    p.b_ds2 = o; o += up(M * dm);
+    p.b_dh = o; o += up(M * p.ff);
+    p.b_ds1 = o; o += up(M * dm);
+    p.b_dqkv = o; o += up(M * 3 * dm);
     p.per_layer = o;
     o = p.per_layer * p.L;
     p.t_g0 = o; o += up(M * dm);
     p.t_g1 = o; o += up(M * dm);
-    p.t_ds = o; o += up(M * dm);
-    p.t_dh = o; o += up(M * p.ff);
     p.t_dx1 = o; o += up(M * dm);
     p.t_dctx = o; o += up(M * dm);
-    p.t_dqkv = o; o += up(M * 3 * dm);
     p.t_dS = o; o += up((size_t)d->bs * p.H * p.S * p.S);
     p.total = o;
     return true;
@@ -511,8 +536,11 @@ static void lin_nn(const float* A, int lda, const float* W, int ldw, const float
                    int N, int cols, hipStream_t st) {
     hipLaunchKernelGGL(k_lin_nn, dim3(cols / 16, (M + 63) / 64), dim3(512), 0, st, A, lda, W, ldw, Hm, ldh, R, ldr, C, ldc, M, N);
 }
-static void lin_tn(const float* dY, int ldy, const float* X, int ldx, float* dW, int ldw, float* db, int M, int N, int Kd, hipStream_t st) {
-    hipLaunchKernelGGL(k_lin_tn, dim3(Kd / 64, N / 64), dim3(64), 0, st, dY, ldy, X, ldx, dW, ldw, db, M);
+static void add_tn(TnBatch& b, int& tiles, const float* dY, int ldy, const float* X, int ldx, float* dW, int ldw, float* db, int N, int Kd) {
+    TnJob& J = b.job[b.n_jobs++];
+    J.dY = dY; J.X = X; J.dW = dW; J.db = db;
+    J.ldy = ldy; J.ldx = ldx; J.ldw = ldw; J.tiles_x = Kd / 64; J.tile0 = tiles;
+    tiles += (Kd / 64) * (N / 64);
 }
 
 }  // namespace ctrl
@@ -571,30 +599,37 @@ extern "C" int mst_ctrl_backward(const mst_ctrl_desc* d, const float* tokens, co
     const size_t lds1 = (size_t)2 * p.S * kPitch * sizeof(float), lds2 = ((size_t)3 * p.S * kPitch + 8 * kMaxS) * sizeof(float);
     const dim3 lnb((M + 3) / 4 + (dm + 63) / 64);
     const float* g = grad_out;
+    TnBatch tb;  // filled here, passed by value (3.6 KB of kernel arguments)
+    tb.n_jobs = 0;
+    tb.M = M;
+    int tiles = 0;
     for (int l = p.L - 1; l >= 0; --l) {
         float* L = ws + p.per_layer * l;
         const mst_ctrl_layer& w = layers[l];
         const mst_ctrl_layer_grads& gw = grads[l];
         const float* x = l == 0 ? tokens : ws + p.per_layer * (l - 1) + p.x2;
         float* gout = l == 0 ? grad_tokens : ws + ((l & 1) ? p.t_g1 : p.t_g0);
-        float *ds = ws + p.t_ds, *dh = ws + p.t_dh, *dx1 = ws + p.t_dx1, *dctx = ws + p.t_dctx, *dqkv = ws + p.t_dqkv, *dS = ws + p.t_dS;
+        float *ds2 = L + p.b_ds2, *dh = L + p.b_dh, *ds1 = L + p.b_ds1, *dqkv = L + p.b_dqkv;
+        float *dx1 = ws + p.t_dx1, *dctx = ws + p.t_dctx, *dS = ws + p.t_dS;
         // LayerNorm 2 (input s2 = x1 + ffn)
-        hipLaunchKernelGGL(k_ln_bwd, lnb, dim3(256), 0, st, g, L + p.s2, L + p.st2, w.norm2_weight, ds, gw.norm2_weight, gw.norm2_bias, M, dm);
+        hipLaunchKernelGGL(k_ln_bwd, lnb, dim3(256), 0, st, g, L + p.s2, L + p.st2, w.norm2_weight, ds2, gw.norm2_weight, gw.norm2_bias, M, dm);
         // feed-forward
-        lin_tn(ds, dm, L + p.h, ff, gw.linear2_weight, ff, gw.linear2_bias, M, dm, ff, st);
-        lin_nn(ds, dm, w.linear2_weight, ff, L + p.h, ff, nullptr, 0, dh, ff, M, dm, ff, st);
-        lin_tn(dh, ff, L + p.x1, dm, gw.linear1_weight, dm, gw.linear1_bias, M, ff, dm, st);
-        lin_nn(dh, ff, w.linear1_weight, dm, nullptr, 0, ds, dm, dx1, dm, M, ff, dm, st);
-        // LayerNorm 1 (input s1 = x + attention); `ds` is free again
-        hipLaunchKernelGGL(k_ln_bwd, lnb, dim3(256), 0, st, dx1, L + p.s1, L + p.st1, w.norm1_weight, ds, gw.norm1_weight, gw.norm1_bias, M, dm);
+        lin_nn(ds2, dm, w.linear2_weight, ff, L + p.h, ff, nullptr, 0, dh, ff, M, dm, ff, st);
+        lin_nn(dh, ff, w.linear1_weight, dm, nullptr, 0, ds2, dm, dx1, dm, M, ff, dm, st);
+        // LayerNorm 1 (input s1 = x + attention)
+        hipLaunchKernelGGL(k_ln_bwd, lnb, dim3(256), 0, st, dx1, L + p.s1, L + p.st1, w.norm1_weight, ds1, gw.norm1_weight, gw.norm1_bias, M, dm);
         // attention
-        lin_tn(ds, dm, L + p.ctx, dm, gw.out_proj_weight, dm, gw.out_proj_bias, M, dm, dm, st);
-        lin_nn(ds, dm, w.out_proj_weight, dm, nullptr, 0, nullptr, 0, dctx, dm, M, dm, dm, st);
+        lin_nn(ds1, dm, w.out_proj_weight, dm, nullptr, 0, nullptr, 0, dctx, dm, M, dm, dm, st);
         hipLaunchKernelGGL(k_attn_bwd1, dim3(p.H, d->bs, (p.S + kRowsPerWg - 1) / kRowsPerWg), dim3(256), lds1, st, L + p.qkv, dctx, L + p.P, dS, p.S, dm, p.dh);
         hipLaunchKernelGGL(k_attn_bwd2, dim3(p.H, d->bs, (p.S + kRowsPerWg - 1) / kRowsPerWg), dim3(256), lds2, st, L + p.qkv, dctx, L + p.P, dS, dqkv, p.S, dm, p.dh, scale);
-        lin_tn(dqkv, 3 * dm, x, dm, gw.in_proj_weight, dm, gw.in_proj_bias, M, 3 * dm, dm, st);
-        lin_nn(dqkv, 3 * dm, w.in_proj_weight, dm, nullptr, 0, ds, dm, gout, dm, M, 3 * dm, dm, st);
+        lin_nn(dqkv, 3 * dm, w.in_proj_weight, dm, nullptr, 0, ds1, dm, gout, dm, M, 3 * dm, dm, st);
+        // the layer's weight gradients: queued for the batched launch
+        add_tn(tb, tiles, ds2, dm, L + p.h, ff, gw.linear2_weight, ff, gw.linear2_bias, dm, ff);
+        add_tn(tb, tiles, dh, ff, L + p.x1, dm, gw.linear1_weight, dm, gw.linear1_bias, ff, dm);
+        add_tn(tb, tiles, ds1, dm, L + p.ctx, dm, gw.out_proj_weight, dm, gw.out_proj_bias, dm, dm);
+        add_tn(tb, tiles, dqkv, 3 * dm, x, dm, gw.in_proj_weight, dm, gw.in_proj_bias, 3 * dm, dm);
         g = gout;
     }
+    hipLaunchKernelGGL(k_lin_tn_batch, dim3(tiles), dim3(64), 0, st, tb);
     return (int)hipGetLastError();
 }
