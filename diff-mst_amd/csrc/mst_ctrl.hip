@@ -31,12 +31,18 @@ __device__ __forceinline__ float comp(const float4& v, int j) { return j == 0 ? 
 template <bool RELU>
 __global__ __launch_bounds__(512) void k_lin_nt(const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw,
                                                 const float* __restrict__ bias, const float* __restrict__ R, int ldr,
-                                                float* __restrict__ C, int ldc, int M, int K) {
+                                                float* __restrict__ C, int ldc, int M, int K, size_t part_stride) {
     __shared__ float red[8][4][4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
     const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 64;
     const int nmt = min(4, (M - m0 + 15) >> 4);
-    const int kq = K >> 3, kb = wave * kq;  // K % 128 == 0: every wave owns a multiple of 16
+    // gridDim.z > 1: workgroup z multiplies the z-th slice of K into partial output z (the consuming LayerNorm kernel folds the
+    // partials in a fixed order; bias and residual ride in partial 0) - a K = 2048 product on 32 workgroups is bound by the
+    // fp32 matrix pipes of 32 CUs
+    const int Kz = K / (int)gridDim.z;
+    const int kq = Kz >> 3, kb = blockIdx.z * Kz + wave * kq;  // Kz % 128 == 0: every wave owns a multiple of 16
+    C += blockIdx.z * part_stride;
+    if (blockIdx.z) { bias = nullptr; R = nullptr; }
     f32x4 acc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -97,12 +103,15 @@ __global__ __launch_bounds__(512) void k_lin_nt(const float* __restrict__ A, int
 // ---- C[m][c] = (sum_n A[m][n] W[n][c]) (. [Hm[m][c] > 0]) (+ R[m][c]);  grid (cols / 16, ceil(M / 64)), 512 lanes ------------
 __global__ __launch_bounds__(512) void k_lin_nn(const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw,
                                                 const float* __restrict__ Hm, int ldh, const float* __restrict__ R, int ldr,
-                                                float* __restrict__ C, int ldc, int M, int N) {
+                                                float* __restrict__ C, int ldc, int M, int N, size_t part_stride) {
     __shared__ float red[8][4][4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
     const int c0 = blockIdx.x * 16, m0 = blockIdx.y * 64;
     const int nmt = min(4, (M - m0 + 15) >> 4);
-    const int nq = N >> 3, nb = wave * nq;
+    const int Nz = N / (int)gridDim.z;  // reduction slices over grid.z -> partial outputs, as in k_lin_nt (no mask with partials)
+    const int nq = Nz >> 3, nb = blockIdx.z * Nz + wave * nq;
+    C += blockIdx.z * part_stride;
+    if (blockIdx.z) R = nullptr;
     f32x4 acc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -393,8 +402,11 @@ __global__ __launch_bounds__(256) void k_attn_bwd2(const float* __restrict__ qkv
 
 // ---- LayerNorm (rows of width d <= 1024, one wave per row) --------------------------------------------------------------
 constexpr int kLnMax = 16;  // columns per lane
+constexpr int kMaxSplit = 4;  // partial buffers a LayerNorm kernel folds on load
 
-__global__ __launch_bounds__(256) void k_ln_fwd(const float* __restrict__ s, const float* __restrict__ gamma, const float* __restrict__ beta,
+// s = the sum of `np` partial buffers `part_stride` floats apart (np > 1: folded here, in order, and written to s_out)
+__global__ __launch_bounds__(256) void k_ln_fwd(const float* __restrict__ s, int np, size_t part_stride, float* __restrict__ s_out,
+                                                const float* __restrict__ gamma, const float* __restrict__ beta,
                                                 float* __restrict__ y, float* __restrict__ stats, int M, int d, float eps) {
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -405,8 +417,29 @@ __global__ __launch_bounds__(256) void k_ln_fwd(const float* __restrict__ s, con
     for (int t = 0; t < kLnMax; ++t) {
         const int c = lane + 64 * t;
         v[t] = c < d ? x[c] : 0.f;
-        sum += v[t];
     }
+    if (np > 1) {  // partials 1 .. np - 1: a whole row of independent loads per partial, added in order
+#pragma unroll
+        for (int q = 1; q < kMaxSplit; ++q) {
+            if (q < np) {
+                float u[kLnMax];
+#pragma unroll
+                for (int t = 0; t < kLnMax; ++t) {
+                    const int c = lane + 64 * t;
+                    u[t] = c < d ? x[q * part_stride + c] : 0.f;
+                }
+#pragma unroll
+                for (int t = 0; t < kLnMax; ++t) v[t] += u[t];
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < kLnMax; ++t) {
+            const int c = lane + 64 * t;
+            if (c < d) s_out[(int64_t)row * d + c] = v[t];
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < kLnMax; ++t) sum += v[t];
     const float mean = wave_sum(sum) / (float)d;
     float sq = 0.f;
 #pragma unroll
@@ -427,8 +460,15 @@ __global__ __launch_bounds__(256) void k_ln_fwd(const float* __restrict__ s, con
     }
 }
 
-__device__ __forceinline__ void ln_bwd_dx(const float* __restrict__ dy, const float* __restrict__ s, const float* __restrict__ stats,
-                                          const float* __restrict__ gamma, float* __restrict__ dx, int M, int d, int blk) {
+__device__ __forceinline__ float fold_parts(const float* __restrict__ p, int np, size_t part_stride) {
+    float u[kMaxSplit];
+#pragma unroll
+    for (int q = 0; q < kMaxSplit; ++q) u[q] = q < np ? p[q * part_stride] : 0.f;  // independent loads, fixed order of addition
+    return ((u[0] + u[1]) + u[2]) + u[3];
+}
+__device__ __forceinline__ void ln_bwd_dx(const float* __restrict__ dy, int np, size_t part_stride, const float* __restrict__ s,
+                                          const float* __restrict__ stats, const float* __restrict__ gamma, float* __restrict__ dx, int M,
+                                          int d, int blk) {
     const int lane = threadIdx.x & 63, row = blk * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
     const float mean = stats[2 * row], rstd = stats[2 * row + 1];
@@ -440,7 +480,7 @@ __device__ __forceinline__ void ln_bwd_dx(const float* __restrict__ dy, const fl
         xh[t] = gh[t] = 0.f;
         if (c < d) {
             xh[t] = (s[(int64_t)row * d + c] - mean) * rstd;
-            gh[t] = dy[(int64_t)row * d + c] * gamma[c];
+            gh[t] = fold_parts(dy + (int64_t)row * d + c, np, part_stride) * gamma[c];
         }
         c1 += gh[t];
         c2 = fmaf(gh[t], xh[t], c2);
@@ -455,14 +495,15 @@ __device__ __forceinline__ void ln_bwd_dx(const float* __restrict__ dy, const fl
 }
 
 // dgamma[c] = sum_rows dy xhat, dbeta[c] = sum_rows dy: 64 columns per workgroup, 4 row groups folded through LDS in a fixed order
-__device__ __forceinline__ void ln_bwd_gb(const float* __restrict__ dy, const float* __restrict__ s, const float* __restrict__ stats,
-                                          float* __restrict__ dgamma, float* __restrict__ dbeta, int M, int d, int blk) {
+__device__ __forceinline__ void ln_bwd_gb(const float* __restrict__ dy, int np, size_t part_stride, const float* __restrict__ s,
+                                          const float* __restrict__ stats, float* __restrict__ dgamma, float* __restrict__ dbeta, int M, int d,
+                                          int blk) {
     __shared__ float part[2][4][64];
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6, c = blk * 64 + lane;
     float a = 0.f, b = 0.f;
     if (c < d)
         for (int row = grp; row < M; row += 4) {
-            const float g = dy[(int64_t)row * d + c];
+            const float g = fold_parts(dy + (int64_t)row * d + c, np, part_stride);
             a = fmaf(g, (s[(int64_t)row * d + c] - stats[2 * row]) * stats[2 * row + 1], a);
             b += g;
         }
@@ -476,20 +517,25 @@ __device__ __forceinline__ void ln_bwd_gb(const float* __restrict__ dy, const fl
 }
 
 // one launch: workgroups [0, ceil(M / 4)) form dx (a wave per row), the next ceil(d / 64) the column sums
-__global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ dy, const float* __restrict__ s, const float* __restrict__ stats,
-                                                const float* __restrict__ gamma, float* __restrict__ dx, float* __restrict__ dgamma,
-                                                float* __restrict__ dbeta, int M, int d) {
+// (dy = the sum of `np` partial buffers, like k_ln_fwd's input)
+__global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ dy, int np, size_t part_stride, const float* __restrict__ s,
+                                                const float* __restrict__ stats, const float* __restrict__ gamma, float* __restrict__ dx,
+                                                float* __restrict__ dgamma, float* __restrict__ dbeta, int M, int d) {
     const int nrow = (M + 3) >> 2;
-    if ((int)blockIdx.x < nrow) ln_bwd_dx(dy, s, stats, gamma, dx, M, d, blockIdx.x);
-    else ln_bwd_gb(dy, s, stats, dgamma, dbeta, M, d, blockIdx.x - nrow);
+    if ((int)blockIdx.x < nrow) ln_bwd_dx(dy, np, part_stride, s, stats, gamma, dx, M, d, blockIdx.x);
+    else ln_bwd_gb(dy, np, part_stride, s, stats, dgamma, dbeta, M, d, blockIdx.x - nrow);
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------------
+// reduction slices of a product whose consumer folds partials: 512 per slice from 1024 up (2048 -> 4, 1536 -> 3)
+static int split_of(int K) { return (K >= 1024 && K % 512 == 0 && K / 512 <= kMaxSplit) ? K / 512 : 1; }
+
 struct Plan {
     int M, S, d, H, dh, ff, L;
     size_t qkv, P, ctx, s1, st1, x1, h, s2, st2, x2, b_ds2, b_dh, b_ds1, b_dqkv, per_layer;  // float offsets inside one layer's slab
                                                                                   // (b_*: the backward's dY operands, kept for the batched weight gradient)
-    size_t t_g0, t_g1, t_dx1, t_dctx, t_dS, total;  // backward temporaries (floats, after the slabs)
+    size_t t_part, t_g0, t_g1, t_dx1, t_dctx, t_dS, part, total;  // temporaries (floats, after the slabs); t_part / t_g* / t_dx1 hold
+                                                                  // up to kMaxSplit partial buffers `part` floats apart
 };
 
 static bool make_plan(const mst_ctrl_desc* d, Plan& p) {
@@ -517,9 +563,11 @@ static bool make_plan(const mst_ctrl_desc* d, Plan& p) {
     p.b_dqkv = o; o += up(M * 3 * dm);
     p.per_layer = o;
     o = p.per_layer * p.L;
-    p.t_g0 = o; o += up(M * dm);
-    p.t_g1 = o; o += up(M * dm);
-    p.t_dx1 = o; o += up(M * dm);
+    p.part = up(M * dm);
+    p.t_part = o; o += kMaxSplit * p.part;
+    p.t_g0 = o; o += kMaxSplit * p.part;
+    p.t_g1 = o; o += kMaxSplit * p.part;
+    p.t_dx1 = o; o += kMaxSplit * p.part;
     p.t_dctx = o; o += up(M * dm);
     p.t_dS = o; o += up((size_t)d->bs * p.H * p.S * p.S);
     p.total = o;
@@ -527,14 +575,14 @@ static bool make_plan(const mst_ctrl_desc* d, Plan& p) {
 }
 
 static void lin_nt(bool relu, const float* A, int lda, const float* W, int ldw, const float* bias, const float* R, int ldr, float* C, int ldc,
-                   int M, int N, int K, hipStream_t st) {
-    const dim3 grid(N / 16, (M + 63) / 64);
-    if (relu) hipLaunchKernelGGL(k_lin_nt<true>, grid, dim3(512), 0, st, A, lda, W, ldw, bias, R, ldr, C, ldc, M, K);
-    else hipLaunchKernelGGL(k_lin_nt<false>, grid, dim3(512), 0, st, A, lda, W, ldw, bias, R, ldr, C, ldc, M, K);
+                   int M, int N, int K, hipStream_t st, int split = 1, size_t part_stride = 0) {
+    const dim3 grid(N / 16, (M + 63) / 64, split);
+    if (relu) hipLaunchKernelGGL(k_lin_nt<true>, grid, dim3(512), 0, st, A, lda, W, ldw, bias, R, ldr, C, ldc, M, K, part_stride);
+    else hipLaunchKernelGGL(k_lin_nt<false>, grid, dim3(512), 0, st, A, lda, W, ldw, bias, R, ldr, C, ldc, M, K, part_stride);
 }
 static void lin_nn(const float* A, int lda, const float* W, int ldw, const float* Hm, int ldh, const float* R, int ldr, float* C, int ldc, int M,
-                   int N, int cols, hipStream_t st) {
-    hipLaunchKernelGGL(k_lin_nn, dim3(cols / 16, (M + 63) / 64), dim3(512), 0, st, A, lda, W, ldw, Hm, ldh, R, ldr, C, ldc, M, N);
+                   int N, int cols, hipStream_t st, int split = 1, size_t part_stride = 0) {
+    hipLaunchKernelGGL(k_lin_nn, dim3(cols / 16, (M + 63) / 64, split), dim3(512), 0, st, A, lda, W, ldw, Hm, ldh, R, ldr, C, ldc, M, N, part_stride);
 }
 static void add_tn(TnBatch& b, int& tiles, const float* dY, int ldy, const float* X, int ldx, float* dW, int ldw, float* db, int N, int Kd) {
     TnJob& J = b.job[b.n_jobs++];
@@ -578,10 +626,12 @@ extern "C" int mst_ctrl_forward(const mst_ctrl_desc* d, const float* tokens, con
         lin_nt(false, x, dm, w.in_proj_weight, dm, w.in_proj_bias, nullptr, 0, L + p.qkv, 3 * dm, M, 3 * dm, dm, st);
         hipLaunchKernelGGL(k_attn_fwd, dim3(p.H, d->bs, (p.S + kRowsPerWg - 1) / kRowsPerWg), dim3(256), lds_attn, st, L + p.qkv, key_padding_mask, L + p.P, L + p.ctx, p.S, dm, p.dh, scale);
         lin_nt(false, L + p.ctx, dm, w.out_proj_weight, dm, w.out_proj_bias, x, dm, L + p.s1, dm, M, dm, dm, st);
-        hipLaunchKernelGGL(k_ln_fwd, dim3((M + 3) / 4), dim3(256), 0, st, L + p.s1, w.norm1_weight, w.norm1_bias, L + p.x1, L + p.st1, M, dm, d->ln_eps);
+        hipLaunchKernelGGL(k_ln_fwd, dim3((M + 3) / 4), dim3(256), 0, st, L + p.s1, 1, (size_t)0, (float*)nullptr, w.norm1_weight, w.norm1_bias, L + p.x1, L + p.st1, M, dm, d->ln_eps);
         lin_nt(true, L + p.x1, dm, w.linear1_weight, dm, w.linear1_bias, nullptr, 0, L + p.h, ff, M, ff, dm, st);
-        lin_nt(false, L + p.h, ff, w.linear2_weight, ff, w.linear2_bias, L + p.x1, dm, L + p.s2, dm, M, dm, ff, st);
-        hipLaunchKernelGGL(k_ln_fwd, dim3((M + 3) / 4), dim3(256), 0, st, L + p.s2, w.norm2_weight, w.norm2_bias, x2, L + p.st2, M, dm, d->ln_eps);
+        const int sp = split_of(ff);  // feed-forward output: K slices into partials, folded (and stored as s2) by the LayerNorm kernel
+        float* s2p = sp > 1 ? ws + p.t_part : L + p.s2;
+        lin_nt(false, L + p.h, ff, w.linear2_weight, ff, w.linear2_bias, L + p.x1, dm, s2p, dm, M, dm, ff, st, sp, p.part);
+        hipLaunchKernelGGL(k_ln_fwd, dim3((M + 3) / 4), dim3(256), 0, st, s2p, sp, p.part, L + p.s2, w.norm2_weight, w.norm2_bias, x2, L + p.st2, M, dm, d->ln_eps);
         x = x2;
     }
     return (int)hipGetLastError();
@@ -599,6 +649,7 @@ extern "C" int mst_ctrl_backward(const mst_ctrl_desc* d, const float* tokens, co
     const size_t lds1 = (size_t)2 * p.S * kPitch * sizeof(float), lds2 = ((size_t)3 * p.S * kPitch + 8 * kMaxS) * sizeof(float);
     const dim3 lnb((M + 3) / 4 + (dm + 63) / 64);
     const float* g = grad_out;
+    int g_parts = 1;  // partial buffers behind `g`
     TnBatch tb;  // filled here, passed by value (3.6 KB of kernel arguments)
     tb.n_jobs = 0;
     tb.M = M;
@@ -609,20 +660,22 @@ extern "C" int mst_ctrl_backward(const mst_ctrl_desc* d, const float* tokens, co
         const mst_ctrl_layer_grads& gw = grads[l];
         const float* x = l == 0 ? tokens : ws + p.per_layer * (l - 1) + p.x2;
         float* gout = l == 0 ? grad_tokens : ws + ((l & 1) ? p.t_g1 : p.t_g0);
+        const int sp_out = l == 0 ? 1 : split_of(3 * dm), sp_ff = split_of(ff);  // partials of this layer's dx and of dx1
         float *ds2 = L + p.b_ds2, *dh = L + p.b_dh, *ds1 = L + p.b_ds1, *dqkv = L + p.b_dqkv;
         float *dx1 = ws + p.t_dx1, *dctx = ws + p.t_dctx, *dS = ws + p.t_dS;
         // LayerNorm 2 (input s2 = x1 + ffn)
-        hipLaunchKernelGGL(k_ln_bwd, lnb, dim3(256), 0, st, g, L + p.s2, L + p.st2, w.norm2_weight, ds2, gw.norm2_weight, gw.norm2_bias, M, dm);
+        hipLaunchKernelGGL(k_ln_bwd, lnb, dim3(256), 0, st, g, g_parts, p.part, L + p.s2, L + p.st2, w.norm2_weight, ds2, gw.norm2_weight, gw.norm2_bias, M, dm);
         // feed-forward
         lin_nn(ds2, dm, w.linear2_weight, ff, L + p.h, ff, nullptr, 0, dh, ff, M, dm, ff, st);
-        lin_nn(dh, ff, w.linear1_weight, dm, nullptr, 0, ds2, dm, dx1, dm, M, ff, dm, st);
+        lin_nn(dh, ff, w.linear1_weight, dm, nullptr, 0, ds2, dm, dx1, dm, M, ff, dm, st, sp_ff, p.part);
         // LayerNorm 1 (input s1 = x + attention)
-        hipLaunchKernelGGL(k_ln_bwd, lnb, dim3(256), 0, st, dx1, L + p.s1, L + p.st1, w.norm1_weight, ds1, gw.norm1_weight, gw.norm1_bias, M, dm);
+        hipLaunchKernelGGL(k_ln_bwd, lnb, dim3(256), 0, st, dx1, sp_ff, p.part, L + p.s1, L + p.st1, w.norm1_weight, ds1, gw.norm1_weight, gw.norm1_bias, M, dm);
         // attention
         lin_nn(ds1, dm, w.out_proj_weight, dm, nullptr, 0, nullptr, 0, dctx, dm, M, dm, dm, st);
         hipLaunchKernelGGL(k_attn_bwd1, dim3(p.H, d->bs, (p.S + kRowsPerWg - 1) / kRowsPerWg), dim3(256), lds1, st, L + p.qkv, dctx, L + p.P, dS, p.S, dm, p.dh);
         hipLaunchKernelGGL(k_attn_bwd2, dim3(p.H, d->bs, (p.S + kRowsPerWg - 1) / kRowsPerWg), dim3(256), lds2, st, L + p.qkv, dctx, L + p.P, dS, dqkv, p.S, dm, p.dh, scale);
-        lin_nn(dqkv, 3 * dm, w.in_proj_weight, dm, nullptr, 0, ds1, dm, gout, dm, M, 3 * dm, dm, st);
+        lin_nn(dqkv, 3 * dm, w.in_proj_weight, dm, nullptr, 0, ds1, dm, gout, dm, M, 3 * dm, dm, st, sp_out, p.part);
+        g_parts = sp_out;
         // the layer's weight gradients: queued for the batched launch
         add_tn(tb, tiles, ds2, dm, L + p.h, ff, gw.linear2_weight, ff, gw.linear2_bias, dm, ff);
         add_tn(tb, tiles, dh, ff, L + p.x1, dm, gw.linear1_weight, dm, gw.linear1_bias, ff, dm);
