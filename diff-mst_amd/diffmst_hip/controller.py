@@ -15,10 +15,14 @@ _PARAM_NAMES = ("self_attn.in_proj_weight", "self_attn.in_proj_bias", "self_attn
 
 def layer_parameters(encoder: torch.nn.TransformerEncoder):
     """The twelve parameters of every layer, in ``mst_ctrl_layer`` order (a flat list, layer-major)."""
+    cached = encoder.__dict__.get("_mst_layer_parameters")  # the Parameter objects of a module are stable; 144 dict walks per call are not free
+    if cached is not None and len(cached) == len(_PARAM_NAMES) * len(encoder.layers):
+        return cached
     flat = []
     for layer in encoder.layers:
         named = dict(layer.named_parameters())
         flat.extend(named[n] for n in _PARAM_NAMES)
+    encoder.__dict__["_mst_layer_parameters"] = flat
     return flat
 
 
@@ -57,7 +61,7 @@ class _EncoderStack(torch.autograd.Function):
         lib = _hip.lib()
         dev = tokens.device
         x = tokens.float().contiguous()
-        ps = [p.detach().float().contiguous() for p in params]
+        ps = [p.detach() if (p.dtype is torch.float32 and p.is_contiguous()) else p.detach().float().contiguous() for p in params]
         m = None if mask is None else mask.to(torch.uint8).contiguous()
         nbytes = lib.mst_ctrl_workspace_bytes(ctypes.byref(desc))
         if nbytes == 0:
