@@ -611,13 +611,8 @@ extern "C" int mst_ctrl_forward(const mst_ctrl_desc* d, const float* tokens, con
     const int M = p.M, dm = p.d, ff = p.ff;
     const float scale = 1.0f / sqrtf((float)p.dh);
     const size_t lds_attn = ((size_t)3 * p.S * kPitch + 4 * kMaxS) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)k_attn_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (3 * kMaxS * kPitch + 4 * kMaxS) * 4);
-        (void)hipFuncSetAttribute((const void*)k_attn_bwd1, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kMaxS * kPitch * 4);
-        (void)hipFuncSetAttribute((const void*)k_attn_bwd2, hipFuncAttributeMaxDynamicSharedMemorySize, (3 * kMaxS * kPitch + 8 * kMaxS) * 4);
-        attr_set = true;
-    }
+    if (lds_attn > 64 * 1024)  // sequences past ~80 tokens: raise the kernel's dynamic-LDS cap (idempotent; nothing is cached here)
+        (void)hipFuncSetAttribute((const void*)k_attn_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_attn);
     const float* x = tokens;
     for (int l = 0; l < p.L; ++l) {
         float* L = ws + p.per_layer * l;
@@ -648,6 +643,10 @@ extern "C" int mst_ctrl_backward(const mst_ctrl_desc* d, const float* tokens, co
     const float scale = 1.0f / sqrtf((float)p.dh);
     const size_t lds1 = (size_t)2 * p.S * kPitch * sizeof(float), lds2 = ((size_t)3 * p.S * kPitch + 8 * kMaxS) * sizeof(float);
     const dim3 lnb((M + 3) / 4 + (dm + 63) / 64);
+    if (lds2 > 64 * 1024) {
+        (void)hipFuncSetAttribute((const void*)k_attn_bwd1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+        (void)hipFuncSetAttribute((const void*)k_attn_bwd2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+    }
     const float* g = grad_out;
     int g_parts = 1;  // partial buffers behind `g`
     TnBatch tb;  // filled here, passed by value (3.6 KB of kernel arguments)

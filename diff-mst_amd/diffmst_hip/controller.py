@@ -62,7 +62,9 @@ class _EncoderStack(torch.autograd.Function):
         dev = tokens.device
         x = tokens.float().contiguous()
         ps = [p.detach() if (p.dtype is torch.float32 and p.is_contiguous()) else p.detach().float().contiguous() for p in params]
-        m = None if mask is None else mask.to(torch.uint8).contiguous()
+        m = None  # (bs, seq) bytes, non-zero = padded key; a bool tensor is viewed, not converted
+        if mask is not None:
+            m = mask.contiguous().view(torch.uint8) if mask.dtype is torch.bool else (mask != 0).contiguous().view(torch.uint8)
         nbytes = lib.mst_ctrl_workspace_bytes(ctypes.byref(desc))
         if nbytes == 0:
             raise ValueError("TransformerController: this encoder stack is outside the kernels' limits (controller.supported)")

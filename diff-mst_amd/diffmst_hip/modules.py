@@ -574,6 +574,11 @@ class TransformerController(torch.nn.Module):
             return self._graphed_forward(track_embeds, mix_embeds, track_padding_mask)
         return self._eager_forward(track_embeds, mix_embeds, track_padding_mask)
 
+    def __getstate__(self):  # captured graphs are per-process objects: pickling / deepcopy carries the module, not them
+        state = dict(self.__dict__)
+        state["_graphs"] = {}
+        return state
+
     def _graphed_forward(self, track_embeds, mix_embeds, track_padding_mask):
         key = (tuple(track_embeds.shape), tuple(mix_embeds.shape), track_padding_mask is not None, str(track_embeds.device))
         fn = self._graphs.get(key)

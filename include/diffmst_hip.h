@@ -260,7 +260,8 @@ int mst_cnn14_backward(const mst_cnn14_desc* d, const float* spec, const mst_cnn
 /* ---- TransformerController encoder stack (reference mst/modules.py:848-854, :893-895: torch.nn.TransformerEncoder of
  * post-norm TransformerEncoderLayer(d_model, nhead, dim_feedforward, relu, dropout 0, batch_first) over the (bs, seq, d_model)
  * token sequence, with the key-padding mask of :880-890).  fp32 operands on v_mfma_f32_16x16x4_f32.  Limits: seq <= 128,
- * d_model % 128 == 0, d_model <= 1024, d_model / nhead <= 64, d_ff % 128 == 0 (workspace_bytes returns 0 otherwise). */
+ * d_model % 128 == 0, d_model <= 1024, d_model / nhead <= 64, d_ff % 128 == 0, n_layers <= 16 (workspace_bytes returns 0 otherwise).
+ * Stateless and re-entrant like the rest of the library; run-to-run deterministic (no atomics). */
 typedef struct mst_ctrl_desc {
     int32_t bs, seq, d_model, nhead, d_ff, n_layers;
     float ln_eps; /* 1e-5 */
