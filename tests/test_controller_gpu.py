@@ -54,11 +54,13 @@ def test_graphed_controller_equals_eager(with_mask, record):
     record(max_rel_err=worst)
 
 
-@pytest.mark.parametrize("bs,T,layers,with_mask", [(2, 6, 2, True), (1, 32, 12, True), (3, 60, 2, False), (2, 124, 1, True)])
-def test_native_encoder_stack_against_torch(bs, T, layers, with_mask, record):
+@pytest.mark.parametrize("bs,T,layers,with_mask,width,heads", [(2, 6, 2, True, 512, 8), (1, 32, 12, True, 512, 8), (3, 60, 2, False, 512, 8),
+                                                               (2, 124, 1, True, 512, 8), (2, 9, 2, True, 256, 8), (1, 20, 1, True, 1024, 16),
+                                                               (2, 5, 1, False, 128, 2)])
+def test_native_encoder_stack_against_torch(bs, T, layers, with_mask, width, heads, record):
     """``TransformerController(native=True)``: the encoder stack on csrc/mst_ctrl.hip (fp32 MFMA) against torch's own
     ``nn.TransformerEncoder`` with the same weights - outputs, input gradients and every parameter gradient, fp32 tolerance
-    (the reference's 1e-4)."""
+    (the reference's 1e-4); other widths / head counts than the reference's 512 / 8 cover the kernels' limits."""
     from mst.modules import TransformerController
 
     dev = torch.device("cuda:0")
@@ -66,13 +68,13 @@ def test_native_encoder_stack_against_torch(bs, T, layers, with_mask, record):
     # zero and its ReLU mask differs between the two fp32 evaluations (that unit's weight-gradient row moves by 9e-2 of the
     # largest entry with 20 rows in the batch; seeds 1-5 agree with float64 to 4e-7, tools/dbg_ctrl.py)
     torch.manual_seed(1 if (bs, T) == (2, 6) else 5 + bs + T)
-    ctrl = TransformerController(512, 27, 25, 26, num_layers=layers, nhead=8).to(dev).train()
+    ctrl = TransformerController(width, 27, 25, 26, num_layers=layers, nhead=heads).to(dev).train()
     with torch.no_grad():  # LayerNorm / bias parameters off their 1 / 0 initial values
         for n, p in ctrl.named_parameters():
             if "norm" in n or n.endswith("bias"):
                 p.add_(0.1 * torch.randn_like(p))
-    te = torch.randn(bs, T, 512, device=dev)
-    me = torch.randn(bs, 2, 512, device=dev)
+    te = torch.randn(bs, T, width, device=dev)
+    me = torch.randn(bs, 2, width, device=dev)
     mask = None
     if with_mask:
         mask = torch.zeros(bs, T, dtype=torch.bool, device=dev)
@@ -129,3 +131,27 @@ def test_native_controller_against_the_real_class(golden_dir, record):
     record(out=e_out, grad_in=e_in, grad_param=e_par)
     assert e_out <= 1e-4 and e_in <= 1e-4, (e_out, e_in)
     assert e_par <= 1e-4, (worst, e_par)
+
+
+def test_native_controller_limits_and_eval_mode():
+    """Outside the kernels' limits ``native=True`` raises instead of silently running another path; inside, eval mode (no
+    gradient) equals training mode (dropout is 0)."""
+    from mst.modules import TransformerController
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    ctrl = TransformerController(512, 27, 25, 26, num_layers=1, nhead=8, native=True).to(dev)
+    te, me = torch.randn(1, 130, 512, device=dev), torch.randn(1, 2, 512, device=dev)  # 134 tokens > 128
+    with pytest.raises(ValueError, match="limits"):
+        ctrl(te, me)
+    odd = TransformerController(192, 27, 25, 26, num_layers=1, nhead=8, native=True).to(dev)  # 192 % 128 != 0
+    with pytest.raises(ValueError, match="limits"):
+        odd(torch.randn(1, 4, 192, device=dev), torch.randn(1, 2, 192, device=dev))
+    te, me = torch.randn(2, 7, 512, device=dev), torch.randn(2, 2, 512, device=dev)
+    ctrl.train()
+    a = ctrl(te, me)
+    ctrl.eval()
+    with torch.no_grad():
+        b = ctrl(te, me)
+    for x, y in zip(a, b):
+        assert torch.equal(x.detach(), y)
