@@ -535,8 +535,15 @@ class SpectrogramEncoder(torch.nn.Module):
 class TransformerController(torch.nn.Module):
     """Reference ``TransformerController`` (mst/modules.py:809-914): learned type embeddings added to the track / mix
     embeddings, one fx-bus and one master-bus token appended, ``torch.nn.TransformerEncoder`` (dropout 0, batch_first),
-    three sigmoid-bounded projections.  Host-library work (rocBLAS GEMMs + SDPA through torch); same parameter names as the
-    reference.
+    three sigmoid-bounded projections; same parameter names as the reference (its checkpoints load).  Default: torch's own
+    layers (rocBLAS GEMMs + SDPA), the reference's behaviour.  Two opt-in keywords, both for the same reason - 12 layers over
+    ~36 tokens are launch-bound, not arithmetic-bound:
+
+    ``native=True``: the encoder stack (everything between the token sequence and the three projections) runs on the
+    hand-written kernels of ``csrc/mst_ctrl.hip`` (``diffmst_hip.controller``; fp32 operands on the matrix cores, forward and
+    backward, every gradient within 4e-7 of torch's): 15 launches per layer and direction pair instead of ~48, 1.5 ms of kernels
+    per cfg #5 step instead of 3.6 ms + gaps.  Limits: <= 128 tokens, embed_dim % 128 == 0 and <= 1024, head width <= 64,
+    <= 16 layers - outside them the call raises (no silent second path).
 
     ``graphed`` (extra keyword, default False = the reference's eager behaviour): 12 layers over ~36 tokens are ~580 kernels of
     a few microseconds each per training step, and at batch 1 the HOST cannot issue them as fast as the GPU retires them
