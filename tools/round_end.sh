@@ -9,3 +9,6 @@ cd $R && timeout 900 python bench.py > gpurun_out/${1:-r3}_bench.log 2>&1; tail 
 # the spectrogram encoder: per-kernel table and MFMA / LDS counters (16 signals x 262144, bf16)
 cd $R && bash tools/encoder_prof.sh 16 262144 bf16 > gpurun_out/${1:-r3}_encoder_prof.txt 2>&1
 cd $R && bash tools/encoder_pmc.sh > gpurun_out/${1:-r3}_encoder_pmc.txt 2>&1; tail -3 gpurun_out/${1:-r3}_encoder_pmc.txt
+# cfg #5 step: kernel trace for the idle-gap attribution / controller kernel table (tools/cfg5_gaps.py, tools/ctrl_prof.py), controller alone
+cd $R && bash tools/cfg5_prof.sh > gpurun_out/${1:-r3}_cfg5_prof.txt 2>&1; tail -3 gpurun_out/${1:-r3}_cfg5_prof.txt
+cd $R && timeout 300 python tools/ctrl_bench.py 2>&1 | grep controller | tee gpurun_out/${1:-r3}_ctrl_bench.txt
