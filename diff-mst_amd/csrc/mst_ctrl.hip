@@ -238,8 +238,12 @@ struct TnBatch {
     int n_jobs, M;
 };
 __global__ __launch_bounds__(64) void k_lin_tn_batch(const TnBatch b) {
-    int j = 0;
-    while (j + 1 < b.n_jobs && (int)blockIdx.x >= b.job[j + 1].tile0) ++j;  // wave-uniform walk over <= 64 entries in SGPRs
+    int j = 0, hi = b.n_jobs - 1;  // wave-uniform binary search over the job table (kernel arguments: scalar loads)
+    while (j < hi) {
+        const int mid = (j + hi + 1) >> 1;
+        if ((int)blockIdx.x >= b.job[mid].tile0) j = mid;
+        else hi = mid - 1;
+    }
     const TnJob& J = b.job[j];
     const int t = blockIdx.x - J.tile0;
     lin_tn_tile(J.dY, J.ldy, J.X, J.ldx, J.dW, J.ldw, J.db, b.M, t % J.tiles_x, t / J.tiles_x);
