@@ -102,7 +102,8 @@ def test_console_denormalised_parameter_path(ranges):
     assert rel(b["grad_mp"] * (mhi - mlo), a["grad_mp"]) < 1e-4
 
 
-@pytest.mark.parametrize("S,n", [(8192, 2 * 4096 + 1237), (65536, 16 * 4096 + 465)])  # 17 blocks: two frame chunks of the dH walk
+@pytest.mark.parametrize("S,n", [(8192, 2 * 4096 + 1237),
+                                 pytest.param(65536, 16 * 4096 + 465, marks=pytest.mark.slow)])  # 17 blocks: two frame chunks of the dH walk; the large case takes 3 min on 8 cores
 def test_console_fx_bus(ranges, S, n):
     """use_fx_bus = True (the reference's default): send bus + noise-shaped reverberation (partitioned FFT convolution on the
     8192-point engine) forward and backward, with a short impulse response (2 partitions) and short band-passes so that the
@@ -223,7 +224,7 @@ def test_mrstft_register_radix_engine():
     assert rel(out["grad_pred"], xo.grad) < 2e-3  # d log|X| / dX ~ 1/|X|: fp32-noise-limited (see the GPU tests)
 
 
-@pytest.mark.parametrize("n", [17000, 40962])  # just above the 16384-sample reflect pad (3 frames); ragged rows (n % 4 = 2), 6 frames
+@pytest.mark.parametrize("n", [17000, pytest.param(40962, marks=pytest.mark.slow)])  # just above the 16384-sample reflect pad (3 frames); ragged rows (n % 4 = 2), 6 frames
 def test_afloss_small(n):
     torch.manual_seed(0)
     w = [0.1, 0.001, 1.0, 1.0, 0.1]
