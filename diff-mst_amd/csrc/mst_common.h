@@ -186,6 +186,34 @@ __device__ __forceinline__ float wave_sum(float v) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
+// ---- block aggregates handed from workgroup to workgroup INSIDE a launch (round 4) --------------------------------------------
+// A zero-state pass used to be its own launch: every workgroup published the aggregate of its block and the run launch read the
+// aggregates of the blocks before it.  The aggregate of block b does not depend on any other block, so the run kernel can publish
+// it itself and pick up its predecessors' as soon as they appear: one launch and one pass over the saved signals less.
+// Protocol = recipe R2 of cdna_hip_programming.md Guideline 16: ONE naturally aligned 8-byte {tag = 1, value} granule written by one
+// agent-scope (sc1, write-through) store and polled with agent-scope loads - the data is the flag, no fence on either side.  The
+// granules are zeroed by an EARLIER kernel of the same call (k_prep: every granule array; k_prep_bwd re-arms the backward's).
+// No serial chain: a workgroup waits only for values that are computed from saved signals, never for another workgroup's wait.
+// Deadlock freedom: block b waits for blocks that were dispatched before it (the grid is walked so that predecessors have lower
+// workgroup ids; an XCD hands out its share of the ids in order), and every spin is bounded (MST_GRAN_SPINS: the wait gives up and
+// returns NaN, which poisons the outputs that depend on it - the launch ends and the failure is visible).
+typedef unsigned long long gran_t;
+#ifndef MST_GRAN_SPINS
+#define MST_GRAN_SPINS (1 << 22)
+#endif
+__device__ __forceinline__ void gran_publish(gran_t* g, float v) {
+    __hip_atomic_store(g, ((gran_t)1 << 32) | (gran_t)(unsigned)__float_as_int(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float gran_wait(const gran_t* g) {
+    gran_t x = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int spins = 0; (x >> 32) != 1; ++spins) {
+        if (spins >= MST_GRAN_SPINS) return __int_as_float(0x7fc00000);
+        __builtin_amdgcn_s_sleep(2);
+        x = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return __int_as_float((int)(unsigned)x);
+}
+
 // ---- workspace layout (element offsets in floats), computed on the host ------------------------
 struct Layout {
     int bs, T, R;            // R = bs*T track rows
@@ -213,6 +241,10 @@ struct Layout {
     int64_t pow1F_t, pow1F_m, pow1A_t, pow1A_m;  // in-wave scan tables rows x kTri2
     int64_t aggF_t, aggF_m, aggA_t, aggA_m;      // tile aggregates sigrows x 12 x kMaxTiles1 (forward / adjoint cascade)
     int64_t wzF_t, wzF_m, wzA_t, wzA_m;          // zero-state maps rows x 64 x 16: chunk end state = W^T chunk (mst_eq.hip, k_eq_zs_mfma)
+    // granules (8 bytes each, float offsets here): block aggregates exchanged inside a launch.  Forward arrays first, then the
+    // backward's: k_prep zeroes [gran_f, gran_f + 2 (gran_nf + gran_nb) floats), k_prep_bwd re-arms the backward part
+    int64_t gran_f, gran_b;                      // gran_f: master smoother (bs x nblkC); gran_b: adjoint smoother, tracks (R x nblkC) then master (bs x nblkC)
+    int64_t gran_nf, gran_nb;                    // granule counts
     // fx bus (only laid out when MST_USE_FX_BUS is set)
     int fxS, fxTaps, fxK, fxBlk, fxBlkIr;         // impulse-response samples, band-pass taps, partitions, signal blocks, ir-bwd blocks
     int64_t fx_rc, fx_in, fx_wnf, fx_ir, fx_Xs, fx_Hs, fx_Ys, fx_dXs, fx_dHs, fx_dir, fx_din, fx_part, fx_Hf, fx_mix, fx_dry;
@@ -298,6 +330,10 @@ inline Layout make_layout(const mst_console_desc* d) {
     L.wzF_m = L.wzF_t + R * kWz;
     L.wzA_t = take((R + B) * kWz);
     L.wzA_m = L.wzA_t + R * kWz;
+    L.gran_nf = B * L.nblkC;
+    L.gran_nb = (R + B) * L.nblkC;
+    L.gran_f = take(2 * (L.gran_nf + L.gran_nb));
+    L.gran_b = L.gran_f + 2 * L.gran_nf;
     if (d->flags & MST_USE_FX_BUS) {
         L.fxS = d->fx_ir_samples;
         L.fxTaps = d->fx_bandpass_taps;

@@ -92,6 +92,38 @@ __device__ __forceinline__ float block_carry(const float* __restrict__ agg, int 
     return S;
 }
 
+// the same from granules that the other workgroups of THIS launch publish (mst_common.h: gran_publish / gran_wait).  The first poll
+// is split off (carry_peek) so that a kernel can request it early, do work that does not need the carry, and only then look at it.
+template <bool REV>
+__device__ __forceinline__ int carry_first(int blk, int tid) { return REV ? blk + 1 + tid : blk - 1 - tid; }
+template <bool REV>
+__device__ __forceinline__ gran_t carry_peek(const gran_t* __restrict__ agg, int blk, int nblk, int tid) {
+    const int j = carry_first<REV>(blk, tid);
+    return (j >= 0 && j < nblk) ? __hip_atomic_load(agg + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+}
+template <bool REV>
+__device__ __forceinline__ float block_carry_g(const gran_t* __restrict__ agg, gran_t peek, int blk, int nblk, float log2a, float* lds, int tid) {
+    float acc = 0.0f;
+    bool first = true;
+    if (REV) {
+        for (int j = blk + 1 + tid; j < nblk; j += kWG, first = false) {
+            const float v = (first && (peek >> 32) == 1) ? __int_as_float((int)(unsigned)peek) : gran_wait(agg + j);
+            acc += __builtin_amdgcn_exp2f((float)(j - blk - 1) * 256.0f * log2a) * v;
+        }
+    } else {
+        for (int j = blk - 1 - tid; j >= 0; j -= kWG, first = false) {
+            const float v = (first && (peek >> 32) == 1) ? __int_as_float((int)(unsigned)peek) : gran_wait(agg + j);
+            acc += __builtin_amdgcn_exp2f((float)(blk - 1 - j) * 256.0f * log2a) * v;
+        }
+    }
+    acc = wave_sum(acc);
+    if ((tid & 63) == 0) lds[4 + (tid >> 6)] = acc;
+    lds_barrier();
+    const float S = (lds[4] + lds[5]) + (lds[6] + lds[7]);
+    lds_barrier();
+    return S;
+}
+
 // zero-entry aggregate of the workgroup's block alone (what the zero-state passes publish): a weighted SUM, not a scan -
 //   forward: sum_t a^(255 - t) z_t,   REV: sum_t a^t z_t   (t = lane chunk index in the block, a = alpha^8)
 // one exp2, six DPP additions and one barrier instead of block_enter's seven ds_bpermute and two barriers.
@@ -211,8 +243,8 @@ __device__ __forceinline__ void apply_tracks_body(const TrackApplyArgs& a) {
         ST8<FAST>(a.fx + ((int64_t)b * 2 + 1) * a.stride, i0, a.n, fxR);
     }
 }
-__device__ __forceinline__ bool block_interior(int64_t n, int lookahead, int aligned) {
-    const int64_t lo = (int64_t)blockIdx.x * kWG * CC, hi = lo + (int64_t)kWG * CC;
+__device__ __forceinline__ bool block_interior(int64_t n, int lookahead, int aligned, int blk = -1) {
+    const int64_t lo = (int64_t)(blk < 0 ? (int)blockIdx.x : blk) * kWG * CC, hi = lo + (int64_t)kWG * CC;
     return aligned && lo - lookahead >= 0 && hi + lookahead <= n;
 }
 __global__ __launch_bounds__(kWG) void k_apply_tracks(TrackApplyArgs a) {
@@ -236,8 +268,6 @@ __device__ __forceinline__ void apply_master_body(const MasterApplyArgs& a) {
         float l[CC], r[CC], g[CC];
         LD8<FAST>(v0, i0, a.n, l);
         LD8<FAST>(v1, i0, a.n, r);
-        LD8S<FAST>(v0, i0 - a.lookahead, a.n, yl);
-        LD8S<FAST>(v1, i0 - a.lookahead, a.n, yr);
         float z = 0.0f;
 #pragma unroll
         for (int i = 0; i < CC; ++i) {
@@ -246,7 +276,16 @@ __device__ __forceinline__ void apply_master_body(const MasterApplyArgs& a) {
             z = fmaf(k.alpha, z, g[i]);
         }
         const float ac = rc[RC_ALPHA_C], l2a = rc[RC_LOG2A_C];
-        const float S = block_carry<false>(a.s0 + (int64_t)b * gridDim.x, blockIdx.x, gridDim.x, l2a, lds, threadIdx.x);
+        // no k_comp_zs launch (a.gran): this block's aggregate is published here, the earlier blocks' are picked up as they appear
+        gran_t* gr = a.gran ? a.gran + (int64_t)b * gridDim.x : nullptr;
+        if (gr) {
+            const float agg = block_aggregate<false>(z, l2a, lds, threadIdx.x);
+            if (threadIdx.x == 0) gran_publish(gr + blockIdx.x, agg);
+        }
+        LD8S<FAST>(v0, i0 - a.lookahead, a.n, yl);  // requested before the wait for the other blocks
+        LD8S<FAST>(v1, i0 - a.lookahead, a.n, yr);
+        const float S = gr ? block_carry_g<false>(gr, carry_peek<false>(gr, blockIdx.x, gridDim.x, threadIdx.x), blockIdx.x, gridDim.x, l2a, lds, threadIdx.x)
+                           : block_carry<false>(a.s0 + (int64_t)b * gridDim.x, blockIdx.x, gridDim.x, l2a, lds, threadIdx.x);
         float s = block_enter<false>(z, ac, l2a, S, lds, threadIdx.x);
 #pragma unroll
         for (int i = 0; i < CC; ++i) {
@@ -356,7 +395,7 @@ __global__ __launch_bounds__(kWG) void k_comp_bwd_zs(CompBwdArgs a) {
 constexpr int kCgPitch = kEqChunk + 4, kCgChunks = kWG * CC / kEqChunk, kCgTile = kCgChunks * kCgPitch;
 static_assert(kCgChunks == 32 && kSections * 32 <= kWG, "one section x 32 chunks per 32 lanes");
 template <bool FAST>
-__device__ __forceinline__ void coefgrad_fused(const CompBwdArgs& a, int sig, const float* __restrict__ rc, int64_t i0, const float* xu,
+__device__ __forceinline__ void coefgrad_fused(const CompBwdArgs& a, int blk, int sig, const float* __restrict__ rc, int64_t i0, const float* xu,
                                                const float* du, float* __restrict__ cg_u, float* __restrict__ cg_g) {
     const int tid = threadIdx.x;
     {
@@ -376,7 +415,7 @@ __device__ __forceinline__ void coefgrad_fused(const CompBwdArgs& a, int sig, co
     if (s < kSections) {
         const float ka1 = rc[RC_SOS + 5 * s + 3], ka2 = rc[RC_SOS + 5 * s + 4];
         const float kc1 = rc[RC_AP + 3 * s], kc2 = rc[RC_AP + 3 * s + 1], kib0 = rc[RC_AP + 3 * s + 2];
-        const int64_t base = ((int64_t)sig * 24 + 4 * s) * a.ap_nc_pad + (int64_t)blockIdx.x * kCgChunks + c;
+        const int64_t base = ((int64_t)sig * 24 + 4 * s) * a.ap_nc_pad + (int64_t)blk * kCgChunks + c;
         float wa1 = a.ap_s0[base], wa2 = a.ap_s0[base + a.ap_nc_pad], wb1 = a.ap_s0[base + 2 * (int64_t)a.ap_nc_pad],
               wb2 = a.ap_s0[base + 3 * (int64_t)a.ap_nc_pad];
         if (MST_CG_ABLATE & 1) wa1 = wa2 = wb1 = wb2 = (float)c;
@@ -411,7 +450,7 @@ __device__ __forceinline__ void coefgrad_fused(const CompBwdArgs& a, int sig, co
             for (int m = 16; m >= 1; m >>= 1) acc[i] += __shfl_xor(acc[i], m);  // the 32 chunk lanes of the section (one half wave), fixed order
         }
         if (c == 0) {
-            float* o = a.ep + ((int64_t)sig * gridDim.x + blockIdx.x) * EP_COUNT + 5 * s;
+            float* o = a.ep + ((int64_t)sig * gridDim.x + blk) * EP_COUNT + 5 * s;
 #pragma unroll
             for (int i = 0; i < 5; ++i) o[i] = acc[i];
         }
@@ -421,10 +460,10 @@ __device__ __forceinline__ void coefgrad_fused(const CompBwdArgs& a, int sig, co
 
 // FXS: the fx send bus is on (tracks only) - its cotangent rows are read and the send-gain sum is formed
 template <bool MASTER, bool FAST, bool FXS>
-__device__ __forceinline__ void comp_bwd_run_body(const CompBwdArgs& a, float* __restrict__ cg_u, float* __restrict__ cg_g) {
+__device__ __forceinline__ void comp_bwd_run_body(const CompBwdArgs& a, int blk, float* __restrict__ cg_u, float* __restrict__ cg_g) {
     constexpr int NCH = MASTER ? 2 : 1;
     __shared__ float red[4][CP_COUNT];  // red[0] doubles as the 8-float scan scratch
-    const int tid = threadIdx.x, row = blockIdx.y, chunk = blockIdx.x * kWG + tid;
+    const int tid = threadIdx.x, row = blockIdx.y, chunk = blk * kWG + tid;
     const int64_t i0 = (int64_t)chunk * CC;
     const float* rc = a.rc + (int64_t)row * RC_STRIDE;
     const float* u0 = a.u + (int64_t)(row * NCH) * a.stride;
@@ -450,6 +489,26 @@ __device__ __forceinline__ void comp_bwd_run_body(const CompBwdArgs& a, float* _
     if (a.comp_on) {
         const CompK k = load_comp(rc);
         float x0[CC], x1[CC], xd0[CC], xd1[CC], g[CC];
+        // what the adjoint smoother's zero-state value needs comes first: with a.gran the block's aggregate is published as early as
+        // possible (no k_comp_bwd_zs launch) and the later blocks' aggregates are awaited only after every other load has been requested
+        LD8S<FAST>(u0, i0 - a.lookahead, a.n, xd0);
+        if (MASTER) LD8S<FAST>(u1, i0 - a.lookahead, a.n, xd1);
+        LD8<FAST>(a.gs + (int64_t)row * a.stride, i0, a.n, g);
+        float dgsv[CC];
+        float zq = 0.0f;
+#pragma unroll
+        for (int i = CC - 1; i >= 0; --i) {
+            const float Gi = lin_gain(g[i], k);
+            const float dot = MASTER ? pl * (gl[i] * xd0[i] + gr[i] * xd1[i]) : (pl * gl[i] + pr * gr[i]) * xd0[i];
+            dgsv[i] = (FAST || i0 + i < a.n) ? dot * Gi * kLn10Over20 : 0.0f;
+            zq = fmaf(k.alpha, zq, dgsv[i]);
+        }
+        const float ac = rc[RC_ALPHA_C], l2a = rc[RC_LOG2A_C];
+        gran_t* gq = a.gran ? a.gran + (int64_t)row * gridDim.x : nullptr;
+        if (gq) {
+            const float agg = block_aggregate<true>(zq, l2a, red[0], tid);
+            if (tid == 0) gran_publish(gq + blk, agg);
+        }
         // look-ahead branch: du[i] += gy[i+L] * G[i+L].  Folded to one (two: master) value per sample right after the loads -
         // three arrays less are alive across the block scan (the kernel ran at 152 registers = 3 waves per SIMD)
         float fwd0[CC], fwd1[MASTER ? CC : 1];
@@ -468,34 +527,22 @@ __device__ __forceinline__ void comp_bwd_run_body(const CompBwdArgs& a, float* _
         LD8<FAST>(u0, i0, a.n, x0);
 #pragma unroll
         for (int i = 0; i < CC; ++i) xu[i] = x0[i];
-        LD8S<FAST>(u0, i0 - a.lookahead, a.n, xd0);
         if (MASTER) {
             LD8<FAST>(u1, i0, a.n, x1);
 #pragma unroll
             for (int i = 0; i < CC; ++i) xu1[i] = x1[i];
-            LD8S<FAST>(u1, i0 - a.lookahead, a.n, xd1);
         }
-        LD8<FAST>(a.gs + (int64_t)row * a.stride, i0, a.n, g);
         const float g_prev0 = (i0 > 0 && i0 - 1 < a.n) ? a.gs[(int64_t)row * a.stride + i0 - 1] : 0.0f;
-        float dgsv[CC];
-        float zq = 0.0f;
-#pragma unroll
-        for (int i = CC - 1; i >= 0; --i) {
-            const float Gi = lin_gain(g[i], k);
-            const float dot = MASTER ? pl * (gl[i] * xd0[i] + gr[i] * xd1[i]) : (pl * gl[i] + pr * gr[i]) * xd0[i];
-            dgsv[i] = (FAST || i0 + i < a.n) ? dot * Gi * kLn10Over20 : 0.0f;
-            zq = fmaf(k.alpha, zq, dgsv[i]);
-        }
-        const float ac = rc[RC_ALPHA_C], l2a = rc[RC_LOG2A_C];
-        const float S = block_carry<true>(a.s0 + (int64_t)row * gridDim.x, blockIdx.x, gridDim.x, l2a, red[0], tid);
-        float q = block_enter<true>(zq, ac, l2a, S, red[0], tid);
+        // first look at the later blocks' aggregates: requested here, examined after the arithmetic below, which does not need them
+        const gran_t peek = gq ? carry_peek<true>(gq, blk, gridDim.x, tid) : 0ull;
+        // Everything that does not involve the adjoint smoother's state q (static curve, knee derivatives, the 1 / side of the side
+        // chain, the pan / make-up sums) - five values per sample are kept for the short q-dependent loop behind the wait:
+        //   dgc = oma q;  alpha += q A;  kappa += dgc Fv;  thr -= dgc Kp;  knee += dgc Kw;  du = dgc E + look-ahead branch
+        float cA[CC], cFv[CC], cKp[CC], cKw[CC], cE[CC];
 #pragma unroll
         for (int i = CC - 1; i >= 0; --i) {
             const bool live = FAST || i0 + i < a.n;
-            const float G = lin_gain(g[i], k);  // recomputed (one exp2): eight registers less across the block scan
-            const float dgs = dgsv[i];
-            q = fmaf(k.alpha, q, dgs);
-            const float dgc = k.oma * q;
+            const float G = lin_gain(g[i], k);  // recomputed (one exp2): eight registers less across the zero-state loop
             const float side = MASTER ? x0[i] + x1[i] : x0[i];
             float d;
             const float gc = gain_computer(side, k, d);
@@ -510,13 +557,15 @@ __device__ __forceinline__ void comp_bwd_run_body(const CompBwdArgs& a, float* _
                 fp = t * k.invw;
                 fw = t * (k.hw - d) * k.inv2w * k.invw;
             }
-            const float dxdb = dgc * k.kappa * fp;
+            const float kp = k.kappa * fp;
+            cA[i] = live ? gprev - gc : 0.0f;
+            cFv[i] = live ? fval : 0.0f;
+            cKp[i] = live ? kp : 0.0f;
+            cKw[i] = live ? k.kappa * fw : 0.0f;
+            // side chain: d x_db / d side = (20/ln10) / side, clamp kills it below eps
+            cE[i] = (fabsf(side) >= kCompEps) ? kp * 8.685889638065035f * __builtin_amdgcn_rcpf(side) : 0.0f;
             if (live) {
-                p[CP_ALPHA] = fmaf(q, gprev - gc, p[CP_ALPHA]);
-                p[CP_KAPPA] = fmaf(dgc, fval, p[CP_KAPPA]);
-                p[CP_THR] -= dxdb;
-                p[CP_KNEE] = fmaf(dgc * k.kappa, fw, p[CP_KNEE]);
-                p[CP_MAKEUP] += dgs;
+                p[CP_MAKEUP] += dgsv[i];
                 if (MASTER) {
                     // cotangent of the output-fader gain: sum(grad_mix * out_before_fader)
                     p[CP_PANL] = fmaf(gl[i] * xd0[i] + gr[i] * xd1[i], G, p[CP_PANL]);
@@ -527,8 +576,19 @@ __device__ __forceinline__ void comp_bwd_run_body(const CompBwdArgs& a, float* _
                     if (FXS) p[CP_SEND] = fmaf(fsum[i], yv, p[CP_SEND]);
                 }
             }
-            // side chain: d x_db / d side = (20/ln10) / side, clamp kills it below eps
-            const float ds = (fabsf(side) >= kCompEps) ? dxdb * 8.685889638065035f * __builtin_amdgcn_rcpf(side) : 0.0f;
+        }
+        const float S = gq ? block_carry_g<true>(gq, peek, blk, gridDim.x, l2a, red[0], tid)
+                           : block_carry<true>(a.s0 + (int64_t)row * gridDim.x, blk, gridDim.x, l2a, red[0], tid);
+        float q = block_enter<true>(zq, ac, l2a, S, red[0], tid);
+#pragma unroll
+        for (int i = CC - 1; i >= 0; --i) {
+            q = fmaf(k.alpha, q, dgsv[i]);
+            const float dgc = k.oma * q;
+            p[CP_ALPHA] = fmaf(q, cA[i], p[CP_ALPHA]);
+            p[CP_KAPPA] = fmaf(dgc, cFv[i], p[CP_KAPPA]);
+            p[CP_THR] = fmaf(-dgc, cKp[i], p[CP_THR]);
+            p[CP_KNEE] = fmaf(dgc, cKw[i], p[CP_KNEE]);
+            const float ds = dgc * cE[i];
             du0[i] = ds + fwd0[i];
             if (MASTER) du1[i] = ds + fwd1[i];
         }
@@ -560,8 +620,8 @@ __device__ __forceinline__ void comp_bwd_run_body(const CompBwdArgs& a, float* _
         if (MASTER) ST8<FAST>(a.du + (int64_t)(row * NCH + 1) * a.stride, i0, a.n, du1);
     }
     if (a.ep) {  // signal rows: tracks = row, master = 2 row + channel
-        coefgrad_fused<FAST>(a, row * NCH, rc, i0, xu, du0, cg_u, cg_g);
-        if (MASTER) coefgrad_fused<FAST>(a, row * NCH + 1, rc, i0, xu1, du1, cg_u, cg_g);
+        coefgrad_fused<FAST>(a, blk, row * NCH, rc, i0, xu, du0, cg_u, cg_g);
+        if (MASTER) coefgrad_fused<FAST>(a, blk, row * NCH + 1, rc, i0, xu1, du1, cg_u, cg_g);
     }
 
     const int wave = tid >> 6, lane = tid & 63;
@@ -572,7 +632,7 @@ __device__ __forceinline__ void comp_bwd_run_body(const CompBwdArgs& a, float* _
     }
     lds_barrier();
     if (tid < CP_COUNT)
-        a.part[((int64_t)row * gridDim.x + blockIdx.x) * CP_COUNT + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+        a.part[((int64_t)row * gridDim.x + blk) * CP_COUNT + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
 }
 #ifndef MST_COMP_BWD_W
 #define MST_COMP_BWD_W 1  // min waves per SIMD asked of the compressor backward (A/B switch)
@@ -580,8 +640,11 @@ __device__ __forceinline__ void comp_bwd_run_body(const CompBwdArgs& a, float* _
 template <bool MASTER, bool FXS = false>
 __global__ __launch_bounds__(kWG, (!MASTER && !FXS) ? 4 : MST_COMP_BWD_W) void k_comp_bwd_run(CompBwdArgs a) {  // tracks without fx: 130 registers uncapped, two short of four waves per SIMD
     __shared__ __attribute__((aligned(16))) float cg_u[kCgTile], cg_g[kCgTile];  // one copy for both bodies
-    if (block_interior(a.n, a.lookahead, a.aligned)) comp_bwd_run_body<MASTER, true, FXS>(a, cg_u, cg_g);
-    else comp_bwd_run_body<MASTER, false, FXS>(a, cg_u, cg_g);
+    // a.gran: the blocks a workgroup waits for (LATER in time: the adjoint smoother runs backwards) must have been dispatched before
+    // it, so the grid walks the row from its end
+    const int blk = a.gran ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;
+    if (block_interior(a.n, a.lookahead, a.aligned, blk)) comp_bwd_run_body<MASTER, true, FXS>(a, blk, cg_u, cg_g);
+    else comp_bwd_run_body<MASTER, false, FXS>(a, blk, cg_u, cg_g);
 }
 
 // ---- launch helpers ---------------------------------------------------------------------------------

@@ -29,6 +29,16 @@ static constexpr bool fuse_allpole() {
 #endif
 }
 
+// build-time A/B switch (-DMST_COMP_ZS_SEPARATE): the smoother's zero-state passes as launches of their own (k_comp_zs<2>, k_comp_bwd_zs)
+// instead of block aggregates exchanged inside the run launches (mst_common.h: granules)
+static constexpr bool fuse_comp_zs() {
+#ifdef MST_COMP_ZS_SEPARATE
+    return false;
+#else
+    return true;
+#endif
+}
+
 // build-time A/B switch (-DMST_EQ_ZS_VALU): zero-state EQ passes on the vector ALU (round-2 kernels) instead of the matrix pipe
 static constexpr bool mfma_zs() {
 #ifdef MST_EQ_ZS_VALU
@@ -89,7 +99,7 @@ extern "C" int mst_console_forward(const mst_console_desc* d, const float* track
     PrepArgs pa{track_params, fx_bus_params, master_bus_params, ws + L.rc_t, ws + L.rc_m,
                 ws + L.powF_t, ws + L.powF_m, ws + L.powA_t, ws + L.powA_m, ws + L.powP_t, ws + L.powP_m,
                 ws + L.pow1F_t, ws + L.pow1F_m, ws + L.pow1A_t, ws + L.pow1A_m, ws + L.wzF_t, ws + L.wzF_m, ws + L.wzA_t, ws + L.wzA_m, fx_on ? ws + L.fx_rc : nullptr, fx_on ? ws + L.fx_mix : nullptr, status, L.R, L.bs, L.KE,
-                L.eq1, *d};
+                L.eq1, *d, (gran_t*)(ws + L.gran_f), L.gran_nf + L.gran_nb};
     launch_prep(pa, stream);
 
     // ---- tracks: EQ (zs -> carry scan -> run), compressor smoother (zs -> scan), apply + pan + bus sum
@@ -125,9 +135,9 @@ extern "C" int mst_console_forward(const mst_console_desc* d, const float* track
         else launch_cascade(EQ_FWD, false, ws + L.bus, Ns, nullptr, 0, ws + L.rc_m, 0, nullptr, ws + L.zE_m, L.ncE_pad, n, 2 * L.bs, stream, p1F_m, L.ntE, ws + L.aggF_m);
         if (!L.eq1) launch_scan12(false, ws + L.zE_m, ws + L.sE_m, ws + L.powF_m, 0, L.ncE, L.ncE_pad, L.KE, 2 * L.bs, stream);
         launch_cascade(EQ_FWD, true, ws + L.bus, Ns, ws + L.v_m, Ns, ws + L.rc_m, 0, sE_m, nullptr, L.ncE_pad, n, 2 * L.bs, stream, p1F_m, L.ntE, ws + L.aggF_m, zP_m);
-        launch_comp_zs(2, ws + L.v_m, Ns, ws + L.rc_m, ws + L.zS_m, L.ncC_pad, n, L.bs, stream);
+        if (!fuse_comp_zs()) launch_comp_zs(2, ws + L.v_m, Ns, ws + L.rc_m, ws + L.zS_m, L.ncC_pad, n, L.bs, stream);
         MasterApplyArgs ma{ws + L.v_m, Ns, ws + L.rc_m, ws + L.zS_m, save ? ws + L.gs_m : nullptr, mix, n,
-                           L.ncC_pad, d->master_lookahead, 1, n, aligned};
+                           L.ncC_pad, d->master_lookahead, 1, n, aligned, fuse_comp_zs() ? (gran_t*)(ws + L.gran_f) : nullptr};
         launch_apply_master(ma, L.bs, stream);
     } else if (o_on) {
         MasterApplyArgs ma{ws + L.bus, Ns, ws + L.rc_m, nullptr, nullptr, mix, n, L.ncC_pad, 0, 0, n, aligned};
@@ -169,7 +179,8 @@ extern "C" int mst_console_backward(const mst_console_desc* d, const float* trac
     if (m_on) {
         CompBwdArgs ca{ws + L.v_m, Ns, ws + L.gs_m, ws + L.rc_m, nullptr, ws + L.zQ_m, ws + L.du_m, ws + L.cp_m,
                        grad_mix, n, nullptr, nullptr, 0, 1, L.ncC_pad, d->master_lookahead, 1, n, aligned};
-        launch_comp_bwd(true, false, ca, L.bs, stream);
+        if (fuse_comp_zs()) ca.gran = (gran_t*)(ws + L.gran_b) + (int64_t)L.R * L.nblkC;
+        else launch_comp_bwd(true, false, ca, L.bs, stream);
         ca.s0 = ws + L.zQ_m;
         if (MST_FUSE_COEFGRAD) {  // coefficient-gradient sums of the two bus channels in the run pass (see the tracks below)
             ca.ap_s0 = ws + L.sP_m;
@@ -204,7 +215,8 @@ extern "C" int mst_console_backward(const mst_console_desc* d, const float* trac
                        gbus, gbus_stride, grad_mixed_tracks, fx_on ? ws + L.fx_din : nullptr, Ns, L.T, L.ncC_pad, d->track_lookahead,
                        t_comp ? 1 : 0, n, aligned};
         if (t_comp) {
-            launch_comp_bwd(false, false, ca, L.R, stream);
+            if (fuse_comp_zs()) ca.gran = (gran_t*)(ws + L.gran_b);
+            else launch_comp_bwd(false, false, ca, L.R, stream);
             ca.s0 = ws + L.zQ_t;
         }
         if (MST_FUSE_COEFGRAD) {
@@ -229,7 +241,8 @@ extern "C" int mst_console_backward(const mst_console_desc* d, const float* trac
     }
     PrepBwdArgs pb{track_params, master_bus_params, ws + L.rc_t, ws + L.rc_m, ws + L.cp_t, ws + L.cp_m, ws + L.ep_t, ws + L.ep_m,
                    grad_track_params, grad_master_params, fx_bus_params, fx_on ? ws + L.fx_part : nullptr,
-                   fx_on ? grad_fx_params : nullptr, L.fxBlkIr, fx_on ? ws + L.fx_mix : nullptr, fx_on ? ws + L.fx_dry : nullptr, L.fxBlk, L.R, L.bs, L.nblkC, L.nblkE, L.nblkEt, *d};
+                   fx_on ? grad_fx_params : nullptr, L.fxBlkIr, fx_on ? ws + L.fx_mix : nullptr, fx_on ? ws + L.fx_dry : nullptr, L.fxBlk, L.R, L.bs, L.nblkC, L.nblkE, L.nblkEt, *d,
+                   (gran_t*)(ws + L.gran_b), L.gran_nb};
     launch_prep_bwd(pb, stream);
     return (int)hipGetLastError();
 }

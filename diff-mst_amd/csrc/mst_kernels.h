@@ -30,6 +30,8 @@ struct PrepArgs {
     int KE;  // chunks per scan lane (EQ scans)
     int eq1; // which family of cascade tables to build (Layout::eq1)
     mst_console_desc d;
+    gran_t* gran;       // every granule array of the call (mst_common.h), zeroed here
+    int64_t gran_n;
 };
 struct PrepBwdArgs {
     const float* track_params;
@@ -50,6 +52,8 @@ struct PrepBwdArgs {
     int R, bs, nblkC, nblkE;
     int nblkEt;                            // partial rows per track row (Layout::nblkEt)
     mst_console_desc d;
+    gran_t* gran;                          // the backward's granule arrays, re-armed (zeroed) for a second backward over the same forward
+    int64_t gran_n;
 };
 void launch_prep(const PrepArgs& a, hipStream_t stream);
 void launch_prep_bwd(const PrepBwdArgs& a, hipStream_t stream);
@@ -105,6 +109,7 @@ struct MasterApplyArgs {
     int nc_pad, lookahead, comp_on;
     int64_t n;
     int aligned;
+    gran_t* gran;        // (bs, nblk) zeroed granules: the smoother's block aggregates are exchanged inside this launch (no k_comp_zs); null = read s0
 };
 // One argument block for tracks (NCH = 1) and master (NCH = 2).
 struct CompBwdArgs {
@@ -128,6 +133,7 @@ struct CompBwdArgs {
     const float* ap_s0;   // all-pole states entering every 64-sample chunk (rows, 24, ap_nc_pad)
     int ap_nc_pad;
     float* ep;            // (rows, nblkC, EP_COUNT)
+    gran_t* gran;         // (rows, nblk) zeroed granules: the run pass publishes / awaits the block aggregates itself (no zs launch); null = read s0
 };
 void launch_comp_zs(int nch, const float* u, int64_t stride, const float* rc, float* zs, int nc_pad, int64_t n, int rows,
                     hipStream_t stream);

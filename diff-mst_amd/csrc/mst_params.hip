@@ -152,6 +152,8 @@ __global__ __launch_bounds__(320) void k_prep(PrepArgs a) {
     __shared__ double dblk[2][2][kSections][4];  // diagonal 2x2 blocks of M and M^64, [set][fwd|adj][section]
     __shared__ float coef[32];
     const int row = blockIdx.x, tid = threadIdx.x;
+    // arm the granules through which later launches of this call exchange block aggregates (mst_common.h)
+    for (int64_t i = ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 320 + tid; i < a.gran_n; i += (int64_t)gridDim.x * gridDim.y * 320) a.gran[i] = 0ull;
     const bool is_master = row >= a.R;
     const int mrow = row - a.R;
     const mst_console_desc& d = a.d;
@@ -457,6 +459,8 @@ __global__ __launch_bounds__(256) void k_prep_bwd(PrepBwdArgs a) {
     __shared__ double lanesum[64][EP_COUNT + CP_COUNT + 1];  // per-lane fp64 sums of wave 0 (odd row length: conflict-free columns)
     __shared__ double Jd[kSections][5][3];                   // design Jacobians d{b0 b1 b2 a1 a2} / d{gain, freq, q}
     const int row = blockIdx.x, tid = threadIdx.x;
+    // every compressor launch of this backward has run: re-arm its granules, so that a second backward over the same forward works
+    for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < a.gran_n; i += (int64_t)gridDim.x * 256) a.gran[i] = 0ull;
     const bool is_master = row >= a.R;
     const int mrow = row - a.R;
     const mst_console_desc& d = a.d;
