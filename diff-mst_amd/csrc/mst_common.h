@@ -201,17 +201,49 @@ typedef unsigned long long gran_t;
 #ifndef MST_GRAN_SPINS
 #define MST_GRAN_SPINS (1 << 22)
 #endif
-__device__ __forceinline__ void gran_publish(gran_t* g, float v) {
-    __hip_atomic_store(g, ((gran_t)1 << 32) | (gran_t)(unsigned)__float_as_int(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// Two copies per granule.  The FAR copy is the protocol above: a write-through (sc1) store that any
+// CU of the chip will see - after a trip through the fabric, 3-5 us under load (measured: the run kernels lost 10-16 us to it).  The
+// NEAR copy is a plain store: it stays in the writer's XCD L2, where an L1-bypassing load of a workgroup ON THE SAME XCD finds it
+// within an L2 hit.  A reader polls both; a copy that shows the tag is the value (one 8-byte store each), whichever path it took,
+// so the result never depends on where the workgroups were placed - only the latency does, and the grids that exchange granules
+// are walked so that the blocks of one row share an XCD (row_block_xcd).
+#ifndef MST_GRAN_NEAR
+#define MST_GRAN_NEAR 1
+#endif
+__device__ __forceinline__ gran_t gran_load(const gran_t* g) { return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// g: the FAR copies (rows x nblk); the NEAR copies follow `near_off` granules later (0: none)
+__device__ __forceinline__ void gran_publish(gran_t* g, int64_t near_off, float v) {
+    const gran_t x = ((gran_t)1 << 32) | (gran_t)(unsigned)__float_as_int(v);
+    if (MST_GRAN_NEAR && near_off) __hip_atomic_store(g + near_off, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_store(g, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ float gran_wait(const gran_t* g) {
-    gran_t x = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+__device__ __forceinline__ float gran_wait(const gran_t* g, int64_t near_off) {
+    const bool near = MST_GRAN_NEAR && near_off;
+    gran_t x = gran_load(near ? g + near_off : g);
     for (int spins = 0; (x >> 32) != 1; ++spins) {
         if (spins >= MST_GRAN_SPINS) return __int_as_float(0x7fc00000);
-        __builtin_amdgcn_s_sleep(2);
-        x = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (near && !(spins & 1)) x = gran_load(g);  // alternate: far, near, far, ...
+        else {
+            __builtin_amdgcn_s_sleep(1);
+            x = gran_load(near ? g + near_off : g);
+        }
     }
     return __int_as_float((int)(unsigned)x);
+}
+// Grid walk of the kernels that exchange granules.  Workgroup id L = blockIdx.x + gridDim.x blockIdx.y lands on XCD L % 8 and an XCD
+// hands out its ids in ascending order (observed, MI355X_MICROARCH.md; nothing below is WRONG if it changes, see above): with rows % 8 == 0
+// row r lives on XCD r % 8, and within an XCD the blocks of a row are walked in ascending `step` - the order in which a block's
+// predecessors are dispatched before it.  Other row counts keep the plain (x = step, y = row) walk.
+__device__ __forceinline__ void row_block_xcd(int& row, int& step) {
+    const int nblk = gridDim.x, rows = gridDim.y;
+    if (rows % 8 == 0) {
+        const int L = blockIdx.x + nblk * blockIdx.y, xcd = L & 7, k = L >> 3;
+        row = (k / nblk) * 8 + xcd;
+        step = k % nblk;
+    } else {
+        row = blockIdx.y;
+        step = blockIdx.x;
+    }
 }
 
 // ---- workspace layout (element offsets in floats), computed on the host ------------------------
@@ -243,7 +275,7 @@ struct Layout {
     int64_t wzF_t, wzF_m, wzA_t, wzA_m;          // zero-state maps rows x 64 x 16: chunk end state = W^T chunk (mst_eq.hip, k_eq_zs_mfma)
     // granules (8 bytes each, float offsets here): block aggregates exchanged inside a launch.  Forward arrays first, then the
     // backward's: k_prep zeroes [gran_f, gran_f + 2 (gran_nf + gran_nb) floats), k_prep_bwd re-arms the backward part
-    int64_t gran_f, gran_b;                      // gran_f: master smoother (bs x nblkC); gran_b: adjoint smoother, tracks (R x nblkC) then master (bs x nblkC)
+    int64_t gran_f, gran_b;                      // gran_f: master smoother (bs x nblkC, twice: far + near copies); gran_b: adjoint smoother, tracks (R x nblkC, twice) then master (bs x nblkC, twice)
     int64_t gran_nf, gran_nb;                    // granule counts
     // fx bus (only laid out when MST_USE_FX_BUS is set)
     int fxS, fxTaps, fxK, fxBlk, fxBlkIr;         // impulse-response samples, band-pass taps, partitions, signal blocks, ir-bwd blocks
@@ -330,8 +362,8 @@ inline Layout make_layout(const mst_console_desc* d) {
     L.wzF_m = L.wzF_t + R * kWz;
     L.wzA_t = take((R + B) * kWz);
     L.wzA_m = L.wzA_t + R * kWz;
-    L.gran_nf = B * L.nblkC;
-    L.gran_nb = (R + B) * L.nblkC;
+    L.gran_nf = 2 * B * L.nblkC;         // far copies, then near copies (mst_common.h: gran_publish)
+    L.gran_nb = 2 * (R + B) * L.nblkC;
     L.gran_f = take(2 * (L.gran_nf + L.gran_nb));
     L.gran_b = L.gran_f + 2 * L.gran_nf;
     if (d->flags & MST_USE_FX_BUS) {

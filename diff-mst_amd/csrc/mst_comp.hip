@@ -97,22 +97,22 @@ __device__ __forceinline__ float block_carry(const float* __restrict__ agg, int 
 template <bool REV>
 __device__ __forceinline__ int carry_first(int blk, int tid) { return REV ? blk + 1 + tid : blk - 1 - tid; }
 template <bool REV>
-__device__ __forceinline__ gran_t carry_peek(const gran_t* __restrict__ agg, int blk, int nblk, int tid) {
+__device__ __forceinline__ gran_t carry_peek(const gran_t* __restrict__ agg, int64_t near_off, int blk, int nblk, int tid) {
     const int j = carry_first<REV>(blk, tid);
-    return (j >= 0 && j < nblk) ? __hip_atomic_load(agg + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+    return (j >= 0 && j < nblk) ? gran_load(agg + j + (MST_GRAN_NEAR ? near_off : 0)) : 0ull;
 }
 template <bool REV>
-__device__ __forceinline__ float block_carry_g(const gran_t* __restrict__ agg, gran_t peek, int blk, int nblk, float log2a, float* lds, int tid) {
+__device__ __forceinline__ float block_carry_g(const gran_t* __restrict__ agg, int64_t near_off, gran_t peek, int blk, int nblk, float log2a, float* lds, int tid) {
     float acc = 0.0f;
     bool first = true;
     if (REV) {
         for (int j = blk + 1 + tid; j < nblk; j += kWG, first = false) {
-            const float v = (first && (peek >> 32) == 1) ? __int_as_float((int)(unsigned)peek) : gran_wait(agg + j);
+            const float v = (first && (peek >> 32) == 1) ? __int_as_float((int)(unsigned)peek) : gran_wait(agg + j, near_off);
             acc += __builtin_amdgcn_exp2f((float)(j - blk - 1) * 256.0f * log2a) * v;
         }
     } else {
         for (int j = blk - 1 - tid; j >= 0; j -= kWG, first = false) {
-            const float v = (first && (peek >> 32) == 1) ? __int_as_float((int)(unsigned)peek) : gran_wait(agg + j);
+            const float v = (first && (peek >> 32) == 1) ? __int_as_float((int)(unsigned)peek) : gran_wait(agg + j, near_off);
             acc += __builtin_amdgcn_exp2f((float)(blk - 1 - j) * 256.0f * log2a) * v;
         }
     }
@@ -254,9 +254,9 @@ __global__ __launch_bounds__(kWG) void k_apply_tracks(TrackApplyArgs a) {
 
 // ---- forward: master bus.  grid (nblk, bs).  out = delay(v) * G * gout  (stereo-linked)
 template <bool FAST>
-__device__ __forceinline__ void apply_master_body(const MasterApplyArgs& a) {
+__device__ __forceinline__ void apply_master_body(const MasterApplyArgs& a, int b, int blk) {
     __shared__ float lds[8];
-    const int b = blockIdx.y, chunk = blockIdx.x * kWG + threadIdx.x;
+    const int chunk = blk * kWG + threadIdx.x;
     const int64_t i0 = (int64_t)chunk * CC;
     const float* rc = a.rc + (int64_t)b * RC_STRIDE;
     const float gout = rc[RC_PANL];
@@ -280,12 +280,12 @@ __device__ __forceinline__ void apply_master_body(const MasterApplyArgs& a) {
         gran_t* gr = a.gran ? a.gran + (int64_t)b * gridDim.x : nullptr;
         if (gr) {
             const float agg = block_aggregate<false>(z, l2a, lds, threadIdx.x);
-            if (threadIdx.x == 0) gran_publish(gr + blockIdx.x, agg);
+            if (threadIdx.x == 0) gran_publish(gr + blk, a.gran_near, agg);
         }
         LD8S<FAST>(v0, i0 - a.lookahead, a.n, yl);  // requested before the wait for the other blocks
         LD8S<FAST>(v1, i0 - a.lookahead, a.n, yr);
-        const float S = gr ? block_carry_g<false>(gr, carry_peek<false>(gr, blockIdx.x, gridDim.x, threadIdx.x), blockIdx.x, gridDim.x, l2a, lds, threadIdx.x)
-                           : block_carry<false>(a.s0 + (int64_t)b * gridDim.x, blockIdx.x, gridDim.x, l2a, lds, threadIdx.x);
+        const float S = gr ? block_carry_g<false>(gr, a.gran_near, carry_peek<false>(gr, a.gran_near, blk, gridDim.x, threadIdx.x), blk, gridDim.x, l2a, lds, threadIdx.x)
+                           : block_carry<false>(a.s0 + (int64_t)b * gridDim.x, blk, gridDim.x, l2a, lds, threadIdx.x);
         float s = block_enter<false>(z, ac, l2a, S, lds, threadIdx.x);
 #pragma unroll
         for (int i = 0; i < CC; ++i) {
@@ -309,8 +309,10 @@ __device__ __forceinline__ void apply_master_body(const MasterApplyArgs& a) {
     ST8<FAST>(a.out + ((int64_t)b * 2 + 1) * a.out_stride, i0, a.n, yr);
 }
 __global__ __launch_bounds__(kWG) void k_apply_master(MasterApplyArgs a) {
-    if (block_interior(a.n, a.lookahead, a.aligned)) apply_master_body<true>(a);
-    else apply_master_body<false>(a);
+    int b = blockIdx.y, blk = blockIdx.x;
+    if (a.gran) row_block_xcd(b, blk);  // the blocks of one mix on one XCD, earlier blocks dispatched first (mst_common.h)
+    if (block_interior(a.n, a.lookahead, a.aligned, blk)) apply_master_body<true>(a, b, blk);
+    else apply_master_body<false>(a, b, blk);
 }
 
 // ---- backward ------------------------------------------------------------------------------------
@@ -460,10 +462,10 @@ __device__ __forceinline__ void coefgrad_fused(const CompBwdArgs& a, int blk, in
 
 // FXS: the fx send bus is on (tracks only) - its cotangent rows are read and the send-gain sum is formed
 template <bool MASTER, bool FAST, bool FXS>
-__device__ __forceinline__ void comp_bwd_run_body(const CompBwdArgs& a, int blk, float* __restrict__ cg_u, float* __restrict__ cg_g) {
+__device__ __forceinline__ void comp_bwd_run_body(const CompBwdArgs& a, int row, int blk, float* __restrict__ cg_u, float* __restrict__ cg_g) {
     constexpr int NCH = MASTER ? 2 : 1;
     __shared__ float red[4][CP_COUNT];  // red[0] doubles as the 8-float scan scratch
-    const int tid = threadIdx.x, row = blockIdx.y, chunk = blk * kWG + tid;
+    const int tid = threadIdx.x, chunk = blk * kWG + tid;
     const int64_t i0 = (int64_t)chunk * CC;
     const float* rc = a.rc + (int64_t)row * RC_STRIDE;
     const float* u0 = a.u + (int64_t)(row * NCH) * a.stride;
@@ -507,7 +509,7 @@ __device__ __forceinline__ void comp_bwd_run_body(const CompBwdArgs& a, int blk,
         gran_t* gq = a.gran ? a.gran + (int64_t)row * gridDim.x : nullptr;
         if (gq) {
             const float agg = block_aggregate<true>(zq, l2a, red[0], tid);
-            if (tid == 0) gran_publish(gq + blk, agg);
+            if (tid == 0) gran_publish(gq + blk, a.gran_near, agg);
         }
         // look-ahead branch: du[i] += gy[i+L] * G[i+L].  Folded to one (two: master) value per sample right after the loads -
         // three arrays less are alive across the block scan (the kernel ran at 152 registers = 3 waves per SIMD)
@@ -534,7 +536,7 @@ __device__ __forceinline__ void comp_bwd_run_body(const CompBwdArgs& a, int blk,
         }
         const float g_prev0 = (i0 > 0 && i0 - 1 < a.n) ? a.gs[(int64_t)row * a.stride + i0 - 1] : 0.0f;
         // first look at the later blocks' aggregates: requested here, examined after the arithmetic below, which does not need them
-        const gran_t peek = gq ? carry_peek<true>(gq, blk, gridDim.x, tid) : 0ull;
+        const gran_t peek = gq ? carry_peek<true>(gq, a.gran_near, blk, gridDim.x, tid) : 0ull;
         // Everything that does not involve the adjoint smoother's state q (static curve, knee derivatives, the 1 / side of the side
         // chain, the pan / make-up sums) - five values per sample are kept for the short q-dependent loop behind the wait:
         //   dgc = oma q;  alpha += q A;  kappa += dgc Fv;  thr -= dgc Kp;  knee += dgc Kw;  du = dgc E + look-ahead branch
@@ -577,7 +579,7 @@ __device__ __forceinline__ void comp_bwd_run_body(const CompBwdArgs& a, int blk,
                 }
             }
         }
-        const float S = gq ? block_carry_g<true>(gq, peek, blk, gridDim.x, l2a, red[0], tid)
+        const float S = gq ? block_carry_g<true>(gq, a.gran_near, peek, blk, gridDim.x, l2a, red[0], tid)
                            : block_carry<true>(a.s0 + (int64_t)row * gridDim.x, blk, gridDim.x, l2a, red[0], tid);
         float q = block_enter<true>(zq, ac, l2a, S, red[0], tid);
 #pragma unroll
@@ -642,9 +644,13 @@ __global__ __launch_bounds__(kWG, (!MASTER && !FXS) ? 4 : MST_COMP_BWD_W) void k
     __shared__ __attribute__((aligned(16))) float cg_u[kCgTile], cg_g[kCgTile];  // one copy for both bodies
     // a.gran: the blocks a workgroup waits for (LATER in time: the adjoint smoother runs backwards) must have been dispatched before
     // it, so the grid walks the row from its end
-    const int blk = a.gran ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;
-    if (block_interior(a.n, a.lookahead, a.aligned, blk)) comp_bwd_run_body<MASTER, true, FXS>(a, blk, cg_u, cg_g);
-    else comp_bwd_run_body<MASTER, false, FXS>(a, blk, cg_u, cg_g);
+    int row = blockIdx.y, blk = blockIdx.x;
+    if (a.gran) {
+        row_block_xcd(row, blk);  // the blocks of one row on one XCD (mst_common.h)
+        blk = gridDim.x - 1 - blk;
+    }
+    if (block_interior(a.n, a.lookahead, a.aligned, blk)) comp_bwd_run_body<MASTER, true, FXS>(a, row, blk, cg_u, cg_g);
+    else comp_bwd_run_body<MASTER, false, FXS>(a, row, blk, cg_u, cg_g);
 }
 
 // ---- launch helpers ---------------------------------------------------------------------------------

@@ -48,7 +48,7 @@ static constexpr bool mfma_zs() {
 #endif
 }
 
-extern "C" int mst_abi_version(void) { return 5; }
+extern "C" int mst_abi_version(void) { return 6; }
 
 extern "C" size_t mst_console_fx_tables_bytes(void) { return (size_t)8192 * 2 * sizeof(float); }
 extern "C" int mst_console_fx_init_tables(void* tables, void* stream) {
@@ -137,12 +137,25 @@ extern "C" int mst_console_forward(const mst_console_desc* d, const float* track
         launch_cascade(EQ_FWD, true, ws + L.bus, Ns, ws + L.v_m, Ns, ws + L.rc_m, 0, sE_m, nullptr, L.ncE_pad, n, 2 * L.bs, stream, p1F_m, L.ntE, ws + L.aggF_m, zP_m);
         if (!fuse_comp_zs()) launch_comp_zs(2, ws + L.v_m, Ns, ws + L.rc_m, ws + L.zS_m, L.ncC_pad, n, L.bs, stream);
         MasterApplyArgs ma{ws + L.v_m, Ns, ws + L.rc_m, ws + L.zS_m, save ? ws + L.gs_m : nullptr, mix, n,
-                           L.ncC_pad, d->master_lookahead, 1, n, aligned, fuse_comp_zs() ? (gran_t*)(ws + L.gran_f) : nullptr};
+                           L.ncC_pad, d->master_lookahead, 1, n, aligned, fuse_comp_zs() ? (gran_t*)(ws + L.gran_f) : nullptr, (int64_t)L.bs * L.nblkC};
         launch_apply_master(ma, L.bs, stream);
     } else if (o_on) {
         MasterApplyArgs ma{ws + L.bus, Ns, ws + L.rc_m, nullptr, nullptr, mix, n, L.ncC_pad, 0, 0, n, aligned};
         launch_apply_master(ma, L.bs, stream);
     }
+    return (int)hipGetLastError();
+}
+
+extern "C" int mst_console_backward_prepare(const mst_console_desc* d, void* workspace, size_t workspace_bytes, void* stream_) {
+    if (int e = check_desc(d)) return e;
+    const Layout L = make_layout(d);
+    if (!workspace || workspace_bytes < (size_t)L.total * sizeof(float) || ((uintptr_t)workspace & 255)) return hipErrorInvalidValue;
+    if (!(d->flags & MST_SAVE_FOR_BACKWARD)) return hipErrorInvalidValue;
+    float* ws = (float*)workspace;
+    const int64_t Ns = round_up(L.N, 4);
+    const int nsig_all = L.R + ((d->flags & MST_USE_MASTER_BUS) ? 2 * L.bs : 0);
+    if (!fuse_allpole()) launch_allpole_zs(ws + L.u_t, Ns, ws + L.rc_t, L.R, ws + L.zP_t, L.ncE_pad, L.N, nsig_all, (hipStream_t)stream_);
+    launch_scan2(ws + L.zP_t, ws + L.sP_t, ws + L.powP_t, L.R, L.ncE, L.ncE_pad, L.KE, nsig_all, (hipStream_t)stream_);
     return (int)hipGetLastError();
 }
 
@@ -170,8 +183,10 @@ extern "C" int mst_console_backward(const mst_console_desc* d, const float* trac
     // ---- all-pole states of the coefficient-gradient pass depend only on what forward saved: one
     // launch covers the track rows and the master rows (signal rows [0,R) and [R,R+2bs) of the same arrays)
     const int nsig_all = L.R + (m_on ? 2 * L.bs : 0);
-    if (!fuse_allpole()) launch_allpole_zs(ws + L.u_t, Ns, ws + L.rc_t, L.R, ws + L.zP_t, L.ncE_pad, n, nsig_all, stream);
-    launch_scan2(ws + L.zP_t, ws + L.sP_t, ws + L.powP_t, L.R, L.ncE, L.ncE_pad, L.KE, nsig_all, stream);
+    if (!(d->flags & MST_BWD_PREPARED)) {  // else: mst_console_backward_prepare ran (on a side stream the caller has joined)
+        if (!fuse_allpole()) launch_allpole_zs(ws + L.u_t, Ns, ws + L.rc_t, L.R, ws + L.zP_t, L.ncE_pad, n, nsig_all, stream);
+        launch_scan2(ws + L.zP_t, ws + L.sP_t, ws + L.powP_t, L.R, L.ncE, L.ncE_pad, L.KE, nsig_all, stream);
+    }
 
     // ---- master bus: compressor adjoint, EQ adjoint (-> grad of the stereo bus)
     const float* gbus = grad_mix;  // cotangent of the stereo bus as seen by the track stage
@@ -179,7 +194,10 @@ extern "C" int mst_console_backward(const mst_console_desc* d, const float* trac
     if (m_on) {
         CompBwdArgs ca{ws + L.v_m, Ns, ws + L.gs_m, ws + L.rc_m, nullptr, ws + L.zQ_m, ws + L.du_m, ws + L.cp_m,
                        grad_mix, n, nullptr, nullptr, 0, 1, L.ncC_pad, d->master_lookahead, 1, n, aligned};
-        if (fuse_comp_zs()) ca.gran = (gran_t*)(ws + L.gran_b) + (int64_t)L.R * L.nblkC;
+        if (fuse_comp_zs()) {
+            ca.gran = (gran_t*)(ws + L.gran_b) + 2 * (int64_t)L.R * L.nblkC;
+            ca.gran_near = (int64_t)L.bs * L.nblkC;
+        }
         else launch_comp_bwd(true, false, ca, L.bs, stream);
         ca.s0 = ws + L.zQ_m;
         if (MST_FUSE_COEFGRAD) {  // coefficient-gradient sums of the two bus channels in the run pass (see the tracks below)
@@ -215,7 +233,10 @@ extern "C" int mst_console_backward(const mst_console_desc* d, const float* trac
                        gbus, gbus_stride, grad_mixed_tracks, fx_on ? ws + L.fx_din : nullptr, Ns, L.T, L.ncC_pad, d->track_lookahead,
                        t_comp ? 1 : 0, n, aligned};
         if (t_comp) {
-            if (fuse_comp_zs()) ca.gran = (gran_t*)(ws + L.gran_b);
+            if (fuse_comp_zs()) {
+                ca.gran = (gran_t*)(ws + L.gran_b);
+                ca.gran_near = (int64_t)L.R * L.nblkC;
+            }
             else launch_comp_bwd(false, false, ca, L.R, stream);
             ca.s0 = ws + L.zQ_t;
         }

@@ -109,7 +109,8 @@ struct MasterApplyArgs {
     int nc_pad, lookahead, comp_on;
     int64_t n;
     int aligned;
-    gran_t* gran;        // (bs, nblk) zeroed granules: the smoother's block aggregates are exchanged inside this launch (no k_comp_zs); null = read s0
+    gran_t* gran;        // (bs, nblk) zeroed granules (+ their near copies gran_near granules later): the smoother's block aggregates are exchanged inside this launch (no k_comp_zs); null = read s0
+    int64_t gran_near;
 };
 // One argument block for tracks (NCH = 1) and master (NCH = 2).
 struct CompBwdArgs {
@@ -133,7 +134,8 @@ struct CompBwdArgs {
     const float* ap_s0;   // all-pole states entering every 64-sample chunk (rows, 24, ap_nc_pad)
     int ap_nc_pad;
     float* ep;            // (rows, nblkC, EP_COUNT)
-    gran_t* gran;         // (rows, nblk) zeroed granules: the run pass publishes / awaits the block aggregates itself (no zs launch); null = read s0
+    gran_t* gran;         // (rows, nblk) zeroed granules (+ near copies gran_near granules later): the run pass publishes / awaits the block aggregates itself (no zs launch); null = read s0
+    int64_t gran_near;
 };
 void launch_comp_zs(int nch, const float* u, int64_t stride, const float* rc, float* zs, int nc_pad, int64_t n, int rows,
                     hipStream_t stream);

@@ -22,8 +22,9 @@ USE_OUTPUT_FADER = 0x40
 SAVE_FOR_BACKWARD = 0x100
 DEV_MULTIPASS_EQ = 0x200
 NO_RANGE_CHECK = 0x400
+BWD_PREPARED = 0x800
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class ConsoleDesc(C.Structure):
@@ -111,6 +112,7 @@ SIGNATURES = {
     "mst_console_forward": (C.c_int, [C.POINTER(ConsoleDesc), _P, _P, _P, _P, C.POINTER(ConsoleFx), _P, _P, _P, _P, C.c_size_t, _P]),
     "mst_console_backward": (C.c_int, [C.POINTER(ConsoleDesc), _P, _P, _P, _P, C.POINTER(ConsoleFx), _P, _P, _P, _P, _P, _P, _P,
                                        C.c_size_t, _P]),
+    "mst_console_backward_prepare": (C.c_int, [C.POINTER(ConsoleDesc), _P, C.c_size_t, _P]),
     "mst_mrstft_tables_bytes": (C.c_size_t, [C.POINTER(MrstftDesc)]),
     "mst_mrstft_init_tables": (C.c_int, [C.POINTER(MrstftDesc), _P, _P]),
     "mst_mrstft_workspace_bytes": (C.c_size_t, [C.POINTER(MrstftDesc)]),

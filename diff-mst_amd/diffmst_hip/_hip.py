@@ -44,6 +44,12 @@ def require_cuda(*tensors):
             )
 
 
+def require_same_device(device, *tensors):
+    for t in tensors:
+        if t is not None and t.device != device:
+            raise RuntimeError(f"mst (MI355X build): every tensor of a call must live on {device} (got one on {t.device})")
+
+
 def check(rc: int, what: str):
     if rc != 0:
         raise RuntimeError(f"{what} failed with hipError {rc}")

@@ -15,14 +15,24 @@ _PARAM_NAMES = ("self_attn.in_proj_weight", "self_attn.in_proj_bias", "self_attn
 
 def layer_parameters(encoder: torch.nn.TransformerEncoder):
     """The twelve parameters of every layer, in ``mst_ctrl_layer`` order (a flat list, layer-major)."""
-    cached = encoder.__dict__.get("_mst_layer_parameters")  # the Parameter objects of a module are stable; 144 dict walks per call are not free
-    if cached is not None and len(cached) == len(_PARAM_NAMES) * len(encoder.layers):
-        return cached
-    flat = []
+    # 144 attribute walks per call are not free, so the list is cached - and validated by IDENTITY against the modules' own parameter
+    # dictionaries (load_state_dict(assign=True), parametrizations, swap_tensors or a plain `layer.linear1.weight = ...` replace the
+    # objects; a stale list would compute with, and route gradients to, tensors the module no longer owns)
+    cached = encoder.__dict__.get("_mst_layer_parameters")
+    if cached is not None and len(cached[0]) == len(_PARAM_NAMES) * len(encoder.layers):
+        flat, owners = cached
+        if all(o[k] is p for (o, k), p in zip(owners, flat)):
+            return flat
+    flat, owners = [], []
     for layer in encoder.layers:
-        named = dict(layer.named_parameters())
-        flat.extend(named[n] for n in _PARAM_NAMES)
-    encoder.__dict__["_mst_layer_parameters"] = flat
+        for n in _PARAM_NAMES:
+            *path, leaf = n.split(".")
+            mod = layer
+            for part in path:
+                mod = getattr(mod, part)
+            flat.append(mod._parameters[leaf])
+            owners.append((mod._parameters, leaf))
+    encoder.__dict__["_mst_layer_parameters"] = (flat, owners)
     return flat
 
 
@@ -57,9 +67,10 @@ def _layer_array(tensors, n_layers):
 class _EncoderStack(torch.autograd.Function):
     @staticmethod
     def forward(ctx, tokens, mask, desc, *params):
-        _hip.require_cuda(tokens)
+        _hip.require_cuda(tokens, mask, *params)  # host pointers must raise here, not fault on the device
         lib = _hip.lib()
         dev = tokens.device
+        _hip.require_same_device(dev, mask, *params)
         x = tokens.float().contiguous()
         ps = [p.detach() if (p.dtype is torch.float32 and p.is_contiguous()) else p.detach().float().contiguous() for p in params]
         m = None  # (bs, seq) bytes, non-zero = padded key; a bool tensor is viewed, not converted

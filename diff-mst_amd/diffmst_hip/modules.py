@@ -95,6 +95,18 @@ class _LazyParamDict(Mapping):
         return dict(self._fill())
 
 
+_AUX_STREAMS = {}
+
+
+def _aux_stream(dev):
+    """One side stream per device for work that overlaps the caller's stream (``mst_console_backward_prepare``)."""
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    s = _AUX_STREAMS.get(key)
+    if s is None:
+        s = _AUX_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return s
+
+
 class _ConsoleFunction(torch.autograd.Function):
     """One fused forward / backward pair over the C ABI (mst_console_forward / _backward)."""
 
@@ -140,6 +152,17 @@ class _ConsoleFunction(torch.autograd.Function):
             )
         _hip.check(rc, "mst_console_forward")
         console._note_status(status)
+        ctx.prep_event = None
+        if need_grad and console.overlap_backward_prepare and not torch.cuda.is_current_stream_capturing():
+            # The first 15 us of the backward (all-pole carry scan) depend only on what forward saved: queue them on a side stream
+            # now, where they run beside whatever the caller puts between the two calls (the loss), instead of on the critical path.
+            cur, aux = torch.cuda.current_stream(dev), _aux_stream(dev)
+            aux.wait_stream(cur)
+            with torch.cuda.device(dev):
+                rc = lib.mst_console_backward_prepare(ctypes.byref(desc), _cabi.ptr(ws), nbytes, ctypes.c_void_p(aux.cuda_stream))
+            _hip.check(rc, "mst_console_backward_prepare")
+            ctx.prep_event = aux.record_event()
+            ws.record_stream(aux)
         if need_grad:
             ctx.desc, ctx.nbytes, ctx.dev = desc, nbytes, dev
             ctx.want_mixed = want_mixed
@@ -169,6 +192,11 @@ class _ConsoleFunction(torch.autograd.Function):
         if ctx.fx_on:
             fx = _cabi.ConsoleFx(None, None, fx_keep[0].data_ptr())
             g_fx = torch.empty(bs, _cabi.NUM_FX_PARAMS, dtype=torch.float32, device=dev)
+        if ctx.prep_event is not None:  # mst_console_backward_prepare ran on the side stream: join it, skip it below
+            torch.cuda.current_stream(dev).wait_event(ctx.prep_event)
+            prepared = _cabi.ConsoleDesc.from_buffer_copy(desc)
+            prepared.flags |= _cabi.BWD_PREPARED
+            desc = prepared
         # fx bus off: the fx parameters never reach the mix - their gradient is None, as in the reference (no zero fill)
         with torch.cuda.device(dev):
             rc = lib.mst_console_backward(
@@ -195,6 +223,13 @@ class AdvancedMixConsole(torch.nn.Module):
       param_dicts                "eager" : the three returned parameter dictionaries are built during the
                                            call, like the reference (three small affine-map launches);
                                  "lazy"  : read-only mappings computed on first access.
+      overlap_backward_prepare   False   : everything on the caller's stream (default).
+                                 True    : a forward that saves for backward queues the part of the backward that depends on
+                                           nothing but the forward (``mst_console_backward_prepare``, 15 us) on a side stream, where
+                                           it overlaps with the loss; the backward joins it.  Same arithmetic, same results.
+                                           Measured on MI355X / ROCm 7.2 (tools/overlap_probe.py, cfg #2 step): 0.567 ms against
+                                           0.555 ms without - the two cross-stream dependencies cost more than the 15 us they
+                                           hide; kept for stacks where an event wait is cheaper.
     """
 
     def __init__(
@@ -217,9 +252,11 @@ class AdvancedMixConsole(torch.nn.Module):
         materialize_mixed_tracks: bool = True,
         validate: str = "sync",
         param_dicts: str = "eager",
+        overlap_backward_prepare: bool = False,
     ):
         super().__init__()
         self.sample_rate = sample_rate
+        self.overlap_backward_prepare = bool(overlap_backward_prepare)
         top = (sample_rate // 2) - 1000
         eq_freq = {
             "low_shelf": (20, 2000), "band0": (80, 2000), "band1": (2000, 8000),
@@ -485,12 +522,17 @@ class SpectrogramEncoder(torch.nn.Module):
 
     The STFT runs on the register-radix FFT engine of the loss kernels (``mst_spectrogram_forward``), the CNN on the matrix
     cores (``diffmst_hip.panns.Cnn14``); same constructor keywords, same ``window`` buffer and ``model.*`` parameter names as
-    the reference, so its checkpoints load.  ``precision`` ("bf16" | "fp32") is an extra keyword (see ``Cnn14``)."""
+    the reference, so its checkpoints load.  ``precision`` ("fp32" = the reference's arithmetic, the default | "bf16", opt-in) is an
+    extra keyword (see ``Cnn14``; ``MST_ENCODER_PRECISION`` sets the default for an unmodified YAML).
+
+    The waveform is NOT differentiated through (the reference's ``torch.stft`` is): nothing in the reference asks for that gradient -
+    the encoders see input audio, the loss reaches them through the controller - so a waveform that requires grad raises instead of
+    silently receiving none."""
 
     _TABLES = {}
 
     def __init__(self, embed_dim: int = 128, n_inputs: int = 1, n_fft: int = 2048, hop_length: int = 512,
-                 input_batchnorm: bool = False, encoder_batchnorm: bool = True, precision: str = "bf16") -> None:
+                 input_batchnorm: bool = False, encoder_batchnorm: bool = True, precision: str | None = None) -> None:
         super().__init__()
         from .panns import Cnn14
 
@@ -517,6 +559,9 @@ class SpectrogramEncoder(torch.nn.Module):
             with torch.cuda.device(dev):
                 _hip.check(lib.mst_spectrogram_init_tables(_cabi.ptr(tables), _hip.current_stream_ptr(dev)), "mst_spectrogram_init_tables")
             self._TABLES[key] = tables
+        if x.requires_grad and torch.is_grad_enabled():
+            raise NotImplementedError("SpectrogramEncoder (MI355X build): the STFT front end has no adjoint - the waveform gets no gradient "
+                                      "(the reference never asks for one); detach() the input or run under torch.no_grad()")
         x = x.detach().float().contiguous()
         rows, n = x.shape
         spec = torch.empty(rows, 1 + n // self.hop_length, self.n_fft // 2 + 1, dtype=torch.float32, device=dev)

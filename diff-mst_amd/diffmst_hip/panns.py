@@ -7,8 +7,9 @@ the twelve 3x3 convolutions (implicit GEMM on MFMA), BatchNorm, ReLU, average po
 all run in ``csrc/mst_cnn*.hip`` through ``mst_cnn14_forward`` / ``mst_cnn14_backward`` (include/diffmst_hip.h), forward and
 reverse mode; autograd sees ONE function.
 
-``precision``: ``"bf16"`` (default) - bf16 operands and activations, fp32 accumulation / statistics / gradients;
-``"fp32"`` - fp32 operands on the fp32 MFMA (the parity setting).
+``precision``: ``"fp32"`` (default, the reference's ``precision: 32``, configs/config.yaml:42) - fp32 operands on the fp32 MFMA;
+``"bf16"`` (opt-in: constructor keyword, or ``MST_ENCODER_PRECISION=bf16`` in the environment for an unmodified YAML) - bf16 operands and
+activations, fp32 accumulation / statistics / gradients: 2x faster, training-mode weight gradients 20-40 % from the fp32 ones.
 """
 from __future__ import annotations
 
@@ -23,6 +24,16 @@ from . import _cabi, _hip
 _CHANNELS = (64, 128, 256, 512, 1024, 2048)
 # pool sizes over (bins, frames) as the reference passes them (mst/panns.py:186-197)
 POOL_SIZES = ((2, 2), (4, 4), (4, 2), (4, 2), (4, 2), (2, 2))
+
+
+def default_precision() -> str:
+    """The encoder precision of a model built without the keyword: fp32 like the reference, unless the environment opts in."""
+    import os
+
+    p = os.environ.get("MST_ENCODER_PRECISION", "fp32")
+    if p not in ("bf16", "fp32"):
+        raise ValueError("MST_ENCODER_PRECISION must be 'bf16' or 'fp32'")
+    return p
 
 
 def init_layer(layer):
@@ -61,9 +72,13 @@ class _Cnn14Function(torch.autograd.Function):
     @staticmethod
     def forward(ctx, spec, module, training, *params):
         """spec (n, frames, bins) fp32; params = 12 conv weights, 12 BN weights, 12 BN biases, fc weight, fc bias."""
-        _hip.require_cuda(spec)
+        bns = module._bns()
+        # every pointer below goes straight to the kernels: a model left on the host (load_diffmst maps checkpoints to the CPU) must
+        # raise here, not fault on the device
+        _hip.require_cuda(spec, *params, *(bn.running_mean for bn in bns), *(bn.running_var for bn in bns))
         lib = _hip.lib()
         dev = spec.device
+        _hip.require_same_device(dev, *params, *(bn.running_mean for bn in bns), *(bn.running_var for bn in bns))
         n, frames, bins = spec.shape
         desc = _cabi.Cnn14Desc(n, frames, bins, module.fc.out_features, 0 if module.precision == "bf16" else 1, int(training),
                                float(module.conv_block1.bn1.eps))
@@ -72,7 +87,6 @@ class _Cnn14Function(torch.autograd.Function):
             raise ValueError(f"Cnn14: unsupported spectrogram size {(frames, bins)} (six pooling stages need >= 128 frames x 1024 bins)")
         convs, gammas, betas = params[0:12], params[12:24], params[24:36]
         fc_w, fc_b = params[36], params[37]
-        bns = module._bns()
         keep = [t.detach().float().contiguous() for t in (*convs, *gammas, *betas, fc_w, fc_b)]
         rmean = [bn.running_mean.detach().float().contiguous() for bn in bns]
         rvar = [bn.running_var.detach().float().contiguous() for bn in bns]
@@ -125,8 +139,9 @@ class _Cnn14Function(torch.autograd.Function):
 class Cnn14(nn.Module):
     """Drop-in for reference ``mst.panns.Cnn14`` (:126-209): ``(bs, 1, bins, frames)`` spectrogram -> ``(bs, num_classes)``."""
 
-    def __init__(self, num_classes: int, n_inputs: int = 1, use_batchnorm: bool = True, precision: str = "bf16"):
+    def __init__(self, num_classes: int, n_inputs: int = 1, use_batchnorm: bool = True, precision: str | None = None):
         super().__init__()
+        precision = default_precision() if precision is None else precision
         if n_inputs != 1:
             raise NotImplementedError("n_inputs = 1 (the reference's SpectrogramEncoder default) is what the first-layer kernel is built for")
         if precision not in ("bf16", "fp32"):

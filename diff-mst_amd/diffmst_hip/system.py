@@ -45,7 +45,10 @@ class CommonStep(torch.nn.Module):
         # "sync" = the reference's `if torch.isnan(ref_mix).any(): raise` (:178-180): one device -> host readback in the middle
         # of every step, after which the GPU idles until the host has issued the encoder's first kernels.  "deferred" keeps the
         # flag on the device: `check_finite()` - called at the top of the NEXT step, when the flag has long been written -
-        # raises the same ValueError one step later and the host never waits (cfg #5: DESIGN 9.5).
+        # raises the same ValueError one step later and the host never waits (cfg #5: DESIGN 9.5).  The reference aborts BEFORE
+        # backward; with "deferred" the caller owns that guarantee: call `check_finite()` before `optimizer.step()` (it costs the
+        # readback then, but after the backward has been queued) and once more when the loop ends, otherwise the flag of the last
+        # step is never looked at and an optimizer step on a NaN batch goes through (bench.py and tools/cfg5_step.py do both).
         self.nan_check = nan_check
         self._nan_flag = None
         self.model = model
@@ -96,7 +99,8 @@ class CommonStep(torch.nn.Module):
         )
 
     def check_finite(self):
-        """Deferred NaN guard: raise the reference's ValueError if a reference mix of an earlier step held a NaN."""
+        """Deferred NaN guard: raise the reference's ValueError if a reference mix of an earlier step held a NaN.  Runs at the top
+        of every forward(); with nan_check="deferred" the training loop calls it again before ``optimizer.step()`` and at loop end."""
         flag, self._nan_flag = self._nan_flag, None
         if flag is not None and bool(flag):
             raise ValueError("Found nan in ref_mix")

@@ -87,8 +87,9 @@ def run_diffmst(tracks: torch.Tensor, ref: torch.Tensor, model: torch.nn.Module,
     hopping by 131072, each faded with a periodic Hann window (the first window's first half held at 1) and overlap-added.
 
     Differences, all outside the arithmetic: the caller's ``tracks`` is not scaled in place (the reference's ``track *= ...``
-    writes through a view); the console windows run on ``device`` (default: the model's device if it is a GPU, else the
-    current GPU) and ``pred_mix`` comes back on ``tracks.device``; ``loudness_fn(ndarray (n, 1)) -> float`` replaces the
+    writes through a view); model and console windows run on ``device`` (default: the model's device if it is a GPU, else the
+    current GPU; a model still on the host - what ``load_diffmst`` returns - is moved there with ``model.to(device)``) and
+    ``pred_mix`` comes back on ``tracks.device``; ``loudness_fn(ndarray (n, 1)) -> float`` replaces the
     pyloudnorm meter where that package is absent (it is host-side in the reference too)."""
     if tracks.dim() != 3 or tracks.shape[0] != 1:
         raise ValueError("tracks must be (1, num_tracks, seq_len)")  # the reference's squeeze(0) / zeros(1, 2, n) fix bs = 1
@@ -98,6 +99,11 @@ def run_diffmst(tracks: torch.Tensor, ref: torch.Tensor, model: torch.nn.Module,
         p = next(iter(model.parameters()), None) if isinstance(model, torch.nn.Module) else None
         device = p.device if p is not None and p.is_cuda else torch.device("cuda", torch.cuda.current_device())
     device = torch.device(device)
+    if isinstance(model, torch.nn.Module):
+        # load_diffmst returns the model on the host (map_location="cpu", like the reference, which runs there); this package has no
+        # host path, so the model follows the audio onto the device - in place, like nn.Module.to
+        if any(t.device != device for t in (*model.parameters(), *model.buffers())):
+            model.to(device)
     n = tracks.shape[-1]
     if n >= ANALYSIS_LEN:
         analysis_tracks = tracks[..., track_start_idx:track_start_idx + ANALYSIS_LEN]

@@ -48,6 +48,7 @@ extern "C" {
                                        mst/modules.py:186-314, which applies whatever it is given): no range check; the
                                        caller passes lo = 0, hi = 1 so that the map v*(hi-lo)+lo is the identity and the
                                        returned gradients are w.r.t. the denormalised values */
+#define MST_BWD_PREPARED 0x800u     /* mst_console_backward only: mst_console_backward_prepare has already run on this workspace */
 #define MST_DEV_MULTIPASS_EQ 0x200u /* developer/test switch: keep the EQ carry scan in its own kernel (zero-state pass,
                                        carry scan, run) even when a row is short enough (<= 262144 samples) for the
                                        in-wave scans of the two-kernel path; longer rows always take three kernels */
@@ -132,6 +133,12 @@ int mst_console_backward(const mst_console_desc* d, const float* tracks, const f
                          const float* grad_mix, const float* grad_mixed_tracks, float* grad_track_params,
                          float* grad_fx_params, float* grad_master_params, float* grad_tracks, void* workspace,
                          size_t workspace_bytes, void* stream);
+
+/* The part of the backward that depends only on what forward saved (the all-pole carry scan of the coefficient-gradient
+ * pass, 15 us at 64 x 262144): a caller may enqueue it on ANOTHER stream once forward has finished there, where it overlaps
+ * with whatever runs between the two calls (the loss), make `stream` of mst_console_backward wait for it and pass
+ * MST_BWD_PREPARED in d->flags.  Without the flag mst_console_backward runs it itself.  (diffmst_hip/modules.py does this.) */
+int mst_console_backward_prepare(const mst_console_desc* d, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Multi-resolution STFT loss: auraloss.freq.MultiResolutionSTFTLoss as configured by the
