@@ -257,6 +257,8 @@ struct Layout {
     int KE, KC;              // chunks per scan thread
     int ntE;                 // 4096-sample EQ tiles per row
     int eq1;                 // 1: EQ carries scanned inside the zs / run kernels, 0: separate carry-scan kernel
+    int apscan_fwd;          // 1: the track rows' all-pole carry scan rides on the master-bus forward run (mst_eq.hip), the backward scans the master rows only
+    int apscan_sh;           // 64 = KE 2^apscan_sh
     // offsets
     int64_t rc_t, rc_m;                  // row constants
     int64_t powF_t, powF_m;              // forward cascade scan tables  rows x kPow x 144
@@ -301,6 +303,18 @@ inline Layout make_layout(const mst_console_desc* d) {
     L.KC = (L.ncC + kScanThreads - 1) / kScanThreads;
     L.ntE = (int)((L.N + kTile - 1) / kTile);
     L.eq1 = (L.ntE <= kMaxTiles1 && !(d->flags & MST_DEV_MULTIPASS_EQ)) ? 1 : 0;
+    {   // needs: one tile of chunk states per row (= eq1), KE a power of two <= 64 (the k_scan tables hold (P^KE)^(2^j)), a master-bus run to ride on
+        int sh = 0;
+        while ((L.KE << sh) < 64) ++sh;
+        const bool pow2 = (L.KE << sh) == 64;
+#ifdef MST_APSCAN_SEPARATE
+        const bool on = false;
+#else
+        const bool on = true;
+#endif
+        L.apscan_fwd = (on && L.eq1 && pow2 && (d->flags & MST_USE_MASTER_BUS) && (d->flags & MST_SAVE_FOR_BACKWARD)) ? 1 : 0;
+        L.apscan_sh = sh;
+    }
     int64_t o = 0;
     auto take = [&](int64_t n) {
         int64_t at = o;

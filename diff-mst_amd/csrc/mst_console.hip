@@ -134,7 +134,11 @@ extern "C" int mst_console_forward(const mst_console_desc* d, const float* track
         if (L.eq1 && mfma_zs()) launch_eq_zs_mfma(EQ_FWD, ws + L.bus, Ns, ws + L.wzF_m, 0, ws + L.zE_m, L.ncE_pad, n, 2 * L.bs, stream, p1F_m, L.ntE, ws + L.aggF_m);
         else launch_cascade(EQ_FWD, false, ws + L.bus, Ns, nullptr, 0, ws + L.rc_m, 0, nullptr, ws + L.zE_m, L.ncE_pad, n, 2 * L.bs, stream, p1F_m, L.ntE, ws + L.aggF_m);
         if (!L.eq1) launch_scan12(false, ws + L.zE_m, ws + L.sE_m, ws + L.powF_m, 0, L.ncE, L.ncE_pad, L.KE, 2 * L.bs, stream);
-        launch_cascade(EQ_FWD, true, ws + L.bus, Ns, ws + L.v_m, Ns, ws + L.rc_m, 0, sE_m, nullptr, L.ncE_pad, n, 2 * L.bs, stream, p1F_m, L.ntE, ws + L.aggF_m, zP_m);
+        if (L.apscan_fwd && zP_m && zP_t && p1F_m)  // + the track rows' all-pole carry scan as extra workgroups of this (one wave per SIMD) launch
+            launch_master_run_apscan(ws + L.bus, Ns, ws + L.v_m, Ns, ws + L.rc_m, sE_m, L.ncE_pad, n, 2 * L.bs, stream, p1F_m, L.ntE, ws + L.aggF_m, zP_m,
+                                     ws + L.zP_t, ws + L.sP_t, ws + L.powP_t, L.R * 12, L.ncE, L.apscan_sh);
+        else
+            launch_cascade(EQ_FWD, true, ws + L.bus, Ns, ws + L.v_m, Ns, ws + L.rc_m, 0, sE_m, nullptr, L.ncE_pad, n, 2 * L.bs, stream, p1F_m, L.ntE, ws + L.aggF_m, zP_m);
         if (!fuse_comp_zs()) launch_comp_zs(2, ws + L.v_m, Ns, ws + L.rc_m, ws + L.zS_m, L.ncC_pad, n, L.bs, stream);
         MasterApplyArgs ma{ws + L.v_m, Ns, ws + L.rc_m, ws + L.zS_m, save ? ws + L.gs_m : nullptr, mix, n,
                            L.ncC_pad, d->master_lookahead, 1, n, aligned, fuse_comp_zs() ? (gran_t*)(ws + L.gran_f) : nullptr, (int64_t)L.bs * L.nblkC};
@@ -146,6 +150,16 @@ extern "C" int mst_console_forward(const mst_console_desc* d, const float* track
     return (int)hipGetLastError();
 }
 
+// carry scan of the all-pole bank's chunk states: every row, or - when the forward's master-bus run already carried the track rows'
+// (Layout::apscan_fwd) - the master rows only
+static void allpole_scan(const Layout& L, float* ws, int nsig_all, hipStream_t stream) {
+    if (L.apscan_fwd && fuse_allpole()) {
+        if (nsig_all > L.R) launch_scan2(ws + L.zP_m, ws + L.sP_m, ws + L.powP_m, 0, L.ncE, L.ncE_pad, L.KE, nsig_all - L.R, stream);
+    } else {
+        launch_scan2(ws + L.zP_t, ws + L.sP_t, ws + L.powP_t, L.R, L.ncE, L.ncE_pad, L.KE, nsig_all, stream);
+    }
+}
+
 extern "C" int mst_console_backward_prepare(const mst_console_desc* d, void* workspace, size_t workspace_bytes, void* stream_) {
     if (int e = check_desc(d)) return e;
     const Layout L = make_layout(d);
@@ -155,7 +169,7 @@ extern "C" int mst_console_backward_prepare(const mst_console_desc* d, void* wor
     const int64_t Ns = round_up(L.N, 4);
     const int nsig_all = L.R + ((d->flags & MST_USE_MASTER_BUS) ? 2 * L.bs : 0);
     if (!fuse_allpole()) launch_allpole_zs(ws + L.u_t, Ns, ws + L.rc_t, L.R, ws + L.zP_t, L.ncE_pad, L.N, nsig_all, (hipStream_t)stream_);
-    launch_scan2(ws + L.zP_t, ws + L.sP_t, ws + L.powP_t, L.R, L.ncE, L.ncE_pad, L.KE, nsig_all, (hipStream_t)stream_);
+    allpole_scan(L, ws, nsig_all, (hipStream_t)stream_);
     return (int)hipGetLastError();
 }
 
@@ -185,7 +199,7 @@ extern "C" int mst_console_backward(const mst_console_desc* d, const float* trac
     const int nsig_all = L.R + (m_on ? 2 * L.bs : 0);
     if (!(d->flags & MST_BWD_PREPARED)) {  // else: mst_console_backward_prepare ran (on a side stream the caller has joined)
         if (!fuse_allpole()) launch_allpole_zs(ws + L.u_t, Ns, ws + L.rc_t, L.R, ws + L.zP_t, L.ncE_pad, n, nsig_all, stream);
-        launch_scan2(ws + L.zP_t, ws + L.sP_t, ws + L.powP_t, L.R, L.ncE, L.ncE_pad, L.KE, nsig_all, stream);
+        allpole_scan(L, ws, nsig_all, stream);
     }
 
     // ---- master bus: compressor adjoint, EQ adjoint (-> grad of the stereo bus)

@@ -395,6 +395,130 @@ void launch_eq_zs_mfma(int dir, const float* in, int64_t in_stride, const float*
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_eq_zs_mfma<EQ_ADJ>), grid, block, 0, stream, in, in_stride, wz, split, z, nc_pad, n, pw1, ntiles, agg);
 }
 
+// ---- the all-pole bank's carry scan by ONE wave, riding on the master-bus forward run (round 4) -------------------------------
+// k_scan<2> (mst_scan.hip) opened every backward with 15 us of its own; all it needs is what the TRACK rows' forward run left
+// (zero-state chunk end states zp), and the launch that follows - the 16-row master EQ run - keeps one wave per SIMD busy and the
+// memory system idle.  So the scan of the track rows' 12 R two-state systems rides there as extra one-wave workgroups: a row of
+// <= 4096 chunk states is exactly one "tile" of the slab machinery above (lane l owns chunks 64 l .. 64 l + 63, staged through LDS
+// in 16-element slabs, HBM sees coalesced 16-byte accesses):
+//   pass 1  fold the lane's 64 chunks from zero:  s <- P s + z_c                      (P = A_f^64, table entry 0)
+//   scan    inclusive Hillis-Steele over the lanes with P^(64 2^j) = table entry 1 + sh + j, 64 = KE 2^sh (the tables k_prep makes
+//           for k_scan: (P^KE)^(2^j)), exclusive shift -> the state entering the lane's first chunk
+//   pass 2  replay from there, emitting the state ENTERING every chunk in the layout k_coefgrad / coefgrad_fused read.
+// Same recurrences, same fp32 products as k_scan; the association of the lane-level scan differs (64 x 64 instead of 512 x 8).
+template <bool FAST>
+__device__ __forceinline__ void allpole_scan_tile(const float* __restrict__ z0, float* __restrict__ o0, const float* __restrict__ tab, int nc,
+                                                  int nc_pad, int sh, float* __restrict__ tileA, float* __restrict__ tileB, int tid) {
+    const float* z1 = z0 + nc_pad;
+    float* o1 = o0 + nc_pad;
+    // the whole row in ONE memory round trip (2 x 4 slabs = 32 float4 per lane; the host kernel's register allocation - the cascade's -
+    // is the budget) and kept for the replay: a lone wave has nothing else to hide a second trip behind
+    SlabRegs ra[kNSlab], rb[kNSlab];
+#pragma unroll
+    for (int j = 0; j < kNSlab; ++j) {
+        slab_fetch<FAST>(ra[j], z0, 0, j, nc, tid);
+        slab_fetch<FAST>(rb[j], z1, 0, j, nc, tid);
+    }
+    const float p00 = tab[0], p01 = tab[1], p10 = tab[2], p11 = tab[3];
+    float a = 0.0f, b = 0.0f;
+    float* mineA = &tileA[tid * kLdw];
+    float* mineB = &tileB[tid * kLdw];
+#pragma unroll
+    for (int j = 0; j < kNSlab; ++j) {
+        slab_stash(ra[j], tileA, tid);
+        slab_stash(rb[j], tileB, tid);
+        wave_lds_sync();
+#pragma unroll
+        for (int i4 = 0; i4 < kSlab; i4 += 4) {
+            const float4 va = *reinterpret_cast<const float4*>(&mineA[i4]), vb = *reinterpret_cast<const float4*>(&mineB[i4]);
+            const float xa[4] = {va.x, va.y, va.z, va.w}, xb[4] = {vb.x, vb.y, vb.z, vb.w};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float na = fmaf(p01, b, fmaf(p00, a, xa[t])), nb = fmaf(p11, b, fmaf(p10, a, xb[t]));
+                a = na;
+                b = nb;
+            }
+        }
+        wave_lds_sync();
+    }
+    const int lanes = (nc + kEqChunk - 1) / kEqChunk;
+    for (int j = 0; (1 << j) < lanes; ++j) {
+        const float* T = tab + (1 + sh + j) * 4;
+        const float oa = __shfl_up(a, 1 << j), ob = __shfl_up(b, 1 << j);
+        if (tid >= (1 << j)) {
+            a = fmaf(T[1], ob, fmaf(T[0], oa, a));
+            b = fmaf(T[3], ob, fmaf(T[2], oa, b));
+        }
+    }
+    float ea = __shfl_up(a, 1), eb = __shfl_up(b, 1);
+    if (tid == 0) ea = eb = 0.0f;
+#pragma unroll
+    for (int j = 0; j < kNSlab; ++j) {
+        slab_stash(ra[j], tileA, tid);
+        slab_stash(rb[j], tileB, tid);
+        wave_lds_sync();
+#pragma unroll
+        for (int i4 = 0; i4 < kSlab; i4 += 4) {
+            const float4 va = *reinterpret_cast<const float4*>(&mineA[i4]), vb = *reinterpret_cast<const float4*>(&mineB[i4]);
+            const float xa[4] = {va.x, va.y, va.z, va.w}, xb[4] = {vb.x, vb.y, vb.z, vb.w};
+            float ya[4], yb[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                ya[t] = ea;
+                yb[t] = eb;
+                const float na = fmaf(p01, eb, fmaf(p00, ea, xa[t])), nb = fmaf(p11, eb, fmaf(p10, ea, xb[t]));
+                ea = na;
+                eb = nb;
+            }
+            *reinterpret_cast<float4*>(&mineA[i4]) = make_float4(ya[0], ya[1], ya[2], ya[3]);
+            *reinterpret_cast<float4*>(&mineB[i4]) = make_float4(yb[0], yb[1], yb[2], yb[3]);
+        }
+        wave_lds_sync();
+        slab_store<FAST>(tileA, o0, 0, j, nc, tid);
+        slab_store<FAST>(tileB, o1, 0, j, nc, tid);
+        wave_lds_sync();
+    }
+}
+
+struct ApScanArgs {       // the scan jobs riding on a launch: job q = two-state system (signal row q / 12, filter q % 12)
+    const float* z;       // (jobs, 2, nc_pad) zero-state chunk end states
+    float* s0;            // (jobs, 2, nc_pad) out: state entering every chunk
+    const float* tab;     // (jobs, kPow, 4) power tables (mst_params.hip); job -> table row is the identity for track rows
+    int jobs, nc, nc_pad, sh;
+};
+// master-bus forward run (cascade role: blockIdx.y < nsig) + the track rows' all-pole carry scan (blockIdx.y >= nsig)
+__global__ __launch_bounds__(kEqWG) void k_master_run_apscan(const float* __restrict__ in, int64_t in_stride, float* __restrict__ out,
+                                                           int64_t out_stride, const float* __restrict__ rc, const float* __restrict__ s0,
+                                                           int nc_pad, int64_t n, const float* __restrict__ pw1, int ntiles,
+                                                           float* __restrict__ agg, float* __restrict__ zp, int nsig, ApScanArgs sc) {
+    __shared__ __attribute__((aligned(16))) float tile[2 * kEqWG * kLdw > kTriFloats ? 2 * kEqWG * kLdw : kTriFloats];
+#ifndef MST_DBG_APSCAN
+#define MST_DBG_APSCAN 0  // timing diagnostics only (wrong results): 1 = the scan role returns at once, 2 = the cascade role does
+#endif
+    if ((int)blockIdx.y >= nsig) {
+        const int job = ((int)blockIdx.y - nsig) * gridDim.x + blockIdx.x;
+        if (job >= sc.jobs || MST_DBG_APSCAN == 1) return;
+        const float* z0 = sc.z + (int64_t)job * 2 * sc.nc_pad;
+        float* o0 = sc.s0 + (int64_t)job * 2 * sc.nc_pad;
+        const float* tab = sc.tab + (int64_t)job * kPow * 4;
+        if (sc.nc == kTile) allpole_scan_tile<true>(z0, o0, tab, sc.nc, sc.nc_pad, sc.sh, tile, tile + kEqWG * kLdw, threadIdx.x);
+        else allpole_scan_tile<false>(z0, o0, tab, sc.nc, sc.nc_pad, sc.sh, tile, tile + kEqWG * kLdw, threadIdx.x);
+        return;
+    }
+    if (MST_DBG_APSCAN == 2) return;
+    const int64_t tile_base = (int64_t)blockIdx.x * kTile;
+    const bool fast = tile_fast(in + (int64_t)blockIdx.y * in_stride, tile_base, n) && !((uintptr_t)(out + (int64_t)blockIdx.y * out_stride) & 15);
+    if (fast) cascade_body<EQ_FWD, true, false, true, true, true>(in, in_stride, out, out_stride, rc, 0, s0, nullptr, nc_pad, n, nullptr, 0, pw1, ntiles, agg, tile, zp);
+    else cascade_body<EQ_FWD, true, false, true, false, true>(in, in_stride, out, out_stride, rc, 0, s0, nullptr, nc_pad, n, nullptr, 0, pw1, ntiles, agg, tile, zp);
+}
+void launch_master_run_apscan(const float* in, int64_t in_stride, float* out, int64_t out_stride, const float* rc, const float* s0, int nc_pad,
+                              int64_t n, int nsig, hipStream_t stream, const float* pw1, int ntiles, float* agg, float* zp,
+                              const float* sc_z, float* sc_s0, const float* sc_tab, int sc_jobs, int sc_nc, int sc_sh) {
+    const ApScanArgs sc{sc_z, sc_s0, sc_tab, sc_jobs, sc_nc, nc_pad, sc_sh};
+    const dim3 grid(ntiles, nsig + (sc_jobs + ntiles - 1) / ntiles), block(kEqWG);
+    hipLaunchKernelGGL(k_master_run_apscan, grid, block, 0, stream, in, in_stride, out, out_stride, rc, s0, nc_pad, n, pw1, ntiles, agg, zp, nsig, sc);
+}
+
 // ---- all-pole bank for the coefficient gradients ------------------------------------------------
 // filter f = 2k : w = u - a1 w1 - a2 w2 (1/A_k);  f = 2k+1 : w = u - (b1/b0) w1 - (b2/b0) w2 (b0/B_k: the 1/b0 of 1/B_k is
 // applied once, to the finished inner products - one multiply per sample and section less in all three kernels)

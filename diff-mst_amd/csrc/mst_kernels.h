@@ -73,6 +73,11 @@ void launch_cascade_run_gc(const float* in, int64_t in_stride, float* out, int64
 // zero-state pass of the SCAN1 path on the matrix pipe: chunk end states = W^T chunk (wz: filter rows x 64 x 16, made by k_prep)
 void launch_eq_zs_mfma(int dir, const float* in, int64_t in_stride, const float* wz, int split, float* z, int nc_pad, int64_t n, int nsig,
                        hipStream_t stream, const float* pw1, int ntiles, float* agg);
+// the master-bus forward run (SCAN1, all-pole bank riding along) with the TRACK rows' all-pole carry scan as extra one-wave
+// workgroups of the same launch (mst_eq.hip: k_master_run_apscan); sc_sh: 64 = KE 2^sc_sh
+void launch_master_run_apscan(const float* in, int64_t in_stride, float* out, int64_t out_stride, const float* rc, const float* s0, int nc_pad,
+                              int64_t n, int nsig, hipStream_t stream, const float* pw1, int ntiles, float* agg, float* zp,
+                              const float* sc_z, float* sc_s0, const float* sc_tab, int sc_jobs, int sc_nc, int sc_sh);
 void launch_allpole_zs(const float* u, int64_t u_stride, const float* rc, int split, float* z, int nc_pad, int64_t n, int nsig,
                        hipStream_t stream);
 void launch_coefgrad(const float* u, int64_t u_stride, const float* g, int64_t g_stride, const float* rc, int split,
