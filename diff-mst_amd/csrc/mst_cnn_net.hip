@@ -507,13 +507,15 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(BnBwdArgs a) {
 }
 __global__ void k_bn_bwd_finalize(const double* __restrict__ part, int strips, int C, double count, const float* __restrict__ stat,
                                   const float* __restrict__ gamma, int training, float* __restrict__ coef, float* __restrict__ g_gamma,
-                                  float* __restrict__ g_beta) {
+                                  float* __restrict__ g_beta, double grad_scale) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     double s1 = 0.0, s2 = 0.0;
     colsum_fold(part, strips, C, c, s1, s2);
-    g_beta[c] = (float)s1;
-    g_gamma[c] = (float)s2;
+    // grad_scale = 1 / ranks when the sums span every rank: (global sum) / world is what an averaging DistributedDataParallel
+    // leaves of the per-rank sums torch.nn.SyncBatchNorm hands it
+    g_beta[c] = (float)(s1 * grad_scale);
+    g_gamma[c] = (float)(s2 * grad_scale);
     coef[c * 3] = gamma[c] * stat[C + c];
     coef[c * 3 + 1] = training ? (float)(s1 / count) : 0.f;  // eval mode: the statistics are constants
     coef[c * 3 + 2] = training ? (float)(s2 / count) : 0.f;
@@ -740,8 +742,10 @@ static int ew_grid(int64_t items) {
 
 template <typename T>
 static int cnn_forward_t(const mst_cnn14_desc* d, const CnnPlan& p, const float* spec, const mst_cnn14_params* prm, float* embed, float* batch_stats,
-                         char* ws, hipStream_t s) {
+                         char* ws, hipStream_t s, mst_sync_fn sync, void* user) {
     const int prec = d->precision;
+    const bool synced = sync && d->training && d->world > 1;  // statistics over every rank's signals (SyncBatchNorm)
+    const double ranks = synced ? (double)d->world : 1.0;
     // weights of this call, in both operand layouts (the backward reuses them)
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_prep_weights<float>), dim3(3), dim3(256), 0, s, prm->conv_w[0], (float*)(ws + p.w1), (float*)nullptr, 1, 64);
     for (int l = 1; l < 2 * kBlocks; ++l) {
@@ -770,7 +774,8 @@ static int cnn_forward_t(const mst_cnn14_desc* d, const CnnPlan& p, const float*
             double* cs = (double*)(ws + p.colsum);
             const int slices = colsum_slices(tiles);
             if (d->training) hipLaunchKernelGGL(k_colsum, dim3(C / 32, slices), dim3(256), 0, s, part, tiles, C, cs);
-            hipLaunchKernelGGL(k_bn_finalize, dim3((C + 255) / 256), dim3(256), 0, s, cs, slices, C, (double)P, prm->bn_mean[l], prm->bn_var[l],
+            if (synced) sync(user, cs, (size_t)slices * C * 2, (void*)s);  // slice sums of every rank added element-wise; the fold below sees the global sums
+            hipLaunchKernelGGL(k_bn_finalize, dim3((C + 255) / 256), dim3(256), 0, s, cs, slices, C, (double)P * ranks, prm->bn_mean[l], prm->bn_var[l],
                                d->training, d->bn_eps, stat, batch_stats ? batch_stats + (size_t)l * 2 * 2048 : nullptr);
             if (k == 0) {
                 T* a1 = (T*)(ws + p.a1[b]);
@@ -795,8 +800,10 @@ static int cnn_forward_t(const mst_cnn14_desc* d, const CnnPlan& p, const float*
 
 template <typename T>
 static int cnn_backward_t(const mst_cnn14_desc* d, const CnnPlan& p, const float* spec, const mst_cnn14_params* prm, const float* g_embed,
-                          const mst_cnn14_grads* gr, char* ws, hipStream_t s) {
+                          const mst_cnn14_grads* gr, char* ws, hipStream_t s, mst_sync_fn sync, void* user) {
     const int prec = d->precision, E = d->embed_dim;
+    const bool synced = sync && d->training && d->world > 1;
+    const double ranks = synced ? (double)d->world : 1.0;
     const int H6 = p.H[kBlocks], W6 = p.W[kBlocks];
     hipLaunchKernelGGL(k_fc_bwd_feat, dim3(p.n * (2048 / 64)), dim3(256), 0, s, g_embed, prm->fc_w, (float*)(ws + p.gfeat), p.n, E, 2048);
     hipLaunchKernelGGL(k_fc_bwd_w, dim3((E * 2048 + 255) / 256), dim3(256), 0, s, g_embed, (const float*)(ws + p.feat), gr->fc_w, gr->fc_b, p.n, E, 2048);
@@ -827,8 +834,9 @@ static int cnn_backward_t(const mst_cnn14_desc* d, const CnnPlan& p, const float
             double* cs = (double*)(ws + p.colsum);
             const int slices = colsum_slices((int)strips);
             hipLaunchKernelGGL(k_colsum, dim3(C / 32, slices), dim3(256), 0, s, part, (int)strips, C, cs);
-            hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((C + 255) / 256), dim3(256), 0, s, cs, slices, C, (double)P, (const float*)(ws + p.stat[l]),
-                               prm->bn_gamma[l], d->training, coef, gr->bn_gamma[l], gr->bn_beta[l]);
+            if (synced) sync(user, cs, (size_t)slices * C * 2, (void*)s);  // sum g, sum g xhat over every rank (the adjoint of the shared statistics)
+            hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((C + 255) / 256), dim3(256), 0, s, cs, slices, C, (double)P * ranks, (const float*)(ws + p.stat[l]),
+                               prm->bn_gamma[l], d->training, coef, gr->bn_gamma[l], gr->bn_beta[l], 1.0 / ranks);
             if (k == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bn_bwd_apply<T, true>), dim3(ew_grid(P * cg)), dim3(256), 0, s, ba);
             else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bn_bwd_apply<T, false>), dim3(ew_grid(P * cg)), dim3(256), 0, s, ba);
             // weight gradient
@@ -878,13 +886,26 @@ extern "C" int mst_cnn14_forward(const mst_cnn14_desc* d, const float* spec, con
                                  void* workspace, size_t workspace_bytes, void* stream) {
     const CnnPlan p = cnn_plan(d);
     if (!p.ok || !spec || !params || !embed || !workspace || workspace_bytes < p.total || ((uintptr_t)workspace & 255)) return hipErrorInvalidValue;
-    if (d->precision == 0) return cnn_forward_t<bf16_t>(d, p, spec, params, embed, batch_stats, (char*)workspace, (hipStream_t)stream);
-    return cnn_forward_t<float>(d, p, spec, params, embed, batch_stats, (char*)workspace, (hipStream_t)stream);
+    return mst_cnn14_forward_sync(d, spec, params, embed, batch_stats, workspace, workspace_bytes, stream, nullptr, nullptr);
+}
+extern "C" int mst_cnn14_forward_sync(const mst_cnn14_desc* d, const float* spec, const mst_cnn14_params* params, float* embed, float* batch_stats,
+                                      void* workspace, size_t workspace_bytes, void* stream, mst_sync_fn sync, void* user) {
+    const CnnPlan p = cnn_plan(d);
+    if (!p.ok || !spec || !params || !embed || !workspace || workspace_bytes < p.total || ((uintptr_t)workspace & 255)) return hipErrorInvalidValue;
+    if (d->precision == 0) return cnn_forward_t<bf16_t>(d, p, spec, params, embed, batch_stats, (char*)workspace, (hipStream_t)stream, sync, user);
+    return cnn_forward_t<float>(d, p, spec, params, embed, batch_stats, (char*)workspace, (hipStream_t)stream, sync, user);
 }
 extern "C" int mst_cnn14_backward(const mst_cnn14_desc* d, const float* spec, const mst_cnn14_params* params, const float* grad_embed,
                                   const mst_cnn14_grads* grads, void* workspace, size_t workspace_bytes, void* stream) {
     const CnnPlan p = cnn_plan(d);
     if (!p.ok || !spec || !params || !grad_embed || !grads || !workspace || workspace_bytes < p.total) return hipErrorInvalidValue;
-    if (d->precision == 0) return cnn_backward_t<bf16_t>(d, p, spec, params, grad_embed, grads, (char*)workspace, (hipStream_t)stream);
-    return cnn_backward_t<float>(d, p, spec, params, grad_embed, grads, (char*)workspace, (hipStream_t)stream);
+    return mst_cnn14_backward_sync(d, spec, params, grad_embed, grads, workspace, workspace_bytes, stream, nullptr, nullptr);
+}
+extern "C" int mst_cnn14_backward_sync(const mst_cnn14_desc* d, const float* spec, const mst_cnn14_params* params, const float* grad_embed,
+                                       const mst_cnn14_grads* grads, void* workspace, size_t workspace_bytes, void* stream, mst_sync_fn sync,
+                                       void* user) {
+    const CnnPlan p = cnn_plan(d);
+    if (!p.ok || !spec || !params || !grad_embed || !grads || !workspace || workspace_bytes < p.total) return hipErrorInvalidValue;
+    if (d->precision == 0) return cnn_backward_t<bf16_t>(d, p, spec, params, grad_embed, grads, (char*)workspace, (hipStream_t)stream, sync, user);
+    return cnn_backward_t<float>(d, p, spec, params, grad_embed, grads, (char*)workspace, (hipStream_t)stream, sync, user);
 }

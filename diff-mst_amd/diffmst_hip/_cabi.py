@@ -73,7 +73,10 @@ class MrstftDesc(C.Structure):
 
 class Cnn14Desc(C.Structure):  # mirrors mst_cnn14_desc
     _fields_ = [("n", C.c_int32), ("frames", C.c_int32), ("bins", C.c_int32), ("embed_dim", C.c_int32), ("precision", C.c_int32),
-                ("training", C.c_int32), ("bn_eps", C.c_float)]
+                ("training", C.c_int32), ("bn_eps", C.c_float), ("world", C.c_int32)]
+
+
+SYNC_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)  # mst_sync_fn(user, sums, n_doubles, stream)
 
 
 CNN14_CONVS = 12
@@ -133,6 +136,9 @@ SIGNATURES = {
     "mst_cnn14_workspace_bytes": (C.c_size_t, [C.POINTER(Cnn14Desc)]),
     "mst_cnn14_forward": (C.c_int, [C.POINTER(Cnn14Desc), _P, C.POINTER(Cnn14Params), _P, _P, _P, C.c_size_t, _P]),
     "mst_cnn14_backward": (C.c_int, [C.POINTER(Cnn14Desc), _P, C.POINTER(Cnn14Params), _P, C.POINTER(Cnn14Grads), _P, C.c_size_t, _P]),
+    "mst_cnn14_forward_sync": (C.c_int, [C.POINTER(Cnn14Desc), _P, C.POINTER(Cnn14Params), _P, _P, _P, C.c_size_t, _P, SYNC_FN, _P]),
+    "mst_cnn14_backward_sync": (C.c_int, [C.POINTER(Cnn14Desc), _P, C.POINTER(Cnn14Params), _P, C.POINTER(Cnn14Grads), _P, C.c_size_t, _P,
+                                          SYNC_FN, _P]),
     "mst_afloss_backward": (C.c_int, [_P, _P, C.c_int32, C.c_int64, C.POINTER(C.c_float), _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "mst_ctrl_workspace_bytes": (C.c_size_t, [C.POINTER(CtrlDesc)]),
     "mst_ctrl_forward": (C.c_int, [C.POINTER(CtrlDesc), _P, _P, C.POINTER(CtrlLayer), _P, _P, C.c_size_t, _P]),

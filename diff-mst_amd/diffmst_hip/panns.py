@@ -68,6 +68,49 @@ class ConvBlock(nn.Module):
         raise RuntimeError("ConvBlock is evaluated by Cnn14's fused kernels; call the Cnn14 module")
 
 
+def sync_group_of(module: "Cnn14"):
+    """(process group, world size) over which this encoder's BatchNorm statistics are shared, (None, 1) when they are not.
+
+    The reference trains with Lightning's ``sync_batchnorm: true`` (configs/config.yaml:41), i.e.
+    ``torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)``: the ``nn.BatchNorm2d`` parameter holders of the ConvBlocks become
+    ``nn.SyncBatchNorm`` instances (same parameter names).  The fused kernels honour exactly that: if the holders are SyncBatchNorm
+    modules and a process group of more than one rank is up, every layer's statistics - and their adjoints - are all-reduced over
+    the holders' ``process_group`` (``mst_cnn14_forward_sync``)."""
+    import torch.distributed as dist
+
+    bns = module._bns()
+    if not any(isinstance(bn, nn.SyncBatchNorm) for bn in bns):
+        return None, 1
+    if not all(isinstance(bn, nn.SyncBatchNorm) for bn in bns):
+        raise RuntimeError("Cnn14: either every BatchNorm of the encoder is a SyncBatchNorm or none is")
+    if not (dist.is_available() and dist.is_initialized()):
+        return None, 1
+    group = bns[0].process_group
+    world = dist.get_world_size(group)
+    return (group, world) if world > 1 else (None, 1)
+
+
+class _StatSync:
+    """The ``mst_sync_fn`` of one kernel call: all-reduces (SUM) a span of the call's workspace over the process group."""
+
+    def __init__(self, ws: torch.Tensor, group):
+        self.ws, self.group, self.base, self.error = ws, group, ws.data_ptr(), None
+        self.fn = _cabi.SYNC_FN(self._call)
+
+    def _call(self, _user, ptr, n_doubles, _stream):
+        try:  # an exception must not unwind through the C frames: keep it, the caller re-raises
+            import torch.distributed as dist
+
+            off = ptr - self.base
+            dist.all_reduce(self.ws[off:off + 8 * n_doubles].view(torch.float64), group=self.group)
+        except BaseException as e:  # noqa: BLE001
+            self.error = self.error or e
+
+    def check(self):
+        if self.error is not None:
+            raise self.error
+
+
 class _Cnn14Function(torch.autograd.Function):
     @staticmethod
     def forward(ctx, spec, module, training, *params):
@@ -80,8 +123,9 @@ class _Cnn14Function(torch.autograd.Function):
         dev = spec.device
         _hip.require_same_device(dev, *params, *(bn.running_mean for bn in bns), *(bn.running_var for bn in bns))
         n, frames, bins = spec.shape
+        group, world = sync_group_of(module) if training else (None, 1)
         desc = _cabi.Cnn14Desc(n, frames, bins, module.fc.out_features, 0 if module.precision == "bf16" else 1, int(training),
-                               float(module.conv_block1.bn1.eps))
+                               float(module.conv_block1.bn1.eps), world)
         nbytes = lib.mst_cnn14_workspace_bytes(ctypes.byref(desc))
         if nbytes == 0:
             raise ValueError(f"Cnn14: unsupported spectrogram size {(frames, bins)} (six pooling stages need >= 128 frames x 1024 bins)")
@@ -102,10 +146,14 @@ class _Cnn14Function(torch.autograd.Function):
         embed = torch.empty(n, module.fc.out_features, dtype=torch.float32, device=dev)
         stats = torch.empty(12, 2, 2048, dtype=torch.float32, device=dev) if training else None
         spec = spec.float().contiguous()
+        sync = _StatSync(ws, group) if world > 1 else None
         with torch.cuda.device(dev):
-            _hip.check(lib.mst_cnn14_forward(ctypes.byref(desc), _cabi.ptr(spec), ctypes.byref(prm), _cabi.ptr(embed), _cabi.ptr(stats),
-                                             _cabi.ptr(ws), nbytes, _hip.current_stream_ptr(dev)), "mst_cnn14_forward")
-        ctx.desc, ctx.nbytes, ctx.dev = desc, nbytes, dev
+            rc = lib.mst_cnn14_forward_sync(ctypes.byref(desc), _cabi.ptr(spec), ctypes.byref(prm), _cabi.ptr(embed), _cabi.ptr(stats),
+                                            _cabi.ptr(ws), nbytes, _hip.current_stream_ptr(dev), sync.fn if sync else _cabi.SYNC_FN(), None)
+        if sync:
+            sync.check()
+        _hip.check(rc, "mst_cnn14_forward")
+        ctx.desc, ctx.nbytes, ctx.dev, ctx.group = desc, nbytes, dev, group
         # the backward reads mean / invstd from the workspace; the running statistics (updated in place by the module right
         # after a training-mode call) are only handed over again, never read in training mode
         ctx.running = (rmean, rvar)
@@ -130,9 +178,13 @@ class _Cnn14Function(torch.autograd.Function):
         prm.fc_w, prm.fc_b = keep[36].data_ptr(), keep[37].data_ptr()
         gr.fc_w, gr.fc_b = grads[36].data_ptr(), grads[37].data_ptr()
         g = g_embed.float().contiguous()
+        sync = _StatSync(ws, ctx.group) if ctx.desc.world > 1 else None
         with torch.cuda.device(dev):
-            _hip.check(lib.mst_cnn14_backward(ctypes.byref(ctx.desc), _cabi.ptr(spec), ctypes.byref(prm), _cabi.ptr(g), ctypes.byref(gr),
-                                              _cabi.ptr(ws), ctx.nbytes, _hip.current_stream_ptr(dev)), "mst_cnn14_backward")
+            rc = lib.mst_cnn14_backward_sync(ctypes.byref(ctx.desc), _cabi.ptr(spec), ctypes.byref(prm), _cabi.ptr(g), ctypes.byref(gr),
+                                             _cabi.ptr(ws), ctx.nbytes, _hip.current_stream_ptr(dev), sync.fn if sync else _cabi.SYNC_FN(), None)
+        if sync:
+            sync.check()
+        _hip.check(rc, "mst_cnn14_backward")
         return (None, None, None, *grads)
 
 
@@ -172,6 +224,7 @@ class Cnn14(nn.Module):
         embed, stats = _Cnn14Function.apply(spec, self, training, *self._parameters_in_abi_order())
         if training:  # nn.BatchNorm2d bookkeeping (momentum 0.1, unbiased running variance), on the batch statistics of this call
             n, frames, bins = spec.shape
+            n = n * sync_group_of(self)[1]  # SyncBatchNorm: the statistics (and the unbiased correction) span every rank's signals
             h, w = frames, bins
             with torch.no_grad():
                 # all twelve layers in four multi-tensor launches (48 one-tensor kernels otherwise); same arithmetic as

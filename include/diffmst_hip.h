@@ -236,6 +236,8 @@ typedef struct mst_cnn14_desc {
     int32_t precision;  /* 0: bf16 operands, fp32 accumulate (v_mfma_f32_16x16x32_bf16); 1: fp32 operands (v_mfma_f32_16x16x4_f32) */
     int32_t training;   /* 1: BatchNorm2d with batch statistics (returned in batch_stats); 0: running statistics */
     float bn_eps;       /* 1e-5 */
+    int32_t world;      /* 0 or 1: statistics over this call's signals.  > 1 (with a sync hook, mst_cnn14_forward_sync): BatchNorm statistics
+                         * over `world` calls of equal n - torch.nn.SyncBatchNorm, reference configs/config.yaml:41 sync_batchnorm */
 } mst_cnn14_desc;
 typedef struct mst_cnn14_params { /* device pointers, fp32, torch layouts */
     const float* conv_w[MST_CNN14_CONVS];   /* (co, ci, 3, 3); channels 1-64-64-128-128-...-2048-2048 */
@@ -263,6 +265,21 @@ int mst_cnn14_forward(const mst_cnn14_desc* d, const float* spec, const mst_cnn1
  * audio, which the reference never differentiates: mst/system.py:284-300). */
 int mst_cnn14_backward(const mst_cnn14_desc* d, const float* spec, const mst_cnn14_params* params, const float* grad_embed,
                        const mst_cnn14_grads* grads, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Cross-rank BatchNorm statistics (reference: Lightning's sync_batchnorm = torch.nn.SyncBatchNorm over the process group,
+ * configs/config.yaml:41, mst/panns.py:27-85).  The library has no communication of its own: between the per-channel fp64 sums of a
+ * layer and their use it calls `sync(user, sums, n_doubles, stream)`, which must leave the ELEMENT-WISE SUM over all ranks in `sums`,
+ * ordered after everything already queued on `stream` and before everything queued later (torch.distributed.all_reduce on a tensor that
+ * aliases the workspace does exactly that).  Twelve calls per forward (sum, sum of squares of every convolution's output) and twelve
+ * per backward (sum g, sum g xhat of every BatchNorm adjoint).  d->world = number of ranks (equal n on every rank).  The parameter
+ * gradients of BatchNorm come out as (global sum) / world on every rank - what an averaging DistributedDataParallel leaves of the
+ * per-rank sums.  sync == NULL or world <= 1 or training == 0: identical to mst_cnn14_forward / _backward. */
+typedef void (*mst_sync_fn)(void* user, double* sums, size_t n_doubles, void* stream);
+int mst_cnn14_forward_sync(const mst_cnn14_desc* d, const float* spec, const mst_cnn14_params* params, float* embed,
+                           float* batch_stats, void* workspace, size_t workspace_bytes, void* stream, mst_sync_fn sync, void* user);
+int mst_cnn14_backward_sync(const mst_cnn14_desc* d, const float* spec, const mst_cnn14_params* params, const float* grad_embed,
+                            const mst_cnn14_grads* grads, void* workspace, size_t workspace_bytes, void* stream, mst_sync_fn sync,
+                            void* user);
 
 /* ---- TransformerController encoder stack (reference mst/modules.py:848-854, :893-895: torch.nn.TransformerEncoder of
  * post-norm TransformerEncoderLayer(d_model, nhead, dim_feedforward, relu, dropout 0, batch_first) over the (bs, seq, d_model)

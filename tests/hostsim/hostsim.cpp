@@ -16,6 +16,8 @@ int mst_spectrogram_forward(const float*, int32_t, int64_t, int32_t, int32_t, co
 size_t mst_cnn14_workspace_bytes(const mst_cnn14_desc*) { return 0; }
 int mst_cnn14_forward(const mst_cnn14_desc*, const float*, const mst_cnn14_params*, float*, float*, void*, size_t, void*) { return 801; }
 int mst_cnn14_backward(const mst_cnn14_desc*, const float*, const mst_cnn14_params*, const float*, const mst_cnn14_grads*, void*, size_t, void*) { return 801; }
+int mst_cnn14_forward_sync(const mst_cnn14_desc*, const float*, const mst_cnn14_params*, float*, float*, void*, size_t, void*, mst_sync_fn, void*) { return 801; }
+int mst_cnn14_backward_sync(const mst_cnn14_desc*, const float*, const mst_cnn14_params*, const float*, const mst_cnn14_grads*, void*, size_t, void*, mst_sync_fn, void*) { return 801; }
 // the controller's encoder stack (fp32 matrix-core kernels) is GPU-only as well
 size_t mst_ctrl_workspace_bytes(const mst_ctrl_desc*) { return 0; }
 int mst_ctrl_forward(const mst_ctrl_desc*, const float*, const uint8_t*, const mst_ctrl_layer*, float*, void*, size_t, void*) { return 801; }

@@ -94,9 +94,9 @@ def test_workspace_sizes_and_validation(lib):
     assert lib.mst_afloss_workspace_bytes(8, 16384) == 0  # reflect padding needs n > 16384
     assert lib.mst_peak_normalize_workspace_bytes(8, 262144) > 0
     # spectrogram encoder: 513 x 1025 images (262144 samples), 16 signals - a few GB of bf16 activations; too few frames for six pools -> 0
-    e = _cabi.Cnn14Desc(16, 513, 1025, 512, 0, 1, 1e-5)
+    e = _cabi.Cnn14Desc(16, 513, 1025, 512, 0, 1, 1e-5, 1)
     assert 2e9 < lib.mst_cnn14_workspace_bytes(ctypes.byref(e)) < 2e10
-    e32 = _cabi.Cnn14Desc(16, 513, 1025, 512, 1, 1, 1e-5)
+    e32 = _cabi.Cnn14Desc(16, 513, 1025, 512, 1, 1, 1e-5, 1)
     assert lib.mst_cnn14_workspace_bytes(ctypes.byref(e32)) > lib.mst_cnn14_workspace_bytes(ctypes.byref(e))
-    assert lib.mst_cnn14_workspace_bytes(ctypes.byref(_cabi.Cnn14Desc(1, 100, 1025, 512, 0, 1, 1e-5))) == 0
+    assert lib.mst_cnn14_workspace_bytes(ctypes.byref(_cabi.Cnn14Desc(1, 100, 1025, 512, 0, 1, 1e-5, 1))) == 0
     assert lib.mst_spectrogram_tables_bytes() == 3 * 2048 * 4
