@@ -72,11 +72,49 @@ def shard_batch(global_batch: int, rank: int, world: int):
 
 
 def reduce_loss(loss: torch.Tensor, world: int):
-    """Mean of the per-rank losses == single-process loss over the global batch (per-example terms)."""
+    """Mean of the per-rank losses == single-process loss over the global batch (per-example terms).  Blocking form (tests)."""
     if world > 1:
         dist.all_reduce(loss, op=dist.ReduceOp.SUM)
         loss = loss / world
     return loss
+
+
+class AsyncLossReduce:
+    """The loss scalar is logging output: nothing on the device waits for its all-reduce.  Each step's value is copied into a slot of a
+    resident ring on the compute stream; a side stream waits for that copy, all-reduces the slot (RCCL, async_op) and is joined ONCE,
+    before the line is printed - the compute stream never waits for the collective ('async, off the critical path')."""
+
+    def __init__(self, world: int, dev, slots: int):
+        self.world, self.dev = world, dev
+        self.ring = torch.zeros(max(slots, 1), device=dev)
+        self.side = torch.cuda.Stream(device=dev) if world > 1 else None
+        self.i = 0
+        self.works = []
+
+    def push(self, loss: torch.Tensor):
+        if self.world == 1:  # nothing to reduce: no copy, no launch
+            self.last = loss.detach()
+            return self.last
+        slot = self.ring[self.i % self.ring.numel()].view(())
+        self.i += 1
+        slot.copy_(loss.detach())
+        if self.world > 1:
+            self.side.wait_stream(torch.cuda.current_stream(self.dev))
+            with torch.cuda.stream(self.side):
+                self.works.append(dist.all_reduce(slot, op=dist.ReduceOp.SUM, async_op=True))
+        return slot
+
+    def join(self):
+        """Wait for every queued all-reduce (host + compute stream) and return the mean loss of the last step."""
+        if self.world == 1:
+            return self.last
+        for w in self.works:
+            w.wait()
+        self.works.clear()
+        if self.side is not None:
+            torch.cuda.current_stream(self.dev).wait_stream(self.side)
+        last = self.ring[(self.i - 1) % self.ring.numel()]
+        return last / self.world
 
 
 # ---------------------------------------------------------------------------------------------- CPU baseline
@@ -243,57 +281,125 @@ MFMA_PEAK_BF16_TF = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak
 
 
 def encoder_lines(dev):
-    """the spectrogram encoder (STFT front end + Cnn14 on MFMA), forward + backward, and the cfg #5 step."""
+    """the spectrogram encoder (STFT front end + Cnn14 on MFMA), forward + backward, and the cfg #5 step - each at the
+    reference's precision (fp32 operands on the fp32 MFMA, configs/config.yaml:42 `precision: 32`) and with bf16 operand storage."""
+    from mst.modules import SpectrogramEncoder
+
+    out = []
+    ns = 34  # the 32 tracks + 2 reference-mix channels one cfg #5 mix sends through the encoders
+    fl = 3.0 * ns * conv_flops(1 + N // 512, 1025)
+    for precision in ("fp32", "bf16"):
+        torch.manual_seed(3000)
+        enc = SpectrogramEncoder(embed_dim=512, precision=precision).to(dev).train()
+        x = (0.1 * torch.randn(ns, 1, N)).to(dev)
+        g = torch.randn(ns, 512, device=dev)
+
+        def enc_step():
+            enc.zero_grad(set_to_none=True)
+            enc(x).backward(g)
+
+        med, mean = time_steps(enc_step, 5, 2)
+        peak = MFMA_PEAK_BF16_TF if precision == "bf16" else VALU_PEAK_TF  # fp32 MFMA runs at the fp32 vector rate (MI355X_MICROARCH.md)
+        out.append({"workload": f"SpectrogramEncoder + Cnn14 (embed 512) fwd+bwd, {ns} signals x {N} samples, "
+                                + ("fp32 operands on v_mfma_f32_16x16x4_f32 = the reference's precision" if precision == "fp32" else
+                                   "bf16 operand storage / fp32 accumulate (NOT the reference's arithmetic: training-mode weight gradients 20-40 % "
+                                   "from fp32, DESIGN 9.3)") + " (reference mst/modules.py:740-806, mst/panns.py:126-209)",
+                    "precision": precision, "ms_per_step_median": med, "ms_per_step_mean": mean, "steps": 5, "signals_per_s": ns / (med * 1e-3),
+                    "conv_TFLOPs_per_s": fl / (med * 1e-3) / 1e12, "frac_of_dense_mfma_peak_of_that_dtype": fl / (med * 1e-3) / 1e12 / peak,
+                    "note": "flops = 3 x forward multiply-adds x 2 of the twelve convolutions; time = whole encoder step incl. STFT, BatchNorm, "
+                            "pooling, weight re-layout"})
+        del enc, x, g
+        torch.cuda.empty_cache()
+    # cfg #5 on one GPU, one mix per step: full step with the real model structure (configs/models/naive+feat.yaml sizes); parity of this
+    # exact configuration: tests/test_system_gpu.py::test_cfg5_step_as_benchmarked
+    for precision in ("fp32", "bf16"):
+        model, step = build_cfg5(dev, precision)
+        torch.manual_seed(3002)
+        tracks = (0.05 * torch.randn(1, 32, N)).to(dev)
+        batch = (tracks, None, None, torch.zeros(1, 32, dtype=torch.bool, device=dev), None, ["a"])
+
+        def sys_step():
+            model.zero_grad(set_to_none=True)
+            loss, _ = step(batch, train=True)
+            loss.backward()
+
+        med, mean = time_steps(sys_step, 5, 2)
+        step.check_finite()
+        out.append({"workload": "cfg #5 step on ONE GPU, batch 1: System.common_step order (two naive_random_mix reference mixes, peak normalise, "
+                                "A/B split) + MixStyleTransferModel (2 x SpectrogramEncoder/Cnn14 on MFMA for 32 tracks + 2 mix channels of 131072 "
+                                "samples, 12-layer TransformerController on csrc/mst_ctrl.hip) + AdvancedMixConsole 32 tracks + AudioFeatureLoss, fwd+bwd "
+                                "to every weight; no host readback inside the step (deferred range / NaN checks, checked after the loop)",
+                    "encoder_precision": precision, "ms_per_step_median": med, "ms_per_step_mean": mean, "steps": 5, "mixes_per_s": 1.0 / (med * 1e-3)})
+        del model, step, tracks
+        torch.cuda.empty_cache()
+    return out
+
+
+def build_cfg5(dev, precision, world=1):
+    """The cfg #5 step exactly as tests/test_system_gpu.py::test_cfg5_step_as_benchmarked checks it against the oracle."""
     from mst.loss import AudioFeatureLoss
     from mst.mixing import naive_random_mix
     from mst.modules import AdvancedMixConsole, MixStyleTransferModel, SpectrogramEncoder, TransformerController
     from mst.system import CommonStep
 
-    out = []
-    torch.manual_seed(3000)
-    ns = 34  # the 32 tracks + 2 reference-mix channels one cfg #5 mix sends through the encoders
-    enc = SpectrogramEncoder(embed_dim=512).to(dev).train()
-    x = (0.1 * torch.randn(ns, 1, N)).to(dev)
-    g = torch.randn(ns, 512, device=dev)
-
-    def enc_step():
-        enc.zero_grad(set_to_none=True)
-        enc(x).backward(g)
-
-    med, mean = time_steps(enc_step, 5, 2)
-    fl = 3.0 * ns * conv_flops(1 + N // 512, 1025)
-    out.append({"workload": f"SpectrogramEncoder + Cnn14 (embed 512) fwd+bwd, {ns} signals x {N} samples, bf16 MFMA operands / fp32 accumulate "
-                            "(reference mst/modules.py:740-806, mst/panns.py:126-209)",
-                "ms_per_step_median": med, "ms_per_step_mean": mean, "steps": 5, "signals_per_s": ns / (med * 1e-3),
-                "conv_TFLOPs_per_s": fl / (med * 1e-3) / 1e12, "frac_of_dense_bf16_mfma_peak": fl / (med * 1e-3) / 1e12 / MFMA_PEAK_BF16_TF,
-                "note": "flops = 3 x forward multiply-adds x 2 of the twelve convolutions; time = whole encoder step incl. STFT, BatchNorm, pooling, "
-                        "weight re-layout; per-kernel MFMA counters: profiles/round3_encoder_counters.md"})
-    del enc, x, g
-    torch.cuda.empty_cache()
-    # cfg #5 on one GPU, one mix per step: full step with the real model structure (configs/models/naive+feat.yaml sizes)
     torch.manual_seed(3001)
-    model = MixStyleTransferModel(SpectrogramEncoder(embed_dim=512), SpectrogramEncoder(embed_dim=512),
+    model = MixStyleTransferModel(SpectrogramEncoder(embed_dim=512, precision=precision), SpectrogramEncoder(embed_dim=512, precision=precision),
                                   TransformerController(512, 27, 25, 26, num_layers=12, nhead=8, native=True)).to(dev).train()
-    step = CommonStep(model, AdvancedMixConsole(SR, materialize_mixed_tracks=False, validate="deferred", param_dicts="lazy"), naive_random_mix,
+    wrapped = model
+    if world > 1:  # reference configs/config.yaml:40-41: strategy ddp_find_unused_parameters_true, sync_batchnorm true
+        from torch.nn.parallel import DistributedDataParallel
+
+        wrapped = DistributedDataParallel(torch.nn.SyncBatchNorm.convert_sync_batchnorm(model), device_ids=[dev.index],
+                                          find_unused_parameters=True)
+    step = CommonStep(wrapped, AdvancedMixConsole(SR, materialize_mixed_tracks=False, validate="deferred", param_dicts="lazy"), naive_random_mix,
                       AudioFeatureLoss(AF_WEIGHTS, SR), generate_mix=True, active_eq_epoch=0, active_compressor_epoch=0,
                       active_fx_bus_epoch=1000, active_master_bus_epoch=0, nan_check="deferred")
+    return model, step
+
+
+def main_cfg5(args, dev, world, rank, backend):
+    """`--config 5 --gpus N`: one 32-track mix per GPU; SyncBatchNorm + DDP over RCCL (weak scaling); same barrier / max-over-ranks timing."""
+    model, step = build_cfg5(dev, args.precision, world)
+    torch.manual_seed(4000 + rank)
     tracks = (0.05 * torch.randn(1, 32, N)).to(dev)
     batch = (tracks, None, None, torch.zeros(1, 32, dtype=torch.bool, device=dev), None, ["a"])
 
-    def sys_step():
+    def one():
         model.zero_grad(set_to_none=True)
         loss, _ = step(batch, train=True)
         loss.backward()
+        return loss.detach()
 
-    med, mean = time_steps(sys_step, 5, 2)
-    out.append({"workload": "cfg #5 step on ONE GPU, batch 1: System.common_step order (two naive_random_mix reference mixes, peak normalise, "
-                            "A/B split) + MixStyleTransferModel (2 x SpectrogramEncoder/Cnn14 on MFMA for 32 tracks + 2 mix channels of 131072 "
-                            "samples, 12-layer TransformerController on csrc/mst_ctrl.hip) + AdvancedMixConsole 32 tracks + AudioFeatureLoss, fwd+bwd "
-                            "to every weight; no host readback inside the step (deferred range / NaN checks)",
-                "ms_per_step_median": med, "ms_per_step_mean": mean, "steps": 5, "mixes_per_s": 1.0 / (med * 1e-3)})
-    del model, step, tracks
-    torch.cuda.empty_cache()
-    return out
+    for _ in range(args.warmup):
+        one()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = one()
+    step.check_finite()  # deferred NaN guard: before an optimizer would step, and at loop end (diffmst_hip/system.py)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    assert torch.isfinite(last).all()
+    if rank == 0:
+        print(json.dumps({
+            "metric": "mixes/sec (full System step, 32-track x 262144-sample mix, fwd+bwd to every weight)", "value": world * args.steps / elapsed,
+            "unit": "mixes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16 operands / f32 accumulate",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE cfg #5: System.common_step order (two naive_random_mix reference mixes, peak normalise, A/B split) + "
+                                   "MixStyleTransferModel (2 x SpectrogramEncoder/Cnn14 embed 512, 12-layer TransformerController on csrc/mst_ctrl.hip) + "
+                                   "AdvancedMixConsole 32 tracks + AudioFeatureLoss; one mix per GPU",
+                       "per_gpu_batch": 1, "global_batch": world, "tracks": 32, "samples": N, "encoder_precision": args.precision,
+                       "parallelism": f"DistributedDataParallel(find_unused_parameters=True) + SyncBatchNorm x{world}; backend: {backend}"}}))
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def secondary_lines(dev):
@@ -332,6 +438,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--config", type=int, default=2, choices=(2, 5),
+                    help="2 = BASELINE cfg #2 (the headline; default).  5 = the full System step (cfg #5): one 32-track mix per GPU, model wrapped "
+                         "in SyncBatchNorm + DistributedDataParallel(find_unused_parameters=True) when --gpus > 1")
+    ap.add_argument("--precision", default="fp32", choices=("fp32", "bf16"), help="encoder operand precision of --config 5 (reference: fp32)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -344,15 +454,26 @@ def main():
     assert world == args.gpus or world == 1, (world, args.gpus)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    backend = "single process"
+    if world > 1:
+        # one process per device: every rank must sit on its own GPU (torchrun sets LOCAL_RANK; a mis-launch would time 8 ranks on one GPU)
+        backend = f"{dist.get_backend()} (RCCL), world_size {dist.get_world_size()}"
+        ids = [None] * world
+        dist.all_gather_object(ids, (os.uname().nodename, torch.cuda.current_device()))
+        assert len(set(ids)) == world, f"ranks share a device: {ids}"
+    if args.config == 5:
+        return main_cfg5(args, dev, world, rank, backend)
 
     lo, hi = shard_batch(BS * world, rank, world)  # this rank's mixes of the global batch
     step_fn = make_workload(dev, hi - lo, T, N, "mrstft", seed=1000 + rank, lean=True)
+    reducer = AsyncLossReduce(world, dev, args.steps + args.warmup + 8)
 
     def step(marks=None):
-        return reduce_loss(step_fn(marks), world)
+        return reducer.push(step_fn(marks))
 
     for _ in range(args.warmup):
         step()
+    reducer.join()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -360,8 +481,9 @@ def main():
     t0 = time.perf_counter()
     evs[0].record()
     for i in range(args.steps):
-        last = step()
+        step()
         evs[i + 1].record()
+    last = reducer.join()  # the queued loss all-reduces finish inside the timed region
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -384,6 +506,7 @@ def main():
     ev["s"].record()
     step(ev)
     ev["e"].record()
+    reducer.join()
     torch.cuda.synchronize()
     stages = {"console_fwd_ms": ev["s"].elapsed_time(ev["fwd"]), "loss_fwd_ms": ev["fwd"].elapsed_time(ev["loss"]),
               "loss_bwd_ms": ev["loss"].elapsed_time(ev["lbwd"]), "console_bwd_ms": ev["lbwd"].elapsed_time(ev["e"])}
@@ -405,7 +528,7 @@ def main():
                 "workload": "BASELINE cfg #2: AdvancedMixConsole 8 tracks x 262144 @44.1kHz, batch 8 per GPU, "
                             "fwd+bwd + MR-STFT loss (512/2048/8192)",
                 "per_gpu_batch": BS, "global_batch": BS * world, "tracks": T, "samples": N,
-                "parallelism": f"batch-sharded x{world}, loss all-reduce only (RCCL)",
+                "parallelism": f"batch-sharded x{world}, loss all-reduce only (async, side stream); backend: {backend}",
                 "mixed_tracks": "not materialised (lean variant, SURVEY 8d)", "range_check": "deferred flag readback",
             },
             "roofline": {

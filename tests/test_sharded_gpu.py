@@ -51,6 +51,10 @@ def _worker(rank, world, port, ret):
     for name, kw in (("per_example", {}), ("global_sc", dict(sc_per_example=False, sync_group=True))):
         loss, gtp, gmp = _step(lo, hi, kw)
         out[name] = (bench.reduce_loss(loss.clone(), world).item(), loss.item(), gtp, gmp)
+        # the bench's own reduction (queued on a side stream, joined once) must give the same number
+        red = bench.AsyncLossReduce(world, torch.device("cuda:0"), 4)
+        red.push(loss.to("cuda:0"))
+        assert abs(red.join().item() - out[name][0]) <= 1e-7 * abs(out[name][0])
     ret[rank] = (lo, hi, out)
     dist.barrier()
     dist.destroy_process_group()
