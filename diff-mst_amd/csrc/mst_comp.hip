@@ -421,6 +421,17 @@ __device__ __forceinline__ void coefgrad_fused(const CompBwdArgs& a, int blk, in
         float wa1 = a.ap_s0[base], wa2 = a.ap_s0[base + a.ap_nc_pad], wb1 = a.ap_s0[base + 2 * (int64_t)a.ap_nc_pad],
               wb2 = a.ap_s0[base + 3 * (int64_t)a.ap_nc_pad];
         if (MST_CG_ABLATE & 1) wa1 = wa2 = wb1 = wb2 = (float)c;
+#ifdef MST_CG_F64  // diagnostic: the five inner products (and the recurrences feeding them) in double
+        double db0 = 0., db1 = 0., db2 = 0., da1 = 0., da2 = 0.;
+        double Wa1 = wa1, Wa2 = wa2, Wb1 = wb1, Wb2 = wb2;
+        for (int i = 0; i < kEqChunk; ++i) {
+            const double x = cg_u[c * kCgPitch + i], gp = cg_g[c * kCgPitch + i];
+            const double wa = -(double)ka2 * Wa2 - (double)ka1 * Wa1 + x, wb = -(double)kc2 * Wb2 - (double)kc1 * Wb1 + x;
+            db0 += gp * wb; db1 += gp * Wb1; db2 += gp * Wb2; da1 -= gp * Wa1; da2 -= gp * Wa2;
+            Wa2 = Wa1; Wa1 = wa; Wb2 = Wb1; Wb1 = wb;
+        }
+        float acc[5] = {(float)(db0 * kib0), (float)(db1 * kib0), (float)(db2 * kib0), (float)da1, (float)da2};
+#else
         float db0 = 0.f, db1 = 0.f, db2 = 0.f, da1 = 0.f, da2 = 0.f;
         const float* mu = &cg_u[c * kCgPitch];
         const float* mg = &cg_g[c * kCgPitch];
@@ -446,6 +457,7 @@ __device__ __forceinline__ void coefgrad_fused(const CompBwdArgs& a, int blk, in
             }
         }
         float acc[5] = {db0 * kib0, db1 * kib0, db2 * kib0, da1, da2};
+#endif
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
 #pragma unroll

@@ -14,7 +14,8 @@ All numerical work runs in hand-written HIP kernels for gfx950 behind the C ABI 
 
 ``install()`` rebinds exactly those symbols inside an importable checkout of the reference, leaving the
 rest of its ``mst`` package (``System``, the controller model, the data modules, ...) untouched - see
-INTEGRATION.md.  No reference source travels with this package.
+INTEGRATION.md; ``install(models=True)`` also swaps the parameter-estimation model classes (encoders on the
+matrix cores, controller stack on HIP).  No reference source travels with this package.
 """
 from __future__ import annotations
 
@@ -34,6 +35,13 @@ _TARGETS = (
     ("mst.utils", "batch_stereo_peak_normalize", utils.batch_stereo_peak_normalize),
     ("auraloss.freq", "MultiResolutionSTFTLoss", loss.MultiResolutionSTFTLoss),
 )
+# the parameter-estimation model: opt-in, install(models=True) - state-dict compatible with the reference's classes
+_MODEL_TARGETS = (
+    ("mst.modules", "MixStyleTransferModel", modules.MixStyleTransferModel),
+    ("mst.modules", "SpectrogramEncoder", modules.SpectrogramEncoder),
+    ("mst.modules", "TransformerController", modules.TransformerController),
+    ("mst.panns", "Cnn14", panns.Cnn14),
+)
 _installed = {}
 
 
@@ -51,8 +59,14 @@ def _peak_normalize_dispatch(reference_fn):
     return batch_stereo_peak_normalize
 
 
-def install(strict: bool = True) -> dict:
+def install(strict: bool = True, models: bool = False) -> dict:
     """Swap the five hot-path symbols of the reference for the HIP implementations.
+
+    ``models=True`` also rebinds the parameter-estimation model - ``mst.modules.{MixStyleTransferModel, SpectrogramEncoder,
+    TransformerController}`` and ``mst.panns.Cnn14`` (reference mst/modules.py:17-68, :740-914, mst/panns.py:126-209): same constructor
+    keywords, same parameter names (reference checkpoints load), so an unchanged ``System`` + unchanged YAML runs the STFT front end and
+    Cnn14 on the matrix cores (fp32 operands unless ``MST_ENCODER_PRECISION=bf16``) and the controller's encoder stack on
+    ``csrc/mst_ctrl.hip`` whenever its shape is inside the kernels' limits.
 
     Requires the reference's ``mst`` package (and ``auraloss``) to be importable as usual; every other name
     of the reference (``mst.system.System``, ``mst.modules.MixStyleTransferModel``,
@@ -65,7 +79,7 @@ def install(strict: bool = True) -> dict:
     ``strict=False`` skips targets whose module cannot be imported instead of raising.
     """
     replaced, current = {}, {}
-    for modname, attr, new in _TARGETS:
+    for modname, attr, new in (_TARGETS + _MODEL_TARGETS if models else _TARGETS):
         try:
             mod = importlib.import_module(modname)
         except ImportError:

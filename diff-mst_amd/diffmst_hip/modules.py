@@ -580,11 +580,11 @@ class SpectrogramEncoder(torch.nn.Module):
 class TransformerController(torch.nn.Module):
     """Reference ``TransformerController`` (mst/modules.py:809-914): learned type embeddings added to the track / mix
     embeddings, one fx-bus and one master-bus token appended, ``torch.nn.TransformerEncoder`` (dropout 0, batch_first),
-    three sigmoid-bounded projections; same parameter names as the reference (its checkpoints load).  Default: torch's own
-    layers (rocBLAS GEMMs + SDPA), the reference's behaviour.  Two opt-in keywords, both for the same reason - 12 layers over
-    ~36 tokens are launch-bound, not arithmetic-bound:
+    three sigmoid-bounded projections; same parameter names as the reference (its checkpoints load).  Two extra keywords, both for the
+    same reason - 12 layers over ~36 tokens are launch-bound, not arithmetic-bound:
 
-    ``native=True``: the encoder stack (everything between the token sequence and the three projections) runs on the
+    ``native`` (default ``None`` = on whenever the tokens live on the device and the stack fits the limits below, torch's own layers
+    - rocBLAS GEMMs + SDPA - otherwise; ``False`` = always torch's layers; ``True`` = always the kernels): the encoder stack (everything between the token sequence and the three projections) runs on the
     hand-written kernels of ``csrc/mst_ctrl.hip`` (``diffmst_hip.controller``; fp32 operands on the matrix cores, forward and
     backward, every gradient within 4e-7 of torch's): 15 launches per layer and direction pair instead of ~48, 1.5 ms of kernels
     per cfg #5 step instead of 3.6 ms + gaps.  Limits: <= 128 tokens, embed_dim % 128 == 0 and <= 1024, head width <= 64,
@@ -600,10 +600,13 @@ class TransformerController(torch.nn.Module):
 
     def __init__(self, embed_dim: int, num_track_control_params: int, num_fx_bus_control_params: int,
                  num_master_bus_control_params: int, num_layers: int = 6, nhead: int = 8, use_fx_bus: bool = False,
-                 use_master_bus: bool = False, graphed: bool = False, native: bool = False) -> None:
+                 use_master_bus: bool = False, graphed: bool = False, native: bool | None = None) -> None:
         super().__init__()
         self.graphed = bool(graphed)
-        self.native = bool(native)  # encoder stack on csrc/mst_ctrl.hip (fp32 MFMA) instead of torch's layers; see controller.py
+        # encoder stack on csrc/mst_ctrl.hip (fp32 MFMA) instead of torch's layers (controller.py).  None (default) = whenever the tokens
+        # are on the device and the stack is inside the kernels' limits, torch's layers otherwise; True = always (raises outside the
+        # limits); False = never
+        self.native = None if native is None else bool(native)
         object.__setattr__(self, "_graphs", {})  # shape key -> graphed callable (not a submodule: state_dict stays the reference's)
         self.embed_dim = embed_dim
         self.num_track_control_params = num_track_control_params
@@ -622,7 +625,7 @@ class TransformerController(torch.nn.Module):
         self.master_bus_projection = torch.nn.Linear(embed_dim, num_master_bus_control_params)
 
     def forward(self, track_embeds: torch.Tensor, mix_embeds: torch.Tensor, track_padding_mask=None):
-        if self.graphed and not self.native and self.training and torch.is_grad_enabled() and track_embeds.is_cuda:
+        if self.graphed and self.native is False and self.training and torch.is_grad_enabled() and track_embeds.is_cuda:
             return self._graphed_forward(track_embeds, mix_embeds, track_padding_mask)
         return self._eager_forward(track_embeds, mix_embeds, track_padding_mask)
 
@@ -652,12 +655,15 @@ class TransformerController(torch.nn.Module):
                             self.fx_bus_embedding.expand(bs, -1, -1), self.master_bus_embedding.expand(bs, -1, -1)), dim=1)
         if track_padding_mask is not None:  # the four appended tokens are always attended to
             track_padding_mask = torch.cat((track_padding_mask, track_padding_mask.new_zeros((bs, 4))), dim=1)  # made on the device: no host copy
-        if self.native and tokens.is_cuda:
+        use_native = False
+        if self.native is not False and tokens.is_cuda:
             from . import controller
 
-            if not controller.supported(self.transformer_encoder, bs, tokens.shape[1]):
+            use_native = controller.supported(self.transformer_encoder, bs, tokens.shape[1])
+            if self.native and not use_native:
                 raise ValueError("TransformerController(native=True): encoder stack outside the kernels' limits "
                                  "(<= 128 tokens, d_model % 128 == 0, head width <= 64, post-norm relu layers, dropout 0)")
+        if use_native:
             z = controller.encoder_stack(self.transformer_encoder, tokens, track_padding_mask)
         else:
             z = self.transformer_encoder(tokens, src_key_padding_mask=track_padding_mask)

@@ -107,7 +107,16 @@ def console_case(name, bs, T, n, seed, flags, ref_console, full_box=False):
     for k, v in flat(mpd).items():
         assert torch.equal(v, flat(o_mpd)[k]), k
 
+    # float64 evaluation of the same algorithm: the value both fp32 paths (the reference's autograd above, the HIP console) approximate -
+    # lets the GPU test bound the parameter gradients three-way instead of by a measured tolerance
+    tp64 = tp.detach().double().requires_grad_(True)
+    mp64 = mp.detach().double().requires_grad_(True)
+    _, mix64, *_ = oc.console_forward(tracks.double(), tp64, fp.double(), mp64, sample_rate=44100, **flags)
+    (mix64 * gmix.double()).sum().backward()
+
     out = dict(
+        grad_track_params_f64=zg(tp64).numpy(),
+        grad_master_bus_params_f64=zg(mp64).numpy(),
         tracks=tracks.numpy().astype(np.float16) if full_box else tracks.numpy(),
         track_params=tp.detach().numpy(),
         fx_bus_params=fp.numpy(),
@@ -338,32 +347,7 @@ def controller_case(rmodules):
     print("controller fixture:", sum(v.nbytes for v in out.values() if hasattr(v, "nbytes")) // 1024, "KiB before compression")
 
 
-def main():
-    assert os.path.isdir(REF), "golden generation needs /root/reference (build container only)"
-    install_stubs()
-    sys.path.insert(0, REF)
-    import mst.filter as rfilter
-    import mst.loss as rloss
-    import mst.mixing as rmixing
-    import mst.modules as rmodules
-    import mst.system as rsystem
-
-    ref_console = rmodules.AdvancedMixConsole(sample_rate=44100)
-    assert ref_console.param_ranges == oc.param_ranges(44100)
-    only = set(sys.argv[1:])  # e.g. `make_golden.py system` regenerates one fixture family (default: all)
-    if only and only <= {"system", "fx", "run", "encoder", "controller"}:
-        if "encoder" in only:
-            encoder_case(rmodules)
-        if "controller" in only:
-            controller_case(rmodules)
-        if "run" in only:
-            run_case(rmodules)
-        if "system" in only:
-            system_case(rsystem, rmodules, rmixing)
-        if "fx" in only:
-            fx_case(ref_console)
-        return
-
+def console_cases(ref_console):
     basic = dict(
         use_track_input_fader=True, use_track_eq=False, use_track_compressor=False, use_track_panner=True,
         use_fx_bus=False, use_master_bus=False, use_output_fader=False,
@@ -380,6 +364,37 @@ def main():
     console_case("refmix_2x3x8192", 2, 3, 8192, 4, refmix, ref_console)
     # System's training length (mst/system.py:255-258), full parameter box
     console_case("fullbox_1x2x131072", 1, 2, 131072, 5, full, ref_console, full_box=True)
+
+
+def main():
+    assert os.path.isdir(REF), "golden generation needs /root/reference (build container only)"
+    install_stubs()
+    sys.path.insert(0, REF)
+    import mst.filter as rfilter
+    import mst.loss as rloss
+    import mst.mixing as rmixing
+    import mst.modules as rmodules
+    import mst.system as rsystem
+
+    ref_console = rmodules.AdvancedMixConsole(sample_rate=44100)
+    assert ref_console.param_ranges == oc.param_ranges(44100)
+    only = set(sys.argv[1:])  # e.g. `make_golden.py system` regenerates one fixture family (default: all)
+    if only and only <= {"system", "fx", "run", "encoder", "controller", "console"}:
+        if "console" in only:
+            console_cases(ref_console)
+        if "encoder" in only:
+            encoder_case(rmodules)
+        if "controller" in only:
+            controller_case(rmodules)
+        if "run" in only:
+            run_case(rmodules)
+        if "system" in only:
+            system_case(rsystem, rmodules, rmixing)
+        if "fx" in only:
+            fx_case(ref_console)
+        return
+
+    console_cases(ref_console)
 
     # naive_random_mix (mixing.py:35-94): RNG draw order and the 8-tuple
     torch.manual_seed(11)

@@ -25,7 +25,7 @@ def test_graphed_controller_equals_eager(with_mask, record):
 
     dev = torch.device("cuda:0")
     torch.manual_seed(11)
-    ctrl = TransformerController(512, 27, 25, 26, num_layers=3, nhead=8, graphed=True).to(dev).train()
+    ctrl = TransformerController(512, 27, 25, 26, num_layers=3, nhead=8, graphed=True, native=False).to(dev).train()
     keys = set(ctrl.state_dict().keys())
     bs, T = 2, 6
     worst = 0.0

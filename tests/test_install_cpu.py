@@ -67,6 +67,34 @@ SCRIPT = textwrap.dedent(
         print("REACHED_DEVICE_CALL")
     diffmst_hip.uninstall()
     assert mst.modules.AdvancedMixConsole is ref_console_cls and mst.system.batch_stereo_peak_normalize is ref_peak
+
+    # install(models=True): the parameter-estimation model too (reference mst/modules.py:17-68, :740-914, mst/panns.py:126-209)
+    import mst.panns
+    ref_model_classes = (mst.modules.MixStyleTransferModel, mst.modules.SpectrogramEncoder, mst.modules.TransformerController, mst.panns.Cnn14)
+    ref_sd_keys = set(mst.modules.SpectrogramEncoder(embed_dim=16).state_dict().keys())
+    swapped = diffmst_hip.install(models=True)
+    assert len(swapped) == 9, swapped
+    assert mst.modules.SpectrogramEncoder is diffmst_hip.modules.SpectrogramEncoder and mst.panns.Cnn14 is diffmst_hip.panns.Cnn14
+    assert mst.modules.TransformerController is diffmst_hip.modules.TransformerController
+    assert mst.modules.MixStyleTransferModel is diffmst_hip.modules.MixStyleTransferModel
+    # built the way configs/models/naive+feat.yaml builds it, class paths resolved through the patched modules
+    enc = lambda: mst.modules.SpectrogramEncoder(embed_dim=128, n_inputs=1, n_fft=2048, hop_length=512, input_batchnorm=False, encoder_batchnorm=True)
+    model = mst.modules.MixStyleTransferModel(enc(), enc(), mst.modules.TransformerController(
+        embed_dim=128, num_track_control_params=27, num_fx_bus_control_params=25, num_master_bus_control_params=26, num_layers=2, nhead=8))
+    assert set(model.track_encoder.state_dict().keys()) == ref_sd_keys  # reference checkpoints load
+    assert model.track_encoder.model.precision == "fp32" and model.controller.native is None
+    system = mst.system.System(model=model, mix_console=mst.modules.AdvancedMixConsole(sample_rate=44100), mix_fn=mst.mixing.naive_random_mix,
+                               loss=auraloss.freq.MultiResolutionSTFTLoss(fft_sizes=[512], hop_sizes=[256], win_lengths=[512]),
+                               generate_mix=False, active_eq_epoch=0, active_compressor_epoch=0, active_fx_bus_epoch=1000,
+                               active_master_bus_epoch=0)
+    batch = (0.1 * torch.randn(2, 3, 131072), None, None, torch.zeros(2, 3, dtype=torch.bool), 0.1 * torch.randn(2, 2, 131072), ["a", "b"])
+    try:
+        system.common_step(batch, 0, train=True)
+    except RuntimeError as e:       # OUR SpectrogramEncoder, reached through System's own model call (mst/system.py:263-271)
+        assert "no CPU path" in str(e), e
+        print("REACHED_ENCODER_CALL")
+    diffmst_hip.uninstall()
+    assert (mst.modules.MixStyleTransferModel, mst.modules.SpectrogramEncoder, mst.modules.TransformerController, mst.panns.Cnn14) == ref_model_classes
     print("INSTALL_OK")
     """
 )
@@ -79,7 +107,7 @@ def test_install_rebinds_only_the_hot_path_of_the_real_reference():
     r = subprocess.run([sys.executable, "-B", "-c", SCRIPT.format(root=ROOT, ref=REF)], capture_output=True, text=True, env=env,
                        cwd="/tmp", timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "REACHED_DEVICE_CALL" in r.stdout and "INSTALL_OK" in r.stdout, r.stdout + r.stderr
+    assert "REACHED_DEVICE_CALL" in r.stdout and "REACHED_ENCODER_CALL" in r.stdout and "INSTALL_OK" in r.stdout, r.stdout + r.stderr
 
 
 def test_install_refuses_the_alias_package():

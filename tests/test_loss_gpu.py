@@ -78,6 +78,61 @@ def test_mrstft_three_way(bs, n, kw, seeds, dev, record):
     assert med <= 1.5, ratios
 
 
+@pytest.mark.parametrize("bs,n,seed", [(2, 65536, 21), (8, 262144, 22)])
+def test_mrstft_log_magnitude_adjoint_away_from_the_clamp(bs, n, seed, dev, record):
+    """The sign() / |X| adjoint of the log-magnitude term with a deterministic per-draw bound (round-3 review, weak 3): once the two
+    things that make test_mrstft_three_way a statistic are out of the picture, every single draw must sit within the three-way bound
+    (HIP no further from float64 than twice the fp32 reference path, + 1e-4) - no median, no 10x allowance.
+      * the reflect-padded edge frames (real-even spectra: |X| crosses zero between bins) see silence - the signals are zero over the
+        first and last 8192 samples, so every frame that touches the padding is all-zero, sits BELOW the 1e-8 clamp for both
+        implementations and contributes exactly nothing;
+      * no remaining bin is within a factor 4 of the clamp, where a cotangent of ~1e4 switches on or off with the last bit of |X|^2 -
+        checked here in float64 on every bin of every resolution, for prediction and target (a self-check of the construction, not a
+        mask applied to the result: with complex Gaussian spectra of variance >= 17 such a bin has probability 2e-9).
+    What is left is the plain arithmetic of cotangent, inverse transform, window and overlap-add - and the 1 / |X| weighting of the
+    fp32 transform's own round-off: for a complex Gaussian spectrum E[1 / |X|^2] diverges logarithmically, so the rel-L2 error of this
+    gradient is ~1e-3 for ANY fp32 evaluation (measured: HIP 1.2e-3, the reference's fp32 path 8e-4 at 2 x 2 x 65536) and an absolute
+    1e-4 is not a property fp32 has here; the smooth terms (test_mrstft_well_conditioned_terms) pin the linear part to 5e-6."""
+    from oracle import loss_restated as ol
+
+    # (the real-valued DC / Nyquist bins are chi-square with ONE degree of freedom: ~5e-5 of them fall into the band, i.e. a handful at
+    # 8 x 2 x 262144 - so the first seed of a short deterministic sequence that has none is used)
+    for attempt in range(16):
+        torch.manual_seed(seed + 100 * attempt)
+        x = 0.3 * torch.randn(bs, 2, n)
+        y = 0.5 * x + 0.2 * torch.randn(bs, 2, n)
+        for t in (x, y):
+            t[..., :8192] = 0.0
+            t[..., -8192:] = 0.0
+        near = 0
+        for n_fft, hop, win in RES:
+            for t in (x, y):
+                X = torch.stft(t.double().reshape(-1, n), n_fft, hop, win, torch.hann_window(win, dtype=torch.float64), return_complex=True)
+                p2 = X.real**2 + X.imag**2
+                near += int(((p2 > 0.25e-8) & (p2 < 4e-8)).sum())
+        if near == 0:
+            break
+    assert near == 0, f"{near} bins within a factor 4 of the clamp after 16 seeds"
+    kw = dict(w_sc=0.0, w_log_mag=1.0)
+    xd = x.to(dev).requires_grad_(True)
+    loss = make_loss(**kw)(xd, y.to(dev))
+    loss.backward()
+    outs = {}
+    for dt in (torch.float32, torch.float64):
+        xo = x.clone().to(dt).requires_grad_(True)
+        lo = ol.mrstft_loss(xo, y.to(dt), RES, **kw)
+        lo.backward()
+        outs[dt] = (lo.item(), xo.grad)
+    l64, g64 = outs[torch.float64]
+    h64, r64 = rel(xd.grad, g64), rel(outs[torch.float32][1], g64)
+    e_loss = abs(loss.item() - l64) / l64
+    print(f"\n[log-magnitude adjoint, {bs}x2x{n}] loss {e_loss:.2e}; gradient HIP vs f64 {h64:.2e} (fp32 oracle vs f64 {r64:.2e})")
+    record(loss=e_loss, grad_hip_vs_f64=h64, grad_ref32_vs_f64=r64)
+    assert e_loss < 1e-5
+    assert h64 <= 2 * r64 + 1e-4, (h64, r64)
+    assert float(xd.grad[..., :4096].abs().max()) == 0.0 and float(xd.grad[..., -4096:].abs().max()) == 0.0  # silence below the clamp: no gradient
+
+
 @pytest.mark.parametrize("kw", [dict(w_sc=1.0, w_log_mag=0.0), dict(w_sc=1.0, w_log_mag=0.0, sc_per_example=False)])
 def test_mrstft_well_conditioned_terms(kw, dev):
     """The spectral-convergence term is smooth (no 1/|X| factor, no sign()): its gradient pins the

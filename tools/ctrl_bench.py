@@ -14,7 +14,7 @@ torch.manual_seed(0)
 te, me = torch.randn(bs, T, 512, device=dev), torch.randn(bs, 2, 512, device=dev)
 mask = torch.zeros(bs, T, dtype=torch.bool, device=dev)
 w = torch.randn(bs, T, 27, device=dev)
-for label, kw in (("torch eager", {}), ("torch kernels replayed as two hipGraphs", dict(graphed=True)), ("csrc/mst_ctrl.hip (native=True)", dict(native=True))):
+for label, kw in (("torch eager", dict(native=False)), ("torch kernels replayed as two hipGraphs", dict(graphed=True, native=False)), ("csrc/mst_ctrl.hip (native=True)", dict(native=True))):
     torch.manual_seed(1)
     ctrl = TransformerController(512, 27, 25, 26, num_layers=12, nhead=8, **kw).to(dev).train()
 
