@@ -419,13 +419,36 @@ def secondary_lines(dev):
     for name, kw, materialised, steps, warm in specs:
         step = make_workload(dev, seed=2000, **kw)
         med, mean = time_steps(step, steps, warm)
+        graphed = None
+        if kw.get("basic"):
+            # cfg #1 is three console launches (20 us of kernels, profiles/round4_cfg1.md) inside ~130 us of host work per eager step
+            # (autograd bookkeeping, the loss's own torch kernels): the same step captured once and replayed as ONE hipGraph shows the
+            # device-side cost.  Replay is bit-equal to eager (checked below).
+            ref_loss = step().clone()
+            ref_grad = step.params[0].grad.clone()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    step()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                g_loss = step()
+            torch.cuda.synchronize()
+            gmed, gmean = time_steps(graph.replay, 200, 20)
+            torch.cuda.synchronize()
+            assert torch.equal(g_loss, ref_loss) and torch.equal(step.params[0].grad, ref_grad), "hipGraph replay differs from the eager step"
+            graphed = {"ms_per_step_median": gmed, "ms_per_step_mean": gmean, "steps": 200, "mixes_per_s": kw["bs"] / (gmed * 1e-3),
+                       "note": "the same step replayed as one hipGraph (torch.cuda.CUDAGraph), bit-equal to eager"}
         if kw.get("lean", True):
             step.console.check_parameters()
         b = kw["bs"] * bytes_per_mix(kw["n_tracks"], kw["n"], materialised, loss=kw["loss_kind"] != "none")
         gbs = b / (med * 1e-3) / 1e9
         out.append({"workload": name, "ms_per_step_median": med, "ms_per_step_mean": mean, "steps": steps,
                     "mixes_per_s": kw["bs"] / (med * 1e-3), "algorithmic_bytes_per_step": b, "achieved_GBs": gbs,
-                    "frac_of_hbm_peak": gbs / HBM_PEAK_GBS})
+                    "frac_of_hbm_peak": gbs / HBM_PEAK_GBS, **({"hipgraph_replay": graphed} if graphed else {})})
         del step
         torch.cuda.empty_cache()
     return out

@@ -95,6 +95,12 @@ extern "C" int mst_console_forward(const mst_console_desc* d, const float* track
     const bool o_on = d->flags & MST_USE_OUTPUT_FADER;
     const bool fx_on = d->flags & MST_USE_FX_BUS;
     if (fx_on && (!fx || !fx->noise || !fx->filters || !fx->tables)) return hipErrorInvalidValue;
+    if (basic_path(d)) {  // BASELINE cfg #1: gain + pan + bus sum in one launch
+        BasicArgs ba{tracks, track_params, fx_bus_params, master_bus_params, mix, mixed_tracks, status, nullptr, nullptr, nullptr, nullptr, nullptr,
+                     ws + L.cp_t, *d};
+        launch_basic_forward(ba, stream);
+        return (int)hipGetLastError();
+    }
 
     PrepArgs pa{track_params, fx_bus_params, master_bus_params, ws + L.rc_t, ws + L.rc_m,
                 ws + L.powF_t, ws + L.powF_m, ws + L.powA_t, ws + L.powA_m, ws + L.powP_t, ws + L.powP_m,
@@ -191,8 +197,14 @@ extern "C" int mst_console_backward(const mst_console_desc* d, const float* trac
     const bool o_on = d->flags & MST_USE_OUTPUT_FADER;
     const bool fx_on = d->flags & MST_USE_FX_BUS;
     if (fx_on && (!fx || !fx->tables || !fx_bus_params)) return hipErrorInvalidValue;
-    (void)tracks;
     const int aligned = (n % 4 == 0) && !((uintptr_t)grad_mix & 15) && !((uintptr_t)grad_mixed_tracks & 15);
+    if (basic_path(d)) {
+        if (!tracks) return hipErrorInvalidValue;
+        BasicArgs ba{tracks, track_params, fx_bus_params, master_bus_params, nullptr, nullptr, nullptr, grad_mix, grad_mixed_tracks,
+                     grad_track_params, grad_master_params, grad_tracks, ws + L.cp_t, *d};
+        launch_basic_backward(ba, stream);
+        return (int)hipGetLastError();
+    }
 
     // ---- all-pole states of the coefficient-gradient pass depend only on what forward saved: one
     // launch covers the track rows and the master rows (signal rows [0,R) and [R,R+2bs) of the same arrays)

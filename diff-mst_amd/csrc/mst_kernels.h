@@ -55,6 +55,34 @@ struct PrepBwdArgs {
     gran_t* gran;                          // the backward's granule arrays, re-armed (zeroed) for a second backward over the same forward
     int64_t gran_n;
 };
+// BASELINE cfg #1 (gain + pan + bus sum only): one forward launch, two backward launches, no k_prep chain (mst_params.hip)
+constexpr int kBasicMaxTracks = 256;
+struct BasicArgs {
+    const float* tracks;         // (bs, T, n), row stride d.track_row_stride
+    const float* track_params;   // (bs, T, 27)
+    const float* fx_params;      // (bs, 25)   range check only
+    const float* master_params;  // (bs, 26)   range check only
+    float* mix;                  // (bs, 2, n) forward out
+    float* mixed;                // (bs, 2, T, n) forward out or null
+    int32_t* status;
+    const float* grad_mix;       // backward in
+    const float* grad_mixed;     // (bs, 2, T, n) or null
+    float* grad_track_params;    // (bs, T, 27) out
+    float* grad_master_params;   // (bs, 26) out (zeros) or null
+    float* grad_tracks;          // (bs, T, n) out or null
+    float* part;                 // (bs, nblk, T, 2) scratch
+    mst_console_desc d;
+};
+inline bool basic_path(const mst_console_desc* d) {  // every stage but input fader / panner off, and few enough tracks for the LDS table
+    const uint32_t stages = MST_USE_TRACK_EQ | MST_USE_TRACK_COMPRESSOR | MST_USE_FX_BUS | MST_USE_MASTER_BUS | MST_USE_OUTPUT_FADER;
+#ifdef MST_NO_BASIC_PATH
+    return false;
+#else
+    return !(d->flags & stages) && (d->flags & MST_USE_TRACK_PANNER) && d->n_tracks <= kBasicMaxTracks && !(d->flags & MST_DEV_MULTIPASS_EQ);
+#endif
+}
+void launch_basic_forward(const BasicArgs& a, hipStream_t stream);
+void launch_basic_backward(const BasicArgs& a, hipStream_t stream);
 void launch_prep(const PrepArgs& a, hipStream_t stream);
 void launch_prep_bwd(const PrepBwdArgs& a, hipStream_t stream);
 

@@ -616,6 +616,155 @@ __global__ __launch_bounds__(256) void k_prep_bwd(PrepBwdArgs a) {
     }
 }
 
+// =====================================================================================================================
+// BASELINE cfg #1: gain + pan + bus sum only (BasicMixConsole; contract inferred from reference mst/mixing.py:122-164,
+// :935-945: two parameters per track).  The general path would run k_prep's table chains, two EQ launches over identity
+// sections, the apply kernel and the whole backward chain (0.28 ms per step at 2 x 4 x 65536); here the call is ONE forward
+// launch and TWO backward launches with the same arithmetic per sample: y = gin x (the identity cascade's only product),
+// bus_c = sum_t fma(pan_c, y, bus_c) in track order.  Built in this file for its contraction-free denormalisation.
+struct BasicConst { float gin, pl, pr; };
+__device__ __forceinline__ BasicConst basic_consts(const float* p, const mst_console_desc& d) {
+#pragma clang fp contract(off)
+    BasicConst k;
+    k.gin = 1.0f;
+    if (d.flags & MST_USE_TRACK_INPUT_FADER) k.gin = (float)exp2((double)(denorm(p[0], d.track_lo[0], d.track_hi[0]) / 20.0f) * 3.321928094887362);
+    const float half_pi = 1.5707963267948966f, two_over_pi = 0.6366197723675814f;
+    const float theta = denorm(p[25], d.track_lo[25], d.track_hi[25]) * half_pi;
+    k.pl = sqrtf(((half_pi - theta) * two_over_pi) * (float)cos((double)theta));
+    k.pr = sqrtf((theta * two_over_pi) * (float)sin((double)theta));
+    return k;
+}
+constexpr int kBasicSpan = 8 * 256;  // samples per workgroup: 8 per lane, like the compressor kernels
+__global__ __launch_bounds__(256) void k_basic_fwd(BasicArgs a) {
+    __shared__ BasicConst kc[kBasicMaxTracks];
+    const int b = blockIdx.y, tid = threadIdx.x, T = a.d.n_tracks;
+    const float* tp = a.track_params + (int64_t)b * T * MST_NUM_TRACK_PARAMS;
+    if (tid < T) kc[tid] = basic_consts(tp + (int64_t)tid * MST_NUM_TRACK_PARAMS, a.d);
+    if (blockIdx.x == 0 && !(a.d.flags & MST_NO_RANGE_CHECK)) {  // reference mst/modules.py:86-89, same status codes as k_prep
+        for (int i = tid; i < T * MST_NUM_TRACK_PARAMS; i += 256) {
+            const float v = tp[i];
+            if (v < 0.0f || v > 1.0f) atomicMax(a.status, 1000 - (1 + i % MST_NUM_TRACK_PARAMS));
+        }
+        if (tid < MST_NUM_FX_PARAMS - 1) {
+            const float v = a.fx_params[(int64_t)b * MST_NUM_FX_PARAMS + tid];
+            if (v < 0.0f || v > 1.0f) atomicMax(a.status, 1000 - (1 + 27 + tid));
+        }
+        if (tid >= 64 && tid < 64 + MST_NUM_MASTER_PARAMS) {
+            const float v = a.master_params[(int64_t)b * MST_NUM_MASTER_PARAMS + tid - 64];
+            if (v < 0.0f || v > 1.0f) atomicMax(a.status, 1000 - (1 + 52 + tid - 64));
+        }
+    }
+    __syncthreads();
+    const int64_t i0 = (int64_t)blockIdx.x * kBasicSpan + tid * 8, n = a.d.n_samples;
+    float4 L[2] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)}, R[2] = {L[0], L[0]};
+    for (int t = 0; t < T; ++t) {
+        const float* row = a.tracks + ((int64_t)b * T + t) * a.d.track_row_stride;
+        const BasicConst k = kc[t];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float4 x = load4(row, i0 + 4 * h, n);
+            const float4 y = make_float4(k.gin * x.x, k.gin * x.y, k.gin * x.z, k.gin * x.w);
+            L[h] = make_float4(fmaf(k.pl, y.x, L[h].x), fmaf(k.pl, y.y, L[h].y), fmaf(k.pl, y.z, L[h].z), fmaf(k.pl, y.w, L[h].w));
+            R[h] = make_float4(fmaf(k.pr, y.x, R[h].x), fmaf(k.pr, y.y, R[h].y), fmaf(k.pr, y.z, R[h].z), fmaf(k.pr, y.w, R[h].w));
+            if (a.mixed) {
+                store4(a.mixed + (((int64_t)b * 2 + 0) * T + t) * n, i0 + 4 * h, n, make_float4(k.pl * y.x, k.pl * y.y, k.pl * y.z, k.pl * y.w));
+                store4(a.mixed + (((int64_t)b * 2 + 1) * T + t) * n, i0 + 4 * h, n, make_float4(k.pr * y.x, k.pr * y.y, k.pr * y.z, k.pr * y.w));
+            }
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        store4(a.mix + ((int64_t)b * 2 + 0) * n, i0 + 4 * h, n, L[h]);
+        store4(a.mix + ((int64_t)b * 2 + 1) * n, i0 + 4 * h, n, R[h]);
+    }
+}
+// backward, stage 1: per (mix, block) and track the sums <gL, y>, <gR, y> (y = gin x); grad_tracks = gin (pl gL + pr gR) (+ the
+// mixed_tracks cotangent) when asked for.  part: (bs, nblk, T, 2)
+__global__ __launch_bounds__(256) void k_basic_bwd_part(BasicArgs a) {
+    __shared__ BasicConst kc[kBasicMaxTracks];
+    __shared__ float red[4][2];
+    const int b = blockIdx.y, tid = threadIdx.x, T = a.d.n_tracks;
+    if (tid < T) kc[tid] = basic_consts(a.track_params + ((int64_t)b * T + tid) * MST_NUM_TRACK_PARAMS, a.d);
+    __syncthreads();
+    const int64_t i0 = (int64_t)blockIdx.x * kBasicSpan + tid * 8, n = a.d.n_samples;
+    float gl[8], gr[8];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const float4 l = load4(a.grad_mix + ((int64_t)b * 2 + 0) * n, i0 + 4 * h, n), r = load4(a.grad_mix + ((int64_t)b * 2 + 1) * n, i0 + 4 * h, n);
+        gl[4 * h] = l.x; gl[4 * h + 1] = l.y; gl[4 * h + 2] = l.z; gl[4 * h + 3] = l.w;
+        gr[4 * h] = r.x; gr[4 * h + 1] = r.y; gr[4 * h + 2] = r.z; gr[4 * h + 3] = r.w;
+    }
+    for (int t = 0; t < T; ++t) {
+        const float* row = a.tracks + ((int64_t)b * T + t) * a.d.track_row_stride;
+        const BasicConst k = kc[t];
+        float sl = 0.0f, sr = 0.0f;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float4 x4 = load4(row, i0 + 4 * h, n);
+            const float x[4] = {x4.x, x4.y, x4.z, x4.w};
+            float ml[4] = {0, 0, 0, 0}, mr[4] = {0, 0, 0, 0};
+            if (a.grad_mixed) {
+                const float4 u = load4(a.grad_mixed + (((int64_t)b * 2 + 0) * T + t) * n, i0 + 4 * h, n);
+                const float4 v = load4(a.grad_mixed + (((int64_t)b * 2 + 1) * T + t) * n, i0 + 4 * h, n);
+                ml[0] = u.x; ml[1] = u.y; ml[2] = u.z; ml[3] = u.w;
+                mr[0] = v.x; mr[1] = v.y; mr[2] = v.z; mr[3] = v.w;
+            }
+            float gx[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float y = k.gin * x[e], cl = gl[4 * h + e] + ml[e], cr = gr[4 * h + e] + mr[e];
+                sl = fmaf(cl, y, sl);
+                sr = fmaf(cr, y, sr);
+                gx[e] = k.gin * fmaf(k.pr, cr, k.pl * cl);
+            }
+            if (a.grad_tracks) store4(a.grad_tracks + ((int64_t)b * T + t) * n, i0 + 4 * h, n, make_float4(gx[0], gx[1], gx[2], gx[3]));
+        }
+        sl = wave_sum(sl);
+        sr = wave_sum(sr);
+        if ((tid & 63) == 0) { red[tid >> 6][0] = sl; red[tid >> 6][1] = sr; }
+        __syncthreads();
+        if (tid < 2) a.part[(((int64_t)b * gridDim.x + blockIdx.x) * T + t) * 2 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+        __syncthreads();
+    }
+}
+// stage 2: one lane per track row folds the blocks in order (fp64) and applies the chain rule of k_prep_bwd (gain: d gin / d dB =
+// gin ln10 / 20; constant-power pan law); every other column of the (bs, T, 27) gradient is zero, like autograd's unused leaves
+__global__ void k_basic_bwd_final(BasicArgs a, int nblk) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x, T = a.d.n_tracks;
+    if (r >= a.d.bs * T) return;
+    const int b = r / T, t = r % T;
+    double sl = 0.0, sr = 0.0;
+    for (int k = 0; k < nblk; ++k) {
+        sl += (double)a.part[(((int64_t)b * nblk + k) * T + t) * 2];
+        sr += (double)a.part[(((int64_t)b * nblk + k) * T + t) * 2 + 1];
+    }
+    const float* p = a.track_params + (int64_t)r * MST_NUM_TRACK_PARAMS;
+    const BasicConst k = basic_consts(p, a.d);
+    float* g = a.grad_track_params + (int64_t)r * MST_NUM_TRACK_PARAMS;
+    for (int i = 0; i < MST_NUM_TRACK_PARAMS; ++i) g[i] = 0.0f;
+    const float* lo = a.d.track_lo;
+    const float* hi = a.d.track_hi;
+    if (a.d.flags & MST_USE_TRACK_INPUT_FADER)  // gin dL/dgin = sum (pl gL + pr gR) y
+        g[0] = (float)(((double)k.pl * sl + (double)k.pr * sr) * (double)kLn10Over20 * (double)(hi[0] - lo[0]));
+    const double half_pi = 1.5707963267948966, two_over_pi = 0.6366197723675814;
+    const double theta = (double)denorm(p[25], lo[25], hi[25]) * half_pi, L = k.pl, Rr = k.pr;
+    double dLdth = 0.0, dRdth = 0.0;
+    if (L > 0.0) dLdth = (-two_over_pi * cos(theta) - (half_pi - theta) * two_over_pi * sin(theta)) / (2.0 * L);
+    if (Rr > 0.0) dRdth = (two_over_pi * sin(theta) + theta * two_over_pi * cos(theta)) / (2.0 * Rr);
+    g[25] = (float)((sl * dLdth + sr * dRdth) * half_pi * (double)(hi[25] - lo[25]));
+    if (t == 0 && a.grad_master_params)
+        for (int i = 0; i < MST_NUM_MASTER_PARAMS; ++i) a.grad_master_params[(int64_t)b * MST_NUM_MASTER_PARAMS + i] = 0.0f;
+}
+void launch_basic_forward(const BasicArgs& a, hipStream_t stream) {
+    const int nblk = (int)((a.d.n_samples + kBasicSpan - 1) / kBasicSpan);
+    hipLaunchKernelGGL(k_basic_fwd, dim3(nblk, a.d.bs), dim3(256), 0, stream, a);
+}
+void launch_basic_backward(const BasicArgs& a, hipStream_t stream) {
+    const int nblk = (int)((a.d.n_samples + kBasicSpan - 1) / kBasicSpan), rows = a.d.bs * a.d.n_tracks;
+    hipLaunchKernelGGL(k_basic_bwd_part, dim3(nblk, a.d.bs), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(k_basic_bwd_final, dim3((rows + 63) / 64), dim3(64), 0, stream, a, nblk);
+}
+
 void launch_prep(const PrepArgs& a, hipStream_t stream) {
     hipLaunchKernelGGL(k_prep, dim3(a.R + a.bs, 2), dim3(320), 0, stream, a);
 }
