@@ -173,26 +173,47 @@ __global__ __launch_bounds__(kWG) void k_comp_zs(const float* __restrict__ u, in
 }
 
 // ---- forward: tracks.  grid (nblk, bs).  Accumulates the stereo bus over the T tracks of mix b.
-template <bool FAST>
+// The loop over the tracks is software-pipelined: track t + 1's EQ output (at both offsets) is requested before track t's block scans, so
+// its memory round trip hides behind four barriers and the static-curve arithmetic instead of opening every iteration (round-3 counters:
+// 19 % VALU issue, 66 % of the wave cycles waiting).  FX (fx send bus) is a template parameter: its two accumulators cost 16 registers
+// that the prefetch needs (123 of 128 before).
+template <bool FAST, bool FX>
 __device__ __forceinline__ void apply_tracks_body(const TrackApplyArgs& a) {
     __shared__ float lds[8];
     const int b = blockIdx.y, chunk = blockIdx.x * kWG + threadIdx.x;
     const int64_t i0 = (int64_t)chunk * CC;
-    float accL[CC], accR[CC], fxL[CC], fxR[CC];
+    float accL[CC], accR[CC], fxL[FX ? CC : 1], fxR[FX ? CC : 1];
 #pragma unroll
-    for (int i = 0; i < CC; ++i) accL[i] = accR[i] = fxL[i] = fxR[i] = 0.0f;
+    for (int i = 0; i < CC; ++i) accL[i] = accR[i] = 0.0f;
+    if (FX) {
+#pragma unroll
+        for (int i = 0; i < CC; ++i) fxL[i] = fxR[i] = 0.0f;
+    }
+    float xn[CC], xdn[CC];  // the NEXT track's samples (comp_on: at i0 and at i0 - lookahead)
+    {
+        const float* u0 = a.u + (int64_t)(b * a.T) * a.stride;
+        LD8<FAST>(u0, i0, a.n, xn);
+        if (a.comp_on) LD8S<FAST>(u0, i0 - a.lookahead, a.n, xdn);
+    }
     for (int t = 0; t < a.T; ++t) {
         const int row = b * a.T + t;
         const float* rc = a.rc + (int64_t)row * RC_STRIDE;
         const float pl = rc[RC_PANL], pr = rc[RC_PANR];
-        const float sl = a.fx ? pl * rc[RC_SEND] : 0.0f, sr = a.fx ? pr * rc[RC_SEND] : 0.0f;  // fx send bus: sum_t send_t * panned track
-        const float* urow = a.u + (int64_t)row * a.stride;
-        float y[CC];
+        const float sl = FX ? pl * rc[RC_SEND] : 0.0f, sr = FX ? pr * rc[RC_SEND] : 0.0f;  // fx send bus: sum_t send_t * panned track
+        float y[CC], x[CC], xd[CC];
+#pragma unroll
+        for (int i = 0; i < CC; ++i) {
+            x[i] = xn[i];
+            xd[i] = xdn[i];
+        }
+        if (t + 1 < a.T) {
+            const float* un = a.u + (int64_t)(row + 1) * a.stride;
+            LD8<FAST>(un, i0, a.n, xn);
+            if (a.comp_on) LD8S<FAST>(un, i0 - a.lookahead, a.n, xdn);
+        }
         if (a.comp_on) {
             const CompK k = load_comp(rc);
-            float x[CC], xd[CC], g[CC];
-            LD8<FAST>(urow, i0, a.n, x);
-            LD8S<FAST>(urow, i0 - a.lookahead, a.n, xd);
+            float g[CC];
             float z = 0.0f;
 #pragma unroll
             for (int i = 0; i < CC; ++i) {
@@ -211,14 +232,15 @@ __device__ __forceinline__ void apply_tracks_body(const TrackApplyArgs& a) {
             }
             if (a.gs) ST8<FAST>(a.gs + (int64_t)row * a.stride, i0, a.n, g);
         } else {
-            LD8<FAST>(urow, i0, a.n, y);
+#pragma unroll
+            for (int i = 0; i < CC; ++i) y[i] = x[i];
         }
 #pragma unroll
         for (int i = 0; i < CC; ++i) {
             accL[i] = fmaf(pl, y[i], accL[i]);
             accR[i] = fmaf(pr, y[i], accR[i]);
         }
-        if (a.fx) {
+        if (FX) {
 #pragma unroll
             for (int i = 0; i < CC; ++i) {
                 fxL[i] = fmaf(sl, y[i], fxL[i]);
@@ -238,7 +260,7 @@ __device__ __forceinline__ void apply_tracks_body(const TrackApplyArgs& a) {
     }
     ST8<FAST>(a.bus + ((int64_t)b * 2 + 0) * a.bus_stride, i0, a.n, accL);
     ST8<FAST>(a.bus + ((int64_t)b * 2 + 1) * a.bus_stride, i0, a.n, accR);
-    if (a.fx) {  // (bs, 2, stride) rows of the workspace: always 16-byte aligned
+    if (FX) {  // (bs, 2, stride) rows of the workspace: always 16-byte aligned
         ST8<FAST>(a.fx + ((int64_t)b * 2 + 0) * a.stride, i0, a.n, fxL);
         ST8<FAST>(a.fx + ((int64_t)b * 2 + 1) * a.stride, i0, a.n, fxR);
     }
@@ -247,9 +269,10 @@ __device__ __forceinline__ bool block_interior(int64_t n, int lookahead, int ali
     const int64_t lo = (int64_t)(blk < 0 ? (int)blockIdx.x : blk) * kWG * CC, hi = lo + (int64_t)kWG * CC;
     return aligned && lo - lookahead >= 0 && hi + lookahead <= n;
 }
+template <bool FX>
 __global__ __launch_bounds__(kWG) void k_apply_tracks(TrackApplyArgs a) {
-    if (block_interior(a.n, a.lookahead, a.aligned)) apply_tracks_body<true>(a);
-    else apply_tracks_body<false>(a);
+    if (block_interior(a.n, a.lookahead, a.aligned)) apply_tracks_body<true, FX>(a);
+    else apply_tracks_body<false, FX>(a);
 }
 
 // ---- forward: master bus.  grid (nblk, bs).  out = delay(v) * G * gout  (stereo-linked)
@@ -394,7 +417,10 @@ __global__ __launch_bounds__(kWG) void k_comp_bwd_zs(CompBwdArgs a) {
 #ifndef MST_CG_ABLATE
 #define MST_CG_ABLATE 0  // timing diagnostics only (wrong results): 1 = no state loads, 2 = four samples instead of 64
 #endif
-constexpr int kCgPitch = kEqChunk + 4, kCgChunks = kWG * CC / kEqChunk, kCgTile = kCgChunks * kCgPitch;
+#ifndef MST_CG_PITCH
+#define MST_CG_PITCH (kEqChunk + 4)
+#endif
+constexpr int kCgPitch = MST_CG_PITCH, kCgChunks = kWG * CC / kEqChunk, kCgTile = kCgChunks * kCgPitch;
 static_assert(kCgChunks == 32 && kSections * 32 <= kWG, "one section x 32 chunks per 32 lanes");
 template <bool FAST>
 __device__ __forceinline__ void coefgrad_fused(const CompBwdArgs& a, int blk, int sig, const float* __restrict__ rc, int64_t i0, const float* xu,
@@ -405,15 +431,22 @@ __device__ __forceinline__ void coefgrad_fused(const CompBwdArgs& a, int blk, in
         float g[CC];
 #pragma unroll
         for (int i = 0; i < CC; ++i) g[i] = (FAST || i0 + i < a.n) ? du[i] : 0.0f;
-        float* pu = &cg_u[c * kCgPitch + off];
-        float* pg = &cg_g[c * kCgPitch + off];
+        // chunk row image: sample 8 j + 4 h + e sits at float h 32 + 4 j + e (j = lane of the chunk, h = half of its eight samples), so that
+        // the eight lanes of a ds_write_b128 group cover 32 consecutive banks (sample order 8 j + e put lanes j and j + 4 on the same banks:
+        // a 2-way conflict on every store of the transposition - round-3 counters: 43 % of this kernel's LDS cycles)
+        (void)off;
+        float* pu = &cg_u[c * kCgPitch + 4 * (tid & 7)];
+        float* pg = &cg_g[c * kCgPitch + 4 * (tid & 7)];
         *reinterpret_cast<float4*>(pu) = make_float4(xu[0], xu[1], xu[2], xu[3]);
-        *reinterpret_cast<float4*>(pu + 4) = make_float4(xu[4], xu[5], xu[6], xu[7]);
+        *reinterpret_cast<float4*>(pu + 32) = make_float4(xu[4], xu[5], xu[6], xu[7]);
         *reinterpret_cast<float4*>(pg) = make_float4(g[0], g[1], g[2], g[3]);
-        *reinterpret_cast<float4*>(pg + 4) = make_float4(g[4], g[5], g[6], g[7]);
+        *reinterpret_cast<float4*>(pg + 32) = make_float4(g[4], g[5], g[6], g[7]);
     }
     lds_barrier();
-    const int s = tid >> 5, c = tid & 31;
+#ifndef MST_CG_ROT
+#define MST_CG_ROT 0  // A/B: chunk rotation of the upper half wave (lanes l and l + 32 then read different LDS rows)
+#endif
+    const int s = tid >> 5, c = ((tid & 31) + ((tid & 32) ? MST_CG_ROT : 0)) & 31;
     if (s < kSections) {
         const float ka1 = rc[RC_SOS + 5 * s + 3], ka2 = rc[RC_SOS + 5 * s + 4];
         const float kc1 = rc[RC_AP + 3 * s], kc2 = rc[RC_AP + 3 * s + 1], kib0 = rc[RC_AP + 3 * s + 2];
@@ -425,7 +458,8 @@ __device__ __forceinline__ void coefgrad_fused(const CompBwdArgs& a, int blk, in
         double db0 = 0., db1 = 0., db2 = 0., da1 = 0., da2 = 0.;
         double Wa1 = wa1, Wa2 = wa2, Wb1 = wb1, Wb2 = wb2;
         for (int i = 0; i < kEqChunk; ++i) {
-            const double x = cg_u[c * kCgPitch + i], gp = cg_g[c * kCgPitch + i];
+            const int at = ((i >> 2) & 1) * 32 + (i >> 3) * 4 + (i & 3);
+            const double x = cg_u[c * kCgPitch + at], gp = cg_g[c * kCgPitch + at];
             const double wa = -(double)ka2 * Wa2 - (double)ka1 * Wa1 + x, wb = -(double)kc2 * Wb2 - (double)kc1 * Wb1 + x;
             db0 += gp * wb; db1 += gp * Wb1; db2 += gp * Wb2; da1 -= gp * Wa1; da2 -= gp * Wa2;
             Wa2 = Wa1; Wa1 = wa; Wb2 = Wb1; Wb1 = wb;
@@ -437,8 +471,9 @@ __device__ __forceinline__ void coefgrad_fused(const CompBwdArgs& a, int blk, in
         const float* mg = &cg_g[c * kCgPitch];
 #pragma unroll 2
         for (int i4 = 0; i4 < ((MST_CG_ABLATE & 2) ? 4 : kEqChunk); i4 += 4) {
-            const float4 xv = *reinterpret_cast<const float4*>(&mu[i4]);
-            const float4 gv = *reinterpret_cast<const float4*>(&mg[i4]);
+            const int at = ((i4 >> 2) & 1) * 32 + (i4 >> 3) * 4;  // samples i4 .. i4 + 3 in the row image (see the stores above)
+            const float4 xv = *reinterpret_cast<const float4*>(&mu[at]);
+            const float4 gv = *reinterpret_cast<const float4*>(&mg[at]);
             const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, gs[4] = {gv.x, gv.y, gv.z, gv.w};
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -458,12 +493,21 @@ __device__ __forceinline__ void coefgrad_fused(const CompBwdArgs& a, int blk, in
         }
         float acc[5] = {db0 * kib0, db1 * kib0, db2 * kib0, da1, da2};
 #endif
+        // sum over the 32 chunk lanes of the section (one half wave), fixed order: four DPP row shifts leave every 16-lane row's total in
+        // its last lane, row_bcast:15 adds row 0's into row 1 (row 2's into row 3) - lane 31 / 63 holds the half-wave sum.  (The five
+        // ds_bpermute levels this replaces were 50 of the kernel's 64 LDS-crossbar round trips and what rocprof reported as 40 % "bank
+        // conflict" cycles: the LDS images themselves are conflict-free, tools/lds_conflicts.py.)
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
-#pragma unroll
-            for (int m = 16; m >= 1; m >>= 1) acc[i] += __shfl_xor(acc[i], m);  // the 32 chunk lanes of the section (one half wave), fixed order
+            float v = acc[i];
+            v = dpp_add<0x111, 0xf>(v);
+            v = dpp_add<0x112, 0xf>(v);
+            v = dpp_add<0x114, 0xf>(v);
+            v = dpp_add<0x118, 0xf>(v);
+            v = dpp_add<0x142, 0xa>(v);
+            acc[i] = v;
         }
-        if (c == 0) {
+        if ((tid & 31) == 31) {
             float* o = a.ep + ((int64_t)sig * gridDim.x + blk) * EP_COUNT + 5 * s;
 #pragma unroll
             for (int i = 0; i < 5; ++i) o[i] = acc[i];
@@ -673,7 +717,8 @@ void launch_comp_zs(int nch, const float* u, int64_t stride, const float* rc, fl
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_comp_zs<2>), grid, block, 0, stream, u, stride, rc, zs, nc_pad, n);
 }
 void launch_apply_tracks(const TrackApplyArgs& a, int bs, hipStream_t stream) {
-    hipLaunchKernelGGL(k_apply_tracks, dim3(a.nc_pad / kWG, bs), dim3(kWG), 0, stream, a);
+    if (a.fx) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_apply_tracks<true>), dim3(a.nc_pad / kWG, bs), dim3(kWG), 0, stream, a);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_apply_tracks<false>), dim3(a.nc_pad / kWG, bs), dim3(kWG), 0, stream, a);
 }
 void launch_apply_master(const MasterApplyArgs& a, int bs, hipStream_t stream) {
     hipLaunchKernelGGL(k_apply_master, dim3(a.nc_pad / kWG, bs), dim3(kWG), 0, stream, a);
