@@ -54,11 +54,12 @@ FLOPS_PER_MIX = 0.63e9 + 0.26e9
 def committed_profile():
     """Numbers that need the profiler (bench.py cannot run rocprofv3 on itself): HBM bytes per step from the PMC passes
     and VALU instructions per step from the SQ passes of this same command, committed under profiles/."""
-    for name in ("round3_traffic.json", "round2_traffic.json", "round1_traffic.json"):
+    for name in ("round4_traffic.json", "round3_traffic.json", "round2_traffic.json", "round1_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 d = json.load(f)
-            return float(d["hbm_bytes_per_step_raw"]), d.get("valu_lane_instructions_per_step"), name
+            # round 4 on: corrected bytes (2 x FETCH_SIZE + WRITE_SIZE, profiles/round4_hbm_calibration.md); earlier files hold the raw sum
+            return float(d.get("hbm_bytes_per_step", d["hbm_bytes_per_step_raw"])), d.get("valu_lane_instructions_per_step"), name
         except (OSError, KeyError, ValueError):
             continue
     return None, None, None

@@ -178,9 +178,9 @@ __global__ __launch_bounds__(kWG) void k_comp_zs(const float* __restrict__ u, in
 // 19 % VALU issue, 66 % of the wave cycles waiting).  FX (fx send bus) is a template parameter: its two accumulators cost 16 registers
 // that the prefetch needs (123 of 128 before).
 template <bool FAST, bool FX>
-__device__ __forceinline__ void apply_tracks_body(const TrackApplyArgs& a) {
+__device__ __forceinline__ void apply_tracks_body(const TrackApplyArgs& a, int b, int blk) {
     __shared__ float lds[8];
-    const int b = blockIdx.y, chunk = blockIdx.x * kWG + threadIdx.x;
+    const int chunk = blk * kWG + threadIdx.x;
     const int64_t i0 = (int64_t)chunk * CC;
     float accL[CC], accR[CC], fxL[FX ? CC : 1], fxR[FX ? CC : 1];
 #pragma unroll
@@ -222,7 +222,7 @@ __device__ __forceinline__ void apply_tracks_body(const TrackApplyArgs& a) {
                 z = fmaf(k.alpha, z, g[i]);
             }
             const float ac = rc[RC_ALPHA_C], l2a = rc[RC_LOG2A_C];
-            const float S = block_carry<false>(a.s0 + (int64_t)row * gridDim.x, blockIdx.x, gridDim.x, l2a, lds, threadIdx.x);
+            const float S = block_carry<false>(a.s0 + (int64_t)row * gridDim.x, blk, gridDim.x, l2a, lds, threadIdx.x);
             float s = block_enter<false>(z, ac, l2a, S, lds, threadIdx.x);
 #pragma unroll
             for (int i = 0; i < CC; ++i) {
@@ -271,8 +271,12 @@ __device__ __forceinline__ bool block_interior(int64_t n, int lookahead, int ali
 }
 template <bool FX>
 __global__ __launch_bounds__(kWG) void k_apply_tracks(TrackApplyArgs a) {
-    if (block_interior(a.n, a.lookahead, a.aligned)) apply_tracks_body<true, FX>(a);
-    else apply_tracks_body<false, FX>(a);
+    // consecutive blocks of one mix on one XCD (mst_common.h: row_block_xcd): the look-ahead read of block b (samples 2048 earlier) is what
+    // block b - 1 has just streamed through the same L2 - on the plain walk it was a second trip over the fabric for the whole of u
+    int b, blk;
+    row_block_xcd(b, blk);
+    if (block_interior(a.n, a.lookahead, a.aligned, blk)) apply_tracks_body<true, FX>(a, b, blk);
+    else apply_tracks_body<false, FX>(a, b, blk);
 }
 
 // ---- forward: master bus.  grid (nblk, bs).  out = delay(v) * G * gout  (stereo-linked)

@@ -689,3 +689,182 @@ extern "C" int mst_ctrl_backward(const mst_ctrl_desc* d, const float* tokens, co
     hipLaunchKernelGGL(k_lin_tn_batch, dim3(tiles), dim3(64), 0, st, tb);
     return (int)hipGetLastError();
 }
+
+// =====================================================================================================================
+// The controller's own ends (reference mst/modules.py:841-859, :866-914): token sequence in, three sigmoid heads out.
+// Tiny, launch-bound work that used to be ~40 torch kernels and 7 rocBLAS GEMMs per step (profiles/round3_cfg5.md):
+//   tokens  = cat(track_embeds + track_embedding, mix_embeds + mix_embedding, fx_bus_embedding, master_bus_embedding)   (+ the mask
+//             extended by four always-attended tokens)
+//   heads   = sigmoid(Linear) of the track tokens / the fx token (seq - 2) / the master token (seq - 1)
+// fp32 vector arithmetic, a wave per token row, fixed summation orders (deterministic).
+namespace mst {
+namespace ctrl {
+
+__global__ __launch_bounds__(128) void k_ctrl_tokens(const float* __restrict__ te, const float* __restrict__ me, const uint8_t* __restrict__ mask,
+                                                     mst_ctrl_io io, float* __restrict__ tokens, uint8_t* __restrict__ mask_out, int T, int D) {
+    const int s = blockIdx.x, b = blockIdx.y, S = T + 4;
+    float* o = tokens + ((size_t)b * S + s) * D;
+    for (int k = threadIdx.x; k < D; k += 128) {
+        float v;
+        if (s < T) v = te[((size_t)b * T + s) * D + k] + io.track_embedding[k];
+        else if (s < T + 2) v = me[((size_t)b * 2 + (s - T)) * D + k] + io.mix_embedding[(s - T) * D + k];
+        else v = (s == T + 2 ? io.fx_bus_embedding : io.master_bus_embedding)[k];
+        o[k] = v;
+    }
+    if (mask_out && threadIdx.x == 0) mask_out[(size_t)b * S + s] = (mask && s < T) ? (mask[(size_t)b * T + s] ? 1 : 0) : 0;
+}
+// head of row r: rows [0, bs T) track tokens, [bs T, bs T + bs) fx tokens, then master tokens
+struct HeadSel { const float* W; const float* B; float* out; const float* g; int n; size_t tok; size_t orow; };
+__device__ __forceinline__ HeadSel head_of(int r, int bs, int T, const mst_ctrl_io& io, int nt, int nf, int nm, float* ot, float* of, float* om,
+                                           const float* gt, const float* gf, const float* gm) {
+    HeadSel h;
+    const int S = T + 4;
+    if (r < bs * T) {
+        const int b = r / T, t = r % T;
+        h = {io.track_w, io.track_b, ot, gt, nt, (size_t)b * S + t, (size_t)r};
+    } else if (r < bs * T + bs) {
+        const int b = r - bs * T;
+        h = {io.fx_w, io.fx_b, of, gf, nf, (size_t)b * S + T + 2, (size_t)b};
+    } else {
+        const int b = r - bs * T - bs;
+        h = {io.master_w, io.master_b, om, gm, nm, (size_t)b * S + T + 3, (size_t)b};
+    }
+    return h;
+}
+constexpr int kHeadK = 16;  // d_model <= 1024 = 64 lanes x 16
+__global__ __launch_bounds__(64) void k_ctrl_heads_fwd(const float* __restrict__ z, mst_ctrl_io io, int nt, int nf, int nm, float* ot, float* of,
+                                                       float* om, int bs, int T, int D) {
+    const int lane = threadIdx.x;
+    const HeadSel h = head_of(blockIdx.x, bs, T, io, nt, nf, nm, ot, of, om, nullptr, nullptr, nullptr);
+    const float* x = z + h.tok * D;
+    float xv[kHeadK];
+#pragma unroll
+    for (int j = 0; j < kHeadK; ++j) xv[j] = lane + 64 * j < D ? x[lane + 64 * j] : 0.0f;
+    for (int o = 0; o < h.n; ++o) {
+        const float* w = h.W + (size_t)o * D;
+        float acc = 0.0f;
+#pragma unroll
+        for (int j = 0; j < kHeadK; ++j) acc = fmaf(lane + 64 * j < D ? w[lane + 64 * j] : 0.0f, xv[j], acc);
+        acc = wave_sum(acc) + h.B[o];
+        if (lane == 0) h.out[h.orow * h.n + o] = 1.0f / (1.0f + __expf(-acc));
+    }
+}
+// grad_z rows (every token row of the sequence is written: the mix tokens get zeros) and the pre-activation cotangents
+// dpre (rows_total x 32) that the weight-gradient kernel sums over
+__global__ __launch_bounds__(64) void k_ctrl_heads_bwd_dz(mst_ctrl_io io, int nt, int nf, int nm, const float* ot, const float* of, const float* om,
+                                                          const float* gt, const float* gf, const float* gm, float* __restrict__ dz,
+                                                          float* __restrict__ dpre, int bs, int T, int D) {
+    const int lane = threadIdx.x, S = T + 4, r = blockIdx.x, rows = bs * (T + 2);
+    if (r >= rows) {  // the 2 bs mix-token rows: no head reads them
+        const int q = r - rows, b = q / 2, s = T + (q & 1);
+        for (int k = lane; k < D; k += 64) dz[((size_t)b * S + s) * D + k] = 0.0f;
+        return;
+    }
+    const HeadSel h = head_of(r, bs, T, io, nt, nf, nm, const_cast<float*>(ot), const_cast<float*>(of), const_cast<float*>(om), gt, gf, gm);
+    float dp = 0.0f;
+    if (lane < h.n && h.g) {
+        const float y = h.out[h.orow * h.n + lane];
+        dp = h.g[h.orow * h.n + lane] * y * (1.0f - y);
+    }
+    if (lane < 32) dpre[(size_t)r * 32 + lane] = dp;
+    float acc[kHeadK];
+#pragma unroll
+    for (int j = 0; j < kHeadK; ++j) acc[j] = 0.0f;
+    for (int o = 0; o < h.n; ++o) {
+        const float d = __shfl(dp, o);
+        const float* w = h.W + (size_t)o * D;
+#pragma unroll
+        for (int j = 0; j < kHeadK; ++j)
+            if (lane + 64 * j < D) acc[j] = fmaf(d, w[lane + 64 * j], acc[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < kHeadK; ++j)
+        if (lane + 64 * j < D) dz[h.tok * D + lane + 64 * j] = acc[j];
+}
+// dW[o][k] = sum_rows dpre[row][o] z[token(row)][k], db[o] = sum_rows dpre[row][o]; grid (n_t + n_f + n_m), rows folded in order
+__global__ __launch_bounds__(256) void k_ctrl_heads_bwd_dw(const float* __restrict__ z, const float* __restrict__ dpre, mst_ctrl_io_grads g, int nt,
+                                                           int nf, int nm, int have_f, int have_m, int bs, int T, int D) {
+    const int S = T + 4;
+    int o = blockIdx.x, head = 0;
+    if (o >= nt) { o -= nt; head = 1; }
+    if (head == 1 && o >= nf) { o -= nf; head = 2; }
+    if ((head == 1 && !have_f) || (head == 2 && !have_m)) return;  // unused head: its gradients stay None on the Python side
+    float* dW = head == 0 ? g.track_w : (head == 1 ? g.fx_w : g.master_w);
+    float* dB = head == 0 ? g.track_b : (head == 1 ? g.fx_b : g.master_b);
+    const int r0 = head == 0 ? 0 : (head == 1 ? bs * T : bs * T + bs), nr = head == 0 ? bs * T : bs;
+    for (int k = threadIdx.x; k < D; k += 256) {
+        float acc = 0.0f;
+        for (int q = 0; q < nr; ++q) {
+            const int r = r0 + q;
+            const size_t tok = head == 0 ? (size_t)(q / T) * S + (q % T) : (size_t)q * S + T + 1 + head;
+            acc = fmaf(dpre[(size_t)r * 32 + o], z[tok * D + k], acc);
+        }
+        dW[(size_t)o * D + k] = acc;
+    }
+    if (threadIdx.x == 0) {
+        float acc = 0.0f;
+        for (int q = 0; q < nr; ++q) acc += dpre[(size_t)(r0 + q) * 32 + o];
+        dB[o] = acc;
+    }
+}
+// gradients of the four type embeddings: sums of the token cotangents over the batch (and the tracks)
+__global__ __launch_bounds__(256) void k_ctrl_tokens_bwd(const float* __restrict__ gtok, mst_ctrl_io_grads g, int bs, int T, int D) {
+    const int k = blockIdx.x * 256 + threadIdx.x, S = T + 4;
+    if (k >= D) return;
+    float a = 0.0f, m0 = 0.0f, m1 = 0.0f, f = 0.0f, ms = 0.0f;
+    for (int b = 0; b < bs; ++b) {
+        const float* row = gtok + (size_t)b * S * D + k;
+        for (int t = 0; t < T; ++t) a += row[(size_t)t * D];
+        m0 += row[(size_t)T * D];
+        m1 += row[(size_t)(T + 1) * D];
+        f += row[(size_t)(T + 2) * D];
+        ms += row[(size_t)(T + 3) * D];
+    }
+    g.track_embedding[k] = a;
+    g.mix_embedding[k] = m0;
+    g.mix_embedding[D + k] = m1;
+    g.fx_bus_embedding[k] = f;
+    g.master_bus_embedding[k] = ms;
+}
+
+}  // namespace ctrl
+}  // namespace mst
+
+static bool io_ok(const mst_ctrl_desc* d, int T, int nt, int nf, int nm) {
+    return d && d->bs > 0 && T > 0 && d->seq == T + 4 && d->d_model > 0 && d->d_model <= 64 * kHeadK && nt > 0 && nt <= 32 && nf > 0 && nf <= 32 && nm > 0 &&
+           nm <= 32;
+}
+extern "C" int mst_ctrl_tokens_forward(const mst_ctrl_desc* d, int32_t n_tracks, const float* track_embeds, const float* mix_embeds,
+                                       const uint8_t* track_padding_mask, const mst_ctrl_io* io, float* tokens, uint8_t* key_padding_mask_out,
+                                       void* stream) {
+    if (!io_ok(d, n_tracks, 1, 1, 1) || !track_embeds || !mix_embeds || !io || !tokens) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_ctrl_tokens, dim3(d->seq, d->bs), dim3(128), 0, (hipStream_t)stream, track_embeds, mix_embeds, track_padding_mask, *io, tokens,
+                       key_padding_mask_out, n_tracks, d->d_model);
+    return (int)hipGetLastError();
+}
+extern "C" int mst_ctrl_heads_forward(const mst_ctrl_desc* d, int32_t n_tracks, const float* z, const mst_ctrl_io* io, int32_t n_t, int32_t n_f,
+                                      int32_t n_m, float* out_t, float* out_f, float* out_m, void* stream) {
+    if (!io_ok(d, n_tracks, n_t, n_f, n_m) || !z || !io || !out_t || !out_f || !out_m) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_ctrl_heads_fwd, dim3(d->bs * (n_tracks + 2)), dim3(64), 0, (hipStream_t)stream, z, *io, n_t, n_f, n_m, out_t, out_f, out_m, d->bs,
+                       n_tracks, d->d_model);
+    return (int)hipGetLastError();
+}
+extern "C" size_t mst_ctrl_heads_scratch_bytes(const mst_ctrl_desc* d, int32_t n_tracks) {
+    return (d && n_tracks > 0) ? (size_t)d->bs * (n_tracks + 2) * 32 * sizeof(float) : 0;
+}
+extern "C" int mst_ctrl_heads_backward(const mst_ctrl_desc* d, int32_t n_tracks, const float* z, const mst_ctrl_io* io, int32_t n_t, int32_t n_f,
+                                       int32_t n_m, const float* out_t, const float* out_f, const float* out_m, const float* g_t, const float* g_f,
+                                       const float* g_m, const mst_ctrl_io_grads* grads, float* grad_z, void* scratch, void* stream) {
+    if (!io_ok(d, n_tracks, n_t, n_f, n_m) || !z || !io || !out_t || !out_f || !out_m || !grads || !grad_z || !scratch) return hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_ctrl_heads_bwd_dz, dim3(d->bs * (n_tracks + 4)), dim3(64), 0, st, *io, n_t, n_f, n_m, out_t, out_f, out_m, g_t, g_f, g_m, grad_z,
+                       (float*)scratch, d->bs, n_tracks, d->d_model);
+    hipLaunchKernelGGL(k_ctrl_heads_bwd_dw, dim3(n_t + n_f + n_m), dim3(256), 0, st, z, (const float*)scratch, *grads, n_t, n_f, n_m, g_f ? 1 : 0,
+                       g_m ? 1 : 0, d->bs, n_tracks, d->d_model);
+    return (int)hipGetLastError();
+}
+extern "C" int mst_ctrl_tokens_backward(const mst_ctrl_desc* d, int32_t n_tracks, const float* grad_tokens, const mst_ctrl_io_grads* grads, void* stream) {
+    if (!io_ok(d, n_tracks, 1, 1, 1) || !grad_tokens || !grads) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_ctrl_tokens_bwd, dim3((d->d_model + 255) / 256), dim3(256), 0, (hipStream_t)stream, grad_tokens, *grads, d->bs, n_tracks, d->d_model);
+    return (int)hipGetLastError();
+}

@@ -101,6 +101,14 @@ class CtrlDesc(C.Structure):  # mirrors mst_ctrl_desc
                 ("n_layers", C.c_int32), ("ln_eps", C.c_float)]
 
 
+CTRL_IO_FIELDS = ("track_embedding", "mix_embedding", "fx_bus_embedding", "master_bus_embedding", "track_w", "track_b", "fx_w", "fx_b",
+                  "master_w", "master_b")
+
+
+class CtrlIO(C.Structure):  # mirrors mst_ctrl_io and mst_ctrl_io_grads (same ten pointers)
+    _fields_ = [(name, C.c_void_p) for name in CTRL_IO_FIELDS]
+
+
 class CtrlLayer(C.Structure):  # mirrors mst_ctrl_layer and mst_ctrl_layer_grads (same twelve pointers)
     _fields_ = [(name, C.c_void_p) for name in CTRL_FIELDS]
 
@@ -143,6 +151,12 @@ SIGNATURES = {
     "mst_ctrl_workspace_bytes": (C.c_size_t, [C.POINTER(CtrlDesc)]),
     "mst_ctrl_forward": (C.c_int, [C.POINTER(CtrlDesc), _P, _P, C.POINTER(CtrlLayer), _P, _P, C.c_size_t, _P]),
     "mst_ctrl_backward": (C.c_int, [C.POINTER(CtrlDesc), _P, C.POINTER(CtrlLayer), _P, C.POINTER(CtrlLayer), _P, _P, C.c_size_t, _P]),
+    "mst_ctrl_tokens_forward": (C.c_int, [C.POINTER(CtrlDesc), C.c_int32, _P, _P, _P, C.POINTER(CtrlIO), _P, _P, _P]),
+    "mst_ctrl_heads_forward": (C.c_int, [C.POINTER(CtrlDesc), C.c_int32, _P, C.POINTER(CtrlIO), C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P]),
+    "mst_ctrl_heads_scratch_bytes": (C.c_size_t, [C.POINTER(CtrlDesc), C.c_int32]),
+    "mst_ctrl_heads_backward": (C.c_int, [C.POINTER(CtrlDesc), C.c_int32, _P, C.POINTER(CtrlIO), C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P,
+                                          C.POINTER(CtrlIO), _P, _P, _P]),
+    "mst_ctrl_tokens_backward": (C.c_int, [C.POINTER(CtrlDesc), C.c_int32, _P, C.POINTER(CtrlIO), _P]),
 }
 
 

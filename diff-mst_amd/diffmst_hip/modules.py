@@ -651,18 +651,21 @@ class TransformerController(torch.nn.Module):
 
     def _eager_forward(self, track_embeds: torch.Tensor, mix_embeds: torch.Tensor, track_padding_mask=None):
         bs, num_tracks, _ = track_embeds.size()
+        use_native = False
+        if self.native is not False and track_embeds.is_cuda:
+            from . import controller
+
+            use_native = controller.supported(self.transformer_encoder, bs, num_tracks + 4)
+            if self.native and not use_native:
+                raise ValueError("TransformerController(native=True): encoder stack outside the kernels' limits "
+                                 "(<= 128 tokens, d_model % 128 == 0, head width <= 64, post-norm relu layers, dropout 0)")
+            if use_native and controller.heads_supported(self):
+                # token assembly, mask extension, the stack and the three sigmoid heads: one autograd node, no torch / rocBLAS kernel
+                return controller.controller_forward(self, track_embeds, mix_embeds, track_padding_mask)
         tokens = torch.cat((track_embeds + self.track_embedding, mix_embeds + self.mix_embedding,
                             self.fx_bus_embedding.expand(bs, -1, -1), self.master_bus_embedding.expand(bs, -1, -1)), dim=1)
         if track_padding_mask is not None:  # the four appended tokens are always attended to
             track_padding_mask = torch.cat((track_padding_mask, track_padding_mask.new_zeros((bs, 4))), dim=1)  # made on the device: no host copy
-        use_native = False
-        if self.native is not False and tokens.is_cuda:
-            from . import controller
-
-            use_native = controller.supported(self.transformer_encoder, bs, tokens.shape[1])
-            if self.native and not use_native:
-                raise ValueError("TransformerController(native=True): encoder stack outside the kernels' limits "
-                                 "(<= 128 tokens, d_model % 128 == 0, head width <= 64, post-norm relu layers, dropout 0)")
         if use_native:
             z = controller.encoder_stack(self.transformer_encoder, tokens, track_padding_mask)
         else:

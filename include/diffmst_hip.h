@@ -327,6 +327,42 @@ int mst_ctrl_forward(const mst_ctrl_desc* d, const float* tokens, const uint8_t*
 int mst_ctrl_backward(const mst_ctrl_desc* d, const float* tokens, const mst_ctrl_layer* layers, const float* grad_out,
                       const mst_ctrl_layer_grads* grads, float* grad_tokens, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The controller's own ends (reference mst/modules.py:841-859, :866-914): the token sequence
+ *   cat(track_embeds + track_embedding, mix_embeds + mix_embedding, fx_bus_embedding, master_bus_embedding)  (seq = n_tracks + 4)
+ * with the key-padding mask extended by four always-attended tokens, and the three heads sigmoid(Linear) of the track tokens, the fx
+ * token (seq - 2) and the master token (seq - 1).  n_t / n_f / n_m <= 32 outputs, d_model <= 1024.  A NULL head cotangent (g_f, g_m) means
+ * that head's output was not used: its weight gradients are NOT written (the caller reports None, like autograd). */
+typedef struct mst_ctrl_io { /* device pointers, fp32 */
+    const float* track_embedding;      /* (d_model) */
+    const float* mix_embedding;        /* (2, d_model) */
+    const float* fx_bus_embedding;     /* (d_model) */
+    const float* master_bus_embedding; /* (d_model) */
+    const float* track_w;  const float* track_b;   /* track_projection (n_t, d_model), (n_t) */
+    const float* fx_w;     const float* fx_b;
+    const float* master_w; const float* master_b;
+} mst_ctrl_io;
+typedef struct mst_ctrl_io_grads { /* same entries; written by the two backward calls */
+    float* track_embedding;
+    float* mix_embedding;
+    float* fx_bus_embedding;
+    float* master_bus_embedding;
+    float* track_w;  float* track_b;
+    float* fx_w;     float* fx_b;
+    float* master_w; float* master_b;
+} mst_ctrl_io_grads;
+int mst_ctrl_tokens_forward(const mst_ctrl_desc* d, int32_t n_tracks, const float* track_embeds, const float* mix_embeds,
+                            const uint8_t* track_padding_mask, const mst_ctrl_io* io, float* tokens, uint8_t* key_padding_mask_out,
+                            void* stream);
+int mst_ctrl_heads_forward(const mst_ctrl_desc* d, int32_t n_tracks, const float* z, const mst_ctrl_io* io, int32_t n_t, int32_t n_f,
+                           int32_t n_m, float* out_t, float* out_f, float* out_m, void* stream);
+size_t mst_ctrl_heads_scratch_bytes(const mst_ctrl_desc* d, int32_t n_tracks);
+/* grad_z (bs, seq, d_model): every row is written (the mix tokens get zeros); grads: the six head entries */
+int mst_ctrl_heads_backward(const mst_ctrl_desc* d, int32_t n_tracks, const float* z, const mst_ctrl_io* io, int32_t n_t, int32_t n_f,
+                            int32_t n_m, const float* out_t, const float* out_f, const float* out_m, const float* g_t, const float* g_f,
+                            const float* g_m, const mst_ctrl_io_grads* grads, float* grad_z, void* scratch, void* stream);
+/* grads: the four embedding entries; the cotangents of track_embeds / mix_embeds are the rows [0, T) / [T, T + 2) of grad_tokens */
+int mst_ctrl_tokens_backward(const mst_ctrl_desc* d, int32_t n_tracks, const float* grad_tokens, const mst_ctrl_io_grads* grads, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

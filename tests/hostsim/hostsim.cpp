@@ -22,4 +22,9 @@ int mst_cnn14_backward_sync(const mst_cnn14_desc*, const float*, const mst_cnn14
 size_t mst_ctrl_workspace_bytes(const mst_ctrl_desc*) { return 0; }
 int mst_ctrl_forward(const mst_ctrl_desc*, const float*, const uint8_t*, const mst_ctrl_layer*, float*, void*, size_t, void*) { return 801; }
 int mst_ctrl_backward(const mst_ctrl_desc*, const float*, const mst_ctrl_layer*, const float*, const mst_ctrl_layer_grads*, float*, void*, size_t, void*) { return 801; }
+int mst_ctrl_tokens_forward(const mst_ctrl_desc*, int32_t, const float*, const float*, const uint8_t*, const mst_ctrl_io*, float*, uint8_t*, void*) { return 801; }
+int mst_ctrl_heads_forward(const mst_ctrl_desc*, int32_t, const float*, const mst_ctrl_io*, int32_t, int32_t, int32_t, float*, float*, float*, void*) { return 801; }
+size_t mst_ctrl_heads_scratch_bytes(const mst_ctrl_desc*, int32_t) { return 0; }
+int mst_ctrl_heads_backward(const mst_ctrl_desc*, int32_t, const float*, const mst_ctrl_io*, int32_t, int32_t, int32_t, const float*, const float*, const float*, const float*, const float*, const float*, const mst_ctrl_io_grads*, float*, void*, void*) { return 801; }
+int mst_ctrl_tokens_backward(const mst_ctrl_desc*, int32_t, const float*, const mst_ctrl_io_grads*, void*) { return 801; }
 }
