@@ -234,14 +234,20 @@ __device__ __forceinline__ float gran_wait(const gran_t* g, int64_t near_off) {
 // hands out its ids in ascending order (observed, MI355X_MICROARCH.md; nothing below is WRONG if it changes, see above): with rows % 8 == 0
 // row r lives on XCD r % 8, and within an XCD the blocks of a row are walked in ascending `step` - the order in which a block's
 // predecessors are dispatched before it.  Other row counts keep the plain (x = step, y = row) walk.
-__device__ __forceinline__ void row_block_xcd(int& row, int& step) {
-    const int nblk = gridDim.x, rows = gridDim.y;
-    if (rows % 8 == 0) {
-        const int L = blockIdx.x + nblk * blockIdx.y, xcd = L & 7, k = L >> 3;
-        row = (k / nblk) * 8 + xcd;
-        step = k % nblk;
+// `group` > 1: rows come in groups (the tracks of one mix) that read the same shared data (the bus cotangent of that mix): the whole
+// group is kept on one XCD and its rows are interleaved block by block, so that the shared block is fetched once per XCD instead of
+// once per row (with row r on XCD r % 8 the eight tracks of a mix sat on eight XCDs: 8 x 16 MB of bus cotangent over the fabric).
+__device__ __forceinline__ void row_block_xcd(int& row, int& step, int group = 1, int rows = 0, int skip_rows = 0) {
+    // rows: 0 = the whole grid; skip_rows: grid rows in FRONT of the mapped ones that belong to another role of the launch
+    const int nblk = gridDim.x;
+    if (rows <= 0) rows = gridDim.y - skip_rows;
+    if (group >= 1 && rows % (8 * group) == 0 && (nblk * skip_rows) % 8 == 0) {
+        const int L = blockIdx.x + nblk * ((int)blockIdx.y - skip_rows), xcd = L & 7, k = L >> 3;
+        const int per_group = group * nblk, gi = k / per_group, rem = k % per_group;
+        row = (gi * 8 + xcd) * group + rem % group;
+        step = rem / group;
     } else {
-        row = blockIdx.y;
+        row = blockIdx.y - skip_rows;
         step = blockIdx.x;
     }
 }

@@ -700,14 +700,38 @@ __device__ __forceinline__ void comp_bwd_run_body(const CompBwdArgs& a, int row,
 #define MST_COMP_BWD_W 1  // min waves per SIMD asked of the compressor backward (A/B switch)
 #endif
 template <bool MASTER, bool FXS = false>
-__global__ __launch_bounds__(kWG, (!MASTER && !FXS) ? 4 : MST_COMP_BWD_W) void k_comp_bwd_run(CompBwdArgs a) {  // tracks without fx: 130 registers uncapped, two short of four waves per SIMD
+#ifndef MST_COMP_BWD_WT
+#define MST_COMP_BWD_WT 4
+#endif
+__global__ __launch_bounds__(kWG, (!MASTER && !FXS) ? MST_COMP_BWD_WT : MST_COMP_BWD_W) void k_comp_bwd_run(CompBwdArgs a) {  // tracks without fx: 130 registers uncapped, two short of four waves per SIMD
     __shared__ __attribute__((aligned(16))) float cg_u[kCgTile], cg_g[kCgTile];  // one copy for both bodies
     // a.gran: the blocks a workgroup waits for (LATER in time: the adjoint smoother runs backwards) must have been dispatched before
     // it, so the grid walks the row from its end
     int row = blockIdx.y, blk = blockIdx.x;
+    const int extra = MASTER ? 0 : a.cg2_rows, main_rows = (int)gridDim.y - extra;
+    if (!MASTER && row < extra) {
+        // coefficient-gradient walk only: one channel of a master bus (its compressor adjoint ran in the master launch).  These light
+        // rows come FIRST in the grid: behind the track rows they were a 21 us tail of half-empty rounds.
+        const int j = row;
+        const int64_t i0 = ((int64_t)blk * kWG + threadIdx.x) * CC;
+        const bool fast = a.aligned && (int64_t)(blk + 1) * kWG * CC <= a.n;
+        float xu[CC], du[CC];
+        if (fast) {
+            ld8f(a.cg2_u + (int64_t)j * a.stride, i0, xu);
+            ld8f(a.cg2_du + (int64_t)j * a.stride, i0, du);
+            coefgrad_fused<true>(a, blk, main_rows + j, a.cg2_rc + (int64_t)(j >> 1) * RC_STRIDE, i0, xu, du, cg_u, cg_g);
+        } else {
+            ld8(a.cg2_u + (int64_t)j * a.stride, i0, a.n, xu);
+            ld8(a.cg2_du + (int64_t)j * a.stride, i0, a.n, du);
+            coefgrad_fused<false>(a, blk, main_rows + j, a.cg2_rc + (int64_t)(j >> 1) * RC_STRIDE, i0, xu, du, cg_u, cg_g);
+        }
+        return;
+    }
     if (a.gran) {
-        row_block_xcd(row, blk);  // the blocks of one row on one XCD (mst_common.h)
+        row_block_xcd(row, blk, MASTER ? 1 : a.T, main_rows, extra);  // the blocks of one row - and the tracks of one mix - on one XCD (mst_common.h)
         blk = gridDim.x - 1 - blk;
+    } else {
+        row -= extra;
     }
     if (block_interior(a.n, a.lookahead, a.aligned, blk)) comp_bwd_run_body<MASTER, true, FXS>(a, row, blk, cg_u, cg_g);
     else comp_bwd_run_body<MASTER, false, FXS>(a, row, blk, cg_u, cg_g);
@@ -728,7 +752,7 @@ void launch_apply_master(const MasterApplyArgs& a, int bs, hipStream_t stream) {
     hipLaunchKernelGGL(k_apply_master, dim3(a.nc_pad / kWG, bs), dim3(kWG), 0, stream, a);
 }
 void launch_comp_bwd(bool master, bool run, const CompBwdArgs& a, int rows, hipStream_t stream) {
-    dim3 grid(a.nc_pad / kWG, rows), block(kWG);
+    dim3 grid(a.nc_pad / kWG, rows + ((!master && run) ? a.cg2_rows : 0)), block(kWG);
     if (master && !run) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_comp_bwd_zs<true>), grid, block, 0, stream, a);
     else if (master && run) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_comp_bwd_run<true>), grid, block, 0, stream, a);
     else if (!master && !run) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_comp_bwd_zs<false>), grid, block, 0, stream, a);

@@ -160,7 +160,8 @@ extern "C" int mst_console_forward(const mst_console_desc* d, const float* track
 // (Layout::apscan_fwd) - the master rows only
 static void allpole_scan(const Layout& L, float* ws, int nsig_all, hipStream_t stream) {
     if (L.apscan_fwd && fuse_allpole()) {
-        if (nsig_all > L.R) launch_scan2(ws + L.zP_m, ws + L.sP_m, ws + L.powP_m, 0, L.ncE, L.ncE_pad, L.KE, nsig_all - L.R, stream);
+        // nothing up front: the track rows' scans rode on the forward's master-bus run, the master rows' ride on the backward's adjoint run
+        (void)nsig_all;
     } else {
         launch_scan2(ws + L.zP_t, ws + L.sP_t, ws + L.powP_t, L.R, L.ncE, L.ncE_pad, L.KE, nsig_all, stream);
     }
@@ -226,7 +227,11 @@ extern "C" int mst_console_backward(const mst_console_desc* d, const float* trac
         }
         else launch_comp_bwd(true, false, ca, L.bs, stream);
         ca.s0 = ws + L.zQ_m;
-        if (MST_FUSE_COEFGRAD) {  // coefficient-gradient sums of the two bus channels in the run pass (see the tracks below)
+        // coefficient-gradient sums of the two bus channels: in this launch (round 3), or - when the all-pole scans ride on other launches
+        // (Layout::apscan_fwd) - as extra rows of the TRACKS' run launch below: the master launch is one lockstep round of lone
+        // workgroups, where two more 64-sample walks per workgroup are pure latency (31 -> 18 us), the track launch absorbs them
+        const bool master_cg_later = MST_FUSE_COEFGRAD && L.apscan_fwd && fuse_allpole();
+        if (MST_FUSE_COEFGRAD && !master_cg_later) {
             ca.ap_s0 = ws + L.sP_m;
             ca.ap_nc_pad = L.ncE_pad;
             ca.ep = ws + L.ep_m;
@@ -236,8 +241,12 @@ extern "C" int mst_console_backward(const mst_console_desc* d, const float* trac
         if (L.eq1 && mfma_zs()) launch_eq_zs_mfma(EQ_ADJ, ws + L.du_m, Ns, ws + L.wzA_m, 0, ws + L.zA_m, L.ncE_pad, n, 2 * L.bs, stream, p1A_m, L.ntE, ws + L.aggA_m);
         else launch_cascade(EQ_ADJ, false, ws + L.du_m, Ns, nullptr, 0, ws + L.rc_m, 0, nullptr, ws + L.zA_m, L.ncE_pad, n, 2 * L.bs, stream, p1A_m, L.ntE, ws + L.aggA_m);
         if (!L.eq1) launch_scan12(true, ws + L.zA_m, ws + L.sA_m, ws + L.powA_m, 0, L.ncE, L.ncE_pad, L.KE, 2 * L.bs, stream);
-        launch_cascade(EQ_ADJ, true, ws + L.du_m, Ns, ws + L.dbus, Ns, ws + L.rc_m, 0, L.eq1 ? ws + L.zA_m : ws + L.sA_m, nullptr, L.ncE_pad, n,
-                       2 * L.bs, stream, p1A_m, L.ntE, ws + L.aggA_m);
+        if (master_cg_later)  // + the master rows' own all-pole carry scans as extra workgroups of this (one wave per SIMD) launch
+            launch_master_run_apscan(ws + L.du_m, Ns, ws + L.dbus, Ns, ws + L.rc_m, ws + L.zA_m, L.ncE_pad, n, 2 * L.bs, stream, p1A_m, L.ntE, ws + L.aggA_m,
+                                     nullptr, ws + L.zP_m, ws + L.sP_m, ws + L.powP_m, 2 * L.bs * 12, L.ncE, L.apscan_sh, EQ_ADJ);
+        else
+            launch_cascade(EQ_ADJ, true, ws + L.du_m, Ns, ws + L.dbus, Ns, ws + L.rc_m, 0, L.eq1 ? ws + L.zA_m : ws + L.sA_m, nullptr, L.ncE_pad, n,
+                           2 * L.bs, stream, p1A_m, L.ntE, ws + L.aggA_m);
         gbus = ws + L.dbus;
         gbus_stride = Ns;
     } else if (o_on) {
@@ -273,6 +282,12 @@ extern "C" int mst_console_backward(const mst_console_desc* d, const float* trac
             ca.ap_nc_pad = L.ncE_pad;
             ca.ep = ws + L.ep_t;
             if (!grad_tracks) ca.du = nullptr;
+            if (m_on && L.apscan_fwd && fuse_allpole()) {  // the master channels' coefficient-gradient walks ride here (see above)
+                ca.cg2_u = ws + L.v_m;
+                ca.cg2_du = ws + L.du_m;
+                ca.cg2_rc = ws + L.rc_m;
+                ca.cg2_rows = 2 * L.bs;
+            }
         }
         launch_comp_bwd(false, true, ca, L.R, stream);
         // without the fusion: one k_coefgrad launch for the track rows and the master rows (which follow the tracks in the same arrays)

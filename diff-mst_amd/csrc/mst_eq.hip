@@ -483,10 +483,14 @@ __device__ __forceinline__ void allpole_scan_tile(const float* __restrict__ z0, 
 struct ApScanArgs {       // the scan jobs riding on a launch: job q = two-state system (signal row q / 12, filter q % 12)
     const float* z;       // (jobs, 2, nc_pad) zero-state chunk end states
     float* s0;            // (jobs, 2, nc_pad) out: state entering every chunk
-    const float* tab;     // (jobs, kPow, 4) power tables (mst_params.hip); job -> table row is the identity for track rows
+    const float* tab;     // (filter rows x 12, kPow, 4) power tables (mst_params.hip)
     int jobs, nc, nc_pad, sh;
+    int stereo;           // 0: job q uses table row q (track rows); 1: signal rows are L/R pairs sharing filter row (q / 12) / 2 (master buses)
 };
-// master-bus forward run (cascade role: blockIdx.y < nsig) + the track rows' all-pole carry scan (blockIdx.y >= nsig)
+// master-bus run (cascade role: blockIdx.y < nsig) + all-pole carry-scan jobs (blockIdx.y >= nsig).  DIR = EQ_FWD: the forward run
+// (all-pole bank riding along) carries the TRACK rows' scans; DIR = EQ_ADJ: the adjoint run of the backward carries the MASTER rows' own
+// (their coefficient-gradient walk happens later, in the tracks' compressor-backward launch)
+template <int DIR>
 __global__ __launch_bounds__(kEqWG) void k_master_run_apscan(const float* __restrict__ in, int64_t in_stride, float* __restrict__ out,
                                                            int64_t out_stride, const float* __restrict__ rc, const float* __restrict__ s0,
                                                            int nc_pad, int64_t n, const float* __restrict__ pw1, int ntiles,
@@ -500,7 +504,8 @@ __global__ __launch_bounds__(kEqWG) void k_master_run_apscan(const float* __rest
         if (job >= sc.jobs || MST_DBG_APSCAN == 1) return;
         const float* z0 = sc.z + (int64_t)job * 2 * sc.nc_pad;
         float* o0 = sc.s0 + (int64_t)job * 2 * sc.nc_pad;
-        const float* tab = sc.tab + (int64_t)job * kPow * 4;
+        const int trow = sc.stereo ? ((job / 12) >> 1) * 12 + job % 12 : job;
+        const float* tab = sc.tab + (int64_t)trow * kPow * 4;
         if (sc.nc == kTile) allpole_scan_tile<true>(z0, o0, tab, sc.nc, sc.nc_pad, sc.sh, tile, tile + kEqWG * kLdw, threadIdx.x);
         else allpole_scan_tile<false>(z0, o0, tab, sc.nc, sc.nc_pad, sc.sh, tile, tile + kEqWG * kLdw, threadIdx.x);
         return;
@@ -508,15 +513,19 @@ __global__ __launch_bounds__(kEqWG) void k_master_run_apscan(const float* __rest
     if (MST_DBG_APSCAN == 2) return;
     const int64_t tile_base = (int64_t)blockIdx.x * kTile;
     const bool fast = tile_fast(in + (int64_t)blockIdx.y * in_stride, tile_base, n) && !((uintptr_t)(out + (int64_t)blockIdx.y * out_stride) & 15);
-    if (fast) cascade_body<EQ_FWD, true, false, true, true, true>(in, in_stride, out, out_stride, rc, 0, s0, nullptr, nc_pad, n, nullptr, 0, pw1, ntiles, agg, tile, zp);
-    else cascade_body<EQ_FWD, true, false, true, false, true>(in, in_stride, out, out_stride, rc, 0, s0, nullptr, nc_pad, n, nullptr, 0, pw1, ntiles, agg, tile, zp);
+    constexpr bool AP = DIR == EQ_FWD;
+    if (fast) cascade_body<DIR, true, false, true, true, AP>(in, in_stride, out, out_stride, rc, 0, s0, nullptr, nc_pad, n, nullptr, 0, pw1, ntiles, agg, tile, zp);
+    else cascade_body<DIR, true, false, true, false, AP>(in, in_stride, out, out_stride, rc, 0, s0, nullptr, nc_pad, n, nullptr, 0, pw1, ntiles, agg, tile, zp);
 }
 void launch_master_run_apscan(const float* in, int64_t in_stride, float* out, int64_t out_stride, const float* rc, const float* s0, int nc_pad,
                               int64_t n, int nsig, hipStream_t stream, const float* pw1, int ntiles, float* agg, float* zp,
-                              const float* sc_z, float* sc_s0, const float* sc_tab, int sc_jobs, int sc_nc, int sc_sh) {
-    const ApScanArgs sc{sc_z, sc_s0, sc_tab, sc_jobs, sc_nc, nc_pad, sc_sh};
+                              const float* sc_z, float* sc_s0, const float* sc_tab, int sc_jobs, int sc_nc, int sc_sh, int dir) {
+    const ApScanArgs sc{sc_z, sc_s0, sc_tab, sc_jobs, sc_nc, nc_pad, sc_sh, dir == EQ_ADJ ? 1 : 0};
     const dim3 grid(ntiles, nsig + (sc_jobs + ntiles - 1) / ntiles), block(kEqWG);
-    hipLaunchKernelGGL(k_master_run_apscan, grid, block, 0, stream, in, in_stride, out, out_stride, rc, s0, nc_pad, n, pw1, ntiles, agg, zp, nsig, sc);
+    if (dir == EQ_FWD)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_master_run_apscan<EQ_FWD>), grid, block, 0, stream, in, in_stride, out, out_stride, rc, s0, nc_pad, n, pw1, ntiles, agg, zp, nsig, sc);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_master_run_apscan<EQ_ADJ>), grid, block, 0, stream, in, in_stride, out, out_stride, rc, s0, nc_pad, n, pw1, ntiles, agg, zp, nsig, sc);
 }
 
 // ---- all-pole bank for the coefficient gradients ------------------------------------------------

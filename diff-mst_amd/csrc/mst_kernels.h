@@ -105,7 +105,7 @@ void launch_eq_zs_mfma(int dir, const float* in, int64_t in_stride, const float*
 // workgroups of the same launch (mst_eq.hip: k_master_run_apscan); sc_sh: 64 = KE 2^sc_sh
 void launch_master_run_apscan(const float* in, int64_t in_stride, float* out, int64_t out_stride, const float* rc, const float* s0, int nc_pad,
                               int64_t n, int nsig, hipStream_t stream, const float* pw1, int ntiles, float* agg, float* zp,
-                              const float* sc_z, float* sc_s0, const float* sc_tab, int sc_jobs, int sc_nc, int sc_sh);
+                              const float* sc_z, float* sc_s0, const float* sc_tab, int sc_jobs, int sc_nc, int sc_sh, int dir = EQ_FWD);
 void launch_allpole_zs(const float* u, int64_t u_stride, const float* rc, int split, float* z, int nc_pad, int64_t n, int nsig,
                        hipStream_t stream);
 void launch_coefgrad(const float* u, int64_t u_stride, const float* g, int64_t g_stride, const float* rc, int split,
@@ -167,6 +167,12 @@ struct CompBwdArgs {
     const float* ap_s0;   // all-pole states entering every 64-sample chunk (rows, 24, ap_nc_pad)
     int ap_nc_pad;
     float* ep;            // (rows, nblkC, EP_COUNT)
+    // tracks launch only: extra signal rows whose coefficient-gradient sums ride along (the two channels of every master bus: their
+    // compressor adjoint ran in the master launch, all that is left is the all-pole walk over u2 = master EQ output and du2 = its cotangent)
+    const float* cg2_u;   // (cg2_rows, stride)
+    const float* cg2_du;  // (cg2_rows, stride)
+    const float* cg2_rc;  // (cg2_rows / 2, RC_STRIDE) filter rows
+    int cg2_rows;         // 0: none; signal row of extra row j = main rows + j (all-pole states, partial sums)
     gran_t* gran;         // (rows, nblk) zeroed granules (+ near copies gran_near granules later): the run pass publishes / awaits the block aggregates itself (no zs launch); null = read s0
     int64_t gran_near;
 };
