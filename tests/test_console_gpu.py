@@ -398,3 +398,62 @@ def test_zero_input_and_silence(console, dev):
     mix.sum().backward()
     assert float(mix.detach().abs().max()) == 0.0
     assert torch.isfinite(tp.grad).all() and torch.isfinite(mp.grad).all()
+
+
+def test_in_launch_aggregate_exchange_under_uneven_load(console, dev):
+    """Round 4: the compressor's block aggregates travel from workgroup to workgroup INSIDE k_apply_master / k_comp_bwd_run (8-byte
+    granules, csrc/mst_common.h) instead of through a zero-state launch.  A hand-off that is only correct on an idle chip passes every
+    other test (cdna_hip_programming.md Guideline 16: 'test every hand-off under UNEVEN load ... checking every word'), so: the same
+    forward + backward 12 times while a second stream streams 1 GiB copies and small kernels at random phases - every mix sample and
+    every parameter gradient of every repetition must be BIT-equal to the quiet run (the exchange has no timing-dependent arithmetic:
+    fixed summation order, a late granule is waited for, never skipped; a give-up would poison the result with NaN)."""
+    torch.manual_seed(17)
+    bs, T, n = 8, 8, 262144
+    tracks = (0.1 * torch.randn(bs, T, n)).to(dev)
+    tp, fp, mp = torch.rand(bs, T, 27), torch.rand(bs, 25), torch.rand(bs, 26)
+    gmix = torch.randn(bs, 2, n).to(dev)
+
+    def run():
+        a, b = tp.to(dev).requires_grad_(True), mp.to(dev).requires_grad_(True)
+        _, mix, *_ = console(tracks, a, fp.to(dev), b, **FULL)
+        mix.backward(gmix)
+        return mix.detach(), a.grad, b.grad
+
+    quiet = run()
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(t).all() for t in quiet)
+    noise_stream = torch.cuda.Stream()
+    big = torch.empty(1 << 28, dtype=torch.float32, device=dev)  # 1 GiB
+    gen = torch.Generator().manual_seed(3)
+    for rep in range(12):
+        with torch.cuda.stream(noise_stream):
+            for _ in range(int(torch.randint(1, 6, (1,), generator=gen))):
+                big[: 1 << 27].copy_(big[1 << 27:])  # 512 MiB read + 512 MiB write
+                big[:4096].add_(1.0)
+        got = run()
+        torch.cuda.synchronize()
+        for q, g, name in zip(quiet, got, ("mix", "grad_track_params", "grad_master_params")):
+            assert torch.equal(q, g), (rep, name, float((q - g).abs().max()))
+
+
+def test_second_backward_over_the_same_forward(console, dev):
+    """The granules of the backward are armed by the forward's k_prep and RE-armed by every backward's last kernel (k_prep_bwd): a second
+    backward over the same forward (retain_graph) with ANOTHER cotangent must see fresh granules, not the first backward's aggregates."""
+    torch.manual_seed(19)
+    bs, T, n = 2, 4, 65536
+    tracks = (0.1 * torch.randn(bs, T, n)).to(dev)
+    tp, fp, mp = torch.rand(bs, T, 27), torch.rand(bs, 25), torch.rand(bs, 26)
+    g1, g2 = torch.randn(bs, 2, n).to(dev), torch.randn(bs, 2, n).to(dev)
+    a, b = tp.to(dev).requires_grad_(True), mp.to(dev).requires_grad_(True)
+    _, mix, *_ = console(tracks, a, fp.to(dev), b, **FULL)
+    mix.backward(g1, retain_graph=True)
+    first = (a.grad.clone(), b.grad.clone())
+    a.grad = b.grad = None
+    mix.backward(g2)
+    second = (a.grad.clone(), b.grad.clone())
+    # fresh forward + backward with g2
+    a2, b2 = tp.to(dev).requires_grad_(True), mp.to(dev).requires_grad_(True)
+    _, mix2, *_ = console(tracks, a2, fp.to(dev), b2, **FULL)
+    mix2.backward(g2)
+    assert torch.equal(second[0], a2.grad) and torch.equal(second[1], b2.grad)
+    assert not torch.equal(first[0], second[0])
