@@ -732,22 +732,21 @@ __device__ __forceinline__ HeadSel head_of(int r, int bs, int T, const mst_ctrl_
     return h;
 }
 constexpr int kHeadK = 16;  // d_model <= 1024 = 64 lanes x 16
+// one wave per (row, output): 16 independent loads per operand, one wave sum (a loop over the 27 outputs inside one wave was 27 serial
+// memory round trips)
 __global__ __launch_bounds__(64) void k_ctrl_heads_fwd(const float* __restrict__ z, mst_ctrl_io io, int nt, int nf, int nm, float* ot, float* of,
                                                        float* om, int bs, int T, int D) {
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x, o = blockIdx.y;
     const HeadSel h = head_of(blockIdx.x, bs, T, io, nt, nf, nm, ot, of, om, nullptr, nullptr, nullptr);
+    if (o >= h.n) return;
     const float* x = z + h.tok * D;
-    float xv[kHeadK];
+    const float* w = h.W + (size_t)o * D;
+    float acc = 0.0f;
 #pragma unroll
-    for (int j = 0; j < kHeadK; ++j) xv[j] = lane + 64 * j < D ? x[lane + 64 * j] : 0.0f;
-    for (int o = 0; o < h.n; ++o) {
-        const float* w = h.W + (size_t)o * D;
-        float acc = 0.0f;
-#pragma unroll
-        for (int j = 0; j < kHeadK; ++j) acc = fmaf(lane + 64 * j < D ? w[lane + 64 * j] : 0.0f, xv[j], acc);
-        acc = wave_sum(acc) + h.B[o];
-        if (lane == 0) h.out[h.orow * h.n + o] = 1.0f / (1.0f + __expf(-acc));
-    }
+    for (int j = 0; j < kHeadK; ++j)
+        if (lane + 64 * j < D) acc = fmaf(w[lane + 64 * j], x[lane + 64 * j], acc);
+    acc = wave_sum(acc) + h.B[o];
+    if (lane == 0) h.out[h.orow * h.n + o] = 1.0f / (1.0f + __expf(-acc));
 }
 // grad_z rows (every token row of the sequence is written: the mix tokens get zeros) and the pre-activation cotangents
 // dpre (rows_total x 32) that the weight-gradient kernel sums over
@@ -770,12 +769,20 @@ __global__ __launch_bounds__(64) void k_ctrl_heads_bwd_dz(mst_ctrl_io io, int nt
     float acc[kHeadK];
 #pragma unroll
     for (int j = 0; j < kHeadK; ++j) acc[j] = 0.0f;
-    for (int o = 0; o < h.n; ++o) {
-        const float d = __shfl(dp, o);
-        const float* w = h.W + (size_t)o * D;
+    // grid.y splits the 64-float column slices of the row: lane (y, l) owns columns y 256 + l + 64 j, j < 4; the outputs go four at a time
+    // with all sixteen weight loads in flight (one output per iteration was 27 serial round trips: 57 us for 36 rows)
+    for (int o0 = 0; o0 < h.n; o0 += 4) {
+        float wv[4][kHeadK];
 #pragma unroll
-        for (int j = 0; j < kHeadK; ++j)
-            if (lane + 64 * j < D) acc[j] = fmaf(d, w[lane + 64 * j], acc[j]);
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < kHeadK; ++j) wv[q][j] = (o0 + q < h.n && lane + 64 * j < D) ? h.W[(size_t)(o0 + q) * D + lane + 64 * j] : 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float d = __shfl(dp, o0 + q < h.n ? o0 + q : 0);
+#pragma unroll
+            for (int j = 0; j < kHeadK; ++j) acc[j] = fmaf(o0 + q < h.n ? d : 0.0f, wv[q][j], acc[j]);
+        }
     }
 #pragma unroll
     for (int j = 0; j < kHeadK; ++j)
@@ -794,10 +801,17 @@ __global__ __launch_bounds__(256) void k_ctrl_heads_bwd_dw(const float* __restri
     const int r0 = head == 0 ? 0 : (head == 1 ? bs * T : bs * T + bs), nr = head == 0 ? bs * T : bs;
     for (int k = threadIdx.x; k < D; k += 256) {
         float acc = 0.0f;
-        for (int q = 0; q < nr; ++q) {
-            const int r = r0 + q;
-            const size_t tok = head == 0 ? (size_t)(q / T) * S + (q % T) : (size_t)q * S + T + 1 + head;
-            acc = fmaf(dpre[(size_t)r * 32 + o], z[tok * D + k], acc);
+        for (int q0 = 0; q0 < nr; q0 += 8) {  // eight rows' operands in flight, folded in row order
+            float dv[8], zv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int q = q0 + u;
+                const size_t tok = head == 0 ? (size_t)(q / T) * S + (q % T) : (size_t)q * S + T + 1 + head;
+                dv[u] = q < nr ? dpre[(size_t)(r0 + q) * 32 + o] : 0.0f;
+                zv[u] = q < nr ? z[tok * D + k] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = fmaf(dv[u], zv[u], acc);
         }
         dW[(size_t)o * D + k] = acc;
     }
@@ -814,7 +828,13 @@ __global__ __launch_bounds__(256) void k_ctrl_tokens_bwd(const float* __restrict
     float a = 0.0f, m0 = 0.0f, m1 = 0.0f, f = 0.0f, ms = 0.0f;
     for (int b = 0; b < bs; ++b) {
         const float* row = gtok + (size_t)b * S * D + k;
-        for (int t = 0; t < T; ++t) a += row[(size_t)t * D];
+        for (int t0 = 0; t0 < T; t0 += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = t0 + u < T ? row[(size_t)(t0 + u) * D] : 0.0f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a += v[u];
+        }
         m0 += row[(size_t)T * D];
         m1 += row[(size_t)(T + 1) * D];
         f += row[(size_t)(T + 2) * D];
@@ -845,8 +865,9 @@ extern "C" int mst_ctrl_tokens_forward(const mst_ctrl_desc* d, int32_t n_tracks,
 extern "C" int mst_ctrl_heads_forward(const mst_ctrl_desc* d, int32_t n_tracks, const float* z, const mst_ctrl_io* io, int32_t n_t, int32_t n_f,
                                       int32_t n_m, float* out_t, float* out_f, float* out_m, void* stream) {
     if (!io_ok(d, n_tracks, n_t, n_f, n_m) || !z || !io || !out_t || !out_f || !out_m) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_ctrl_heads_fwd, dim3(d->bs * (n_tracks + 2)), dim3(64), 0, (hipStream_t)stream, z, *io, n_t, n_f, n_m, out_t, out_f, out_m, d->bs,
-                       n_tracks, d->d_model);
+    const int nmax = n_t > n_f ? (n_t > n_m ? n_t : n_m) : (n_f > n_m ? n_f : n_m);
+    hipLaunchKernelGGL(k_ctrl_heads_fwd, dim3(d->bs * (n_tracks + 2), nmax), dim3(64), 0, (hipStream_t)stream, z, *io, n_t, n_f, n_m, out_t, out_f, out_m,
+                       d->bs, n_tracks, d->d_model);
     return (int)hipGetLastError();
 }
 extern "C" size_t mst_ctrl_heads_scratch_bytes(const mst_ctrl_desc* d, int32_t n_tracks) {
