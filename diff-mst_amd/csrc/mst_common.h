@@ -14,7 +14,11 @@ namespace mst {
 #endif
 constexpr int kSections = 6;           // low shelf, 4 peaking, high shelf (reference mst/modules.py:125-143)
 constexpr int kStates = 2 * kSections; // DF2T state of the whole cascade
-constexpr int kWG = 256;               // lanes per workgroup in the compressor kernels
+#ifndef MST_COMP_WG
+#define MST_COMP_WG 256
+#endif
+constexpr int kWG = MST_COMP_WG;       // lanes per workgroup in the compressor kernels (A/B: 64 = one wave per block, no workgroup barrier)
+constexpr int kCompWaves = kWG / 64;
 constexpr int kEqWG = 64;              // lanes per workgroup in the EQ kernels: ONE wave per 4096-sample tile, so
                                        // a CU hosts many independent tiles at different phases (no lockstep)
 constexpr int kEqChunk = 64;           // samples one lane filters sequentially (EQ kernels)

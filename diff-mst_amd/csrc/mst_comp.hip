@@ -49,6 +49,20 @@ __device__ __forceinline__ void st8(float* row, int64_t i, int64_t n, const floa
     store4(row, i + 4, n, make_float4(v[4], v[5], v[6], v[7]));
 }
 
+// sum of one value per wave over the workgroup's waves (fixed order), through four LDS floats at `slot`; trailing barrier so that the
+// slots may be reused at once.  One-wave workgroups (MST_COMP_WG = 64): the identity, no LDS, no barrier.
+__device__ __forceinline__ float waves_sum(float v, float* slot, int tid) {
+    if (kCompWaves == 1) return v;
+    if ((tid & 63) == 0) slot[tid >> 6] = v;
+    lds_barrier();
+    float s = 0.0f;
+    if constexpr (kCompWaves == 4) s = (slot[0] + slot[1]) + (slot[2] + slot[3]);
+    else
+        for (int w = 0; w < kCompWaves; ++w) s += slot[w];
+    lds_barrier();
+    return s;
+}
+
 // ---- first-order carry machinery -------------------------------------------------------------------
 // Per lane chunk the smoother is  s_out = a s_in + z  (a = alpha^8, z = zero-state end value).
 // block_enter<REV>() returns the state ENTERING this lane's chunk given the state S entering the
@@ -57,7 +71,7 @@ __device__ __forceinline__ void st8(float* row, int64_t i, int64_t n, const floa
 template <bool REV>
 __device__ __forceinline__ float block_enter(float z, float a, float log2a, float S, float* lds, int tid) {
     const int lane = tid & 63, wave = tid >> 6;
-    const int rl = REV ? 63 - lane : lane, rw = REV ? 3 - wave : wave;
+    const int rl = REV ? 63 - lane : lane, rw = REV ? kCompWaves - 1 - wave : wave;
     float v = z, p = a;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -65,13 +79,15 @@ __device__ __forceinline__ float block_enter(float z, float a, float log2a, floa
         if (rl >= d) v = fmaf(p, o, v);
         p *= p;
     }
-    if (rl == 63) lds[rw] = v;  // zero-entry aggregate of this wave
-    lds_barrier();
     float sw = S;  // state entering this wave
-    for (int w = 0; w < rw; ++w) sw = fmaf(p, sw, lds[w]);  // p == a^64
+    if (kCompWaves > 1) {
+        if (rl == 63) lds[rw] = v;  // zero-entry aggregate of this wave
+        lds_barrier();
+        for (int w = 0; w < rw; ++w) sw = fmaf(p, sw, lds[w]);  // p == a^64
+    }
     float ex = REV ? __shfl_down(v, 1) : __shfl_up(v, 1);
     if (rl == 0) ex = 0.0f;
-    lds_barrier();  // lds may be reused by the caller's next call
+    if (kCompWaves > 1) lds_barrier();  // lds may be reused by the caller's next call
     return fmaf(__builtin_amdgcn_exp2f((float)rl * log2a), sw, ex);
 }
 // state entering block `blk` from the aggregates of the blocks before it (after it when REV):
@@ -80,16 +96,12 @@ template <bool REV>
 __device__ __forceinline__ float block_carry(const float* __restrict__ agg, int blk, int nblk, float log2a, float* lds, int tid) {
     float acc = 0.0f;
     if (REV) {
-        for (int j = blk + 1 + tid; j < nblk; j += kWG) acc += __builtin_amdgcn_exp2f((float)(j - blk - 1) * 256.0f * log2a) * agg[j];
+        for (int j = blk + 1 + tid; j < nblk; j += kWG) acc += __builtin_amdgcn_exp2f((float)(j - blk - 1) * (float)kWG * log2a) * agg[j];
     } else {
-        for (int j = blk - 1 - tid; j >= 0; j -= kWG) acc += __builtin_amdgcn_exp2f((float)(blk - 1 - j) * 256.0f * log2a) * agg[j];
+        for (int j = blk - 1 - tid; j >= 0; j -= kWG) acc += __builtin_amdgcn_exp2f((float)(blk - 1 - j) * (float)kWG * log2a) * agg[j];
     }
     acc = wave_sum(acc);
-    if ((tid & 63) == 0) lds[4 + (tid >> 6)] = acc;
-    lds_barrier();
-    const float S = (lds[4] + lds[5]) + (lds[6] + lds[7]);
-    lds_barrier();
-    return S;
+    return waves_sum(acc, lds + 4, tid);
 }
 
 // the same from granules that the other workgroups of THIS launch publish (mst_common.h: gran_publish / gran_wait).  The first poll
@@ -108,20 +120,16 @@ __device__ __forceinline__ float block_carry_g(const gran_t* __restrict__ agg, i
     if (REV) {
         for (int j = blk + 1 + tid; j < nblk; j += kWG, first = false) {
             const float v = (first && (peek >> 32) == 1) ? __int_as_float((int)(unsigned)peek) : gran_wait(agg + j, near_off);
-            acc += __builtin_amdgcn_exp2f((float)(j - blk - 1) * 256.0f * log2a) * v;
+            acc += __builtin_amdgcn_exp2f((float)(j - blk - 1) * (float)kWG * log2a) * v;
         }
     } else {
         for (int j = blk - 1 - tid; j >= 0; j -= kWG, first = false) {
             const float v = (first && (peek >> 32) == 1) ? __int_as_float((int)(unsigned)peek) : gran_wait(agg + j, near_off);
-            acc += __builtin_amdgcn_exp2f((float)(blk - 1 - j) * 256.0f * log2a) * v;
+            acc += __builtin_amdgcn_exp2f((float)(blk - 1 - j) * (float)kWG * log2a) * v;
         }
     }
     acc = wave_sum(acc);
-    if ((tid & 63) == 0) lds[4 + (tid >> 6)] = acc;
-    lds_barrier();
-    const float S = (lds[4] + lds[5]) + (lds[6] + lds[7]);
-    lds_barrier();
-    return S;
+    return waves_sum(acc, lds + 4, tid);
 }
 
 // zero-entry aggregate of the workgroup's block alone (what the zero-state passes publish): a weighted SUM, not a scan -
@@ -131,9 +139,7 @@ template <bool REV>
 __device__ __forceinline__ float block_aggregate(float z, float log2a, float* lds, int tid) {
     const float w = __builtin_amdgcn_exp2f((float)(REV ? tid : kWG - 1 - tid) * log2a);
     const float v = wave_sum(w * z);
-    if ((tid & 63) == 0) lds[tid >> 6] = v;
-    lds_barrier();
-    return (lds[0] + lds[1]) + (lds[2] + lds[3]);
+    return waves_sum(v, lds, tid);
 }
 
 // ---- forward: zero-state end value of the smoother per 2048-sample block ---------------------------
@@ -425,7 +431,7 @@ __global__ __launch_bounds__(kWG) void k_comp_bwd_zs(CompBwdArgs a) {
 #define MST_CG_PITCH (kEqChunk + 4)
 #endif
 constexpr int kCgPitch = MST_CG_PITCH, kCgChunks = kWG * CC / kEqChunk, kCgTile = kCgChunks * kCgPitch;
-static_assert(kCgChunks == 32 && kSections * 32 <= kWG, "one section x 32 chunks per 32 lanes");
+static_assert((kCgChunks == 32 || kCgChunks == 8) && kSections * kCgChunks <= kWG, "one section x kCgChunks chunks per lane group");
 template <bool FAST>
 __device__ __forceinline__ void coefgrad_fused(const CompBwdArgs& a, int blk, int sig, const float* __restrict__ rc, int64_t i0, const float* xu,
                                                const float* du, float* __restrict__ cg_u, float* __restrict__ cg_g) {
@@ -446,11 +452,12 @@ __device__ __forceinline__ void coefgrad_fused(const CompBwdArgs& a, int blk, in
         *reinterpret_cast<float4*>(pg) = make_float4(g[0], g[1], g[2], g[3]);
         *reinterpret_cast<float4*>(pg + 32) = make_float4(g[4], g[5], g[6], g[7]);
     }
-    lds_barrier();
+    if (kCompWaves > 1) lds_barrier();
+    else wave_lds_sync();
 #ifndef MST_CG_ROT
 #define MST_CG_ROT 0  // A/B: chunk rotation of the upper half wave (lanes l and l + 32 then read different LDS rows)
 #endif
-    const int s = tid >> 5, c = ((tid & 31) + ((tid & 32) ? MST_CG_ROT : 0)) & 31;
+    const int s = tid / kCgChunks, c = kCgChunks == 32 ? (((tid & 31) + ((tid & 32) ? MST_CG_ROT : 0)) & 31) : tid % kCgChunks;
     if (s < kSections) {
         const float ka1 = rc[RC_SOS + 5 * s + 3], ka2 = rc[RC_SOS + 5 * s + 4];
         const float kc1 = rc[RC_AP + 3 * s], kc2 = rc[RC_AP + 3 * s + 1], kib0 = rc[RC_AP + 3 * s + 2];
@@ -504,27 +511,34 @@ __device__ __forceinline__ void coefgrad_fused(const CompBwdArgs& a, int blk, in
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
             float v = acc[i];
-            v = dpp_add<0x111, 0xf>(v);
-            v = dpp_add<0x112, 0xf>(v);
-            v = dpp_add<0x114, 0xf>(v);
-            v = dpp_add<0x118, 0xf>(v);
-            v = dpp_add<0x142, 0xa>(v);
+            if (kCgChunks == 32) {
+                v = dpp_add<0x111, 0xf>(v);
+                v = dpp_add<0x112, 0xf>(v);
+                v = dpp_add<0x114, 0xf>(v);
+                v = dpp_add<0x118, 0xf>(v);
+                v = dpp_add<0x142, 0xa>(v);
+            } else {  // eight chunk lanes per section: xor 1, xor 2 (quad permutes), then the other quad of the 8-lane group (row_half_mirror)
+                v = dpp_add<0xb1, 0xf>(v);   // quad_perm [1,0,3,2]
+                v = dpp_add<0x4e, 0xf>(v);   // quad_perm [2,3,0,1]
+                v = dpp_add<0x141, 0xf>(v);  // row_half_mirror
+            }
             acc[i] = v;
         }
-        if ((tid & 31) == 31) {
+        if ((tid % kCgChunks) == kCgChunks - 1) {
             float* o = a.ep + ((int64_t)sig * gridDim.x + blk) * EP_COUNT + 5 * s;
 #pragma unroll
             for (int i = 0; i < 5; ++i) o[i] = acc[i];
         }
     }
-    lds_barrier();  // red[] below and the next use of the tiles
+    if (kCompWaves > 1) lds_barrier();  // red[] below and the next use of the tiles
+    else wave_lds_sync();
 }
 
 // FXS: the fx send bus is on (tracks only) - its cotangent rows are read and the send-gain sum is formed
 template <bool MASTER, bool FAST, bool FXS>
 __device__ __forceinline__ void comp_bwd_run_body(const CompBwdArgs& a, int row, int blk, float* __restrict__ cg_u, float* __restrict__ cg_g) {
     constexpr int NCH = MASTER ? 2 : 1;
-    __shared__ float red[4][CP_COUNT];  // red[0] doubles as the 8-float scan scratch
+    __shared__ float red[kCompWaves > 1 ? kCompWaves : 1][CP_COUNT];  // red[0] doubles as the 8-float scan scratch
     const int tid = threadIdx.x, chunk = blk * kWG + tid;
     const int64_t i0 = (int64_t)chunk * CC;
     const float* rc = a.rc + (int64_t)row * RC_STRIDE;
@@ -692,9 +706,15 @@ __device__ __forceinline__ void comp_bwd_run_body(const CompBwdArgs& a, int row,
         const float v = wave_sum(p[i]);
         if (lane == 0) red[wave][i] = v;
     }
-    lds_barrier();
-    if (tid < CP_COUNT)
-        a.part[((int64_t)row * gridDim.x + blk) * CP_COUNT + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    if (kCompWaves > 1) lds_barrier();
+    else wave_lds_sync();
+    if (tid < CP_COUNT) {
+        float t = 0.0f;
+        if constexpr (kCompWaves == 4) t = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+        else
+            for (int w = 0; w < kCompWaves; ++w) t += red[w][tid];
+        a.part[((int64_t)row * gridDim.x + blk) * CP_COUNT + tid] = t;
+    }
 }
 #ifndef MST_COMP_BWD_W
 #define MST_COMP_BWD_W 1  // min waves per SIMD asked of the compressor backward (A/B switch)

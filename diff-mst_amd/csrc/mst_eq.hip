@@ -276,18 +276,20 @@ __device__ __forceinline__ void cascade_body(const float* __restrict__ in, int64
         }
     }
     if (FUSE_GC) {
-        // fold the 32 lane values of each 2048-sample block: v_l += a64^d v_(l-d) inside 32-lane segments
+        // fold the lane values of each compressor block (kBlkLanes EQ lanes = kWG * kCompChunk samples): v_l += a64^d v_(l-d) inside the
+        // lane segments
+        constexpr int kBlkLanes = kWG * kCompChunk / kEqChunk;
         const float l2a64 = 8.0f * rc[(int64_t)filter_row(sig, split) * RC_STRIDE + RC_LOG2A_C];  // log2(alpha^64)
         float p = __builtin_amdgcn_exp2f(l2a64);
-        const int l32 = tid & 31;
+        const int lseg = tid & (kBlkLanes - 1);
 #pragma unroll
-        for (int d = 1; d < 32; d <<= 1) {
+        for (int d = 1; d < kBlkLanes; d <<= 1) {
             const float o = __shfl_up(zacc, d);
-            if (l32 >= d) zacc = fmaf(p, o, zacc);
+            if (lseg >= d) zacc = fmaf(p, o, zacc);
             p *= p;
         }
-        const int blk = chunk >> 5;  // (kEqChunk * 32) = 2048 samples per compressor block
-        if (l32 == 31 && blk < nblk_comp) zs_comp[(int64_t)sig * nblk_comp + blk] = zacc;
+        const int blk = chunk / kBlkLanes;
+        if (lseg == kBlkLanes - 1 && blk < nblk_comp) zs_comp[(int64_t)sig * nblk_comp + blk] = zacc;
     }
 }
 
@@ -752,7 +754,7 @@ void launch_cascade(int dir, bool run, const float* in, int64_t in_stride, float
 void launch_cascade_run_gc(const float* in, int64_t in_stride, float* out, int64_t out_stride, const float* rc, int split,
                            const float* s0, int nc_pad, int64_t n, int nsig, float* zs_comp, int nblk_comp, hipStream_t stream,
                            const float* pw1, int ntiles, float* agg, float* zp) {
-    static_assert(kEqChunk * 32 == kWG * kCompChunk, "a compressor block must be 32 EQ lanes");
+    static_assert(kWG * kCompChunk % kEqChunk == 0 && kEqWG % (kWG * kCompChunk / kEqChunk) == 0, "a compressor block must be a power-of-two group of EQ lanes");
     const dim3 grid(pw1 ? ntiles : nc_pad / kEqWG, nsig), block(kEqWG);
     if (zp) {
         if (pw1)
