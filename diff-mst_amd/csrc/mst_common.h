@@ -295,6 +295,13 @@ struct Layout {
     int64_t total;                       // floats
 };
 
+// floats between consecutive signal rows of the workspace arrays (u, g_s, bus, du ...): the row length rounded to 16 bytes, plus
+// MST_ROW_PAD floats (A/B switch: rows exactly 2^k bytes apart put the same block of every row on the same memory channel)
+#ifndef MST_ROW_PAD
+#define MST_ROW_PAD 0
+#endif
+inline int64_t row_stride(int64_t n) { return round_up(n, 4) + MST_ROW_PAD; }
+
 inline Layout make_layout(const mst_console_desc* d) {
     Layout L{};
     L.bs = d->bs;
@@ -331,7 +338,7 @@ inline Layout make_layout(const mst_console_desc* d) {
         o += round_up(n, 64);  // keep every array 256-byte aligned
         return at;
     };
-    const int64_t R = L.R, B = L.bs, N = round_up(L.N, 4);
+    const int64_t R = L.R, B = L.bs, N = row_stride(L.N);
     // Track rows come first and the master rows follow IN THE SAME ARRAY wherever a kernel can serve
     // both in one launch (signal rows [0,R) = tracks, [R, R+2bs) = master L/R; filter rows [0,R), [R,R+bs)).
     L.rc_t = take((R + B) * RC_STRIDE);

@@ -90,6 +90,31 @@ __device__ __forceinline__ float block_enter(float z, float a, float log2a, floa
     if (kCompWaves > 1) lds_barrier();  // lds may be reused by the caller's next call
     return fmaf(__builtin_amdgcn_exp2f((float)rl * log2a), sw, ex);
 }
+// The same scan with the entering state S left open: the state entering this lane's chunk is Q0 + W S.  Everything here is known
+// before S is (for the in-launch exchange: before the other workgroups' aggregates have arrived).
+template <bool REV>
+__device__ __forceinline__ void block_enter_split(float z, float a, float log2a, float* lds, int tid, float& Q0, float& W) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const int rl = REV ? 63 - lane : lane, rw = REV ? kCompWaves - 1 - wave : wave;
+    float v = z, p = a;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const float o = REV ? __shfl_down(v, d) : __shfl_up(v, d);
+        if (rl >= d) v = fmaf(p, o, v);
+        p *= p;
+    }
+    float sw = 0.0f;  // zero-entry state entering this wave
+    if (kCompWaves > 1) {
+        if (rl == 63) lds[rw] = v;
+        lds_barrier();
+        for (int w = 0; w < rw; ++w) sw = fmaf(p, sw, lds[w]);  // p == a^64
+    }
+    float ex = REV ? __shfl_down(v, 1) : __shfl_up(v, 1);
+    if (rl == 0) ex = 0.0f;
+    if (kCompWaves > 1) lds_barrier();
+    Q0 = fmaf(__builtin_amdgcn_exp2f((float)rl * log2a), sw, ex);
+    W = __builtin_amdgcn_exp2f((float)(rl + 64 * rw) * log2a);
+}
 // state entering block `blk` from the aggregates of the blocks before it (after it when REV):
 //   S = sum_j A^(dist-1) agg[j],  A = a^256, computed in a fixed order by the whole workgroup
 template <bool REV>
@@ -432,9 +457,31 @@ __global__ __launch_bounds__(kWG) void k_comp_bwd_zs(CompBwdArgs a) {
 #endif
 constexpr int kCgPitch = MST_CG_PITCH, kCgChunks = kWG * CC / kEqChunk, kCgTile = kCgChunks * kCgPitch;
 static_assert((kCgChunks == 32 || kCgChunks == 8) && kSections * kCgChunks <= kWG, "one section x kCgChunks chunks per lane group");
+// the four all-pole states entering this lane's (section, chunk) walk.  They depend on nothing the kernel computes: the compressor
+// adjoint requests them with its first loads, so that their latency is not exposed behind the transposition barrier (MST_CBR_EARLY)
+struct CgStates { float wa1, wa2, wb1, wb2; };
+__device__ __forceinline__ int cg_chunk_of(int tid) {
+#ifndef MST_CG_ROT
+#define MST_CG_ROT 0  // A/B: chunk rotation of the upper half wave (lanes l and l + 32 then read different LDS rows)
+#endif
+    return kCgChunks == 32 ? (((tid & 31) + ((tid & 32) ? MST_CG_ROT : 0)) & 31) : tid % kCgChunks;
+}
+__device__ __forceinline__ CgStates coefgrad_states(const CompBwdArgs& a, int blk, int sig) {
+    const int tid = threadIdx.x, s = tid / kCgChunks, c = cg_chunk_of(tid);
+    CgStates w = {0.f, 0.f, 0.f, 0.f};
+    if (s < kSections) {
+        const int64_t base = ((int64_t)sig * 24 + 4 * s) * a.ap_nc_pad + (int64_t)blk * kCgChunks + c;
+        w.wa1 = a.ap_s0[base];
+        w.wa2 = a.ap_s0[base + a.ap_nc_pad];
+        w.wb1 = a.ap_s0[base + 2 * (int64_t)a.ap_nc_pad];
+        w.wb2 = a.ap_s0[base + 3 * (int64_t)a.ap_nc_pad];
+    }
+    return w;
+}
 template <bool FAST>
 __device__ __forceinline__ void coefgrad_fused(const CompBwdArgs& a, int blk, int sig, const float* __restrict__ rc, int64_t i0, const float* xu,
-                                               const float* du, float* __restrict__ cg_u, float* __restrict__ cg_g) {
+                                               const float* du, float* __restrict__ cg_u, float* __restrict__ cg_g,
+                                               bool have_pre = false, CgStates pre = {0.f, 0.f, 0.f, 0.f}) {
     const int tid = threadIdx.x;
     {
         const int c = tid >> 3, off = (tid & 7) * CC;  // 8 lanes x 8 samples = one chunk
@@ -454,16 +501,12 @@ __device__ __forceinline__ void coefgrad_fused(const CompBwdArgs& a, int blk, in
     }
     if (kCompWaves > 1) lds_barrier();
     else wave_lds_sync();
-#ifndef MST_CG_ROT
-#define MST_CG_ROT 0  // A/B: chunk rotation of the upper half wave (lanes l and l + 32 then read different LDS rows)
-#endif
-    const int s = tid / kCgChunks, c = kCgChunks == 32 ? (((tid & 31) + ((tid & 32) ? MST_CG_ROT : 0)) & 31) : tid % kCgChunks;
+    const int s = tid / kCgChunks, c = cg_chunk_of(tid);
     if (s < kSections) {
         const float ka1 = rc[RC_SOS + 5 * s + 3], ka2 = rc[RC_SOS + 5 * s + 4];
         const float kc1 = rc[RC_AP + 3 * s], kc2 = rc[RC_AP + 3 * s + 1], kib0 = rc[RC_AP + 3 * s + 2];
-        const int64_t base = ((int64_t)sig * 24 + 4 * s) * a.ap_nc_pad + (int64_t)blk * kCgChunks + c;
-        float wa1 = a.ap_s0[base], wa2 = a.ap_s0[base + a.ap_nc_pad], wb1 = a.ap_s0[base + 2 * (int64_t)a.ap_nc_pad],
-              wb2 = a.ap_s0[base + 3 * (int64_t)a.ap_nc_pad];
+        const CgStates w0 = have_pre ? pre : coefgrad_states(a, blk, sig);
+        float wa1 = w0.wa1, wa2 = w0.wa2, wb1 = w0.wb1, wb2 = w0.wb2;
         if (MST_CG_ABLATE & 1) wa1 = wa2 = wb1 = wb2 = (float)c;
 #ifdef MST_CG_F64  // diagnostic: the five inner products (and the recurrences feeding them) in double
         double db0 = 0., db1 = 0., db2 = 0., da1 = 0., da2 = 0.;
@@ -477,9 +520,39 @@ __device__ __forceinline__ void coefgrad_fused(const CompBwdArgs& a, int blk, in
         }
         float acc[5] = {(float)(db0 * kib0), (float)(db1 * kib0), (float)(db2 * kib0), (float)da1, (float)da2};
 #else
-        float db0 = 0.f, db1 = 0.f, db2 = 0.f, da1 = 0.f, da2 = 0.f;
+        // The two recurrences (1 / B_s and 1 / A_s driven by the same input) and the lag-1 / lag-2 inner products are the same arithmetic
+        // on two values: held as float pairs they take one packed instruction each (v_pk_fma_f32) - five instructions per sample
+        // instead of nine.  Lane x of a pair = the 1 / B_s side (numerator sums), lane y = the 1 / A_s side (its sums enter negated).
+#ifndef MST_CG_PACKED
+#define MST_CG_PACKED 1
+#endif
+        float db0 = 0.f, db1, db2, da1, da2;
         const float* mu = &cg_u[c * kCgPitch];
         const float* mg = &cg_g[c * kCgPitch];
+#if MST_CG_PACKED
+        using f2 = __attribute__((ext_vector_type(2))) float;
+        f2 w1 = {wb1, wa1}, w2 = {wb2, wa2}, acc1 = {0.f, 0.f}, acc2 = {0.f, 0.f};
+        const f2 nk1 = {-kc1, -ka1}, nk2 = {-kc2, -ka2};
+#pragma unroll 2
+        for (int i4 = 0; i4 < ((MST_CG_ABLATE & 2) ? 4 : kEqChunk); i4 += 4) {
+            const int at = ((i4 >> 2) & 1) * 32 + (i4 >> 3) * 4;  // samples i4 .. i4 + 3 in the row image (see the stores above)
+            const float4 xv = *reinterpret_cast<const float4*>(&mu[at]);
+            const float4 gv = *reinterpret_cast<const float4*>(&mg[at]);
+            const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, gs[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const f2 xx = {xs[t], xs[t]}, gg = {gs[t], -gs[t]};
+                const f2 wn = __builtin_elementwise_fma(nk2, w2, __builtin_elementwise_fma(nk1, w1, xx));
+                db0 = fmaf(gs[t], wn.x, db0);
+                acc1 = __builtin_elementwise_fma(gg, w1, acc1);
+                acc2 = __builtin_elementwise_fma(gg, w2, acc2);
+                w2 = w1;
+                w1 = wn;
+            }
+        }
+        db1 = acc1.x; da1 = acc1.y; db2 = acc2.x; da2 = acc2.y;
+#else
+        db1 = db2 = da1 = da2 = 0.f;
 #pragma unroll 2
         for (int i4 = 0; i4 < ((MST_CG_ABLATE & 2) ? 4 : kEqChunk); i4 += 4) {
             const int at = ((i4 >> 2) & 1) * 32 + (i4 >> 3) * 4;  // samples i4 .. i4 + 3 in the row image (see the stores above)
@@ -502,6 +575,7 @@ __device__ __forceinline__ void coefgrad_fused(const CompBwdArgs& a, int blk, in
                 wb1 = wb;
             }
         }
+#endif
         float acc[5] = {db0 * kib0, db1 * kib0, db2 * kib0, da1, da2};
 #endif
         // sum over the 32 chunk lanes of the section (one half wave), fixed order: four DPP row shifts leave every 16-lane row's total in
@@ -550,6 +624,8 @@ __device__ __forceinline__ void comp_bwd_run_body(const CompBwdArgs& a, int row,
     float gl[CC], gr[CC], du0[CC], du1[CC];
     float xu[CC], xu1[MASTER ? CC : 1];  // the compressor input of this lane's samples, kept for the fused coefficient-gradient pass
     load_gy<MASTER, FAST>(a, row, rc, i0, gl, gr);
+    CgStates cgs = {0.f, 0.f, 0.f, 0.f}, cgs1 = {0.f, 0.f, 0.f, 0.f};  // all-pole entry states of the coefficient walk, when requested early
+    bool have_cgs = false;
     const float pl = rc[RC_PANL], pr = rc[RC_PANR];  // master: both = output-fader gain
     // cotangent of the fx send gain: sum_n (pl fL + pr fR)[n] y[n]  (fL, fR = cotangent of the send bus)
     float fsum[FXS ? CC : 1];
@@ -570,6 +646,32 @@ __device__ __forceinline__ void comp_bwd_run_body(const CompBwdArgs& a, int row,
         LD8S<FAST>(u0, i0 - a.lookahead, a.n, xd0);
         if (MASTER) LD8S<FAST>(u1, i0 - a.lookahead, a.n, xd1);
         LD8<FAST>(a.gs + (int64_t)row * a.stride, i0, a.n, g);
+#ifndef MST_CBR_EARLY
+#define MST_CBR_EARLY 0  // bit mask (1 look-ahead operands, 2 x / g[-1], 4 all-pole entry states): every other global load of the block is requested here too, in front of the zero-state loop: one memory latency
+                         // per workgroup instead of two (the loads behind the aggregate's barrier could not start before it)
+#endif
+        float gF[CC], glF[CC], grF[CC];
+        float g_prev0 = 0.0f;
+        if (MST_CBR_EARLY & 1) {
+            LD8S<FAST>(a.gs + (int64_t)row * a.stride, i0 + a.lookahead, a.n, gF);
+            load_gy<MASTER, FAST>(a, row, rc, i0 + a.lookahead, glF, grF);
+        }
+        if (MST_CBR_EARLY & 2) {
+            LD8<FAST>(u0, i0, a.n, x0);
+            if (MASTER) LD8<FAST>(u1, i0, a.n, x1);
+            g_prev0 = (i0 > 0 && i0 - 1 < a.n) ? a.gs[(int64_t)row * a.stride + i0 - 1] : 0.0f;
+        }
+        if ((MST_CBR_EARLY & 4) && a.ep) {
+            cgs = coefgrad_states(a, blk, row * NCH);
+            if (MASTER) cgs1 = coefgrad_states(a, blk, row * NCH + 1);
+            have_cgs = true;
+        }
+#ifndef MST_CBR_SPLIT
+#define MST_CBR_SPLIT 1  // 1: the adjoint smoother's state enters every q-dependent quantity as  zero-state part + Q x homogeneous part
+                         // (q is linear in the state Q entering the lane's chunk), both parts formed BEFORE the other blocks' aggregates
+                         // are awaited: behind the wait are one multiply-add per sample and per sum instead of the q recurrence, and
+                         // the five per-sample coefficient arrays the recurrence needed are not kept (the kernel spilled 23 registers)
+#endif
         float dgsv[CC];
         float zq = 0.0f;
 #pragma unroll
@@ -578,6 +680,21 @@ __device__ __forceinline__ void comp_bwd_run_body(const CompBwdArgs& a, int row,
             const float dot = MASTER ? pl * (gl[i] * xd0[i] + gr[i] * xd1[i]) : (pl * gl[i] + pr * gr[i]) * xd0[i];
             dgsv[i] = (FAST || i0 + i < a.n) ? dot * Gi * kLn10Over20 : 0.0f;
             zq = fmaf(k.alpha, zq, dgsv[i]);
+#if MST_CBR_SPLIT
+            // the pan / make-up / send sums need exactly these operands: formed here, the upstream cotangents and the delayed input
+            // are dead before the static-curve loop starts
+            if (FAST || i0 + i < a.n) {
+                p[CP_MAKEUP] += dgsv[i];
+                if (MASTER) {
+                    p[CP_PANL] = fmaf(gl[i] * xd0[i] + gr[i] * xd1[i], Gi, p[CP_PANL]);  // output-fader gain: sum(grad_mix * out_before_fader)
+                } else {
+                    const float yv = xd0[i] * Gi;
+                    p[CP_PANL] = fmaf(gl[i], yv, p[CP_PANL]);
+                    p[CP_PANR] = fmaf(gr[i], yv, p[CP_PANR]);
+                    if (FXS) p[CP_SEND] = fmaf(fsum[i], yv, p[CP_SEND]);
+                }
+            }
+#endif
         }
         const float ac = rc[RC_ALPHA_C], l2a = rc[RC_LOG2A_C];
         gran_t* gq = a.gran ? a.gran + (int64_t)row * gridDim.x : nullptr;
@@ -589,9 +706,10 @@ __device__ __forceinline__ void comp_bwd_run_body(const CompBwdArgs& a, int row,
         // three arrays less are alive across the block scan (the kernel ran at 152 registers = 3 waves per SIMD)
         float fwd0[CC], fwd1[MASTER ? CC : 1];
         {
-            float gF[CC], glF[CC], grF[CC];
-            LD8S<FAST>(a.gs + (int64_t)row * a.stride, i0 + a.lookahead, a.n, gF);
-            load_gy<MASTER, FAST>(a, row, rc, i0 + a.lookahead, glF, grF);
+            if (!(MST_CBR_EARLY & 1)) {
+                LD8S<FAST>(a.gs + (int64_t)row * a.stride, i0 + a.lookahead, a.n, gF);
+                load_gy<MASTER, FAST>(a, row, rc, i0 + a.lookahead, glF, grF);
+            }
 #pragma unroll
             for (int i = 0; i < CC; ++i) {
                 const bool liveF = FAST || i0 + i + a.lookahead < a.n;
@@ -600,15 +718,78 @@ __device__ __forceinline__ void comp_bwd_run_body(const CompBwdArgs& a, int row,
                 if (MASTER) fwd1[i] = liveF ? pr * grF[i] * GF : 0.0f;
             }
         }
-        LD8<FAST>(u0, i0, a.n, x0);
+        if (!(MST_CBR_EARLY & 2)) {
+            LD8<FAST>(u0, i0, a.n, x0);
+            if (MASTER) LD8<FAST>(u1, i0, a.n, x1);
+            g_prev0 = (i0 > 0 && i0 - 1 < a.n) ? a.gs[(int64_t)row * a.stride + i0 - 1] : 0.0f;
+        }
 #pragma unroll
         for (int i = 0; i < CC; ++i) xu[i] = x0[i];
         if (MASTER) {
-            LD8<FAST>(u1, i0, a.n, x1);
 #pragma unroll
             for (int i = 0; i < CC; ++i) xu1[i] = x1[i];
         }
-        const float g_prev0 = (i0 > 0 && i0 - 1 < a.n) ? a.gs[(int64_t)row * a.stride + i0 - 1] : 0.0f;
+#if MST_CBR_SPLIT
+#ifndef MST_CBR_SCHED
+#define MST_CBR_SCHED 3  // scheduling fences (1: between the phases, 2: between the samples of the static-curve loop): unfenced the
+                         // compiler interleaves all eight samples and needs 172 registers
+#endif
+        if (MST_CBR_SCHED & 1) __builtin_amdgcn_sched_barrier(0);
+        // state entering this lane's chunk = Q0 + W S (S = state entering the block, known after the wait)
+        float Q0 = 0.0f, W = 0.0f;
+        block_enter_split<true>(zq, ac, l2a, red[0], tid, Q0, W);
+        const gran_t peek = gq ? carry_peek<true>(gq, a.gran_near, blk, gridDim.x, tid) : 0ull;
+        // q[i] = zs[i] + pw[i] Q with zs the zero-entry recurrence over this lane's samples and pw[i] = alpha^(CC - i):
+        //   alpha += q A;  kappa += oma q Fv;  thr -= oma q Kp;  knee += oma q Kw;  du = oma q E + look-ahead branch
+        float zs = 0.0f, pw = 1.0f;
+        float sA0 = 0.f, sA1 = 0.f, sF0 = 0.f, sF1 = 0.f, sP0 = 0.f, sP1 = 0.f, sW0 = 0.f, sW1 = 0.f;
+        float db[CC];  // du0 / du1 hold the zero-state part until Q is known
+#pragma unroll
+        for (int i = CC - 1; i >= 0; --i) {
+            const bool live = FAST || i0 + i < a.n;
+            const float side = MASTER ? x0[i] + x1[i] : x0[i];
+            // static curve f, df/dd, df/dknee without branches (two exec-mask branches per sample split this loop into sixteen basic
+            // blocks with every array alive across them): above the knee (d, 1, 0), inside (t^2 / 2w, t / w, t (hw - d) / 2w^2), below 0
+            const float d = kDbPerLog2 * __builtin_amdgcn_logf(fmaxf(fabsf(side), kCompEps)) - k.thr;
+            const float t = d + k.hw;
+            const bool above = d > k.hw, inside = !above && d >= -k.hw;
+            const float fval = above ? d : (inside ? t * t * k.inv2w : 0.0f);
+            const float fp = above ? 1.0f : (inside ? t * k.invw : 0.0f);
+            const float fw = inside ? t * (k.hw - d) * k.inv2w * k.invw : 0.0f;
+            const float gc = k.kappa * fval;
+            const float gprev = (i > 0) ? g[i - 1] : g_prev0;
+            const float kp = k.kappa * fp;
+            const float cA = live ? gprev - gc : 0.0f, cFv = live ? fval : 0.0f, cKp = live ? kp : 0.0f, cKw = live ? k.kappa * fw : 0.0f;
+            // side chain: d x_db / d side = (20/ln10) / side, clamp kills it below eps
+            const float cE = (fabsf(side) >= kCompEps) ? k.oma * kp * 8.685889638065035f * __builtin_amdgcn_rcpf(side) : 0.0f;
+            zs = fmaf(k.alpha, zs, dgsv[i]);
+            pw *= k.alpha;
+            sA0 = fmaf(zs, cA, sA0);
+            sA1 = fmaf(pw, cA, sA1);
+            sF0 = fmaf(zs, cFv, sF0);
+            sF1 = fmaf(pw, cFv, sF1);
+            sP0 = fmaf(zs, cKp, sP0);
+            sP1 = fmaf(pw, cKp, sP1);
+            sW0 = fmaf(zs, cKw, sW0);
+            sW1 = fmaf(pw, cKw, sW1);
+            du0[i] = fmaf(zs, cE, fwd0[i]);
+            if (MASTER) du1[i] = fmaf(zs, cE, fwd1[i]);
+            db[i] = pw * cE;
+            if (MST_CBR_SCHED & 2) __builtin_amdgcn_sched_barrier(0);
+        }
+        const float S = gq ? block_carry_g<true>(gq, a.gran_near, peek, blk, gridDim.x, l2a, red[0], tid)
+                           : block_carry<true>(a.s0 + (int64_t)row * gridDim.x, blk, gridDim.x, l2a, red[0], tid);
+        const float Q = fmaf(W, S, Q0);
+#pragma unroll
+        for (int i = 0; i < CC; ++i) {
+            du0[i] = fmaf(Q, db[i], du0[i]);
+            if (MASTER) du1[i] = fmaf(Q, db[i], du1[i]);
+        }
+        p[CP_ALPHA] = fmaf(Q, sA1, sA0);
+        p[CP_KAPPA] = k.oma * fmaf(Q, sF1, sF0);
+        p[CP_THR] = -k.oma * fmaf(Q, sP1, sP0);
+        p[CP_KNEE] = k.oma * fmaf(Q, sW1, sW0);
+#else
         // first look at the later blocks' aggregates: requested here, examined after the arithmetic below, which does not need them
         const gran_t peek = gq ? carry_peek<true>(gq, a.gran_near, blk, gridDim.x, tid) : 0ull;
         // Everything that does not involve the adjoint smoother's state q (static curve, knee derivatives, the 1 / side of the side
@@ -668,6 +849,7 @@ __device__ __forceinline__ void comp_bwd_run_body(const CompBwdArgs& a, int row,
             du0[i] = ds + fwd0[i];
             if (MASTER) du1[i] = ds + fwd1[i];
         }
+#endif
     } else {
         float x0[CC], x1[CC];
         LD8<FAST>(u0, i0, a.n, x0);
@@ -696,8 +878,8 @@ __device__ __forceinline__ void comp_bwd_run_body(const CompBwdArgs& a, int row,
         if (MASTER) ST8<FAST>(a.du + (int64_t)(row * NCH + 1) * a.stride, i0, a.n, du1);
     }
     if (a.ep) {  // signal rows: tracks = row, master = 2 row + channel
-        coefgrad_fused<FAST>(a, blk, row * NCH, rc, i0, xu, du0, cg_u, cg_g);
-        if (MASTER) coefgrad_fused<FAST>(a, blk, row * NCH + 1, rc, i0, xu1, du1, cg_u, cg_g);
+        coefgrad_fused<FAST>(a, blk, row * NCH, rc, i0, xu, du0, cg_u, cg_g, have_cgs, cgs);
+        if (MASTER) coefgrad_fused<FAST>(a, blk, row * NCH + 1, rc, i0, xu1, du1, cg_u, cg_g, have_cgs, cgs1);
     }
 
     const int wave = tid >> 6, lane = tid & 63;

@@ -66,7 +66,7 @@ static FxPlan fx_plan(const Layout& L) {
     p.nblk = L.fxBlk;
     p.nblk_ir = L.fxBlkIr;
     p.n = L.N;
-    p.Ns = round_up(L.N, 4);
+    p.Ns = row_stride(L.N);
     p.rcfx = L.fx_rc; p.fx_in = L.fx_in; p.wnf = L.fx_wnf; p.ir = L.fx_ir; p.Xs = L.fx_Xs; p.Hs = L.fx_Hs; p.Ys = L.fx_Ys;
     p.dXs = L.fx_dXs; p.dHs = L.fx_dHs; p.dir = L.fx_dir; p.dfx_in = L.fx_din; p.fxpart = L.fx_part; p.Hf = L.fx_Hf; p.mixv = L.fx_mix; p.dry = L.fx_dry;
     return p;
@@ -87,7 +87,7 @@ extern "C" int mst_console_forward(const mst_console_desc* d, const float* track
     if (!tracks || !track_params || !fx_bus_params || !master_bus_params || !mix || !status) return hipErrorInvalidValue;
     hipStream_t stream = (hipStream_t)stream_;
     float* ws = (float*)workspace;
-    const int64_t n = L.N, Ns = round_up(L.N, 4);
+    const int64_t n = L.N, Ns = row_stride(L.N);
     const bool save = d->flags & MST_SAVE_FOR_BACKWARD;
     const int aligned = (n % 4 == 0) && !((uintptr_t)mix & 15) && !((uintptr_t)mixed_tracks & 15);
     const bool t_comp = d->flags & MST_USE_TRACK_COMPRESSOR;
@@ -173,7 +173,7 @@ extern "C" int mst_console_backward_prepare(const mst_console_desc* d, void* wor
     if (!workspace || workspace_bytes < (size_t)L.total * sizeof(float) || ((uintptr_t)workspace & 255)) return hipErrorInvalidValue;
     if (!(d->flags & MST_SAVE_FOR_BACKWARD)) return hipErrorInvalidValue;
     float* ws = (float*)workspace;
-    const int64_t Ns = round_up(L.N, 4);
+    const int64_t Ns = row_stride(L.N);
     const int nsig_all = L.R + ((d->flags & MST_USE_MASTER_BUS) ? 2 * L.bs : 0);
     if (!fuse_allpole()) launch_allpole_zs(ws + L.u_t, Ns, ws + L.rc_t, L.R, ws + L.zP_t, L.ncE_pad, L.N, nsig_all, (hipStream_t)stream_);
     allpole_scan(L, ws, nsig_all, (hipStream_t)stream_);
@@ -192,7 +192,7 @@ extern "C" int mst_console_backward(const mst_console_desc* d, const float* trac
     if (!track_params || !master_bus_params || !grad_mix || !grad_track_params || !grad_master_params) return hipErrorInvalidValue;
     hipStream_t stream = (hipStream_t)stream_;
     float* ws = (float*)workspace;
-    const int64_t n = L.N, Ns = round_up(L.N, 4);
+    const int64_t n = L.N, Ns = row_stride(L.N);
     const bool t_comp = d->flags & MST_USE_TRACK_COMPRESSOR;
     const bool m_on = d->flags & MST_USE_MASTER_BUS;
     const bool o_on = d->flags & MST_USE_OUTPUT_FADER;
