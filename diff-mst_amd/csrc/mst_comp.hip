@@ -741,40 +741,35 @@ __device__ __forceinline__ void comp_bwd_run_body(const CompBwdArgs& a, int row,
         const gran_t peek = gq ? carry_peek<true>(gq, a.gran_near, blk, gridDim.x, tid) : 0ull;
         // q[i] = zs[i] + pw[i] Q with zs the zero-entry recurrence over this lane's samples and pw[i] = alpha^(CC - i):
         //   alpha += q A;  kappa += oma q Fv;  thr -= oma q Kp;  knee += oma q Kw;  du = oma q E + look-ahead branch
-        float zs = 0.0f, pw = 1.0f;
-        float sA0 = 0.f, sA1 = 0.f, sF0 = 0.f, sF1 = 0.f, sP0 = 0.f, sP1 = 0.f, sW0 = 0.f, sW1 = 0.f;
+        // pairs (zero-state part, homogeneous part): one packed multiply-add per sum and sample
+        using f2 = __attribute__((ext_vector_type(2))) float;
+        f2 zp = {0.0f, 1.0f}, sA = {0.f, 0.f}, sF = {0.f, 0.f}, sP = {0.f, 0.f}, sW = {0.f, 0.f};
+        const float kinvw = k.kappa * k.invw, kw2 = k.kappa * k.inv2w * k.invw, ke = k.oma * 8.685889638065035f;
         float db[CC];  // du0 / du1 hold the zero-state part until Q is known
 #pragma unroll
         for (int i = CC - 1; i >= 0; --i) {
             const bool live = FAST || i0 + i < a.n;
             const float side = MASTER ? x0[i] + x1[i] : x0[i];
-            // static curve f, df/dd, df/dknee without branches (two exec-mask branches per sample split this loop into sixteen basic
-            // blocks with every array alive across them): above the knee (d, 1, 0), inside (t^2 / 2w, t / w, t (hw - d) / 2w^2), below 0
-            const float d = kDbPerLog2 * __builtin_amdgcn_logf(fmaxf(fabsf(side), kCompEps)) - k.thr;
-            const float t = d + k.hw;
-            const bool above = d > k.hw, inside = !above && d >= -k.hw;
-            const float fval = above ? d : (inside ? t * t * k.inv2w : 0.0f);
-            const float fp = above ? 1.0f : (inside ? t * k.invw : 0.0f);
-            const float fw = inside ? t * (k.hw - d) * k.inv2w * k.invw : 0.0f;
-            const float gc = k.kappa * fval;
+            // static curve and its derivatives (mst_compdev.h: curve_f): f, kappa df/dd, kappa df/dknee
+            float tc;
+            const float fval = curve_f(curve_t(side, k), k, tc);
             const float gprev = (i > 0) ? g[i - 1] : g_prev0;
-            const float kp = k.kappa * fp;
-            const float cA = live ? gprev - gc : 0.0f, cFv = live ? fval : 0.0f, cKp = live ? kp : 0.0f, cKw = live ? k.kappa * fw : 0.0f;
+            const float kp = tc * kinvw;
+            const float cKw = tc * (k.knee - tc) * kw2;
+            // beyond the row's end the guarded loads return 0: side = 0 gives tc = 0 (f and both derivatives vanish) and the clamp below
+            // kills the side chain; only g[i-1] - g_c has to be masked
+            const float cA = live ? fmaf(-k.kappa, fval, gprev) : 0.0f;
             // side chain: d x_db / d side = (20/ln10) / side, clamp kills it below eps
-            const float cE = (fabsf(side) >= kCompEps) ? k.oma * kp * 8.685889638065035f * __builtin_amdgcn_rcpf(side) : 0.0f;
-            zs = fmaf(k.alpha, zs, dgsv[i]);
-            pw *= k.alpha;
-            sA0 = fmaf(zs, cA, sA0);
-            sA1 = fmaf(pw, cA, sA1);
-            sF0 = fmaf(zs, cFv, sF0);
-            sF1 = fmaf(pw, cFv, sF1);
-            sP0 = fmaf(zs, cKp, sP0);
-            sP1 = fmaf(pw, cKp, sP1);
-            sW0 = fmaf(zs, cKw, sW0);
-            sW1 = fmaf(pw, cKw, sW1);
-            du0[i] = fmaf(zs, cE, fwd0[i]);
-            if (MASTER) du1[i] = fmaf(zs, cE, fwd1[i]);
-            db[i] = pw * cE;
+            const float cE = (fabsf(side) >= kCompEps) ? kp * ke * __builtin_amdgcn_rcpf(side) : 0.0f;
+            zp.x = fmaf(k.alpha, zp.x, dgsv[i]);  // zs: zero-entry recurrence
+            zp.y *= k.alpha;                      // pw = alpha^(CC - i)
+            sA = __builtin_elementwise_fma(zp, f2{cA, cA}, sA);
+            sF = __builtin_elementwise_fma(zp, f2{fval, fval}, sF);
+            sP = __builtin_elementwise_fma(zp, f2{kp, kp}, sP);
+            sW = __builtin_elementwise_fma(zp, f2{cKw, cKw}, sW);
+            du0[i] = fmaf(zp.x, cE, fwd0[i]);
+            if (MASTER) du1[i] = fmaf(zp.x, cE, fwd1[i]);
+            db[i] = zp.y * cE;
             if (MST_CBR_SCHED & 2) __builtin_amdgcn_sched_barrier(0);
         }
         const float S = gq ? block_carry_g<true>(gq, a.gran_near, peek, blk, gridDim.x, l2a, red[0], tid)
@@ -785,10 +780,10 @@ __device__ __forceinline__ void comp_bwd_run_body(const CompBwdArgs& a, int row,
             du0[i] = fmaf(Q, db[i], du0[i]);
             if (MASTER) du1[i] = fmaf(Q, db[i], du1[i]);
         }
-        p[CP_ALPHA] = fmaf(Q, sA1, sA0);
-        p[CP_KAPPA] = k.oma * fmaf(Q, sF1, sF0);
-        p[CP_THR] = -k.oma * fmaf(Q, sP1, sP0);
-        p[CP_KNEE] = k.oma * fmaf(Q, sW1, sW0);
+        p[CP_ALPHA] = fmaf(Q, sA.y, sA.x);
+        p[CP_KAPPA] = k.oma * fmaf(Q, sF.y, sF.x);
+        p[CP_THR] = -k.oma * fmaf(Q, sP.y, sP.x);
+        p[CP_KNEE] = k.oma * fmaf(Q, sW.y, sW.x);
 #else
         // first look at the later blocks' aggregates: requested here, examined after the arithmetic below, which does not need them
         const gran_t peek = gq ? carry_peek<true>(gq, a.gran_near, blk, gridDim.x, tid) : 0ull;
