@@ -185,13 +185,15 @@ __device__ __forceinline__ void cascade_body(const float* __restrict__ in, int64
     float zacc = 0.0f;
     if (FUSE_GC) ck = load_comp(rc + (int64_t)filter_row(sig, split) * RC_STRIDE);
     // the all-pole bank of k_coefgrad, zero state: 1/A_k on (wa1, wa2), b0/B_k on (wb1, wb2); a1, a2 are c[5s+3], c[5s+4]
-    float bc1[kSections], bc2[kSections], wa1[kSections], wa2[kSections], wb1[kSections], wb2[kSections];
+    // held as pairs (1/A_k side, b0/B_k side): the two recurrences of a section are one packed multiply-add each (v_pk_fma_f32)
+    using f2 = __attribute__((ext_vector_type(2))) float;
+    f2 nk1[kSections], nk2[kSections], w1[kSections], w2[kSections];
     if (FUSE_AP) {
 #pragma unroll
         for (int s = 0; s < kSections; ++s) {
-            bc1[s] = coef[RC_AP - RC_SOS + 3 * s];
-            bc2[s] = coef[RC_AP - RC_SOS + 3 * s + 1];
-            wa1[s] = wa2[s] = wb1[s] = wb2[s] = 0.0f;
+            nk1[s] = f2{-c[5 * s + 3], -coef[RC_AP - RC_SOS + 3 * s]};
+            nk2[s] = f2{-c[5 * s + 4], -coef[RC_AP - RC_SOS + 3 * s + 1]};
+            w1[s] = w2[s] = f2{0.0f, 0.0f};
         }
     }
 
@@ -216,12 +218,9 @@ __device__ __forceinline__ void cascade_body(const float* __restrict__ in, int64
                     for (int t = 0; t < 4; ++t) {
 #pragma unroll
                         for (int s = 0; s < kSections; ++s) {
-                            const float wa = fmaf(-c[5 * s + 4], wa2[s], fmaf(-c[5 * s + 3], wa1[s], ys[t]));
-                            wa2[s] = wa1[s];
-                            wa1[s] = wa;
-                            const float wb = fmaf(-bc2[s], wb2[s], fmaf(-bc1[s], wb1[s], ys[t]));
-                            wb2[s] = wb1[s];
-                            wb1[s] = wb;
+                            const f2 wn = __builtin_elementwise_fma(nk2[s], w2[s], __builtin_elementwise_fma(nk1[s], w1[s], f2{ys[t], ys[t]}));
+                            w2[s] = w1[s];
+                            w1[s] = wn;
                         }
                     }
                 }
@@ -269,10 +268,10 @@ __device__ __forceinline__ void cascade_body(const float* __restrict__ in, int64
 #pragma unroll
         for (int s = 0; s < kSections; ++s) {
             const int64_t base = ((int64_t)sig * 24 + 4 * s) * nc_pad + chunk;
-            zp[base] = wa1[s];
-            zp[base + nc_pad] = wa2[s];
-            zp[base + 2 * (int64_t)nc_pad] = wb1[s];
-            zp[base + 3 * (int64_t)nc_pad] = wb2[s];
+            zp[base] = w1[s].x;
+            zp[base + nc_pad] = w2[s].x;
+            zp[base + 2 * (int64_t)nc_pad] = w1[s].y;
+            zp[base + 3 * (int64_t)nc_pad] = w2[s].y;
         }
     }
     if (FUSE_GC) {
