@@ -180,13 +180,13 @@ __device__ __forceinline__ void cascade_body(const float* __restrict__ in, int64
         for (int i = 0; i < kStates; ++i)
             st[i] = MODE_RUN ? s0[((int64_t)sig * kStates + i) * nc_pad + chunk] : 0.0f;
     }
+    using f2 = __attribute__((ext_vector_type(2))) float;
     float* mine = &tile[tid * kLdw];
     CompK ck{};
     float zacc = 0.0f;
     if (FUSE_GC) ck = load_comp(rc + (int64_t)filter_row(sig, split) * RC_STRIDE);
     // the all-pole bank of k_coefgrad, zero state: 1/A_k on (wa1, wa2), b0/B_k on (wb1, wb2); a1, a2 are c[5s+3], c[5s+4]
     // held as pairs (1/A_k side, b0/B_k side): the two recurrences of a section are one packed multiply-add each (v_pk_fma_f32)
-    using f2 = __attribute__((ext_vector_type(2))) float;
     f2 nk1[kSections], nk2[kSections], w1[kSections], w2[kSections];
     if (FUSE_AP) {
 #pragma unroll
@@ -197,6 +197,33 @@ __device__ __forceinline__ void cascade_body(const float* __restrict__ in, int64
         }
     }
 
+#ifndef MST_EQ_PACKED
+#define MST_EQ_PACKED 0  // A/B: forward sections on state pairs (s1, s2) - y = b0 x + s1, then the two state updates as two packed
+                         // multiply-adds on (b1, b2) x + (s2, 0), bit-identical to the scalar form: 47.4 us against 47.0 (the pair
+                         // assembly costs the instruction it saves).  The variant s1' = (b1 x - a1 y) + s2 measured 44.7 against 46.5
+                         // but moved the most ill-conditioned golden fixture from 2.13x to 2.57x the fp32 reference's distance from
+                         // float64 - not taken
+#endif
+    f2 sp[kSections], cb[kSections], can[kSections];
+    if (DIR == EQ_FWD && MST_EQ_PACKED) {
+#pragma unroll
+        for (int s = 0; s < kSections; ++s) {
+            sp[s] = f2{st[2 * s], st[2 * s + 1]};
+            cb[s] = f2{c[5 * s + 1], c[5 * s + 2]};
+            can[s] = f2{-c[5 * s + 3], -c[5 * s + 4]};
+        }
+    }
+    auto step_fwd = [&](float x) {
+        if (!MST_EQ_PACKED) return cascade_step<float>(x, c, st);
+#pragma unroll
+        for (int s = 0; s < MST_DBG_SECTIONS; ++s) {
+            const float y = fmaf(c[5 * s], x, sp[s].x);
+            // same roundings as biquad_step: (n1, t) = (b1, b2) x + (s2, 0);  (s1', s2') = -(a1, a2) y + (n1, t)
+            sp[s] = __builtin_elementwise_fma(can[s], f2{y, y}, __builtin_elementwise_fma(cb[s], f2{x, x}, f2{sp[s].y, 0.0f}));
+            x = y;
+        }
+        return x;
+    };
     for (int jj = 0; jj < kNSlab; ++jj) {
         const int j = order(jj);
         slab_enter<FAST>(pre, inrow, tile_base, j, n, tid);
@@ -207,10 +234,10 @@ __device__ __forceinline__ void cascade_body(const float* __restrict__ in, int64
 #pragma unroll
             for (int i4 = 0; i4 < kSlab; i4 += 4) {
                 float4 v = *reinterpret_cast<float4*>(&mine[i4]);
-                v.x = cascade_step<float>(v.x, c, st);
-                v.y = cascade_step<float>(v.y, c, st);
-                v.z = cascade_step<float>(v.z, c, st);
-                v.w = cascade_step<float>(v.w, c, st);
+                v.x = step_fwd(v.x);
+                v.y = step_fwd(v.y);
+                v.z = step_fwd(v.z);
+                v.w = step_fwd(v.w);
                 if (MODE_RUN) *reinterpret_cast<float4*>(&mine[i4]) = v;
                 if (FUSE_AP) {
                     const float ys[4] = {v.x, v.y, v.z, v.w};
@@ -249,6 +276,13 @@ __device__ __forceinline__ void cascade_body(const float* __restrict__ in, int64
             wave_lds_sync();  // the image is read by other lanes' stores before the next stash overwrites it
         }
         slab_fence();
+    }
+    if (DIR == EQ_FWD && MST_EQ_PACKED) {
+#pragma unroll
+        for (int s = 0; s < kSections; ++s) {
+            st[2 * s] = sp[s].x;
+            st[2 * s + 1] = sp[s].y;
+        }
     }
     if (!MODE_RUN) {
 #pragma unroll
