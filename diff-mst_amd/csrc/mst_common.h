@@ -60,12 +60,25 @@ constexpr float kLog2PerDb = 0.16609640474436813f;   // log2(10)/20
 constexpr float kLn10Over20 = 0.11512925464970229f;  // d/dg 10^(g/20) = that * 10^(g/20)
 constexpr float kCompEps = 1e-8f;                     // clamp of |side chain|
 
-// two fp32 lanes in one 64-bit register pair: arithmetic on it compiles to v_pk_fma_f32 / v_pk_mul_f32
-typedef float f2 __attribute__((vector_size(8)));
-
 __host__ __device__ inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 // filter (parameter) row of signal row `sig`: rows below `split` are mono tracks, the rest stereo pairs
 __host__ __device__ inline int filter_row(int sig, int split) { return sig < split ? sig : split + ((sig - split) >> 1); }
+
+// ---- float pairs for the packed fp32 instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) ----
+// Kernels bound by instruction issue hold values that share their arithmetic as pairs: one packed instruction does both halves.
+// hipcc: a native two-float vector.  g++ only ever compiles these sources for the CPU simulator of tests/hostsim, which has no such
+// type: there a plain struct with the same member names and operators.
+#if defined(__clang__)
+using f2 = float __attribute__((ext_vector_type(2)));
+__host__ __device__ __forceinline__ f2 f2_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+#else
+struct f2 {
+    float x, y;
+};
+inline f2 operator*(f2 a, f2 b) { return f2{a.x * b.x, a.y * b.y}; }
+inline f2 operator+(f2 a, f2 b) { return f2{a.x + b.x, a.y + b.y}; }
+inline f2 f2_fma(f2 a, f2 b, f2 c) { return f2{fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)}; }
+#endif
 
 // ---- one DF2T biquad step: y = b0 x + s1; s1' = b1 x - a1 y + s2; s2' = b2 x - a2 y ---------
 template <typename T>

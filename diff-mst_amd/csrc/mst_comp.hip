@@ -530,7 +530,6 @@ __device__ __forceinline__ void coefgrad_fused(const CompBwdArgs& a, int blk, in
         const float* mu = &cg_u[c * kCgPitch];
         const float* mg = &cg_g[c * kCgPitch];
 #if MST_CG_PACKED
-        using f2 = __attribute__((ext_vector_type(2))) float;
         f2 w1 = {wb1, wa1}, w2 = {wb2, wa2}, acc1 = {0.f, 0.f}, acc2 = {0.f, 0.f};
         const f2 nk1 = {-kc1, -ka1}, nk2 = {-kc2, -ka2};
 #pragma unroll 2
@@ -542,10 +541,10 @@ __device__ __forceinline__ void coefgrad_fused(const CompBwdArgs& a, int blk, in
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const f2 xx = {xs[t], xs[t]}, gg = {gs[t], -gs[t]};
-                const f2 wn = __builtin_elementwise_fma(nk2, w2, __builtin_elementwise_fma(nk1, w1, xx));
+                const f2 wn = f2_fma(nk2, w2, f2_fma(nk1, w1, xx));
                 db0 = fmaf(gs[t], wn.x, db0);
-                acc1 = __builtin_elementwise_fma(gg, w1, acc1);
-                acc2 = __builtin_elementwise_fma(gg, w2, acc2);
+                acc1 = f2_fma(gg, w1, acc1);
+                acc2 = f2_fma(gg, w2, acc2);
                 w2 = w1;
                 w1 = wn;
             }
@@ -742,7 +741,6 @@ __device__ __forceinline__ void comp_bwd_run_body(const CompBwdArgs& a, int row,
         // q[i] = zs[i] + pw[i] Q with zs the zero-entry recurrence over this lane's samples and pw[i] = alpha^(CC - i):
         //   alpha += q A;  kappa += oma q Fv;  thr -= oma q Kp;  knee += oma q Kw;  du = oma q E + look-ahead branch
         // pairs (zero-state part, homogeneous part): one packed multiply-add per sum and sample
-        using f2 = __attribute__((ext_vector_type(2))) float;
         f2 zp = {0.0f, 1.0f}, sA = {0.f, 0.f}, sF = {0.f, 0.f}, sP = {0.f, 0.f}, sW = {0.f, 0.f};
         const float kinvw = k.kappa * k.invw, kw2 = k.kappa * k.inv2w * k.invw, ke = k.oma * 8.685889638065035f;
         float db[CC];  // du0 / du1 hold the zero-state part until Q is known
@@ -763,10 +761,10 @@ __device__ __forceinline__ void comp_bwd_run_body(const CompBwdArgs& a, int row,
             const float cE = (fabsf(side) >= kCompEps) ? kp * ke * __builtin_amdgcn_rcpf(side) : 0.0f;
             zp.x = fmaf(k.alpha, zp.x, dgsv[i]);  // zs: zero-entry recurrence
             zp.y *= k.alpha;                      // pw = alpha^(CC - i)
-            sA = __builtin_elementwise_fma(zp, f2{cA, cA}, sA);
-            sF = __builtin_elementwise_fma(zp, f2{fval, fval}, sF);
-            sP = __builtin_elementwise_fma(zp, f2{kp, kp}, sP);
-            sW = __builtin_elementwise_fma(zp, f2{cKw, cKw}, sW);
+            sA = f2_fma(zp, f2{cA, cA}, sA);
+            sF = f2_fma(zp, f2{fval, fval}, sF);
+            sP = f2_fma(zp, f2{kp, kp}, sP);
+            sW = f2_fma(zp, f2{cKw, cKw}, sW);
             du0[i] = fmaf(zp.x, cE, fwd0[i]);
             if (MASTER) du1[i] = fmaf(zp.x, cE, fwd1[i]);
             db[i] = zp.y * cE;

@@ -180,7 +180,6 @@ __device__ __forceinline__ void cascade_body(const float* __restrict__ in, int64
         for (int i = 0; i < kStates; ++i)
             st[i] = MODE_RUN ? s0[((int64_t)sig * kStates + i) * nc_pad + chunk] : 0.0f;
     }
-    using f2 = __attribute__((ext_vector_type(2))) float;
     float* mine = &tile[tid * kLdw];
     CompK ck{};
     float zacc = 0.0f;
@@ -219,7 +218,7 @@ __device__ __forceinline__ void cascade_body(const float* __restrict__ in, int64
         for (int s = 0; s < MST_DBG_SECTIONS; ++s) {
             const float y = fmaf(c[5 * s], x, sp[s].x);
             // same roundings as biquad_step: (n1, t) = (b1, b2) x + (s2, 0);  (s1', s2') = -(a1, a2) y + (n1, t)
-            sp[s] = __builtin_elementwise_fma(can[s], f2{y, y}, __builtin_elementwise_fma(cb[s], f2{x, x}, f2{sp[s].y, 0.0f}));
+            sp[s] = f2_fma(can[s], f2{y, y}, f2_fma(cb[s], f2{x, x}, f2{sp[s].y, 0.0f}));
             x = y;
         }
         return x;
@@ -245,7 +244,7 @@ __device__ __forceinline__ void cascade_body(const float* __restrict__ in, int64
                     for (int t = 0; t < 4; ++t) {
 #pragma unroll
                         for (int s = 0; s < kSections; ++s) {
-                            const f2 wn = __builtin_elementwise_fma(nk2[s], w2[s], __builtin_elementwise_fma(nk1[s], w1[s], f2{ys[t], ys[t]}));
+                            const f2 wn = f2_fma(nk2[s], w2[s], f2_fma(nk1[s], w1[s], f2{ys[t], ys[t]}));
                             w2[s] = w1[s];
                             w1[s] = wn;
                         }

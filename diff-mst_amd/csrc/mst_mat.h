@@ -51,6 +51,9 @@ __device__ __forceinline__ void matvec_acc(const float* M, const float* v, float
 //   C[k][jj][4]  at 144 + (k (k-1) / 2 + jj) 4     P_k,jj for jj < k
 //   Dp[k][q][4]  at 208 + (16 k + q) 4             D_k^(q+1), q = 0..15
 constexpr int kTriFloats = 592;
+#ifndef MST_SCAN_PACKED
+#define MST_SCAN_PACKED 1  // the LDS image of the tables holds every 2x2 block column-major (wave_scan_tri below)
+#endif
 struct TabRegs {
     float4 v[3];
 };
@@ -65,7 +68,7 @@ __device__ __forceinline__ void tab_stash(const TabRegs& r, float* __restrict__ 
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const int q = lane + 64 * k;
-        if (q < kTriFloats / 4) *reinterpret_cast<float4*>(lds + 4 * q) = r.v[k];
+        if (q < kTriFloats / 4) *reinterpret_cast<float4*>(lds + 4 * q) = MST_SCAN_PACKED ? make_float4(r.v[k].x, r.v[k].z, r.v[k].y, r.v[k].w) : r.v[k];
     }
 }
 // value of the lane CTRL points at; 0 where that lane does not exist (row / wave edge)
@@ -78,6 +81,19 @@ __device__ __forceinline__ float lane_get(float v, int lane) {  // wave-uniform
 }
 // In-place inclusive scan over the 64 lanes of one wave (pos = position in recurrence order; lane = pos, or 63 - pos when REV).
 // Positions that hold no data must carry zeros (they only receive).
+// The LDS image holds every 2x2 block COLUMN-major (tab_stash swaps the middle components on the way in): (m00, m10) and (m01, m11) are
+// register pairs, so  F += M o  is two packed multiply-adds (v_pk_fma_f32) on the state pair F = (f0, f1) - the same roundings, in
+// the same order, as the four scalar ones.
+using scan_f2 = f2;
+struct Mat2c { scan_f2 c0, c1; };  // columns
+__device__ __forceinline__ Mat2c mat_at(const float* __restrict__ tab, int at) {
+    const float4 m = *reinterpret_cast<const float4*>(tab + at);
+    if (MST_SCAN_PACKED) return Mat2c{scan_f2{m.x, m.y}, scan_f2{m.z, m.w}};
+    return Mat2c{scan_f2{m.x, m.z}, scan_f2{m.y, m.w}};  // row-major image
+}
+__device__ __forceinline__ scan_f2 mat_acc(const Mat2c& m, float o0, float o1, scan_f2 f) {  // f + M (o0, o1)
+    return f2_fma(m.c0, scan_f2{o0, o0}, f2_fma(m.c1, scan_f2{o1, o1}, f));
+}
 template <bool REV>
 __device__ __forceinline__ void wave_scan_tri(float* v, const float* __restrict__ tab, int pos) {
     // one position back / d positions back inside the row: towards lower pos = lower lanes, or higher lanes when REV
@@ -87,56 +103,29 @@ __device__ __forceinline__ void wave_scan_tri(float* v, const float* __restrict_
     float prev[kStates];
 #pragma unroll
     for (int k = 0; k < kSections; ++k) {
-        float f0 = v[2 * k], f1 = v[2 * k + 1];
+        scan_f2 f = {v[2 * k], v[2 * k + 1]};
 #pragma unroll
-        for (int jj = 0; jj < k; ++jj) {
-            const float4 c = *reinterpret_cast<const float4*>(tab + 144 + (k * (k - 1) / 2 + jj) * 4);
-            f0 = fmaf(c.x, prev[2 * jj], fmaf(c.y, prev[2 * jj + 1], f0));
-            f1 = fmaf(c.z, prev[2 * jj], fmaf(c.w, prev[2 * jj + 1], f1));
-        }
+        for (int jj = 0; jj < k; ++jj) f = mat_acc(mat_at(tab, 144 + (k * (k - 1) / 2 + jj) * 4), prev[2 * jj], prev[2 * jj + 1], f);
         // inside the rows
-        {
-            const float4 d = *reinterpret_cast<const float4*>(tab + (6 * k + 0) * 4);
-            const float o0 = dpp_get<kRow + 1>(f0), o1 = dpp_get<kRow + 1>(f1);
-            f0 = fmaf(d.x, o0, fmaf(d.y, o1, f0));
-            f1 = fmaf(d.z, o0, fmaf(d.w, o1, f1));
-        }
-        {
-            const float4 d = *reinterpret_cast<const float4*>(tab + (6 * k + 1) * 4);
-            const float o0 = dpp_get<kRow + 2>(f0), o1 = dpp_get<kRow + 2>(f1);
-            f0 = fmaf(d.x, o0, fmaf(d.y, o1, f0));
-            f1 = fmaf(d.z, o0, fmaf(d.w, o1, f1));
-        }
-        {
-            const float4 d = *reinterpret_cast<const float4*>(tab + (6 * k + 2) * 4);
-            const float o0 = dpp_get<kRow + 4>(f0), o1 = dpp_get<kRow + 4>(f1);
-            f0 = fmaf(d.x, o0, fmaf(d.y, o1, f0));
-            f1 = fmaf(d.z, o0, fmaf(d.w, o1, f1));
-        }
-        {
-            const float4 d = *reinterpret_cast<const float4*>(tab + (6 * k + 3) * 4);
-            const float o0 = dpp_get<kRow + 8>(f0), o1 = dpp_get<kRow + 8>(f1);
-            f0 = fmaf(d.x, o0, fmaf(d.y, o1, f0));
-            f1 = fmaf(d.z, o0, fmaf(d.w, o1, f1));
-        }
+        f = mat_acc(mat_at(tab, (6 * k + 0) * 4), dpp_get<kRow + 1>(f.x), dpp_get<kRow + 1>(f.y), f);
+        f = mat_acc(mat_at(tab, (6 * k + 1) * 4), dpp_get<kRow + 2>(f.x), dpp_get<kRow + 2>(f.y), f);
+        f = mat_acc(mat_at(tab, (6 * k + 2) * 4), dpp_get<kRow + 4>(f.x), dpp_get<kRow + 4>(f.y), f);
+        f = mat_acc(mat_at(tab, (6 * k + 3) * 4), dpp_get<kRow + 8>(f.x), dpp_get<kRow + 8>(f.y), f);
         // across the rows: E_r = value at the last position of row r with everything before it included (wave-uniform)
-        const float4 d16 = *reinterpret_cast<const float4*>(tab + (6 * k + 4) * 4);
-        const float e00 = lane_get(f0, REV ? 48 : 15), e01 = lane_get(f1, REV ? 48 : 15);
-        const float r10 = lane_get(f0, REV ? 32 : 31), r11 = lane_get(f1, REV ? 32 : 31);
-        const float r20 = lane_get(f0, REV ? 16 : 47), r21 = lane_get(f1, REV ? 16 : 47);
-        const float e10 = fmaf(d16.x, e00, fmaf(d16.y, e01, r10)), e11 = fmaf(d16.z, e00, fmaf(d16.w, e01, r11));
-        const float e20 = fmaf(d16.x, e10, fmaf(d16.y, e11, r20)), e21 = fmaf(d16.z, e10, fmaf(d16.w, e11, r21));
-        const float c0 = prow == 1 ? e00 : (prow == 2 ? e10 : e20), c1 = prow == 1 ? e01 : (prow == 2 ? e11 : e21);
-        const float4 dp = *reinterpret_cast<const float4*>(tab + 208 + (16 * k + pin) * 4);
-        if (prow >= 1) {
-            f0 = fmaf(dp.x, c0, fmaf(dp.y, c1, f0));
-            f1 = fmaf(dp.z, c0, fmaf(dp.w, c1, f1));
-        }
-        v[2 * k] = f0;
-        v[2 * k + 1] = f1;
+        const Mat2c d16 = mat_at(tab, (6 * k + 4) * 4);
+        const float e00 = lane_get(f.x, REV ? 48 : 15), e01 = lane_get(f.y, REV ? 48 : 15);
+        const float r10 = lane_get(f.x, REV ? 32 : 31), r11 = lane_get(f.y, REV ? 32 : 31);
+        const float r20 = lane_get(f.x, REV ? 16 : 47), r21 = lane_get(f.y, REV ? 16 : 47);
+        const scan_f2 e1 = mat_acc(d16, e00, e01, scan_f2{r10, r11});
+        const scan_f2 e2 = mat_acc(d16, e1.x, e1.y, scan_f2{r20, r21});
+        const float c0 = prow == 1 ? e00 : (prow == 2 ? e1.x : e2.x), c1 = prow == 1 ? e01 : (prow == 2 ? e1.y : e2.y);
+        const Mat2c dp = mat_at(tab, 208 + (16 * k + pin) * 4);
+        if (prow >= 1) f = mat_acc(dp, c0, c1, f);
+        v[2 * k] = f.x;
+        v[2 * k + 1] = f.y;
         if (k + 1 < kSections) {
-            prev[2 * k] = dpp_get<kBack1>(f0);
-            prev[2 * k + 1] = dpp_get<kBack1>(f1);
+            prev[2 * k] = dpp_get<kBack1>(f.x);
+            prev[2 * k + 1] = dpp_get<kBack1>(f.y);
         }
     }
 }

@@ -244,6 +244,7 @@ static inline hostsim_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float 
 static inline float __builtin_amdgcn_logf(float x) { return log2f(x); }
 static inline float __builtin_amdgcn_exp2f(float x) { return exp2f(x); }
 static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
+static inline float __builtin_amdgcn_fmed3f(float a, float b, float c) { return fmaxf(fminf(a, b), fminf(fmaxf(a, b), c)); }
 static inline float __builtin_amdgcn_sqrtf(float x) { return sqrtf(x); }
 static inline float __builtin_amdgcn_rsqf(float x) { return 1.0f / sqrtf(x); }
 static inline float __fdividef(float a, float b) { return a / b; }
