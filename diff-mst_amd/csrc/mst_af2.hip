@@ -115,8 +115,8 @@ __device__ __forceinline__ void af2_forward(float2 (*buf)[AfS::SLOTS], const flo
 
 // ---- forward: magnitude sums over a strip of frames, one half of the bins per workgroup -----------------------------------------
 template <int HALF>
-__device__ __forceinline__ void af2_fwd_body(const AfArgs& a, float2 (*buf)[AfS::SLOTS]) {
-    const int lane = threadIdx.x, grp = blockIdx.x, s = blockIdx.y;
+__device__ __forceinline__ void af2_fwd_body(const AfArgs& a, float2 (*buf)[AfS::SLOTS], int grp, int s) {
+    const int lane = threadIdx.x;
     const float2* twH = reinterpret_cast<const float2*>(a.tables + kAfTwH);
     const float2* twN = reinterpret_cast<const float2*>(a.tables + kAfTwN);
     const float* win = a.tables + kAfWin;
@@ -167,8 +167,23 @@ __device__ __forceinline__ void af2_fwd_body(const AfArgs& a, float2 (*buf)[AfS:
 }
 __global__ __launch_bounds__(kAf2Lanes, MST_AF2_W) void k_af2_bark_fwd(AfArgs a) {
     __shared__ __attribute__((aligned(16))) float2 buf[2][AfS::SLOTS];
-    if (blockIdx.z == 0) af2_fwd_body<0>(a, buf);
-    else af2_fwd_body<1>(a, buf);
+    // The four workgroups that read the same stereo rows (mid / side x even / odd bins of one strip of frames) are walked onto ONE XCD,
+    // next to each other: workgroup id L lands on XCD L % 8 (mst_common.h: row_block_xcd), and with the plain (strip, signal, half) grid
+    // the four sat on four XCDs - every frame (256 KB) crossed the fabric four times, 2.2 GB per launch at bs 32, against an L2 that
+    // 64 resident workgroups x 256 KB overflow anyway.  Any other batch size keeps the plain walk; the result does not depend on it.
+#ifndef MST_AF2_XCD
+#define MST_AF2_XCD 1
+#endif
+    int grp = blockIdx.x, sgn = blockIdx.y, half = blockIdx.z;
+    if (MST_AF2_XCD && (2 * a.bs) % 8 == 0) {
+        const int L = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), xcd = L & 7, k = L >> 3;
+        const int W = 4 * a.n_groups, src = (k / W) * 8 + xcd, rem = k % W, var = rem & 3;  // src = (pred | target, batch item)
+        grp = rem >> 2;
+        half = var >> 1;
+        sgn = (2 * (src / a.bs) + (var & 1)) * a.bs + src % a.bs;
+    }
+    if (half == 0) af2_fwd_body<0>(a, buf, grp, sgn);
+    else af2_fwd_body<1>(a, buf, grp, sgn);
 }
 
 // ---- backward: one frame of one prediction signal per workgroup -----------------------------------------------------------------
@@ -250,7 +265,16 @@ __device__ __forceinline__ void af2_bwd_half(const AfArgs& a, float2 (*buf)[AfS:
 template <int HALF>
 __global__ __launch_bounds__(kAf2Lanes, MST_AF2_W_BWD) void k_af2_bark_bwd(AfArgs a) {
     __shared__ __attribute__((aligned(16))) float2 buf[2][AfS::SLOTS];
-    const int lane = threadIdx.x, f = blockIdx.x, s = blockIdx.y;  // s < 2*bs
+    int f = blockIdx.x, s = blockIdx.y;  // s < 2*bs
+    if (MST_AF2_XCD && a.bs % 8 == 0) {
+        // the 2 x n_frames workgroups of one batch item (mid and side of every frame: frames overlap 4x) on one XCD, frames ascending: the
+        // resident set of an XCD is then a window of ~32 consecutive frames of one stereo pair = 2 MB, which its L2 holds
+        const int L = blockIdx.x + gridDim.x * blockIdx.y, xcd = L & 7, k = L >> 3, per = 2 * a.n_frames;
+        const int b = (k / per) * 8 + xcd, rem = k % per;
+        f = rem >> 1;
+        s = (rem & 1) * a.bs + b;
+    }
+    const int lane = threadIdx.x;
     LaneTw<8192> tw;
     tw.init(reinterpret_cast<const float2*>(a.tables + kAfTwH), lane);
     const float *l, *r;

@@ -30,9 +30,29 @@
 
 namespace mst {
 
+// A/B switch MST_FFT_PK: complex values as float pairs on the packed fp32 instructions (a complex add = one v_pk_add_f32, a product =
+// v_pk_mul_f32 + v_pk_fma_f32 with the swapped, half-negated operand on the op_sel / neg modifiers).  Measured and NOT taken: the
+// instruction count falls 3-10 % only (the pair assembly costs a v_mov for most of what it saves) while the even-aligned pairs raise the
+// register need - 8192 forward spills 49 registers at its 128 cap (33.6 -> 64.1 us), 512 / 2048 backward leave the four-waves-per-SIMD
+// budget (37.2 -> 47.5, 42.7 -> 51.7 us), and even the spill-free 512 forward is slower (20.9 -> 22.4 us).
+#ifndef MST_FFT_PK
+#define MST_FFT_PK 0
+#endif
+#if MST_FFT_PK && defined(__clang__)
+__device__ __forceinline__ f2 c2v(float2 a) { return f2{a.x, a.y}; }
+__device__ __forceinline__ float2 v2c(f2 a) { return make_float2(a.x, a.y); }
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return v2c(c2v(a) + c2v(b)); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return v2c(c2v(a) - c2v(b)); }
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+    return v2c(f2_fma(f2{a.y, a.y}, f2{-b.y, b.x}, f2{a.x, a.x} * c2v(b)));
+}
+__device__ __forceinline__ float2 cscale(float c, float2 a) { return v2c(f2{c, c} * c2v(a)); }
+#else
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ float2 cscale(float c, float2 a) { return make_float2(c * a.x, c * a.y); }
+#endif
 __device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
 __device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }  // a * (-i)
 __device__ __forceinline__ float2 mul_pi(float2 a) { return make_float2(-a.y, a.x); }  // a * (+i)
@@ -55,9 +75,9 @@ __device__ __forceinline__ void butterfly<8>(float2* v) {
     float2 e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6], o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7];
     fft4(e0, e1, e2, e3);
     fft4(o0, o1, o2, o3);
-    o1 = make_float2(c * (o1.x + o1.y), c * (o1.y - o1.x));    // * W8^1 = (c, -c)
-    o2 = mul_mi(o2);                                           // * W8^2 = -i
-    o3 = make_float2(c * (o3.y - o3.x), -c * (o3.x + o3.y));   // * W8^3 = (-c, -c)
+    o1 = cscale(c, cadd(o1, mul_mi(o1)));   // * W8^1 = (c, -c):  c (x + y, y - x)
+    o2 = mul_mi(o2);                        // * W8^2 = -i
+    o3 = cscale(c, csub(mul_mi(o3), o3));   // * W8^3 = (-c, -c):  c (y - x, -(x + y))
     v[0] = cadd(e0, o0); v[4] = csub(e0, o0);
     v[1] = cadd(e1, o1); v[5] = csub(e1, o1);
     v[2] = cadd(e2, o2); v[6] = csub(e2, o2);
