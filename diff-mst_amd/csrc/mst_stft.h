@@ -17,6 +17,112 @@ struct ResInfo {
     int frames_per_wg;                  // forward strip length
 };
 
+// ---- reduction of the partial sums + loss + backward coefficients ---------------------------------
+struct LossArgs {
+    const float* part;   // concatenated per resolution: (rows, n_groups[res], 4)
+    float* sums;         // (n_res, rows, 4)
+    float* coef;         // (n_res, rows, 4)
+    float* loss;         // scalar out
+    int n_res, rows;
+    int n_groups[kMaxRes];
+    int64_t part_off[kMaxRes];
+    float count[kMaxRes];  // rows * n_bins * n_frames
+    float w_sc, w_log, w_lin;
+    int sc_per_example;
+    // sharded evaluation (rows of the batch split over ranks): per-resolution totals of THIS rank's rows out (k_mrstft_totals),
+    // all-reduced totals in (k_mrstft_final) for the batch-global spectral-convergence ratio
+    double* totals;         // (n_res, 4) out, or null
+    const double* gtotals;  // (n_res, 4) in, or null
+    int world;              // ranks that contributed to gtotals (1 when null)
+};
+// fold of one row's strip partials of one resolution (fp64, fixed order) by one wave; lane = 0..63
+__device__ __forceinline__ void mrstft_rowsum(const LossArgs& a, int row, int res, int tid) {
+    const float* p = a.part + a.part_off[res] + (int64_t)row * a.n_groups[res] * 4;
+    double s[4] = {0, 0, 0, 0};
+    const int ng = a.n_groups[res];
+    for (int g0 = tid; g0 < ng; g0 += 256) {  // four strips in flight per lane, folded in ascending order
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int g = g0 + 64 * u;
+            v[u] = g < ng ? *reinterpret_cast<const float4*>(p + (int64_t)g * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (g0 + 64 * u < ng) { s[0] += v[u].x; s[1] += v[u].y; s[2] += v[u].z; s[3] += v[u].w; }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        for (int m = 32; m >= 1; m >>= 1) s[q] += __shfl_xor(s[q], m);
+    if (tid == 0) {
+        float* o = a.sums + ((int64_t)res * a.rows + row) * 4;
+        o[0] = (float)s[0]; o[1] = (float)s[1]; o[2] = (float)s[2]; o[3] = (float)s[3];
+    }
+}
+__device__ __forceinline__ void write_coef(const LossArgs& a, int i, int res, double c_sc) {
+    float* c = a.coef + (int64_t)i * 4;
+    c[0] = (float)(c_sc / a.n_res);
+    c[1] = (float)(a.w_log / a.count[res] / a.n_res);
+    c[2] = (float)(a.w_lin / a.count[res] / a.n_res);
+    c[3] = 0.f;
+}
+// loss scalar + per-row backward coefficients by ONE wave (tid = 0..63; BLOCK_SYNC: that wave is the whole workgroup and the
+// phases are separated by __syncthreads, otherwise by the wave's own LDS ordering).  rs / ratio / srow: LDS scratch; can_stage:
+// ratio and srow hold kMaxRes * 64 entries each.
+template <bool BLOCK_SYNC = true>
+__device__ __forceinline__ void mrstft_final_body(const LossArgs& a, int tid, double (*rs)[4], double* ratio, float4* srow, bool can_stage) {
+    auto sync = [] {
+        if (BLOCK_SYNC) __syncthreads();
+        else wave_lds_sync();
+    };
+    // A lane per resolution walking its rows paid one L2 round trip per row plus a ~150-instruction fp64 sqrt / sqrt / divide chain
+    // (7.2 us for 16 rows).  One lane per (resolution, row) fetches and takes the roots side by side; the fold over the rows below
+    // reads LDS and keeps its fixed order (bitwise the same loss).
+    const bool staged = can_stage && a.n_res * a.rows <= kMaxRes * 64;
+    for (int i = tid; i < a.n_res * a.rows; i += 64) {
+        const float4 sm = *reinterpret_cast<const float4*>(a.sums + (int64_t)i * 4);
+        if (staged) srow[i] = sm;
+        if (a.sc_per_example) {
+            const double s0 = sqrt((double)sm.x), s1 = sqrt((double)sm.y);
+            if (staged) ratio[i] = s0 / s1;
+            double c_sc = a.w_sc / ((double)a.rows * s0 * s1);
+            if (!(c_sc == c_sc) || c_sc > 1e30) c_sc = 0.0;  // identical signals: 0/0 -> no SC gradient
+            write_coef(a, i, i / a.rows, c_sc);
+        }
+    }
+    sync();
+    if (tid < a.n_res) {
+        const int res = tid;
+        double tot[4] = {0, 0, 0, 0}, sc_acc = 0.0;
+        for (int row = 0; row < a.rows; ++row) {
+            const int i = res * a.rows + row;
+            const float4 sm = staged ? srow[i] : *reinterpret_cast<const float4*>(a.sums + (int64_t)i * 4);
+            tot[0] += (double)sm.x; tot[1] += (double)sm.y; tot[2] += (double)sm.z; tot[3] += (double)sm.w;
+            if (a.sc_per_example) sc_acc += staged ? ratio[i] : sqrt((double)sm.x) / sqrt((double)sm.y);  // same roots, same quotient
+        }
+        for (int q = 0; q < 4; ++q) rs[res][q] = tot[q];
+        if (a.gtotals) {  // batch-global ratio over the rows of every rank
+            rs[res][0] = a.gtotals[res * 4 + 0];
+            rs[res][1] = a.gtotals[res * 4 + 1];
+        }
+        const double sc = a.sc_per_example ? sc_acc / a.rows : sqrt(rs[res][0]) / sqrt(rs[res][1]);
+        rs[res][3] = a.w_sc * sc + a.w_log * tot[2] / a.count[res] + a.w_lin * tot[3] / a.count[res];
+    }
+    sync();
+    if (tid == 0) {
+        double total = 0.0;
+        for (int res = 0; res < a.n_res; ++res) total += rs[res][3];
+        a.loss[0] = (float)(total / a.n_res);
+    }
+    if (a.sc_per_example) return;  // coefficients written in the staging loop
+    for (int i = tid; i < a.n_res * a.rows; i += 64) {
+        const int res = i / a.rows;
+        double c_sc = a.w_sc * (double)a.world / (sqrt(rs[res][0]) * sqrt(rs[res][1]));  // world: see mst_mrstft_forward_finish
+        if (!(c_sc == c_sc) || c_sc > 1e30) c_sc = 0.0;  // identical signals: 0/0 -> no SC gradient
+        write_coef(a, i, res, c_sc);
+    }
+}
+
 struct StftArgs {
     const float* pred;     // (rows, n)
     const float* target;   // (rows, n)
@@ -37,6 +143,8 @@ struct StftArgs {
     // exactly those blocks (seam_frames / seam_groups describe the seam launch's strips; seam_hop its block length).
     float* seam;           // (rows, n) scratch, only seam blocks are ever touched
     int seam_frames, seam_groups, seam_hop;
+    // forward, first launch of a call: workgroup (0, 0) zeroes the ticket of k_mrstft_finish (null: nothing to arm)
+    unsigned* tickets;
 };
 
 constexpr float kLn2 = 0.6931471805599453f;

@@ -588,50 +588,33 @@ __global__ void k_stft_tables(float* tables, ResInfo r, int win_length) {
     tables[r.win_off + t] = w;
 }
 
-// ---- reduction of the partial sums + loss + backward coefficients ---------------------------------
-struct LossArgs {
-    const float* part;   // concatenated per resolution: (rows, n_groups[res], 4)
-    float* sums;         // (n_res, rows, 4)
-    float* coef;         // (n_res, rows, 4)
-    float* loss;         // scalar out
-    int n_res, rows;
-    int n_groups[kMaxRes];
-    int64_t part_off[kMaxRes];
-    float count[kMaxRes];  // rows * n_bins * n_frames
-    float w_sc, w_log, w_lin;
-    int sc_per_example;
-    // sharded evaluation (rows of the batch split over ranks): per-resolution totals of THIS rank's rows out (k_mrstft_totals),
-    // all-reduced totals in (k_mrstft_final) for the batch-global spectral-convergence ratio
-    double* totals;         // (n_res, 4) out, or null
-    const double* gtotals;  // (n_res, 4) in, or null
-    int world;              // ranks that contributed to gtotals (1 when null)
-};
 // (One merged 1024-lane launch measured 15.5-21.6 us against 5.0 + 6.7 us for these two: sixteen waves on one CU walking three
 // pairs each lose more to their serial fp64 chains than the second launch costs.)
 // stage 1: one 64-lane workgroup per (row, resolution) folds that row's strip partials (fp64, fixed order)
-__global__ __launch_bounds__(64) void k_mrstft_rowsums(LossArgs a) {
-    const int tid = threadIdx.x, row = blockIdx.x, res = blockIdx.y;
-    const float* p = a.part + a.part_off[res] + (int64_t)row * a.n_groups[res] * 4;
-    double s[4] = {0, 0, 0, 0};
-    const int ng = a.n_groups[res];
-    for (int g0 = tid; g0 < ng; g0 += 256) {  // four strips in flight per lane, folded in ascending order
-        float4 v[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int g = g0 + 64 * u;
-            v[u] = g < ng ? *reinterpret_cast<const float4*>(p + (int64_t)g * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (g0 + 64 * u < ng) { s[0] += v[u].x; s[1] += v[u].y; s[2] += v[u].z; s[3] += v[u].w; }
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-        for (int m = 32; m >= 1; m >>= 1) s[q] += __shfl_xor(s[q], m);
-    if (tid == 0) {
-        float* o = a.sums + ((int64_t)res * a.rows + row) * 4;
-        o[0] = (float)s[0]; o[1] = (float)s[1]; o[2] = (float)s[2]; o[3] = (float)s[3];
-    }
+__global__ __launch_bounds__(64) void k_mrstft_rowsums(LossArgs a) { mrstft_rowsum(a, blockIdx.x, blockIdx.y, threadIdx.x); }
+// stage 2: loss scalar + per-row backward coefficients (without dL/dloss, applied by k_scale_coef)
+__global__ __launch_bounds__(64) void k_mrstft_final(LossArgs a) {
+    __shared__ double rs[kMaxRes][4];
+    __shared__ double ratio[kMaxRes * 64];  // per (resolution, row): sqrt(sum |d|^2) / sqrt(sum |Y|^2)
+    __shared__ float4 srow[kMaxRes * 64];   // the row sums, fetched by all lanes at once
+    mrstft_final_body(a, threadIdx.x, rs, ratio, srow, true);
+}
+// stages 1 + 2 in one launch: every workgroup folds its (row, resolution) pair; the one that finishes LAST (ticket, zeroed by the
+// call's first transform launch) goes on to the loss and the coefficients.  The fences are the textbook last-block pattern: agent
+// scope, because the row sums of the other workgroups may sit in another XCD's L2 (cheap here - the transform kernels have ended,
+// the L2s are clean; the same fences at the end of a transform kernel cost it 70 us).
+__global__ __launch_bounds__(64) void k_mrstft_finish(LossArgs a, unsigned* ticket) {
+    __shared__ double rs[kMaxRes][4];
+    __shared__ double ratio[kMaxRes * 64];
+    __shared__ float4 srow[kMaxRes * 64];
+    __shared__ unsigned mine;
+    mrstft_rowsum(a, blockIdx.x, blockIdx.y, threadIdx.x);
+    __threadfence();
+    if (threadIdx.x == 0) mine = atomicAdd(ticket, 1u);
+    __syncthreads();
+    if (mine != gridDim.x * gridDim.y - 1) return;
+    __threadfence();
+    mrstft_final_body(a, threadIdx.x, rs, ratio, srow, true);
 }
 // sharded evaluation only: this rank's totals per resolution, fixed order over the rows
 __global__ __launch_bounds__(64) void k_mrstft_totals(LossArgs a) {
@@ -641,66 +624,6 @@ __global__ __launch_bounds__(64) void k_mrstft_totals(LossArgs a) {
         double t = 0.0;
         for (int row = 0; row < a.rows; ++row) t += (double)a.sums[((int64_t)res * a.rows + row) * 4 + q];
         a.totals[tid] = t;
-    }
-}
-__device__ __forceinline__ void write_coef(const LossArgs& a, int i, int res, double c_sc) {
-    float* c = a.coef + (int64_t)i * 4;
-    c[0] = (float)(c_sc / a.n_res);
-    c[1] = (float)(a.w_log / a.count[res] / a.n_res);
-    c[2] = (float)(a.w_lin / a.count[res] / a.n_res);
-    c[3] = 0.f;
-}
-// stage 2: loss scalar + per-row backward coefficients (without dL/dloss, applied by k_scale_coef)
-__global__ __launch_bounds__(64) void k_mrstft_final(LossArgs a) {
-    __shared__ double rs[kMaxRes][4];
-    __shared__ double ratio[kMaxRes * 64];  // per (resolution, row): sqrt(sum |d|^2) / sqrt(sum |Y|^2)
-    __shared__ float4 srow[kMaxRes * 64];   // the row sums, fetched by all lanes at once
-    const int tid = threadIdx.x;
-    // A lane per resolution walking its rows paid one L2 round trip per row plus a ~150-instruction fp64 sqrt / sqrt / divide chain
-    // (7.2 us for 16 rows).  One lane per (resolution, row) fetches and takes the roots side by side; the fold over the rows below
-    // reads LDS and keeps its fixed order (bitwise the same loss).
-    const bool staged = a.n_res * a.rows <= kMaxRes * 64;
-    for (int i = tid; i < a.n_res * a.rows; i += 64) {
-        const float4 sm = *reinterpret_cast<const float4*>(a.sums + (int64_t)i * 4);
-        if (staged) srow[i] = sm;
-        if (a.sc_per_example) {
-            const double s0 = sqrt((double)sm.x), s1 = sqrt((double)sm.y);
-            if (staged) ratio[i] = s0 / s1;
-            double c_sc = a.w_sc / ((double)a.rows * s0 * s1);
-            if (!(c_sc == c_sc) || c_sc > 1e30) c_sc = 0.0;  // identical signals: 0/0 -> no SC gradient
-            write_coef(a, i, i / a.rows, c_sc);
-        }
-    }
-    __syncthreads();
-    if (tid < a.n_res) {
-        const int res = tid;
-        double tot[4] = {0, 0, 0, 0}, sc_acc = 0.0;
-        for (int row = 0; row < a.rows; ++row) {
-            const int i = res * a.rows + row;
-            const float4 sm = staged ? srow[i] : *reinterpret_cast<const float4*>(a.sums + (int64_t)i * 4);
-            tot[0] += (double)sm.x; tot[1] += (double)sm.y; tot[2] += (double)sm.z; tot[3] += (double)sm.w;
-            if (a.sc_per_example) sc_acc += staged ? ratio[i] : sqrt((double)sm.x) / sqrt((double)sm.y);  // same roots, same quotient
-        }
-        for (int q = 0; q < 4; ++q) rs[res][q] = tot[q];
-        if (a.gtotals) {  // batch-global ratio over the rows of every rank
-            rs[res][0] = a.gtotals[res * 4 + 0];
-            rs[res][1] = a.gtotals[res * 4 + 1];
-        }
-        const double sc = a.sc_per_example ? sc_acc / a.rows : sqrt(rs[res][0]) / sqrt(rs[res][1]);
-        rs[res][3] = a.w_sc * sc + a.w_log * tot[2] / a.count[res] + a.w_lin * tot[3] / a.count[res];
-    }
-    __syncthreads();
-    if (tid == 0) {
-        double total = 0.0;
-        for (int res = 0; res < a.n_res; ++res) total += rs[res][3];
-        a.loss[0] = (float)(total / a.n_res);
-    }
-    if (a.sc_per_example) return;  // coefficients written in the staging loop
-    for (int i = tid; i < a.n_res * a.rows; i += 64) {
-        const int res = i / a.rows;
-        double c_sc = a.w_sc * (double)a.world / (sqrt(rs[res][0]) * sqrt(rs[res][1]));  // world: see mst_mrstft_forward_finish
-        if (!(c_sc == c_sc) || c_sc > 1e30) c_sc = 0.0;  // identical signals: 0/0 -> no SC gradient
-        write_coef(a, i, res, c_sc);
     }
 }
 }  // namespace mst
@@ -716,7 +639,7 @@ struct Plan {
     int64_t part_off[kMaxRes];
     int64_t tables_floats;
     // workspace (floats): part | sums | coef | coef_scaled
-    int64_t part_total, sums_off, coef_off, coefs_off, seam_off, ws_floats;
+    int64_t part_total, sums_off, coef_off, coefs_off, seam_off, tick_off, ws_floats;
     int seam_res;  // index of the one seam-mode resolution whose seams are handed to a halo-mode launch, or -1
     bool ok;
 };
@@ -776,7 +699,8 @@ Plan make_plan(const mst_mrstft_desc* d) {
     p.sums_off = p.part_total;
     p.coef_off = p.sums_off + round_up((int64_t)d->n_res * d->rows * 4, 64);
     p.coefs_off = p.coef_off + round_up((int64_t)d->n_res * d->rows * 4, 64);
-    p.seam_off = p.coefs_off + round_up((int64_t)d->n_res * d->rows * 4, 64);
+    p.tick_off = p.coefs_off + round_up((int64_t)d->n_res * d->rows * 4, 64);  // rows + 1 tickets of the fused reduction (mst_stft.h)
+    p.seam_off = p.tick_off + 64;
     p.ws_floats = p.seam_off;
     // backward seam hand-over (mst_stft.h): exactly one seam-mode resolution, at least one halo-mode one, all on the round-2 kernels
     p.seam_res = -1;
@@ -862,10 +786,18 @@ static int mrstft_forward_stages(const mst_mrstft_desc* d, const float* pred, co
     la.totals = totals;
     la.gtotals = gtotals;
     la.world = gtotals ? world : 1;
+#ifndef MST_MRSTFT_FUSE_FINISH
+#define MST_MRSTFT_FUSE_FINISH 1
+#endif
+    // single-rank call: row sums, loss and backward coefficients in ONE launch (k_mrstft_finish) whose ticket the first transform
+    // launch zeroes - that launch has to be a round-2 kernel
+    const bool fuse = MST_MRSTFT_FUSE_FINISH && stages == 3 && !totals && !gtotals && p.engine2[0];
     for (int i = 0; i < d->n_res; ++i) {
         la.n_groups[i] = p.n_groups[i];
         la.part_off[i] = p.part_off[i];
         la.count[i] = (float)((double)d->rows * p.res[i].n_bins * p.res[i].n_frames);
+    }
+    for (int i = 0; i < d->n_res; ++i) {
         if (!(stages & 1)) continue;
         StftArgs a{};
         a.pred = pred;
@@ -876,6 +808,7 @@ static int mrstft_forward_stages(const mst_mrstft_desc* d, const float* pred, co
         a.log2n = p.log2n[i];
         a.n = d->n_samples;
         a.eps = d->eps;
+        if (fuse && i == 0) a.tickets = reinterpret_cast<unsigned*>(ws + p.tick_off);
         const dim3 grid(p.n_groups[i], d->rows);
 #define MST_LAUNCH_FWD(NF) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stft_fwd<NF>), grid, dim3(stft_threads(NF)), 0, stream, a)
         if (p.engine2[i]) {
@@ -884,6 +817,10 @@ static int mrstft_forward_stages(const mst_mrstft_desc* d, const float* pred, co
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stft_fwd_ip<8192>), grid, dim3(kIpThreads), 0, stream, a);
         else
             MST_FOR_NFFT(a.r.n_fft, MST_LAUNCH_FWD)
+    }
+    if (fuse) {
+        hipLaunchKernelGGL(k_mrstft_finish, dim3(d->rows, d->n_res), dim3(64), 0, stream, la, reinterpret_cast<unsigned*>(ws + p.tick_off));
+        return (int)hipGetLastError();
     }
     if (stages & 1) {
         hipLaunchKernelGGL(k_mrstft_rowsums, dim3(d->rows, d->n_res), dim3(64), 0, stream, la);

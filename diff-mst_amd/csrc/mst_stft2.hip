@@ -164,6 +164,7 @@ __global__ __launch_bounds__(FftPlan<N>::LG, (N == 8192 ? MST_STFT2_W8192 : 1)) 
         for (int w = 0; w < LG / 64; ++w) v += red[w][lane];
         a.part[((int64_t)row * gridDim.x + blockIdx.x) * 4 + lane] = v;
     }
+    if (a.tickets && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) a.tickets[0] = 0u;  // armed for k_mrstft_finish (mst_stft.hip)
 }
 
 

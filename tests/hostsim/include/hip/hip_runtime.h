@@ -168,6 +168,7 @@ static inline float unsafeAtomicAdd(float* p, float v) {
         if (__atomic_compare_exchange_n((uint32_t*)p, &o, w, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) return old;
     }
 }
+static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 
