@@ -750,7 +750,12 @@ __device__ __forceinline__ void comp_bwd_run_body(const CompBwdArgs& a, int row,
             const float side = MASTER ? x0[i] + x1[i] : x0[i];
             // static curve and its derivatives (mst_compdev.h: curve_f): f, kappa df/dd, kappa df/dknee
             float tc;
+#ifdef MST_CBR_ABLATE  // timing diagnostics only (wrong results): no static curve
+            tc = side;
+            const float fval = side;
+#else
             const float fval = curve_f(curve_t(side, k), k, tc);
+#endif
             const float gprev = (i > 0) ? g[i - 1] : g_prev0;
             const float kp = tc * kinvw;
             const float cKw = tc * (k.knee - tc) * kw2;
@@ -758,7 +763,11 @@ __device__ __forceinline__ void comp_bwd_run_body(const CompBwdArgs& a, int row,
             // kills the side chain; only g[i-1] - g_c has to be masked
             const float cA = live ? fmaf(-k.kappa, fval, gprev) : 0.0f;
             // side chain: d x_db / d side = (20/ln10) / side, clamp kills it below eps
+#ifdef MST_CBR_ABLATE
+            const float cE = kp;
+#else
             const float cE = (fabsf(side) >= kCompEps) ? kp * ke * __builtin_amdgcn_rcpf(side) : 0.0f;
+#endif
             zp.x = fmaf(k.alpha, zp.x, dgsv[i]);  // zs: zero-entry recurrence
             zp.y *= k.alpha;                      // pw = alpha^(CC - i)
             sA = f2_fma(zp, f2{cA, cA}, sA);
