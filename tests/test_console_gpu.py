@@ -232,6 +232,32 @@ def test_flag_combinations(off, console, dev):
     assert float(g[..., 22].abs().max()) == 0.0  # release_ms is unused by the op
 
 
+@pytest.mark.parametrize("knee", [0.0, 0.5, 1.0])
+def test_static_curve_level_sweep(knee, console, dev):
+    """The compressor's static curve is evaluated branch-free (csrc/mst_compdev.h: curve_f - clamp to the knee, no compare / select):
+    a level sweep from -100 dB to 0 dB takes every sample region of it (below, inside and above the knee, and both transitions) in the
+    tracks AND the master compressor, at the narrowest, a middle and the widest knee; forward and gradients three-way against the
+    reference's branchy fp32 / float64 curve.  EQ off: the level reaching the curve is the level of the sweep."""
+    torch.manual_seed(11)
+    bs, T, n = 1, 3, 32768
+    flags = dict(FULL)
+    flags.update(use_track_eq=False)
+    level_db = torch.linspace(-100.0, 0.0, n)
+    tracks = (10.0 ** (level_db / 20.0)) * torch.sign(torch.randn(bs, T, n))  # random polarity, exact envelope
+    tp, fp, mp = torch.rand(bs, T, 27), torch.rand(bs, 25), torch.rand(bs, 26)
+    tp[..., 0] = 0.5                     # input fader mid-range
+    tp[..., 19] = torch.tensor([0.2, 0.5, 0.8])  # thresholds spread over the range
+    tp[..., 23] = knee                   # knee_db: lower end, middle, upper end of its range
+    mp[..., 23 - 1] = knee
+    gmix = torch.randn(bs, 2, n)
+    hip = run_hip(console, dev, tracks, tp, fp, mp, flags, gmix=gmix, grad_tracks=True)
+    r32 = run_oracle(tracks, tp, fp, mp, flags, gmix=gmix, grad_tracks=True)
+    r64 = run_oracle(tracks, tp, fp, mp, flags, gmix=gmix, dtype=torch.float64, grad_tracks=True)
+    assert_three_way(hip, r32, r64, "mix", 1e-4)
+    for k in ("g_tracks", "g_tp", "g_mp"):
+        assert_three_way(hip, r32, r64, k)
+
+
 def test_basic_console_bitlevel(dev):
     """BASELINE cfg #1: gain + pan + bus sum, 4 tracks x 65536, batch 2 - the plumbing gate."""
     from mst.modules import BasicMixConsole
