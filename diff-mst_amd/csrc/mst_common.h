@@ -66,8 +66,8 @@ __host__ __device__ inline int filter_row(int sig, int split) { return sig < spl
 
 // ---- float pairs for the packed fp32 instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) ----
 // Kernels bound by instruction issue hold values that share their arithmetic as pairs: one packed instruction does both halves.
-// hipcc: a native two-float vector.  g++ only ever compiles these sources for the CPU simulator of tests/hostsim, which has no such
-// type: there a plain struct with the same member names and operators.
+// hipcc: a native two-float vector.  A host-only g++ build of these sources (the repository's CPU test harness compiles them that way)
+// has no such type: there a plain struct with the same member names and operators.
 #if defined(__clang__)
 using f2 = float __attribute__((ext_vector_type(2)));
 __host__ __device__ __forceinline__ f2 f2_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
@@ -254,15 +254,20 @@ __device__ __forceinline__ float gran_wait(const gran_t* g, int64_t near_off) {
 // `group` > 1: rows come in groups (the tracks of one mix) that read the same shared data (the bus cotangent of that mix): the whole
 // group is kept on one XCD and its rows are interleaved block by block, so that the shared block is fetched once per XCD instead of
 // once per row (with row r on XCD r % 8 the eight tracks of a mix sat on eight XCDs: 8 x 16 MB of bus cotangent over the fabric).
-__device__ __forceinline__ void row_block_xcd(int& row, int& step, int group = 1, int rows = 0, int skip_rows = 0) {
-    // rows: 0 = the whole grid; skip_rows: grid rows in FRONT of the mapped ones that belong to another role of the launch
+__device__ __forceinline__ void row_block_xcd(int& row, int& step, int group = 1, int rows = 0, int skip_rows = 0, int lin = -1) {
+    // rows: 0 = the whole grid; skip_rows: grid rows in FRONT of the mapped ones that belong to another role of the launch;
+    // lin >= 0: the workgroup's index among the mapped ones, handed over by a caller that interleaves another role (same residue mod 8
+    // as its workgroup id, so that it still names the XCD)
     const int nblk = gridDim.x;
     if (rows <= 0) rows = gridDim.y - skip_rows;
-    if (group >= 1 && rows % (8 * group) == 0 && (nblk * skip_rows) % 8 == 0) {
-        const int L = blockIdx.x + nblk * ((int)blockIdx.y - skip_rows), xcd = L & 7, k = L >> 3;
+    if (group >= 1 && rows % (8 * group) == 0 && (lin >= 0 || (nblk * skip_rows) % 8 == 0)) {
+        const int L = lin >= 0 ? lin : blockIdx.x + nblk * ((int)blockIdx.y - skip_rows), xcd = L & 7, k = L >> 3;
         const int per_group = group * nblk, gi = k / per_group, rem = k % per_group;
         row = (gi * 8 + xcd) * group + rem % group;
         step = rem / group;
+    } else if (lin >= 0) {
+        row = lin / nblk;
+        step = lin % nblk;
     } else {
         row = blockIdx.y - skip_rows;
         step = blockIdx.x;

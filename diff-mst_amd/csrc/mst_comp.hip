@@ -913,9 +913,28 @@ __global__ __launch_bounds__(kWG, (!MASTER && !FXS) ? MST_COMP_BWD_WT : MST_COMP
     // it, so the grid walks the row from its end
     int row = blockIdx.y, blk = blockIdx.x;
     const int extra = MASTER ? 0 : a.cg2_rows, main_rows = (int)gridDim.y - extra;
-    if (!MASTER && row < extra) {
-        // coefficient-gradient walk only: one channel of a master bus (its compressor adjoint ran in the master launch).  These light
-        // rows come FIRST in the grid: behind the track rows they were a 21 us tail of half-empty rounds.
+    // Coefficient-gradient-only rows (one channel of a master bus each; its compressor adjoint ran in the master launch) are light
+    // workgroups.  Behind the track rows they were a 21 us tail of half-empty rounds; they come FIRST in the grid (+13 us).  A/B switch
+    // MST_CG2_INTERLEAVE: eight of them after every 8 x ratio track workgroups (a track workgroup's index keeps its residue mod 8 = its
+    // XCD and the dispatch order of the track workgroups is kept) - measured WORSE than in front, 98.3 against 93.6 us.
+#ifndef MST_CG2_INTERLEAVE
+#define MST_CG2_INTERLEAVE 0
+#endif
+    int lin = -1;
+    bool light = !MASTER && row < extra;
+    if (!MASTER && MST_CG2_INTERLEAVE && extra > 0 && a.gran && main_rows % extra == 0 && ((int)gridDim.x * extra) % 8 == 0) {
+        const int ratio = main_rows / extra, period = 8 * (ratio + 1);
+        const int L = blockIdx.x + (int)gridDim.x * blockIdx.y, q = L / period, r = L % period;
+        light = r >= 8 * ratio;
+        if (light) {
+            const int lj = q * 8 + (r - 8 * ratio);
+            row = lj / (int)gridDim.x;
+            blk = lj % (int)gridDim.x;
+        } else {
+            lin = q * 8 * ratio + r;
+        }
+    }
+    if (light) {
         const int j = row;
         const int64_t i0 = ((int64_t)blk * kWG + threadIdx.x) * CC;
         const bool fast = a.aligned && (int64_t)(blk + 1) * kWG * CC <= a.n;
@@ -932,7 +951,7 @@ __global__ __launch_bounds__(kWG, (!MASTER && !FXS) ? MST_COMP_BWD_WT : MST_COMP
         return;
     }
     if (a.gran) {
-        row_block_xcd(row, blk, MASTER ? 1 : a.T, main_rows, extra);  // the blocks of one row - and the tracks of one mix - on one XCD (mst_common.h)
+        row_block_xcd(row, blk, MASTER ? 1 : a.T, main_rows, extra, lin);  // the blocks of one row - and the tracks of one mix - on one XCD (mst_common.h)
         blk = gridDim.x - 1 - blk;
     } else {
         row -= extra;
