@@ -247,6 +247,56 @@ __device__ __forceinline__ float gran_wait(const gran_t* g, int64_t near_off) {
     }
     return __int_as_float((int)(unsigned)x);
 }
+// Status code a kernel raises (atomic max into the call's status word) when a bounded wait gives up: the values the launch wrote are
+// poisoned (NaN) and the host side turns the code into an error (diffmst_hip/_desc.py: status_to_error) - larger than every
+// range-check code (1000 - index - 1), so it survives the max.
+constexpr int kStatusExchangeTimeout = 2000;
+__device__ __forceinline__ void gran_give_up(int32_t* status) {
+    if (status) atomicMax(status, kStatusExchangeTimeout);
+}
+// the same exchange for a small VECTOR (the 12-state aggregate of an EQ tile): NV consecutive granules.  Lane `src_lane` holds
+// v[0 .. NV); lanes 0 .. NV-1 store one granule each (one store instruction per copy).
+template <int NV>
+__device__ __forceinline__ void gran_publish_vec(gran_t* g, int64_t near_off, const float* v, int src_lane, int lane) {
+    float mine = 0.0f;
+#pragma unroll
+    for (int d = 0; d < NV; ++d) {
+        const float t = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[d]), src_lane));
+        mine = lane == d ? t : mine;
+    }
+    if (lane < NV) gran_publish(g + lane, near_off, mine);
+}
+// lane-private read of NV granules at g (all NV loads of a poll are in flight together; near and far copies are polled in turn).
+// Inactive lanes return zeros.  A wait that gives up returns NaN and raises kStatusExchangeTimeout in *status.
+template <int NV>
+__device__ __forceinline__ void gran_read_vec(const gran_t* g, int64_t near_off, float* out, bool active, int32_t* status) {
+#pragma unroll
+    for (int d = 0; d < NV; ++d) out[d] = 0.0f;
+    if (!active) return;
+    const bool has_near = MST_GRAN_NEAR && near_off;
+    bool use_near = has_near;
+    gran_t x[NV];
+    for (int spins = 0;; ++spins) {
+        const gran_t* p = use_near ? g + near_off : g;
+        bool ok = true;
+#pragma unroll
+        for (int d = 0; d < NV; ++d) x[d] = gran_load(p + d);
+#pragma unroll
+        for (int d = 0; d < NV; ++d) ok = ok && (x[d] >> 32) == 1;
+        if (ok) break;
+        if (spins >= MST_GRAN_SPINS) {
+            gran_give_up(status);
+#pragma unroll
+            for (int d = 0; d < NV; ++d) x[d] = 0x7fc00000ull;
+            break;
+        }
+        if (has_near) use_near = !use_near;
+        if (!has_near || use_near) __builtin_amdgcn_s_sleep(1);
+    }
+#pragma unroll
+    for (int d = 0; d < NV; ++d) out[d] = __int_as_float((int)(unsigned)x[d]);
+}
+
 // Grid walk of the kernels that exchange granules.  Workgroup id L = blockIdx.x + gridDim.x blockIdx.y lands on XCD L % 8 and an XCD
 // hands out its ids in ascending order (observed, MI355X_MICROARCH.md; nothing below is WRONG if it changes, see above): with rows % 8 == 0
 // row r lives on XCD r % 8, and within an XCD the blocks of a row are walked in ascending `step` - the order in which a block's
@@ -307,6 +357,11 @@ struct Layout {
     // backward's: k_prep zeroes [gran_f, gran_f + 2 (gran_nf + gran_nb) floats), k_prep_bwd re-arms the backward part
     int64_t gran_f, gran_b;                      // gran_f: master smoother (bs x nblkC, twice: far + near copies); gran_b: adjoint smoother, tracks (R x nblkC, twice) then master (bs x nblkC, twice)
     int64_t gran_nf, gran_nb;                    // granule counts
+    // round 5: tile aggregates of the EQ runs that carry their own zero-state pass (ZsIn, mst_kernels.h): (signal rows, kMaxTiles1, 12)
+    // granules, far copies then near copies.  eqg_f (inside the forward block): track rows then master rows; eqg_b (inside the
+    // backward block, re-armed by k_prep_bwd): the master rows' adjoint run
+    int64_t eqg_f, eqg_b;
+    int64_t eqg_nf, eqg_nb;                      // granules per copy
     // fx bus (only laid out when MST_USE_FX_BUS is set)
     int fxS, fxTaps, fxK, fxBlk, fxBlkIr;         // impulse-response samples, band-pass taps, partitions, signal blocks, ir-bwd blocks
     int64_t fx_rc, fx_in, fx_wnf, fx_ir, fx_Xs, fx_Hs, fx_Ys, fx_dXs, fx_dHs, fx_dir, fx_din, fx_part, fx_Hf, fx_mix, fx_dry;
@@ -411,10 +466,14 @@ inline Layout make_layout(const mst_console_desc* d) {
     L.wzF_m = L.wzF_t + R * kWz;
     L.wzA_t = take((R + B) * kWz);
     L.wzA_m = L.wzA_t + R * kWz;
-    L.gran_nf = 2 * B * L.nblkC;         // far copies, then near copies (mst_common.h: gran_publish)
-    L.gran_nb = 2 * (R + B) * L.nblkC;
+    L.eqg_nf = (R + 2 * B) * kMaxTiles1 * kStates;
+    L.eqg_nb = 2 * B * kMaxTiles1 * kStates;
+    L.gran_nf = 2 * B * L.nblkC + 2 * L.eqg_nf;         // far copies, then near copies (mst_common.h: gran_publish)
+    L.gran_nb = 2 * (R + B) * L.nblkC + 2 * L.eqg_nb;
     L.gran_f = take(2 * (L.gran_nf + L.gran_nb));
     L.gran_b = L.gran_f + 2 * L.gran_nf;
+    L.eqg_f = L.gran_f + 2 * (2 * B * L.nblkC);
+    L.eqg_b = L.gran_b + 2 * (2 * (R + B) * L.nblkC);
     if (d->flags & MST_USE_FX_BUS) {
         L.fxS = d->fx_ir_samples;
         L.fxTaps = d->fx_bandpass_taps;

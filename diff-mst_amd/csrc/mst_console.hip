@@ -48,7 +48,17 @@ static constexpr bool mfma_zs() {
 #endif
 }
 
-extern "C" int mst_abi_version(void) { return 6; }
+// build-time A/B switch (-DMST_EQ_ZS_SEPARATE): the EQ's zero-state passes as launches of their own (k_eq_zs_mfma) instead of inside the
+// run launches (ZsIn, mst_kernels.h)
+static constexpr bool fuse_eq_zs() {
+#ifdef MST_EQ_ZS_SEPARATE
+    return false;
+#else
+    return true;
+#endif
+}
+
+extern "C" int mst_abi_version(void) { return 7; }
 
 extern "C" size_t mst_console_fx_tables_bytes(void) { return (size_t)8192 * 2 * sizeof(float); }
 extern "C" int mst_console_fx_init_tables(void* tables, void* stream) {
@@ -105,7 +115,12 @@ extern "C" int mst_console_forward(const mst_console_desc* d, const float* track
     PrepArgs pa{track_params, fx_bus_params, master_bus_params, ws + L.rc_t, ws + L.rc_m,
                 ws + L.powF_t, ws + L.powF_m, ws + L.powA_t, ws + L.powA_m, ws + L.powP_t, ws + L.powP_m,
                 ws + L.pow1F_t, ws + L.pow1F_m, ws + L.pow1A_t, ws + L.pow1A_m, ws + L.wzF_t, ws + L.wzF_m, ws + L.wzA_t, ws + L.wzA_m, fx_on ? ws + L.fx_rc : nullptr, fx_on ? ws + L.fx_mix : nullptr, status, L.R, L.bs, L.KE,
-                L.eq1, *d, (gran_t*)(ws + L.gran_f), L.gran_nf + L.gran_nb};
+                L.eq1, *d, (gran_t*)(ws + L.gran_f), L.gran_nf + L.gran_nb, nullptr, 0, 0};
+    if (n % 4 == 0 && d->track_row_stride % 4 == 0 && !((uintptr_t)tracks & 15)) {
+        pa.pf_src = tracks;
+        pa.pf_stride = d->track_row_stride;
+        pa.pf_n = n;
+    }
     launch_prep(pa, stream);
 
     // ---- tracks: EQ (zs -> carry scan -> run), compressor smoother (zs -> scan), apply + pan + bus sum
@@ -117,12 +132,19 @@ extern "C" int mst_console_forward(const mst_console_desc* d, const float* track
     // a call that saves for backward also leaves the all-pole zero-state ends of the coefficient-gradient pass
     float* zP_t = (save && fuse_allpole()) ? ws + L.zP_t : nullptr;
     float* zP_m = (save && fuse_allpole()) ? ws + L.zP_m : nullptr;
-    if (L.eq1 && mfma_zs()) launch_eq_zs_mfma(EQ_FWD, tracks, d->track_row_stride, ws + L.wzF_t, L.R, ws + L.zE_t, L.ncE_pad, n, L.R, stream, p1F_t, L.ntE, ws + L.aggF_t);
+    // round 5: the zero-state pass rides inside the run launch (tile aggregates exchanged as granules) wherever the run is a SCAN1 kernel
+    // with that variant: the tracks' compressor-fused run and both master-bus runs
+    const bool zsin = L.eq1 && mfma_zs() && fuse_eq_zs();
+    const ZsIn zi_t{ws + L.wzF_t, (gran_t*)(ws + L.eqg_f), L.eqg_nf, status};
+    const ZsIn zi_m{ws + L.wzF_m, (gran_t*)(ws + L.eqg_f) + (int64_t)L.R * kMaxTiles1 * kStates, L.eqg_nf, status};
+    const bool zsin_t = zsin && t_comp;
+    if (zsin_t) {}
+    else if (L.eq1 && mfma_zs()) launch_eq_zs_mfma(EQ_FWD, tracks, d->track_row_stride, ws + L.wzF_t, L.R, ws + L.zE_t, L.ncE_pad, n, L.R, stream, p1F_t, L.ntE, ws + L.aggF_t);
     else launch_cascade(EQ_FWD, false, tracks, d->track_row_stride, nullptr, 0, ws + L.rc_t, L.R, nullptr, ws + L.zE_t, L.ncE_pad, n, L.R, stream, p1F_t, L.ntE, ws + L.aggF_t);
     if (!L.eq1) launch_scan12(false, ws + L.zE_t, ws + L.sE_t, ws + L.powF_t, L.R, L.ncE, L.ncE_pad, L.KE, L.R, stream);
     if (t_comp)  // EQ run fused with the gain computer + per-block envelope aggregates
         launch_cascade_run_gc(tracks, d->track_row_stride, ws + L.u_t, Ns, ws + L.rc_t, L.R, sE_t, L.ncE_pad, n, L.R,
-                              ws + L.zS_t, L.nblkC, stream, p1F_t, L.ntE, ws + L.aggF_t, zP_t);
+                              ws + L.zS_t, L.nblkC, stream, p1F_t, L.ntE, ws + L.aggF_t, zP_t, zsin_t ? &zi_t : nullptr);
     else
         launch_cascade(EQ_FWD, true, tracks, d->track_row_stride, ws + L.u_t, Ns, ws + L.rc_t, L.R, sE_t, nullptr, L.ncE_pad, n, L.R, stream, p1F_t, L.ntE, ws + L.aggF_t, zP_t);
     const bool bus_is_mix = !m_on && !o_on;
@@ -137,12 +159,15 @@ extern "C" int mst_console_forward(const mst_console_desc* d, const float* track
 
     // ---- master bus
     if (m_on) {
-        if (L.eq1 && mfma_zs()) launch_eq_zs_mfma(EQ_FWD, ws + L.bus, Ns, ws + L.wzF_m, 0, ws + L.zE_m, L.ncE_pad, n, 2 * L.bs, stream, p1F_m, L.ntE, ws + L.aggF_m);
+        const bool apscan_m = L.apscan_fwd && zP_m && zP_t && p1F_m;
+        const bool zsin_m = zsin && apscan_m;
+        if (zsin_m) {}
+        else if (L.eq1 && mfma_zs()) launch_eq_zs_mfma(EQ_FWD, ws + L.bus, Ns, ws + L.wzF_m, 0, ws + L.zE_m, L.ncE_pad, n, 2 * L.bs, stream, p1F_m, L.ntE, ws + L.aggF_m);
         else launch_cascade(EQ_FWD, false, ws + L.bus, Ns, nullptr, 0, ws + L.rc_m, 0, nullptr, ws + L.zE_m, L.ncE_pad, n, 2 * L.bs, stream, p1F_m, L.ntE, ws + L.aggF_m);
         if (!L.eq1) launch_scan12(false, ws + L.zE_m, ws + L.sE_m, ws + L.powF_m, 0, L.ncE, L.ncE_pad, L.KE, 2 * L.bs, stream);
-        if (L.apscan_fwd && zP_m && zP_t && p1F_m)  // + the track rows' all-pole carry scan as extra workgroups of this (one wave per SIMD) launch
+        if (apscan_m)  // + the track rows' all-pole carry scan as extra workgroups of this (one wave per SIMD) launch
             launch_master_run_apscan(ws + L.bus, Ns, ws + L.v_m, Ns, ws + L.rc_m, sE_m, L.ncE_pad, n, 2 * L.bs, stream, p1F_m, L.ntE, ws + L.aggF_m, zP_m,
-                                     ws + L.zP_t, ws + L.sP_t, ws + L.powP_t, L.R * 12, L.ncE, L.apscan_sh);
+                                     ws + L.zP_t, ws + L.sP_t, ws + L.powP_t, L.R * 12, L.ncE, L.apscan_sh, EQ_FWD, zsin_m ? &zi_m : nullptr);
         else
             launch_cascade(EQ_FWD, true, ws + L.bus, Ns, ws + L.v_m, Ns, ws + L.rc_m, 0, sE_m, nullptr, L.ncE_pad, n, 2 * L.bs, stream, p1F_m, L.ntE, ws + L.aggF_m, zP_m);
         if (!fuse_comp_zs()) launch_comp_zs(2, ws + L.v_m, Ns, ws + L.rc_m, ws + L.zS_m, L.ncC_pad, n, L.bs, stream);
@@ -183,7 +208,7 @@ extern "C" int mst_console_backward_prepare(const mst_console_desc* d, void* wor
 extern "C" int mst_console_backward(const mst_console_desc* d, const float* tracks, const float* track_params,
                                     const float* fx_bus_params, const float* master_bus_params, const mst_console_fx* fx,
                                     const float* grad_mix, const float* grad_mixed_tracks, float* grad_track_params,
-                                    float* grad_fx_params, float* grad_master_params, float* grad_tracks,
+                                    float* grad_fx_params, float* grad_master_params, float* grad_tracks, int32_t* status,
                                     void* workspace, size_t workspace_bytes, void* stream_) {
     if (int e = check_desc(d)) return e;
     const Layout L = make_layout(d);
@@ -238,12 +263,16 @@ extern "C" int mst_console_backward(const mst_console_desc* d, const float* trac
         }
         launch_comp_bwd(true, true, ca, L.bs, stream);
         const float* p1A_m = L.eq1 ? ws + L.pow1A_m : nullptr;
-        if (L.eq1 && mfma_zs()) launch_eq_zs_mfma(EQ_ADJ, ws + L.du_m, Ns, ws + L.wzA_m, 0, ws + L.zA_m, L.ncE_pad, n, 2 * L.bs, stream, p1A_m, L.ntE, ws + L.aggA_m);
+        // round 5: the adjoint run carries its own zero-state pass when it is the SCAN1 kernel with the riders (ZsIn, mst_kernels.h)
+        const bool zsin_a = L.eq1 && mfma_zs() && fuse_eq_zs() && master_cg_later;
+        const ZsIn zi_a{ws + L.wzA_m, (gran_t*)(ws + L.eqg_b), L.eqg_nb, status};
+        if (zsin_a) {}
+        else if (L.eq1 && mfma_zs()) launch_eq_zs_mfma(EQ_ADJ, ws + L.du_m, Ns, ws + L.wzA_m, 0, ws + L.zA_m, L.ncE_pad, n, 2 * L.bs, stream, p1A_m, L.ntE, ws + L.aggA_m);
         else launch_cascade(EQ_ADJ, false, ws + L.du_m, Ns, nullptr, 0, ws + L.rc_m, 0, nullptr, ws + L.zA_m, L.ncE_pad, n, 2 * L.bs, stream, p1A_m, L.ntE, ws + L.aggA_m);
         if (!L.eq1) launch_scan12(true, ws + L.zA_m, ws + L.sA_m, ws + L.powA_m, 0, L.ncE, L.ncE_pad, L.KE, 2 * L.bs, stream);
         if (master_cg_later)  // + the master rows' own all-pole carry scans as extra workgroups of this (one wave per SIMD) launch
             launch_master_run_apscan(ws + L.du_m, Ns, ws + L.dbus, Ns, ws + L.rc_m, ws + L.zA_m, L.ncE_pad, n, 2 * L.bs, stream, p1A_m, L.ntE, ws + L.aggA_m,
-                                     nullptr, ws + L.zP_m, ws + L.sP_m, ws + L.powP_m, 2 * L.bs * 12, L.ncE, L.apscan_sh, EQ_ADJ);
+                                     nullptr, ws + L.zP_m, ws + L.sP_m, ws + L.powP_m, 2 * L.bs * 12, L.ncE, L.apscan_sh, EQ_ADJ, zsin_a ? &zi_a : nullptr);
         else
             launch_cascade(EQ_ADJ, true, ws + L.du_m, Ns, ws + L.dbus, Ns, ws + L.rc_m, 0, L.eq1 ? ws + L.zA_m : ws + L.sA_m, nullptr, L.ncE_pad, n,
                            2 * L.bs, stream, p1A_m, L.ntE, ws + L.aggA_m);

@@ -109,6 +109,51 @@ __device__ __forceinline__ void slab_fence() {
 #endif
 }
 
+// ---- zero-state chunk end states of one tile on the matrix pipe (the arithmetic of k_eq_zs_mfma below, which explains it) ----------
+// On return st[0 .. 12) = end state of chunk `lane` run from zero state.  `w` = the filter row's zero-state map (64 x 16).
+// `tile`: >= 64 x 13 floats of LDS; ends with a wave-level LDS fence (the buffer may be reused at once).
+typedef float f32x4_t __attribute__((vector_size(16)));
+template <bool FAST>
+__device__ __forceinline__ void zs_inline(const float* __restrict__ row, int64_t tile_base, int64_t n, const float* __restrict__ w,
+                                          float* __restrict__ tile, float* st, int lane) {
+    constexpr int kPitch = kStates + 1;
+    const int li = lane & 15, g = lane >> 4;
+    float4 x[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int64_t at = tile_base + (int64_t)(16 * m + li) * kEqChunk + 16 * s + 4 * g;
+            x[m][s] = FAST ? *reinterpret_cast<const float4*>(row + at) : load4(row, at, n);
+        }
+    float wb[16];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) wb[4 * s + e] = w[(16 * s + 4 * g + e) * 16 + li];
+    f32x4_t acc[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        acc[m] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const float xs[4] = {x[m][s].x, x[m][s].y, x[m][s].z, x[m][s].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(xs[e], wb[4 * s + e], acc[m], 0, 0, 0);
+        }
+    }
+    if (li < kStates) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tile[(16 * m + 4 * g + r) * kPitch + li] = acc[m][r];
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int dd = 0; dd < kStates; ++dd) st[dd] = tile[lane * kPitch + dd];
+    wave_lds_sync();
+}
+
 // MODE_RUN = false: zero-state pass, writes z[sig][12][nc_pad]
 // MODE_RUN = true : true pass from s0[sig][12][nc_pad], writes out
 // FUSE_GC (forward run of mono rows only): the compressor's static curve is evaluated on the fresh EQ
@@ -117,20 +162,48 @@ __device__ __forceinline__ void slab_fence() {
 // FUSE_AP (forward run, when the call saves for backward): the all-pole bank of the coefficient-gradient pass
 // (k_allpole_zs) advances on the fresh EQ output too and its zero-state chunk end states go to zp - the backward then
 // starts at the all-pole carry scan, one pass over u less.
-template <int DIR, bool MODE_RUN, bool FUSE_GC, bool SCAN1, bool FAST, bool FUSE_AP>
+template <int DIR, bool MODE_RUN, bool FUSE_GC, bool SCAN1, bool FAST, bool FUSE_AP, bool ZSIN = false>
 __device__ __forceinline__ void cascade_body(const float* __restrict__ in, int64_t in_stride,
                                                  float* __restrict__ out, int64_t out_stride,
                                                  const float* __restrict__ rc, int split,
                                                  const float* __restrict__ s0, float* __restrict__ z,
                                                  int nc_pad, int64_t n, float* __restrict__ zs_comp,
                                                  int nblk_comp, const float* __restrict__ pw1, int ntiles,
-                                                 float* __restrict__ agg, float* __restrict__ tile, float* __restrict__ zp) {
-    const int tid = threadIdx.x, sig = blockIdx.y;
-    const int64_t tile_base = (int64_t)blockIdx.x * kEqWG * kEqChunk;
-    const int chunk = blockIdx.x * kEqWG + tid;
+                                                 float* __restrict__ agg, float* __restrict__ tile, float* __restrict__ zp,
+                                                 const int sig, const int bx, const ZsIn zi = ZsIn{}) {
+    static_assert(!ZSIN || (MODE_RUN && SCAN1), "the in-launch zero-state pass belongs to the SCAN1 run");
+    const int tid = threadIdx.x;
+    const int64_t tile_base = (int64_t)bx * kEqWG * kEqChunk;
+    const int chunk = bx * kEqWG + tid;
     const float* inrow = in + (int64_t)sig * in_stride;
     float* outrow = MODE_RUN ? out + (int64_t)sig * out_stride : nullptr;
     auto order = [](int jj) { return (DIR == EQ_FWD) ? jj : kNSlab - 1 - jj; };
+    const int pos = DIR == EQ_FWD ? tid : kEqWG - 1 - tid;  // position of my chunk in recurrence order inside the tile
+    const float* tab = SCAN1 ? pw1 + (int64_t)filter_row(sig, split) * kTri2 : nullptr;
+    TabRegs tlo, thi;  // table sets of M (lanes of a tile) and M^64 (tiles of a row), mst_mat.h
+    if (SCAN1) tab_fetch(tlo, tab, tid);
+    float st[kStates];
+    const int wt = DIR == EQ_FWD ? bx : ntiles - 1 - bx;  // my tile in recurrence order
+    if (ZSIN) {
+        // Round 5: no zero-state launch in front of this one.  The tile's zero-state chunk end states come off the matrix pipe right
+        // here (the arithmetic of k_eq_zs_mfma below), its aggregate is published as 12 granules, and the aggregates of the tiles
+        // before it are picked up as their workgroups publish them (all of them are resident or gone: they were dispatched earlier).
+        zs_inline<FAST>(inrow, tile_base, n, zi.wz + (int64_t)filter_row(sig, split) * kWz, tile, st, tid);
+        gran_t* gq = zi.gran + ((int64_t)sig * kMaxTiles1) * kStates;
+        {   // st = inclusive scan of the chunk end states: the value at the last position is the tile aggregate
+            float sc[kStates];
+#pragma unroll
+            for (int i = 0; i < kStates; ++i) sc[i] = st[i];
+            tab_stash(tlo, tile, tid);
+            wave_lds_sync();
+            wave_scan_tri<DIR == EQ_ADJ>(sc, tile, pos);
+            wave_lds_sync();
+            gran_publish_vec<kStates>(gq + (int64_t)wt * kStates, zi.gran_near, sc, DIR == EQ_FWD ? kEqWG - 1 : 0, tid);
+        }
+        // forcing of the seeded scan below: the end state of the chunk one position back (nothing at position 0)
+#pragma unroll
+        for (int i = 0; i < kStates; ++i) st[i] = dpp_get<(DIR == EQ_ADJ) ? 0x130 : 0x138>(st[i]);
+    }
     SlabRegs pre;
     slab_first<FAST>(pre, inrow, tile_base, order(0), n, tid);  // first slab in flight while constants load
 
@@ -138,27 +211,27 @@ __device__ __forceinline__ void cascade_body(const float* __restrict__ in, int64
     float c[5 * kSections];
 #pragma unroll
     for (int i = 0; i < 5 * kSections; ++i) c[i] = coef[i];
-    float st[kStates];
-    const int pos = DIR == EQ_FWD ? tid : kEqWG - 1 - tid;  // position of my chunk in recurrence order inside the tile
-    const float* tab = SCAN1 ? pw1 + (int64_t)filter_row(sig, split) * kTri2 : nullptr;
-    TabRegs tlo, thi;  // table sets of M (lanes of a tile) and M^64 (tiles of a row), mst_mat.h
-    if (SCAN1) tab_fetch(tlo, tab, tid);
     if (MODE_RUN && SCAN1) {
         tab_fetch(thi, tab + kTriFloats, tid);
         // s0 = the zs kernel's zero-state chunk end states.  The state entering chunk `pos` is the inclusive scan, over the
         // positions of the tile, of the forcing  { S at position 0, end state of chunk pos-1 elsewhere }  with S = the state
         // entering the tile = the scan over the aggregates of the preceding tiles.
         const int nb = DIR == EQ_FWD ? chunk - 1 : chunk + 1;
+        if (!ZSIN) {
 #pragma unroll
-        for (int i = 0; i < kStates; ++i) st[i] = pos > 0 ? s0[((int64_t)sig * kStates + i) * nc_pad + nb] : 0.0f;
-        const int wt = DIR == EQ_FWD ? (int)blockIdx.x : ntiles - 1 - (int)blockIdx.x;  // my tile in recurrence order
+            for (int i = 0; i < kStates; ++i) st[i] = pos > 0 ? s0[((int64_t)sig * kStates + i) * nc_pad + nb] : 0.0f;
+        }
 #ifndef MST_DBG_NOSCAN
 #define MST_DBG_NOSCAN 0  // timing diagnostics only: 1 skips the in-wave carry scans (wrong results)
 #endif
         if (wt > 0 && !MST_DBG_NOSCAN) {
             float zz[kStates];  // lane q looks at the tile at recurrence position q
+            if (ZSIN) {
+                gran_read_vec<kStates>(zi.gran + ((int64_t)sig * kMaxTiles1 + tid) * kStates, zi.gran_near, zz, tid < wt, zi.status);
+            } else {
 #pragma unroll
-            for (int d = 0; d < kStates; ++d) zz[d] = tid < wt ? agg[((int64_t)sig * kStates + d) * kMaxTiles1 + tid] : 0.0f;
+                for (int d = 0; d < kStates; ++d) zz[d] = tid < wt ? agg[((int64_t)sig * kStates + d) * kMaxTiles1 + tid] : 0.0f;
+            }
             tab_stash(thi, tile, tid);
             wave_lds_sync();
             wave_scan_tri<false>(zz, tile, tid);
@@ -291,7 +364,6 @@ __device__ __forceinline__ void cascade_body(const float* __restrict__ in, int64
             wave_lds_sync();
             wave_scan_tri<DIR == EQ_ADJ>(st, tile, pos);
             if (pos == kEqWG - 1) {  // indexed by the tile's position in recurrence order
-                const int wt = DIR == EQ_FWD ? (int)blockIdx.x : ntiles - 1 - (int)blockIdx.x;
 #pragma unroll
                 for (int i = 0; i < kStates; ++i) agg[((int64_t)sig * kStates + i) * kMaxTiles1 + wt] = st[i];
             }
@@ -345,8 +417,27 @@ __global__ __launch_bounds__(kEqWG, (MODE_RUN && FUSE_GC && FUSE_AP) ? MST_EQ_RU
     const int64_t tile_base = (int64_t)blockIdx.x * kTile;
     const bool fast = tile_fast(in + (int64_t)blockIdx.y * in_stride, tile_base, n) &&
                       (!MODE_RUN || !((uintptr_t)(out + (int64_t)blockIdx.y * out_stride) & 15));
-    if (fast) cascade_body<DIR, MODE_RUN, FUSE_GC, SCAN1, true, FUSE_AP>(in, in_stride, out, out_stride, rc, split, s0, z, nc_pad, n, zs_comp, nblk_comp, pw1, ntiles, agg, tile, zp);
-    else cascade_body<DIR, MODE_RUN, FUSE_GC, SCAN1, false, FUSE_AP>(in, in_stride, out, out_stride, rc, split, s0, z, nc_pad, n, zs_comp, nblk_comp, pw1, ntiles, agg, tile, zp);
+    if (fast) cascade_body<DIR, MODE_RUN, FUSE_GC, SCAN1, true, FUSE_AP>(in, in_stride, out, out_stride, rc, split, s0, z, nc_pad, n, zs_comp, nblk_comp, pw1, ntiles, agg, tile, zp, blockIdx.y, blockIdx.x);
+    else cascade_body<DIR, MODE_RUN, FUSE_GC, SCAN1, false, FUSE_AP>(in, in_stride, out, out_stride, rc, split, s0, z, nc_pad, n, zs_comp, nblk_comp, pw1, ntiles, agg, tile, zp, blockIdx.y, blockIdx.x);
+}
+
+// The SCAN1 run with the zero-state pass inside (round 5, ZsIn in mst_kernels.h): one launch instead of k_eq_zs_mfma + k_cascade.  The
+// grid is walked so that the tiles of a row share an XCD and a tile's predecessors - in recurrence order: the adjoint cascade runs
+// backwards in time - carry lower workgroup ids, i.e. were dispatched before it (row_block_xcd, mst_common.h).
+template <int DIR, bool FUSE_GC, bool FUSE_AP>
+__global__ __launch_bounds__(kEqWG, (FUSE_GC && FUSE_AP) ? MST_EQ_RUN_W : 1) void k_cascade_zsin(const float* __restrict__ in, int64_t in_stride,
+                                                 float* __restrict__ out, int64_t out_stride,
+                                                 const float* __restrict__ rc, int split, int nc_pad, int64_t n,
+                                                 float* __restrict__ zs_comp, int nblk_comp, const float* __restrict__ pw1, int ntiles,
+                                                 float* __restrict__ zp, ZsIn zi) {
+    __shared__ __attribute__((aligned(16))) float tile[kEqWG * kLdw > kTriFloats ? kEqWG * kLdw : kTriFloats];
+    int sig, step;
+    row_block_xcd(sig, step);
+    const int bx = DIR == EQ_FWD ? step : ntiles - 1 - step;
+    const int64_t tile_base = (int64_t)bx * kTile;
+    const bool fast = tile_fast(in + (int64_t)sig * in_stride, tile_base, n) && !((uintptr_t)(out + (int64_t)sig * out_stride) & 15);
+    if (fast) cascade_body<DIR, true, FUSE_GC, true, true, FUSE_AP, true>(in, in_stride, out, out_stride, rc, split, nullptr, nullptr, nc_pad, n, zs_comp, nblk_comp, pw1, ntiles, nullptr, tile, zp, sig, bx, zi);
+    else cascade_body<DIR, true, FUSE_GC, true, false, FUSE_AP, true>(in, in_stride, out, out_stride, rc, split, nullptr, nullptr, nc_pad, n, zs_comp, nblk_comp, pw1, ntiles, nullptr, tile, zp, sig, bx, zi);
 }
 
 // ---- zero-state pass on the matrix pipe ------------------------------------------------------------------------------
@@ -357,61 +448,25 @@ __global__ __launch_bounds__(kEqWG, (MODE_RUN && FUSE_GC && FUSE_AP) ? MST_EQ_RU
 // 16-byte pieces of row 16 m + i; the K order - sample 16 s + 4 g + e at step (s, e) - is the W fragments' order too, so no
 // LDS staging and no shuffles), the results are written out in the chunk-state layout the run kernel reads, transposed
 // through LDS to one chunk per lane, and scanned across the tile like before for the tile aggregate.
-typedef float f32x4_t __attribute__((vector_size(16)));
 template <int DIR>
 __global__ __launch_bounds__(kEqWG) void k_eq_zs_mfma(const float* __restrict__ in, int64_t in_stride, const float* __restrict__ wz, int split,
                                                      float* __restrict__ z, int nc_pad, int64_t n, const float* __restrict__ pw1, int ntiles,
                                                      float* __restrict__ agg) {
     constexpr int kPitch = kStates + 1;
     __shared__ __attribute__((aligned(16))) float tile[kEqWG * kPitch > kTriFloats ? kEqWG * kPitch : kTriFloats];
-    const int lane = threadIdx.x, sig = blockIdx.y, li = lane & 15, g = lane >> 4;
+    const int lane = threadIdx.x, sig = blockIdx.y;
     const int64_t tile_base = (int64_t)blockIdx.x * kTile;
     const float* row = in + (int64_t)sig * in_stride;
     const int frow = filter_row(sig, split);
-    const bool fast = tile_fast(row, tile_base, n);
-    float4 x[4][4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int64_t at = tile_base + (int64_t)(16 * m + li) * kEqChunk + 16 * s + 4 * g;
-            x[m][s] = fast ? *reinterpret_cast<const float4*>(row + at) : load4(row, at, n);
-        }
-    const float* w = wz + (int64_t)frow * kWz;
-    float wb[16];
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) wb[4 * s + e] = w[(16 * s + 4 * g + e) * 16 + li];
     TabRegs tlo;
     tab_fetch(tlo, pw1 + (int64_t)frow * kTri2, lane);
-    f32x4_t acc[4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        acc[m] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const float xs[4] = {x[m][s].x, x[m][s].y, x[m][s].z, x[m][s].w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(xs[e], wb[4 * s + e], acc[m], 0, 0, 0);
-        }
-    }
-    // D: column = state (lane & 15), row = chunk 16 m + 4 g + r
-    const int chunk0 = blockIdx.x * kEqWG;
-    if (li < kStates) {
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            *reinterpret_cast<float4*>(&z[((int64_t)sig * kStates + li) * nc_pad + chunk0 + 16 * m + 4 * g]) =
-                make_float4(acc[m][0], acc[m][1], acc[m][2], acc[m][3]);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) tile[(16 * m + 4 * g + r) * kPitch + li] = acc[m][r];
-        }
-    }
-    wave_lds_sync();
     float st[kStates];
+    if (tile_fast(row, tile_base, n)) zs_inline<true>(row, tile_base, n, wz + (int64_t)frow * kWz, tile, st, lane);
+    else zs_inline<false>(row, tile_base, n, wz + (int64_t)frow * kWz, tile, st, lane);
+    // the chunk-state layout the run kernel reads: z[sig][state][chunk]
+    const int chunk0 = blockIdx.x * kEqWG;
 #pragma unroll
-    for (int dd = 0; dd < kStates; ++dd) st[dd] = tile[lane * kPitch + dd];
-    wave_lds_sync();
+    for (int dd = 0; dd < kStates; ++dd) z[((int64_t)sig * kStates + dd) * nc_pad + chunk0 + lane] = st[dd];
     tab_stash(tlo, tile, lane);
     wave_lds_sync();
     const int pos = DIR == EQ_FWD ? lane : kEqWG - 1 - lane;
@@ -524,11 +579,11 @@ struct ApScanArgs {       // the scan jobs riding on a launch: job q = two-state
 // master-bus run (cascade role: blockIdx.y < nsig) + all-pole carry-scan jobs (blockIdx.y >= nsig).  DIR = EQ_FWD: the forward run
 // (all-pole bank riding along) carries the TRACK rows' scans; DIR = EQ_ADJ: the adjoint run of the backward carries the MASTER rows' own
 // (their coefficient-gradient walk happens later, in the tracks' compressor-backward launch)
-template <int DIR>
+template <int DIR, bool ZSIN>
 __global__ __launch_bounds__(kEqWG) void k_master_run_apscan(const float* __restrict__ in, int64_t in_stride, float* __restrict__ out,
                                                            int64_t out_stride, const float* __restrict__ rc, const float* __restrict__ s0,
                                                            int nc_pad, int64_t n, const float* __restrict__ pw1, int ntiles,
-                                                           float* __restrict__ agg, float* __restrict__ zp, int nsig, ApScanArgs sc) {
+                                                           float* __restrict__ agg, float* __restrict__ zp, int nsig, ApScanArgs sc, ZsIn zi) {
     __shared__ __attribute__((aligned(16))) float tile[2 * kEqWG * kLdw > kTriFloats ? 2 * kEqWG * kLdw : kTriFloats];
 #ifndef MST_DBG_APSCAN
 #define MST_DBG_APSCAN 0  // timing diagnostics only (wrong results): 1 = the scan role returns at once, 2 = the cascade role does
@@ -545,21 +600,34 @@ __global__ __launch_bounds__(kEqWG) void k_master_run_apscan(const float* __rest
         return;
     }
     if (MST_DBG_APSCAN == 2) return;
-    const int64_t tile_base = (int64_t)blockIdx.x * kTile;
-    const bool fast = tile_fast(in + (int64_t)blockIdx.y * in_stride, tile_base, n) && !((uintptr_t)(out + (int64_t)blockIdx.y * out_stride) & 15);
+    int sig = blockIdx.y, bx = blockIdx.x;
+    if (ZSIN) {  // the cascade workgroups (ids 0 .. ntiles nsig - 1, ahead of the scan jobs) exchange tile aggregates: see k_cascade_zsin
+        int step;
+        row_block_xcd(sig, step, 1, nsig);
+        bx = DIR == EQ_FWD ? step : ntiles - 1 - step;
+    }
+    const int64_t tile_base = (int64_t)bx * kTile;
+    const bool fast = tile_fast(in + (int64_t)sig * in_stride, tile_base, n) && !((uintptr_t)(out + (int64_t)sig * out_stride) & 15);
     constexpr bool AP = DIR == EQ_FWD;
-    if (fast) cascade_body<DIR, true, false, true, true, AP>(in, in_stride, out, out_stride, rc, 0, s0, nullptr, nc_pad, n, nullptr, 0, pw1, ntiles, agg, tile, zp);
-    else cascade_body<DIR, true, false, true, false, AP>(in, in_stride, out, out_stride, rc, 0, s0, nullptr, nc_pad, n, nullptr, 0, pw1, ntiles, agg, tile, zp);
+    if (fast) cascade_body<DIR, true, false, true, true, AP, ZSIN>(in, in_stride, out, out_stride, rc, 0, s0, nullptr, nc_pad, n, nullptr, 0, pw1, ntiles, agg, tile, zp, sig, bx, zi);
+    else cascade_body<DIR, true, false, true, false, AP, ZSIN>(in, in_stride, out, out_stride, rc, 0, s0, nullptr, nc_pad, n, nullptr, 0, pw1, ntiles, agg, tile, zp, sig, bx, zi);
 }
 void launch_master_run_apscan(const float* in, int64_t in_stride, float* out, int64_t out_stride, const float* rc, const float* s0, int nc_pad,
                               int64_t n, int nsig, hipStream_t stream, const float* pw1, int ntiles, float* agg, float* zp,
-                              const float* sc_z, float* sc_s0, const float* sc_tab, int sc_jobs, int sc_nc, int sc_sh, int dir) {
+                              const float* sc_z, float* sc_s0, const float* sc_tab, int sc_jobs, int sc_nc, int sc_sh, int dir, const ZsIn* zi) {
     const ApScanArgs sc{sc_z, sc_s0, sc_tab, sc_jobs, sc_nc, nc_pad, sc_sh, dir == EQ_ADJ ? 1 : 0};
     const dim3 grid(ntiles, nsig + (sc_jobs + ntiles - 1) / ntiles), block(kEqWG);
-    if (dir == EQ_FWD)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_master_run_apscan<EQ_FWD>), grid, block, 0, stream, in, in_stride, out, out_stride, rc, s0, nc_pad, n, pw1, ntiles, agg, zp, nsig, sc);
-    else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_master_run_apscan<EQ_ADJ>), grid, block, 0, stream, in, in_stride, out, out_stride, rc, s0, nc_pad, n, pw1, ntiles, agg, zp, nsig, sc);
+    const ZsIn z0 = zi ? *zi : ZsIn{};
+#define MST_LAUNCH_MRA(D, Z) \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_master_run_apscan<D, Z>), grid, block, 0, stream, in, in_stride, out, out_stride, rc, s0, nc_pad, n, pw1, ntiles, agg, zp, nsig, sc, z0)
+    if (dir == EQ_FWD) {
+        if (z0.wz) MST_LAUNCH_MRA(EQ_FWD, true);
+        else MST_LAUNCH_MRA(EQ_FWD, false);
+    } else {
+        if (z0.wz) MST_LAUNCH_MRA(EQ_ADJ, true);
+        else MST_LAUNCH_MRA(EQ_ADJ, false);
+    }
+#undef MST_LAUNCH_MRA
 }
 
 // ---- all-pole bank for the coefficient gradients ------------------------------------------------
@@ -785,9 +853,14 @@ void launch_cascade(int dir, bool run, const float* in, int64_t in_stride, float
 
 void launch_cascade_run_gc(const float* in, int64_t in_stride, float* out, int64_t out_stride, const float* rc, int split,
                            const float* s0, int nc_pad, int64_t n, int nsig, float* zs_comp, int nblk_comp, hipStream_t stream,
-                           const float* pw1, int ntiles, float* agg, float* zp) {
+                           const float* pw1, int ntiles, float* agg, float* zp, const ZsIn* zi) {
     static_assert(kWG * kCompChunk % kEqChunk == 0 && kEqWG % (kWG * kCompChunk / kEqChunk) == 0, "a compressor block must be a power-of-two group of EQ lanes");
     const dim3 grid(pw1 ? ntiles : nc_pad / kEqWG, nsig), block(kEqWG);
+    if (zi && zi->wz && pw1) {  // zero-state pass inside the launch
+        if (zp) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cascade_zsin<EQ_FWD, true, true>), grid, block, 0, stream, in, in_stride, out, out_stride, rc, split, nc_pad, n, zs_comp, nblk_comp, pw1, ntiles, zp, *zi);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cascade_zsin<EQ_FWD, true, false>), grid, block, 0, stream, in, in_stride, out, out_stride, rc, split, nc_pad, n, zs_comp, nblk_comp, pw1, ntiles, zp, *zi);
+        return;
+    }
     if (zp) {
         if (pw1)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cascade<EQ_FWD, true, true, true, true>), grid, block, 0, stream, in, in_stride, out, out_stride,

@@ -32,6 +32,10 @@ struct PrepArgs {
     mst_console_desc d;
     gran_t* gran;       // every granule array of the call (mst_common.h), zeroed here
     int64_t gran_n;
+    // prefetch riders (mst_params.hip: k_prep): R rows of pf_n floats, pf_stride apart, pulled through the Infinity Cache while the
+    // design chains run; null = none.  Rows must be 16-byte aligned with pf_n % 4 == 0.
+    const float* pf_src;
+    int64_t pf_stride, pf_n;
 };
 struct PrepBwdArgs {
     const float* track_params;
@@ -87,6 +91,15 @@ void launch_prep(const PrepArgs& a, hipStream_t stream);
 void launch_prep_bwd(const PrepBwdArgs& a, hipStream_t stream);
 
 // ---- mst_eq.hip
+// The zero-state pass of a SCAN1 run INSIDE the run launch (round 5; wz = nullptr: off - a zs launch went before).  Every tile forms
+// its zero-state chunk end states on the matrix pipe itself, publishes its 12-state aggregate as granules and picks up the aggregates
+// of the tiles before it (mst_common.h: gran_publish_vec / gran_read_vec).
+struct ZsIn {
+    const float* wz;    // zero-state maps, filter rows x 64 x 16 (k_prep)
+    gran_t* gran;       // (signal rows, kMaxTiles1, 12) zeroed granules, indexed by the tile's position in recurrence order
+    int64_t gran_near;  // the near copies follow this many granules later
+    int32_t* status;    // raised to kStatusExchangeTimeout when a wait gives up (may be null)
+};
 // zp != nullptr (forward run only): the all-pole bank of the coefficient-gradient pass rides along, its zero-state chunk
 // end states are written to zp (nsig x 24 x nc_pad) and the backward needs no k_allpole_zs launch.
 // pw1 (in-wave scan tables of these rows) != nullptr: SCAN1 kernels, no carry-scan launch between zs and run (mst_eq.hip);
@@ -97,7 +110,7 @@ void launch_cascade(int dir, bool run, const float* in, int64_t in_stride, float
 // forward run of mono rows fused with the compressor's zero-state block aggregates (replaces k_comp_zs<1>)
 void launch_cascade_run_gc(const float* in, int64_t in_stride, float* out, int64_t out_stride, const float* rc, int split,
                            const float* s0, int nc_pad, int64_t n, int nsig, float* zs_comp, int nblk_comp, hipStream_t stream,
-                           const float* pw1 = nullptr, int ntiles = 0, float* agg = nullptr, float* zp = nullptr);
+                           const float* pw1 = nullptr, int ntiles = 0, float* agg = nullptr, float* zp = nullptr, const ZsIn* zi = nullptr);
 // zero-state pass of the SCAN1 path on the matrix pipe: chunk end states = W^T chunk (wz: filter rows x 64 x 16, made by k_prep)
 void launch_eq_zs_mfma(int dir, const float* in, int64_t in_stride, const float* wz, int split, float* z, int nc_pad, int64_t n, int nsig,
                        hipStream_t stream, const float* pw1, int ntiles, float* agg);
@@ -105,7 +118,8 @@ void launch_eq_zs_mfma(int dir, const float* in, int64_t in_stride, const float*
 // workgroups of the same launch (mst_eq.hip: k_master_run_apscan); sc_sh: 64 = KE 2^sc_sh
 void launch_master_run_apscan(const float* in, int64_t in_stride, float* out, int64_t out_stride, const float* rc, const float* s0, int nc_pad,
                               int64_t n, int nsig, hipStream_t stream, const float* pw1, int ntiles, float* agg, float* zp,
-                              const float* sc_z, float* sc_s0, const float* sc_tab, int sc_jobs, int sc_nc, int sc_sh, int dir = EQ_FWD);
+                              const float* sc_z, float* sc_s0, const float* sc_tab, int sc_jobs, int sc_nc, int sc_sh, int dir = EQ_FWD,
+                              const ZsIn* zi = nullptr);  // zi (wz != null): the master rows' zero-state pass runs inside the launch too (no k_eq_zs_mfma before it)
 void launch_allpole_zs(const float* u, int64_t u_stride, const float* rc, int split, float* z, int nc_pad, int64_t n, int nsig,
                        hipStream_t stream);
 void launch_coefgrad(const float* u, int64_t u_stride, const float* g, int64_t g_stride, const float* rc, int split,

@@ -152,8 +152,29 @@ __global__ __launch_bounds__(320) void k_prep(PrepArgs a) {
     __shared__ double dblk[2][2][kSections][4];  // diagonal 2x2 blocks of M and M^64, [set][fwd|adj][section]
     __shared__ float coef[32];
     const int row = blockIdx.x, tid = threadIdx.x;
+    if (blockIdx.y >= 2) {
+        // Round 5, prefetch riders: this launch is two serial fp64 chains per filter row on 2 (R + bs) workgroups - the memory system idles
+        // for its ~20 us - and the launch after it opens with a pass over the track rows that is bound by HBM (the zero-state map of the
+        // EQ: 67 MB at cfg #2).  The extra workgroups (dispatched behind the real ones) pull the track rows through the Infinity Cache
+        // meanwhile: plain loads whose values are dropped.  Purely a hint: nothing reads what they "produce".
+        if (row < a.R && a.pf_src) {
+            const float4* src = reinterpret_cast<const float4*>(a.pf_src + (int64_t)row * a.pf_stride);
+            const int nseg = gridDim.y - 2, seg = blockIdx.y - 2;
+            const int64_t nv = a.pf_n >> 2, per = (nv + nseg - 1) / nseg, v0 = seg * per, v1 = v0 + per < nv ? v0 + per : nv;
+            for (int64_t g0 = v0 + tid; g0 < v1; g0 += 320 * 8) {
+                float4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = g0 + 320 * u < v1 ? src[g0 + 320 * u] : make_float4(0.f, 0.f, 0.f, 0.f);
+#if defined(__clang__)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) asm volatile("" ::"v"(v[u].x), "v"(v[u].y), "v"(v[u].z), "v"(v[u].w));
+#endif
+            }
+        }
+        return;
+    }
     // arm the granules through which later launches of this call exchange block aggregates (mst_common.h)
-    for (int64_t i = ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 320 + tid; i < a.gran_n; i += (int64_t)gridDim.x * gridDim.y * 320) a.gran[i] = 0ull;
+    for (int64_t i = ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 320 + tid; i < a.gran_n; i += (int64_t)gridDim.x * 2 * 320) a.gran[i] = 0ull;
     const bool is_master = row >= a.R;
     const int mrow = row - a.R;
     const mst_console_desc& d = a.d;
@@ -766,7 +787,11 @@ void launch_basic_backward(const BasicArgs& a, hipStream_t stream) {
 }
 
 void launch_prep(const PrepArgs& a, hipStream_t stream) {
-    hipLaunchKernelGGL(k_prep, dim3(a.R + a.bs, 2), dim3(320), 0, stream, a);
+#ifndef MST_PREP_PREFETCH_SEGS
+#define MST_PREP_PREFETCH_SEGS 12  // rider workgroups per track row (0: none); ~17 sixteen-byte loads per lane at 262144 samples
+#endif
+    const int segs = (a.pf_src && MST_PREP_PREFETCH_SEGS > 0) ? MST_PREP_PREFETCH_SEGS : 0;
+    hipLaunchKernelGGL(k_prep, dim3(a.R + a.bs, 2 + segs), dim3(320), 0, stream, a);
 }
 void launch_prep_bwd(const PrepBwdArgs& a, hipStream_t stream) {
     hipLaunchKernelGGL(k_prep_bwd, dim3(a.R + a.bs), dim3(256), 0, stream, a);

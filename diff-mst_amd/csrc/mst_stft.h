@@ -147,6 +147,17 @@ struct StftArgs {
     unsigned* tickets;
 };
 
+// the three forward transforms of the reference's resolutions in one launch (mst_stft2.hip: k_stft3_fwd).  a[0] / a[1] / a[2] =
+// the 8192- / 2048- / 512-point resolution; groups = strips per row; wg_end = running workgroup counts of the three roles
+struct Stft3Args {
+    StftArgs a[3];
+    int groups[3];
+    int wg_end[3];
+    int rows;
+    unsigned* tickets;  // workgroup 0 zeroes the ticket of k_mrstft_finish (null: nothing to arm)
+};
+void launch_stft3_fwd(const Stft3Args& p, hipStream_t stream);
+
 constexpr float kLn2 = 0.6931471805599453f;
 
 // round-2 launchers (mst_stft2.hip); grid.x = strips per row, grid.y = rows

@@ -797,8 +797,41 @@ static int mrstft_forward_stages(const mst_mrstft_desc* d, const float* pred, co
         la.part_off[i] = p.part_off[i];
         la.count[i] = (float)((double)d->rows * p.res[i].n_bins * p.res[i].n_frames);
     }
+#ifndef MST_STFT3_FUSE
+#define MST_STFT3_FUSE 1  // A/B switch: 0 = one forward launch per resolution
+#endif
+    // the reference's three resolutions, all on the round-2 kernels: ONE forward launch (k_stft3_fwd, mst_stft2.hip)
+    int role[3] = {-1, -1, -1};
+    bool fuse3 = MST_STFT3_FUSE && (stages & 1) && d->n_res == 3;
+    for (int i = 0; i < d->n_res && fuse3; ++i) {
+        const int which = p.res[i].n_fft == 8192 ? 0 : (p.res[i].n_fft == 2048 ? 1 : (p.res[i].n_fft == 512 ? 2 : -1));
+        if (which < 0 || !p.engine2[i] || role[which] >= 0) fuse3 = false;
+        else role[which] = i;
+    }
+    if (fuse3) {
+        Stft3Args q{};
+        for (int w = 0; w < 3; ++w) {
+            const int i = role[w];
+            StftArgs& a = q.a[w];
+            a.pred = pred;
+            a.target = target;
+            a.tables = (const float*)tables;
+            a.part = ws + p.part_off[i];
+            a.r = p.res[i];
+            a.log2n = p.log2n[i];
+            a.n = d->n_samples;
+            a.eps = d->eps;
+            q.groups[w] = p.n_groups[i];
+        }
+        q.rows = d->rows;
+        q.wg_end[0] = q.groups[0] * d->rows;
+        q.wg_end[1] = q.wg_end[0] + q.groups[1] * ((d->rows + 1) / 2);
+        q.wg_end[2] = q.wg_end[1] + (q.groups[2] * d->rows + 7) / 8;
+        q.tickets = fuse ? reinterpret_cast<unsigned*>(ws + p.tick_off) : nullptr;
+        launch_stft3_fwd(q, stream);
+    }
     for (int i = 0; i < d->n_res; ++i) {
-        if (!(stages & 1)) continue;
+        if (!(stages & 1) || fuse3) continue;
         StftArgs a{};
         a.pred = pred;
         a.target = target;

@@ -86,14 +86,15 @@ __device__ __forceinline__ void strip_range(int g, int G, int F, int& f0, int& f
     f1 = (int)(((unsigned)(g + 1) * (unsigned)F) / (unsigned)G);
 }
 
+// Forward of one strip of one row by a group of LG lanes (lane = 0 .. LG-1).  `buf` / `red`: the group's LDS (one transform buffer
+// set, LG / 64 x 4 floats).  strip / nstrips: balanced strips over the row's frames.  live = false: a filler unit of the fused
+// launch (k_stft3_fwd) - it runs the same barriers as its neighbour group and writes nothing.
 template <int N>
-__global__ __launch_bounds__(FftPlan<N>::LG, (N == 8192 ? MST_STFT2_W8192 : 1)) void k_stft2_fwd(StftArgs a) {
+__device__ __forceinline__ void stft2_fwd_body(const StftArgs& a, const int lane, const int strip, const int nstrips, const int row,
+                                               const bool live, float2 (*buf)[FftShape<N>::SLOTS], float (*red)[4]) {
     using S = FftShape<N>;
     using L = FrameLoader<N>;
     constexpr int LG = S::LG, PTS = N / LG, H = N / 2;
-    __shared__ __attribute__((aligned(16))) float2 buf[S::NSEQ][S::SLOTS];
-    __shared__ float red[LG / 64][4];
-    const int lane = threadIdx.x, row = blockIdx.y;
     const ResInfo r = a.r;
     const float2* twg = reinterpret_cast<const float2*>(a.tables + r.tw_off);
     LaneTw<N> tw;
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(FftPlan<N>::LG, (N == 8192 ? MST_STFT2_W8192 : 1)) 
     const float* x = a.pred + (int64_t)row * a.n;
     const float* y = a.target + (int64_t)row * a.n;
     int f0, f1;
-    strip_range(blockIdx.x, gridDim.x, r.n_frames, f0, f1);
+    strip_range(strip, nstrips, r.n_frames, f0, f1);
     float s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f;
     const int nrow = (int)a.n;  // 32-bit sample indices: a row is < 2^31 samples
     // Every frame is fetched whole (consecutive frames share half their samples: the re-read hits L2); the reflection costs
@@ -159,12 +160,62 @@ __global__ __launch_bounds__(FftPlan<N>::LG, (N == 8192 ? MST_STFT2_W8192 : 1)) 
     s1 = wave_sum(s1); s2 = wave_sum(s2); s3 = wave_sum(s3); s4 = wave_sum(s4);
     if (wl_ == 0) { red[wave][0] = s1; red[wave][1] = s2; red[wave][2] = s3; red[wave][3] = s4; }
     group_lds_sync<LG>();
-    if (lane < 4) {
+    if (lane < 4 && live) {
         float v = 0.f;
         for (int w = 0; w < LG / 64; ++w) v += red[w][lane];
-        a.part[((int64_t)row * gridDim.x + blockIdx.x) * 4 + lane] = v;
+        a.part[((int64_t)row * nstrips + strip) * 4 + lane] = v;
     }
-    if (a.tickets && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) a.tickets[0] = 0u;  // armed for k_mrstft_finish (mst_stft.hip)
+}
+
+template <int N>
+__global__ __launch_bounds__(FftPlan<N>::LG, (N == 8192 ? MST_STFT2_W8192 : 1)) void k_stft2_fwd(StftArgs a) {
+    using S = FftShape<N>;
+    __shared__ __attribute__((aligned(16))) float2 buf[S::NSEQ][S::SLOTS];
+    __shared__ float red[S::LG / 64][4];
+    stft2_fwd_body<N>(a, threadIdx.x, blockIdx.x, gridDim.x, blockIdx.y, true, buf, red);
+    if (a.tickets && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) a.tickets[0] = 0u;  // armed for k_mrstft_finish (mst_stft.hip)
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 5: the three forward transforms of the reference's resolutions in ONE launch.  Separate launches cost a drain + ramp
+// each (~2 x 5 us with their table prologues) and each leaves the chip mostly idle in its last round - the 8192-point launch is
+// 2.03 rounds of its 512 resident workgroups (65 frames per row over 32 strips: sixteen workgroups walk a third frame while
+// 496 slots sit empty), the others end ragged as well.  Here every workgroup is 512 lanes and takes one ROLE from its index:
+//   role 0  one strip of the 8192-point transform (512 lanes per frame, as before)
+//   role 1  two strips of the 2048-point transform, one per 256-lane half: the same strip index of two different rows, i.e. the
+//           same frame range, so both halves run the same number of workgroup barriers (an odd row count gives the last half a
+//           filler that repeats a row and writes nothing)
+//   role 2  eight strips of the 512-point transform, one per wave (no workgroup barrier in that role)
+// LDS and registers are the 8192-point kernel's (64 KB, 128: two workgroups per CU = four waves per SIMD, which is what each of
+// the three kernels ran at alone).  Heavy roles first, so that the short ones fill the tail.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, MST_STFT2_W8192) void k_stft3_fwd(Stft3Args p) {
+    __shared__ __attribute__((aligned(16))) float2 lds[2 * FftShape<8192>::SLOTS];
+    __shared__ float red[8][4];
+    const int tid = threadIdx.x, b = blockIdx.x;
+    if (p.tickets && b == 0 && tid == 0) p.tickets[0] = 0u;  // armed for k_mrstft_finish (mst_stft.hip), which runs after this launch
+#ifndef MST_STFT3_ROLES
+#define MST_STFT3_ROLES 7  // diagnostics: bit mask of the roles compiled in
+#endif
+    if (!(MST_STFT3_ROLES & 1) && b < p.wg_end[0]) return;
+    if (!(MST_STFT3_ROLES & 2) && b >= p.wg_end[0] && b < p.wg_end[1]) return;
+    if (!(MST_STFT3_ROLES & 4) && b >= p.wg_end[1]) return;
+    if (b < p.wg_end[0]) {
+        const int G = p.groups[0];
+        stft2_fwd_body<8192>(p.a[0], tid, b % G, G, b / G, true, reinterpret_cast<float2(*)[FftShape<8192>::SLOTS]>(lds), red);
+    } else if (b < p.wg_end[1]) {
+        const int u = b - p.wg_end[0], G = p.groups[1], sub = __builtin_amdgcn_readfirstlane(tid >> 8);  // wave-uniform: keep it scalar
+        const int row = 2 * (u / G) + sub;
+        const bool live = row < p.rows;
+        stft2_fwd_body<2048>(p.a[1], tid & 255, u % G, G, live ? row : p.rows - 1, live,
+                             reinterpret_cast<float2(*)[FftShape<2048>::SLOTS]>(lds + sub * FftShape<2048>::SLOTS), red + 4 * sub);
+    } else {
+        const int G = p.groups[2], wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int u = (b - p.wg_end[1]) * 8 + wave;
+        if (u < G * p.rows)
+            stft2_fwd_body<512>(p.a[2], tid & 63, u % G, G, u / G, true,
+                                reinterpret_cast<float2(*)[FftShape<512>::SLOTS]>(lds + wave * FftShape<512>::SLOTS), red + wave);
+    }
 }
 
 
@@ -514,6 +565,10 @@ void launch_stft2_bwd(const StftArgs& a, int n_groups, int rows, hipStream_t str
     if (a.r.n_fft == 512) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stft2_bwd<512>), grid, dim3(FftPlan<512>::LG), 0, stream, a);
     else if (a.r.n_fft == 2048) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stft2_bwd<2048>), grid, dim3(FftPlan<2048>::LG), 0, stream, a);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stft2_bwd<8192>), grid, dim3(FftPlan<8192>::LG), 0, stream, a);
+}
+
+void launch_stft3_fwd(const Stft3Args& p, hipStream_t stream) {
+    hipLaunchKernelGGL(k_stft3_fwd, dim3(p.wg_end[2]), dim3(512), 0, stream, p);
 }
 
 void launch_stft2_fwd(const StftArgs& a, int n_groups, int rows, hipStream_t stream) {

@@ -37,6 +37,8 @@ FLAG_BITS = {
 }
 
 
+EXCHANGE_TIMEOUT = 2000
+
 _IDENTITY = ([0.0] * 27, [1.0] * 27, [0.0] * 26, [1.0] * 26, [0.0] * 25, [1.0] * 25)
 
 
@@ -86,6 +88,10 @@ def status_to_error(status: int):
     """Decode the device status word into the reference's ValueError (mst/modules.py:86-89)."""
     if status == 0:
         return None
+    if status >= EXCHANGE_TIMEOUT:  # include/diffmst_hip.h: MST_STATUS_EXCHANGE_TIMEOUT
+        return RuntimeError(
+            "diffmst_hip: an in-launch aggregate exchange timed out (status %d); the outputs / gradients of that call are poisoned "
+            "and must not be used" % status)
     code = 1000 - status - 1
     if code < 27:
         effect, name = TRACK_INDEX[code]

@@ -165,6 +165,7 @@ class _ConsoleFunction(torch.autograd.Function):
             ws.record_stream(aux)
         if need_grad:
             ctx.desc, ctx.nbytes, ctx.dev = desc, nbytes, dev
+            ctx.status, ctx.console = status, console
             ctx.want_mixed = want_mixed
             ctx.fx_on = bool(flags["use_fx_bus"])
             # the backward needs the engine tables only: the filtered noise and the spectra are already in the workspace
@@ -202,10 +203,11 @@ class _ConsoleFunction(torch.autograd.Function):
             rc = lib.mst_console_backward(
                 ctypes.byref(desc), _cabi.ptr(rows), _cabi.ptr(tp), _cabi.ptr(fp), _cabi.ptr(mp),
                 ctypes.byref(fx) if fx is not None else None, _cabi.ptr(grad_mix), _cabi.ptr(grad_mixed), _cabi.ptr(g_tp),
-                _cabi.ptr(g_fx) if ctx.fx_on else None, _cabi.ptr(g_mp), _cabi.ptr(g_tracks), _cabi.ptr(ws), ctx.nbytes,
-                _hip.current_stream_ptr(dev),
+                _cabi.ptr(g_fx) if ctx.fx_on else None, _cabi.ptr(g_mp), _cabi.ptr(g_tracks), _cabi.ptr(ctx.status), _cabi.ptr(ws),
+                ctx.nbytes, _hip.current_stream_ptr(dev),
             )
         _hip.check(rc, "mst_console_backward")
+        ctx.console._note_status(ctx.status)  # validate="sync": an in-launch exchange that gave up raises here (deferred: check_parameters())
         return g_tracks, g_tp, g_fx, g_mp, None, None, None, None, None
 
 

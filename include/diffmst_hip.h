@@ -59,7 +59,17 @@ extern "C" {
  *        1 + 52 + k      master-bus parameter index k           (:424-460)
  * the smallest code wins (atomic max of 1000-code), which is the reference's dictionary
  * iteration order (:79-97).  *status is only ever raised (atomic max): the caller zeroes it once and may let
- * several calls accumulate into it before reading (deferred validation). */
+ * several calls accumulate into it before reading (deferred validation).
+ *
+ * MST_STATUS_EXCHANGE_TIMEOUT (2000, above every range code): a kernel of the call gave up waiting for a value that another
+ * workgroup of the SAME launch publishes (the block / tile aggregates of the recurrences are exchanged inside the run launches
+ * instead of by a launch of their own).  The outputs of that call are poisoned (NaN) and must not be used; the Python binding
+ * raises RuntimeError at its next status read (validate="sync": right after the forward; "deferred": check_parameters()).
+ * Forward progress of those waits rests on ONE assumption about the hardware, which HIP does not promise: the workgroups of a launch
+ * are dispatched in ascending order of their linear id (observed on gfx950, MI355X_MICROARCH.md) - a waiting workgroup only ever waits
+ * for workgroups with lower ids, which are therefore resident or finished.  Every wait is bounded (MST_GRAN_SPINS polls), so a
+ * platform that breaks the assumption produces this status, not a hang. */
+#define MST_STATUS_EXCHANGE_TIMEOUT 2000
 
 typedef struct mst_console_desc {
     int32_t bs;
@@ -131,8 +141,10 @@ int mst_console_forward(const mst_console_desc* d, const float* tracks, const fl
 int mst_console_backward(const mst_console_desc* d, const float* tracks, const float* track_params,
                          const float* fx_bus_params, const float* master_bus_params, const mst_console_fx* fx,
                          const float* grad_mix, const float* grad_mixed_tracks, float* grad_track_params,
-                         float* grad_fx_params, float* grad_master_params, float* grad_tracks, void* workspace,
-                         size_t workspace_bytes, void* stream);
+                         float* grad_fx_params, float* grad_master_params, float* grad_tracks, int32_t* status,
+                         void* workspace, size_t workspace_bytes, void* stream);
+/* status (ABI v7; may be null): the forward's status word, raised to MST_STATUS_EXCHANGE_TIMEOUT by a backward launch whose
+ * in-launch exchange gave up - the gradients of that call are poisoned. */
 
 /* The part of the backward that depends only on what forward saved (the all-pole carry scan of the coefficient-gradient
  * pass, 15 us at 64 x 262144): a caller may enqueue it on ANOTHER stream once forward has finished there, where it overlaps

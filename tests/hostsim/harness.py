@@ -78,10 +78,10 @@ def console(param_ranges, tracks, tp, fp, mp, flags, grad_mix=None, want_mixed=T
         gmx = None if grad_mixed is None else grad_mixed.contiguous().float()
         gfp = torch.full((bs, 25), float("nan")) if fx is not None else None
         rc = L.mst_console_backward(C.byref(d), _cabi.ptr(tracks), _cabi.ptr(tp), _cabi.ptr(fp), _cabi.ptr(mp), fxp, _cabi.ptr(gm),
-                                    _cabi.ptr(gmx), _cabi.ptr(gtp), _cabi.ptr(gfp), _cabi.ptr(gmp), _cabi.ptr(gtr), _cabi.ptr(ws),
-                                    nbytes, None)
+                                    _cabi.ptr(gmx), _cabi.ptr(gtp), _cabi.ptr(gfp), _cabi.ptr(gmp), _cabi.ptr(gtr), _cabi.ptr(status),
+                                    _cabi.ptr(ws), nbytes, None)
         assert rc == 0, rc
-        out.update(grad_tp=gtp, grad_mp=gmp, grad_tracks=gtr, grad_fp=gfp)
+        out.update(grad_tp=gtp, grad_mp=gmp, grad_tracks=gtr, grad_fp=gfp, status=int(status.item()))
     return out
 
 
