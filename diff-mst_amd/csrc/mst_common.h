@@ -212,8 +212,9 @@ __device__ __forceinline__ float wave_sum(float v) {
 // granules are zeroed by an EARLIER kernel of the same call (k_prep: every granule array; k_prep_bwd re-arms the backward's).
 // No serial chain: a workgroup waits only for values that are computed from saved signals, never for another workgroup's wait.
 // Deadlock freedom: block b waits for blocks that were dispatched before it (the grid is walked so that predecessors have lower
-// workgroup ids; an XCD hands out its share of the ids in order), and every spin is bounded (MST_GRAN_SPINS: the wait gives up and
-// returns NaN, which poisons the outputs that depend on it - the launch ends and the failure is visible).
+// workgroup ids; an XCD hands out its share of the ids in order), and every spin is bounded (MST_GRAN_SPINS: the wait gives up,
+// returns NaN - which poisons the outputs that depend on it - and raises kStatusExchangeTimeout in the call's status word: the launch
+// ends and the host side turns the status into an error, include/diffmst_hip.h).
 typedef unsigned long long gran_t;
 #ifndef MST_GRAN_SPINS
 #define MST_GRAN_SPINS (1 << 22)
@@ -227,18 +228,31 @@ typedef unsigned long long gran_t;
 #ifndef MST_GRAN_NEAR
 #define MST_GRAN_NEAR 1
 #endif
+// Status code a kernel raises (atomic max into the call's status word) when a bounded wait gives up: the values the launch wrote are
+// poisoned (NaN) and the host side turns the code into an error (diffmst_hip/_desc.py: status_to_error) - larger than every
+// range-check code (1000 - index - 1), so it survives the max.
+constexpr int kStatusExchangeTimeout = 2000;
+__device__ __forceinline__ void gran_give_up(int32_t* status) {
+    if (status) atomicMax(status, kStatusExchangeTimeout);
+}
 __device__ __forceinline__ gran_t gran_load(const gran_t* g) { return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // g: the FAR copies (rows x nblk); the NEAR copies follow `near_off` granules later (0: none)
 __device__ __forceinline__ void gran_publish(gran_t* g, int64_t near_off, float v) {
+#ifdef MST_GRAN_DROP_PUBLISH  // test build only (tests/test_exchange_timeout_gpu.py): nothing is ever published, every wait gives up
+    return;
+#endif
     const gran_t x = ((gran_t)1 << 32) | (gran_t)(unsigned)__float_as_int(v);
     if (MST_GRAN_NEAR && near_off) __hip_atomic_store(g + near_off, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     __hip_atomic_store(g, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ float gran_wait(const gran_t* g, int64_t near_off) {
+__device__ __forceinline__ float gran_wait(const gran_t* g, int64_t near_off, int32_t* status = nullptr) {
     const bool near = MST_GRAN_NEAR && near_off;
     gran_t x = gran_load(near ? g + near_off : g);
     for (int spins = 0; (x >> 32) != 1; ++spins) {
-        if (spins >= MST_GRAN_SPINS) return __int_as_float(0x7fc00000);
+        if (spins >= MST_GRAN_SPINS) {
+            gran_give_up(status);
+            return __int_as_float(0x7fc00000);
+        }
         if (near && !(spins & 1)) x = gran_load(g);  // alternate: far, near, far, ...
         else {
             __builtin_amdgcn_s_sleep(1);
@@ -246,13 +260,6 @@ __device__ __forceinline__ float gran_wait(const gran_t* g, int64_t near_off) {
         }
     }
     return __int_as_float((int)(unsigned)x);
-}
-// Status code a kernel raises (atomic max into the call's status word) when a bounded wait gives up: the values the launch wrote are
-// poisoned (NaN) and the host side turns the code into an error (diffmst_hip/_desc.py: status_to_error) - larger than every
-// range-check code (1000 - index - 1), so it survives the max.
-constexpr int kStatusExchangeTimeout = 2000;
-__device__ __forceinline__ void gran_give_up(int32_t* status) {
-    if (status) atomicMax(status, kStatusExchangeTimeout);
 }
 // the same exchange for a small VECTOR (the 12-state aggregate of an EQ tile): NV consecutive granules.  Lane `src_lane` holds
 // v[0 .. NV); lanes 0 .. NV-1 store one granule each (one store instruction per copy).

@@ -139,17 +139,18 @@ __device__ __forceinline__ gran_t carry_peek(const gran_t* __restrict__ agg, int
     return (j >= 0 && j < nblk) ? gran_load(agg + j + (MST_GRAN_NEAR ? near_off : 0)) : 0ull;
 }
 template <bool REV>
-__device__ __forceinline__ float block_carry_g(const gran_t* __restrict__ agg, int64_t near_off, gran_t peek, int blk, int nblk, float log2a, float* lds, int tid) {
+__device__ __forceinline__ float block_carry_g(const gran_t* __restrict__ agg, int64_t near_off, gran_t peek, int blk, int nblk, float log2a, float* lds, int tid,
+                                               int32_t* status = nullptr) {
     float acc = 0.0f;
     bool first = true;
     if (REV) {
         for (int j = blk + 1 + tid; j < nblk; j += kWG, first = false) {
-            const float v = (first && (peek >> 32) == 1) ? __int_as_float((int)(unsigned)peek) : gran_wait(agg + j, near_off);
+            const float v = (first && (peek >> 32) == 1) ? __int_as_float((int)(unsigned)peek) : gran_wait(agg + j, near_off, status);
             acc += __builtin_amdgcn_exp2f((float)(j - blk - 1) * (float)kWG * log2a) * v;
         }
     } else {
         for (int j = blk - 1 - tid; j >= 0; j -= kWG, first = false) {
-            const float v = (first && (peek >> 32) == 1) ? __int_as_float((int)(unsigned)peek) : gran_wait(agg + j, near_off);
+            const float v = (first && (peek >> 32) == 1) ? __int_as_float((int)(unsigned)peek) : gran_wait(agg + j, near_off, status);
             acc += __builtin_amdgcn_exp2f((float)(blk - 1 - j) * (float)kWG * log2a) * v;
         }
     }
@@ -342,7 +343,7 @@ __device__ __forceinline__ void apply_master_body(const MasterApplyArgs& a, int 
         }
         LD8S<FAST>(v0, i0 - a.lookahead, a.n, yl);  // requested before the wait for the other blocks
         LD8S<FAST>(v1, i0 - a.lookahead, a.n, yr);
-        const float S = gr ? block_carry_g<false>(gr, a.gran_near, carry_peek<false>(gr, a.gran_near, blk, gridDim.x, threadIdx.x), blk, gridDim.x, l2a, lds, threadIdx.x)
+        const float S = gr ? block_carry_g<false>(gr, a.gran_near, carry_peek<false>(gr, a.gran_near, blk, gridDim.x, threadIdx.x), blk, gridDim.x, l2a, lds, threadIdx.x, a.status)
                            : block_carry<false>(a.s0 + (int64_t)b * gridDim.x, blk, gridDim.x, l2a, lds, threadIdx.x);
         float s = block_enter<false>(z, ac, l2a, S, lds, threadIdx.x);
 #pragma unroll
@@ -779,7 +780,7 @@ __device__ __forceinline__ void comp_bwd_run_body(const CompBwdArgs& a, int row,
             db[i] = zp.y * cE;
             if (MST_CBR_SCHED & 2) __builtin_amdgcn_sched_barrier(0);
         }
-        const float S = gq ? block_carry_g<true>(gq, a.gran_near, peek, blk, gridDim.x, l2a, red[0], tid)
+        const float S = gq ? block_carry_g<true>(gq, a.gran_near, peek, blk, gridDim.x, l2a, red[0], tid, a.status)
                            : block_carry<true>(a.s0 + (int64_t)row * gridDim.x, blk, gridDim.x, l2a, red[0], tid);
         const float Q = fmaf(W, S, Q0);
 #pragma unroll
@@ -836,7 +837,7 @@ __device__ __forceinline__ void comp_bwd_run_body(const CompBwdArgs& a, int row,
                 }
             }
         }
-        const float S = gq ? block_carry_g<true>(gq, a.gran_near, peek, blk, gridDim.x, l2a, red[0], tid)
+        const float S = gq ? block_carry_g<true>(gq, a.gran_near, peek, blk, gridDim.x, l2a, red[0], tid, a.status)
                            : block_carry<true>(a.s0 + (int64_t)row * gridDim.x, blk, gridDim.x, l2a, red[0], tid);
         float q = block_enter<true>(zq, ac, l2a, S, red[0], tid);
 #pragma unroll

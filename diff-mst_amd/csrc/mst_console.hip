@@ -172,7 +172,7 @@ extern "C" int mst_console_forward(const mst_console_desc* d, const float* track
             launch_cascade(EQ_FWD, true, ws + L.bus, Ns, ws + L.v_m, Ns, ws + L.rc_m, 0, sE_m, nullptr, L.ncE_pad, n, 2 * L.bs, stream, p1F_m, L.ntE, ws + L.aggF_m, zP_m);
         if (!fuse_comp_zs()) launch_comp_zs(2, ws + L.v_m, Ns, ws + L.rc_m, ws + L.zS_m, L.ncC_pad, n, L.bs, stream);
         MasterApplyArgs ma{ws + L.v_m, Ns, ws + L.rc_m, ws + L.zS_m, save ? ws + L.gs_m : nullptr, mix, n,
-                           L.ncC_pad, d->master_lookahead, 1, n, aligned, fuse_comp_zs() ? (gran_t*)(ws + L.gran_f) : nullptr, (int64_t)L.bs * L.nblkC};
+                           L.ncC_pad, d->master_lookahead, 1, n, aligned, fuse_comp_zs() ? (gran_t*)(ws + L.gran_f) : nullptr, (int64_t)L.bs * L.nblkC, status};
         launch_apply_master(ma, L.bs, stream);
     } else if (o_on) {
         MasterApplyArgs ma{ws + L.bus, Ns, ws + L.rc_m, nullptr, nullptr, mix, n, L.ncC_pad, 0, 0, n, aligned};
@@ -249,6 +249,7 @@ extern "C" int mst_console_backward(const mst_console_desc* d, const float* trac
         if (fuse_comp_zs()) {
             ca.gran = (gran_t*)(ws + L.gran_b) + 2 * (int64_t)L.R * L.nblkC;
             ca.gran_near = (int64_t)L.bs * L.nblkC;
+            ca.status = status;
         }
         else launch_comp_bwd(true, false, ca, L.bs, stream);
         ca.s0 = ws + L.zQ_m;
@@ -300,6 +301,7 @@ extern "C" int mst_console_backward(const mst_console_desc* d, const float* trac
             if (fuse_comp_zs()) {
                 ca.gran = (gran_t*)(ws + L.gran_b);
                 ca.gran_near = (int64_t)L.R * L.nblkC;
+                ca.status = status;
             }
             else launch_comp_bwd(false, false, ca, L.R, stream);
             ca.s0 = ws + L.zQ_t;

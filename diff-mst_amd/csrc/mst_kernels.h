@@ -158,6 +158,7 @@ struct MasterApplyArgs {
     int aligned;
     gran_t* gran;        // (bs, nblk) zeroed granules (+ their near copies gran_near granules later): the smoother's block aggregates are exchanged inside this launch (no k_comp_zs); null = read s0
     int64_t gran_near;
+    int32_t* status;     // raised to kStatusExchangeTimeout when an exchange wait gives up (may be null)
 };
 // One argument block for tracks (NCH = 1) and master (NCH = 2).
 struct CompBwdArgs {
@@ -189,6 +190,7 @@ struct CompBwdArgs {
     int cg2_rows;         // 0: none; signal row of extra row j = main rows + j (all-pole states, partial sums)
     gran_t* gran;         // (rows, nblk) zeroed granules (+ near copies gran_near granules later): the run pass publishes / awaits the block aggregates itself (no zs launch); null = read s0
     int64_t gran_near;
+    int32_t* status;      // raised to kStatusExchangeTimeout when an exchange wait gives up (may be null)
 };
 void launch_comp_zs(int nch, const float* u, int64_t stride, const float* rc, float* zs, int nc_pad, int64_t n, int rows,
                     hipStream_t stream);
