@@ -465,11 +465,32 @@ __global__ __launch_bounds__(FftPlan<N>::LG, (N == 8192 ? MST_STFT2_W8192_BWD : 
         constexpr int M = S::M;                                    // 4096
         // window of samples 2m, 2m + 1 (m = lane + 512 t): 0.5 - 0.5 Re(W_N^(2 lane + c) W_8^t)
         const float2 we = twg[2 * lane], wo = twg[2 * lane + 1];
+#ifndef MST_STFT2_BWD8192_PREFETCH
+#define MST_STFT2_BWD8192_PREFETCH 0  // (measured neutral: 49.2 vs 49.5 us) the next frame's 16 sample pairs are requested before the current frame is transformed: 32 more live
+                                      // registers, free here - the kernel sits at 184 of the 256 that two waves per SIMD allow
+#endif
+        constexpr bool PREF8 = MST_STFT2_BWD8192_PREFETCH;
+        float2 nxt8[PREF8 ? 16 : 1];
+        if (PREF8) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) nxt8[t] = fetch(F0, t);
+        }
         for (int f = F0; f < F1; ++f) {
             int li = lane;
             asm volatile("" : "+v"(li));
             const float2 wlf = twg[li];
-            L::transform([&](int t) { return fetch(f, t); }, win, buf, tw, wlf, lane);
+            if (PREF8) {
+                float2 cur8[16];
+#pragma unroll
+                for (int t = 0; t < 16; ++t) cur8[t] = nxt8[t];
+                if (f + 1 < F1) {
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) nxt8[t] = fetch(f + 1, t);
+                }
+                L::transform([&](int t) { return cur8[t]; }, win, buf, tw, wlf, lane);
+            } else {
+                L::transform([&](int t) { return fetch(f, t); }, win, buf, tw, wlf, lane);
+            }
             // Pair (k, M - k) of the half-size inverse reads the 8192-point bins k, M - k, M + k, N - k: all of k's parity, i.e.
             // all in ONE of the two spectrum buffers (even bins in buf[0], odd in buf[1]).  The odd pairs go first and wait in
             // registers (2 per lane); once every lane has read its odd bins buf[1] is free, and the even pairs (which read

@@ -165,7 +165,7 @@ class _ConsoleFunction(torch.autograd.Function):
             ws.record_stream(aux)
         if need_grad:
             ctx.desc, ctx.nbytes, ctx.dev = desc, nbytes, dev
-            ctx.status, ctx.console = status, console
+            ctx.status = status
             ctx.want_mixed = want_mixed
             ctx.fx_on = bool(flags["use_fx_bus"])
             # the backward needs the engine tables only: the filtered noise and the spectra are already in the workspace
@@ -207,7 +207,8 @@ class _ConsoleFunction(torch.autograd.Function):
                 ctx.nbytes, _hip.current_stream_ptr(dev),
             )
         _hip.check(rc, "mst_console_backward")
-        ctx.console._note_status(ctx.status)  # validate="sync": an in-launch exchange that gave up raises here (deferred: check_parameters())
+        # no readback here: a backward whose in-launch exchange gave up has raised the (sticky) status word - the next forward's check
+        # (validate="sync") or check_parameters() raises; a host sync inside every backward would stall the autograd thread
         return g_tracks, g_tp, g_fx, g_mp, None, None, None, None, None
 
 

@@ -47,7 +47,7 @@ try:
 except RuntimeError as e:
     print("DEFERRED RuntimeError", "timed out" in str(e))
 c.check_parameters()  # cleared: no second raise
-# the backward of a poisoned forward reports through the same word (its own exchanges give up as well)
+# the backward reports through the same (sticky) word: its own exchanges give up as well; read at the next check
 mix.sum().backward()
 torch.cuda.synchronize()
 try:
