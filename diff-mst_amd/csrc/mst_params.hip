@@ -349,6 +349,7 @@ __global__ __launch_bounds__(320) void k_prep(PrepArgs a) {
         float* pw1 = grp == 0 ? (is_master ? a.pow1F_m + (int64_t)mrow * kTri2 : a.pow1F_t + (int64_t)row * kTri2)
                               : (is_master ? a.pow1A_m + (int64_t)mrow * kTri2 : a.pow1A_t + (int64_t)row * kTri2);
         const int ei = e / 12, ec = e % 12, bk = ei >> 1, bj = ec >> 1, sub = (ei & 1) * 2 + (ec & 1);
+        constexpr int kPow1Full = 6;  // last power formed as a full matrix: M^(2^6) = the tile transition
         for (int j = 0; j < kPow1; ++j) {
             if (mat_lane) {
                 float* set = pw1 + (j / 6) * (kTri2 / 2);
@@ -365,15 +366,31 @@ __global__ __launch_bounds__(320) void k_prep(PrepArgs a) {
                 o[2] = Mm[(2 * k + 1) * 12 + 2 * k];
                 o[3] = Mm[(2 * k + 1) * 12 + 2 * k + 1];
             }
-            if (j + 1 < kPow1) {
-                if (mat_lane) mat12_mul(mats[grp][cur], mats[grp][cur], mats[grp][cur ^ 1], e);
-                __syncthreads();
-                cur ^= 1;
-            }
+            // Full 12x12 squarings only up to M^64 (j = 6), whose off-diagonal blocks the tile-level scan needs; of the five powers
+            // beyond it only the diagonal blocks are kept, and those are powers of M^64's own 2x2 diagonal blocks: formed below, by
+            // lanes that square a 2x2 block, instead of five more 12x12 products with their workgroup barriers (round 5: -2.5 us)
+            if (j == kPow1Full) break;
+            if (mat_lane) mat12_mul(mats[grp][cur], mats[grp][cur], mats[grp][cur ^ 1], e);
+            __syncthreads();
+            cur ^= 1;
         }
 #if MST_PREP_STOP == 3
         return;
 #endif
+        __syncthreads();  // the parked diagonal blocks of M^64
+        for (int item = tid; item < 12 * (kPow1 - 1 - kPow1Full); item += 320) {
+            const int nj = kPow1 - 1 - kPow1Full, blk = item / nj, jj = item % nj, g2 = blk / 6, k = blk % 6;
+            const double* d = dblk[1][g2][k];
+            double b0 = d[0], b1 = d[1], b2 = d[2], b3 = d[3];
+            for (int sq = 0; sq <= jj; ++sq) {  // the products of the 12x12 chain in its order: the k-th column pair is all that is non-zero
+                const double n0 = fma(b1, b2, b0 * b0), n1 = fma(b1, b3, b0 * b1), n2 = fma(b3, b2, b2 * b0), n3 = fma(b3, b3, b2 * b1);
+                b0 = n0; b1 = n1; b2 = n2; b3 = n3;
+            }
+            float* base = g2 == 0 ? (is_master ? a.pow1F_m + (int64_t)mrow * kTri2 : a.pow1F_t + (int64_t)row * kTri2)
+                                  : (is_master ? a.pow1A_m + (int64_t)mrow * kTri2 : a.pow1A_t + (int64_t)row * kTri2);
+            const int j = kPow1Full + 1 + jj;
+            *reinterpret_cast<float4*>(base + (j / 6) * (kTri2 / 2) + (6 * k + j % 6) * 4) = make_float4((float)b0, (float)b1, (float)b2, (float)b3);
+        }
         // Dp[k][q] = D_k^(q+1), q < 16 (the in-row fix-up of the scans): 24 (set, cascade, section) blocks x 16 powers, one
         // (block, power) per lane and pass, by binary exponentiation in fp64 (at most 7 products of 2x2 matrices)
         __syncthreads();
