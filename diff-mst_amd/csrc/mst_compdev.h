@@ -12,7 +12,10 @@ __device__ __forceinline__ CompK load_comp(const float* rc) {
     CompK k;
     k.thr = rc[RC_THR];
     k.kappa = rc[RC_KAPPA];
-    k.knee = rc[RC_KNEE];
+    // a zero knee (reachable through forward_mix_console / MST_NO_RANGE_CHECK, which apply denormalised values unchecked) is the hard-knee
+    // curve: kept finite as a knee of 1e-6 dB - the branch-free form below divides by the width (0 x inf = NaN for every sample),
+    // while the reference's torch.where form is finite everywhere but at d == 0
+    k.knee = fmaxf(rc[RC_KNEE], 1e-6f);
     k.hw = 0.5f * k.knee;
     k.invw = 1.0f / k.knee;
     k.inv2w = 0.5f * k.invw;

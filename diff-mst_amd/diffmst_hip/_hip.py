@@ -32,6 +32,10 @@ def lib() -> ctypes.CDLL:
 def current_stream_ptr(device) -> ctypes.c_void_p:
     import torch
 
+    raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)  # the raw handle without building a torch.cuda.Stream object (~10 us)
+    if raw is not None:
+        idx = device.index if getattr(device, "index", None) is not None else torch.cuda.current_device()
+        return ctypes.c_void_p(raw(idx))
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 

@@ -128,12 +128,23 @@ class _ConsoleFunction(torch.autograd.Function):
         word = _desc.flag_word(save_for_backward=need_grad, multipass_eq=console._multipass_eq, **flags)
         if denormalized:  # forward_mix_console: values arrive denormalised and are NOT range-checked (reference :186-314)
             word |= _cabi.NO_RANGE_CHECK
-        desc = _desc.make_desc(console.param_ranges, console.sample_rate, bs, n_tracks, n, row_stride, word,
-                               identity_ranges=denormalized, fx_ir_samples=console.fx_ir_samples,
-                               fx_bandpass_taps=console.fx_bandpass_taps)
-        nbytes = lib.mst_console_workspace_bytes(ctypes.byref(desc))
-        if nbytes == 0:
-            raise RuntimeError("mst_console_workspace_bytes rejected the configuration")
+        # the descriptor (78 range look-ups, ~15 us of host time) and its workspace size are rebuilt only when something they are made of
+        # changes; param_ranges is still READ on every call (a caller may edit it between calls, like the reference's) - as a fingerprint
+        key = (bs, n_tracks, n, row_stride, word, console.sample_rate, console.fx_ir_samples, console.fx_bandpass_taps,
+               tuple(v for d in console.param_ranges.values() for v in d.values()))
+        hit = console._desc_cache.get(key)
+        if hit is None:
+            desc = _desc.make_desc(console.param_ranges, console.sample_rate, bs, n_tracks, n, row_stride, word,
+                                   identity_ranges=denormalized, fx_ir_samples=console.fx_ir_samples,
+                                   fx_bandpass_taps=console.fx_bandpass_taps)
+            nbytes = lib.mst_console_workspace_bytes(ctypes.byref(desc))
+            if nbytes == 0:
+                raise RuntimeError("mst_console_workspace_bytes rejected the configuration")
+            if len(console._desc_cache) > 64:
+                console._desc_cache.clear()
+            console._desc_cache[key] = (desc, nbytes)
+        else:
+            desc, nbytes = hit
         dev = tracks.device
         fx, fx_keep = None, ()
         if flags["use_fx_bus"]:
@@ -304,6 +315,7 @@ class AdvancedMixConsole(torch.nn.Module):
         self._fx_cache = {}
         self._status = {}
         self._affine_cache = {}
+        self._desc_cache = {}
         self._multipass_eq = False  # test switch: EQ carries through the separate carry-scan kernel at any length
 
     # ------------------------------------------------------------------ validation
@@ -610,6 +622,10 @@ class TransformerController(torch.nn.Module):
         # are on the device and the stack is inside the kernels' limits, torch's layers otherwise; True = always (raises outside the
         # limits); False = never
         self.native = None if native is None else bool(native)
+        if self.graphed and native is None:
+            self.native = False  # graphed=True alone selects the graphed torch layers, as it did before `native` existed (advisor, round 4)
+        elif self.graphed and self.native:
+            raise ValueError("TransformerController: graphed=True captures torch's layers and native=True replaces them - pick one")
         object.__setattr__(self, "_graphs", {})  # shape key -> graphed callable (not a submodule: state_dict stays the reference's)
         self.embed_dim = embed_dim
         self.num_track_control_params = num_track_control_params

@@ -124,6 +124,21 @@ class _Cnn14Function(torch.autograd.Function):
         _hip.require_same_device(dev, *params, *(bn.running_mean for bn in bns), *(bn.running_var for bn in bns))
         n, frames, bins = spec.shape
         group, world = sync_group_of(module) if training else (None, 1)
+        if world > 1:
+            # the cross-rank statistics count world x n signals (torch's SyncBatchNorm exchanges the counts; these kernels assume them
+            # equal): checked ONCE per (group, n) - a collective of one integer per rank - instead of silently wrong statistics with
+            # drop_last=False or a variable track count (advisor, round 4)
+            seen = module.__dict__.setdefault("_sync_n_checked", set())
+            if (id(group), n) not in seen:
+                import torch.distributed as dist
+
+                counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+                dist.all_gather(counts, torch.tensor([n], dtype=torch.int64, device=dev), group=group)
+                got = [int(c.item()) for c in counts]
+                if any(c != n for c in got):
+                    raise RuntimeError(f"Cnn14 with SyncBatchNorm: every rank must feed the same number of signals per call (got {got}); "
+                                       "pad the batch or use drop_last=True")
+                seen.add((id(group), n))
         desc = _cabi.Cnn14Desc(n, frames, bins, module.fc.out_features, 0 if module.precision == "bf16" else 1, int(training),
                                float(module.conv_block1.bn1.eps), world)
         nbytes = lib.mst_cnn14_workspace_bytes(ctypes.byref(desc))

@@ -78,6 +78,16 @@ def assert_three_way(hip, r32, r64, key, tol32=None, slack=1e-4):
     assert h32 < (3 * r + slack if tol32 is None else tol32), (key, "hip-vs-ref32", h32, "hip-vs-f64", h64, "ref32-vs-f64", r)
 
 
+# rel(HIP gradient, the reference's fp32 autograd gradient) as measured at the end of round 4 (profiles/parity_r04.json)
+H32_R04 = {
+    ("console_basic_2x4x16384.npz", "grad_track_params"): 1.1e-7,
+    ("console_full_1x8x32768.npz", "grad_master_bus_params"): 3.2e-5, ("console_full_1x8x32768.npz", "grad_track_params"): 1.67e-3,
+    ("console_full_2x4x16384.npz", "grad_master_bus_params"): 1.9e-4, ("console_full_2x4x16384.npz", "grad_track_params"): 2.97e-3,
+    ("console_fullbox_1x2x131072.npz", "grad_master_bus_params"): 5.7e-5, ("console_fullbox_1x2x131072.npz", "grad_track_params"): 5.3e-5,
+    ("console_refmix_2x3x8192.npz", "grad_master_bus_params"): 2.3e-5, ("console_refmix_2x3x8192.npz", "grad_track_params"): 1.7e-5,
+}
+
+
 def parse_flags(arr):
     return {k: v == "True" for k, v in arr}
 
@@ -109,6 +119,12 @@ def test_console_golden(path, console, dev, record):
         h32, h64, r64 = rel(hip_g, t(key)), rel(hip_g, f64), rel(t(key), f64)
         rep[key] = (h32, h64, r64)
         assert h64 <= factor * r64 + 1e-4, (key, "hip-vs-ref32", h32, "hip-vs-f64", h64, "ref32-vs-f64", r64)
+        # ... and a direct regression bound on the distance to the reference's OWN fp32 gradient: 1.5 x the value measured in round 4
+        # (profiles/parity_r04.json) + 1e-5, so that a kernel change that stays inside the three-way bound but moves away from the
+        # reference's arithmetic is seen (advisor, round 4)
+        measured = H32_R04.get((os.path.basename(path), key))
+        if measured is not None:
+            assert h32 <= 1.5 * measured + 1e-5, (key, "hip-vs-ref32", h32, "round-4 value", measured)
     record(**rep)
     assert e_mix < 1e-4 and e_mixed < 1e-4
     if np.abs(g["grad_master_bus_params"]).max() == 0:

@@ -96,6 +96,18 @@ def test_forward_mix_console_round_trip_and_gradients(console, dev, record):
     cpu = lambda d: {e: {k: v.detach().cpu() for k, v in p.items()} for e, p in d.items()}
     ref_mixed, _ = oc.console_chain(tracks.cpu(), cpu(hot), cpu(mpd), 44100, **lin)
     assert rel(m_hot, ref_mixed) < 1e-6
+    # a denormalised knee of 0 dB (nothing checks the range here) is the hard-knee curve: finite, and equal to a vanishing soft knee
+    # (advisor, round 4: the branch-free static curve divides by the knee width)
+    hard, soft = leaf(tpd), leaf(tpd)
+    hard["compressor"]["knee_db"] = torch.zeros_like(hard["compressor"]["knee_db"]).requires_grad_(True)
+    soft["compressor"]["knee_db"] = torch.full_like(soft["compressor"]["knee_db"], 1e-4)
+    _, m_hard = console.forward_mix_console(tracks, hard, fpd, leaf(mpd), *[FULL[k] for k in FLAG_ORDER])
+    with torch.no_grad():
+        _, m_soft = console.forward_mix_console(tracks, soft, fpd, leaf(mpd), *[FULL[k] for k in FLAG_ORDER])
+    assert torch.isfinite(m_hard).all()
+    assert rel(m_hard, m_soft) < 1e-4, rel(m_hard, m_soft)
+    (m_hard * gmix).sum().backward()
+    assert all(torch.isfinite(v.grad).all() for v in hard["compressor"].values() if v.grad is not None)
     missing = leaf(tpd)
     del missing["compressor"]["knee_db"]
     with pytest.raises(KeyError):
