@@ -203,6 +203,26 @@ __device__ __forceinline__ float wave_sum(float v) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
+// the same for a double (its two halves travel as two DPP moves): fixed order, every lane gets lane 63's total
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add_f64(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, ROW_MASK, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xf, true);
+    return v + __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {
+    v = dpp_add_f64<0x111, 0xf>(v);
+    v = dpp_add_f64<0x112, 0xf>(v);
+    v = dpp_add_f64<0x114, 0xf>(v);
+    v = dpp_add_f64<0x118, 0xf>(v);
+    v = dpp_add_f64<0x142, 0xa>(v);
+    v = dpp_add_f64<0x143, 0xc>(v);
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), 63), hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+    return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
+}
+
 // ---- block aggregates handed from workgroup to workgroup INSIDE a launch (round 4) --------------------------------------------
 // A zero-state pass used to be its own launch: every workgroup published the aggregate of its block and the run launch read the
 // aggregates of the blocks before it.  The aggregate of block b does not depend on any other block, so the run kernel can publish

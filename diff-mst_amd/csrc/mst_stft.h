@@ -51,9 +51,9 @@ __device__ __forceinline__ void mrstft_rowsum(const LossArgs& a, int row, int re
         for (int u = 0; u < 4; ++u)
             if (g0 + 64 * u < ng) { s[0] += v[u].x; s[1] += v[u].y; s[2] += v[u].z; s[3] += v[u].w; }
     }
+    // (six DPP additions per value; the butterfly of __shfl_xor it replaces was 48 ds_bpermute round trips, ~2 us of k_mrstft_finish)
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-        for (int m = 32; m >= 1; m >>= 1) s[q] += __shfl_xor(s[q], m);
+    for (int q = 0; q < 4; ++q) s[q] = wave_sum_f64(s[q]);
     if (tid == 0) {
         float* o = a.sums + ((int64_t)res * a.rows + row) * 4;
         o[0] = (float)s[0]; o[1] = (float)s[1]; o[2] = (float)s[2]; o[3] = (float)s[3];
@@ -168,5 +168,9 @@ void launch_stft2_fwd(const StftArgs& a, int n_groups, int rows, hipStream_t str
 int stft2_bwd_groups(int n_fft, int n_frames, int rows);
 bool stft2_bwd_needs_zero(int n_fft);
 void launch_stft2_bwd(const StftArgs& a, int n_groups, int rows, hipStream_t stream);
+// the 512- and the 2048-point backward in one launch (mst_stft2.hip: k_stft2_bwd_512_2048); a512 is the first to touch its samples
+// after any seam-mode launch (accumulate / seam fields as for a stand-alone launch), a2048 adds to what a512 wrote (accumulate = 1)
+bool stft2_bwd_can_fuse(int64_t n_samples);
+void launch_stft2_bwd_512_2048(const StftArgs& a512, const StftArgs& a2048, int rows, hipStream_t stream);
 
 }  // namespace mst

@@ -898,8 +898,21 @@ extern "C" int mst_mrstft_backward(const mst_mrstft_desc* d, const float* pred, 
         if (zero && !handover) (void)hipMemsetAsync(grad_pred, 0, (size_t)d->rows * d->n_samples * sizeof(float), stream);
         bool written = zero;
         bool pending = handover;  // the parked seam halves still wait for a halo-mode launch
+#ifndef MST_STFT2_BWD_FUSE
+#define MST_STFT2_BWD_FUSE 1  // A/B switch: 0 = one backward launch per resolution
+#endif
+        // the 512- and the 2048-point resolution (halo mode both) in one launch: k_stft2_bwd_512_2048, mst_stft2.hip
+        int i512 = -1, i2048 = -1;
+        for (int i = 0; i < d->n_res; ++i) {
+            if (p.res[i].n_fft == 512) i512 = i512 < 0 ? i : -2;
+            if (p.res[i].n_fft == 2048) i2048 = i2048 < 0 ? i : -2;
+        }
+        const bool fuse2 = MST_STFT2_BWD_FUSE && i512 >= 0 && i2048 >= 0 && stft2_bwd_can_fuse(d->n_samples);
+        StftArgs held{};  // the 512-point launch's arguments, kept until the 2048-point resolution comes up
         for (int pass = 0; pass < 2; ++pass) {
-            for (int i = 0; i < d->n_res; ++i) {
+            for (int k = 0; k < d->n_res; ++k) {
+                // fused pair: the 512-point resolution is visited first whatever the caller's order (it owns the samples first)
+                const int i = (fuse2 && pass == 1) ? (k == (i512 < i2048 ? i512 : i2048) ? i512 : (k == (i512 < i2048 ? i2048 : i512) ? i2048 : k)) : k;
                 if (stft2_bwd_needs_zero(p.res[i].n_fft) != (pass == 0)) continue;
                 StftArgs a{};
                 a.pred = pred;
@@ -922,7 +935,13 @@ extern "C" int mst_mrstft_backward(const mst_mrstft_desc* d, const float* pred, 
                     a.seam_hop = sr.n_fft / 2;
                     if (pass == 1) pending = false;
                 }
-                launch_stft2_bwd(a, stft2_bwd_groups(a.r.n_fft, a.r.n_frames, d->rows), d->rows, stream);
+                if (fuse2 && i == i512) {
+                    held = a;  // launched together with the 2048-point resolution below
+                } else if (fuse2 && i == i2048) {
+                    launch_stft2_bwd_512_2048(held, a, d->rows, stream);
+                } else {
+                    launch_stft2_bwd(a, stft2_bwd_groups(a.r.n_fft, a.r.n_frames, d->rows), d->rows, stream);
+                }
                 written = true;
             }
         }

@@ -267,16 +267,15 @@ __device__ __forceinline__ float2 cotangent(const float2 (*buf)[FftShape<N>::SLO
 #define MST_STFT2_W2048_BWD 1  // min waves per SIMD asked of the 2048-point backward (A/B switch; uncapped it takes 144 registers)
 #endif
 constexpr int kStft2Bwd8192Slots = 256;  // resident workgroups of k_stft2_bwd<8192> on the 256 CUs
+// one strip of one row by a group of LG lanes (lane = 0 .. LG - 1); buf / hb: the group's LDS (hb: n_fft <= 2048 only)
 template <int N>
-__global__ __launch_bounds__(FftPlan<N>::LG, (N == 8192 ? MST_STFT2_W8192_BWD : (N == 2048 ? MST_STFT2_W2048_BWD : 1))) void k_stft2_bwd(StftArgs a) {
+__device__ __forceinline__ void stft2_bwd_body(const StftArgs& a, const int lane, const int strip, const int nstrips, const int row,
+                                               float2 (*buf)[FftShape<N>::SLOTS], float2* hb) {
     using S = FftShape<N>;
     using L = FrameLoader<N>;
     constexpr int LG = S::LG, H = N / 2;
     constexpr bool PAIR = S::NSEQ == 1, SEAMS = !PAIR;
     constexpr int K = PAIR ? 4 : 8;  // floats of one half frame per lane
-    __shared__ __attribute__((aligned(16))) float2 buf[S::NSEQ][S::SLOTS];
-    __shared__ __attribute__((aligned(16))) float2 hb[PAIR ? S::SLOTS : 1];  // conj(He_a + i He_b)
-    const int lane = threadIdx.x, row = blockIdx.y;
     const ResInfo r = a.r;
     const float2* twg = reinterpret_cast<const float2*>(a.tables + r.tw_off);
     LaneTw<N> tw;
@@ -292,10 +291,10 @@ __global__ __launch_bounds__(FftPlan<N>::LG, (N == 8192 ? MST_STFT2_W8192_BWD : 
     const int nrow = (int)a.n, B = nrow / H;  // hop blocks per row; frames 0 .. B
     int F0, F1;  // frames [F0, F1) of this strip
     if constexpr (SEAMS) {
-        strip_range(blockIdx.x, gridDim.x, B + 1, F0, F1);
+        strip_range(strip, nstrips, B + 1, F0, F1);
     } else {
         int b0, b1;
-        strip_range(blockIdx.x, gridDim.x, B, b0, b1);
+        strip_range(strip, nstrips, B, b0, b1);
         F0 = b0;
         F1 = b1 + 1;
     }
@@ -558,6 +557,37 @@ __global__ __launch_bounds__(FftPlan<N>::LG, (N == 8192 ? MST_STFT2_W8192_BWD : 
     // trailing second half of a strip that does not end the row: the seam shared with the next strip (halo mode: the next
     // strip recomputes this frame and owns the block)
     if (SEAMS && have_carry) seam(F1 - 1, carry, false);
+}
+
+template <int N>
+__global__ __launch_bounds__(FftPlan<N>::LG, (N == 8192 ? MST_STFT2_W8192_BWD : (N == 2048 ? MST_STFT2_W2048_BWD : 1))) void k_stft2_bwd(StftArgs a) {
+    using S = FftShape<N>;
+    __shared__ __attribute__((aligned(16))) float2 buf[S::NSEQ][S::SLOTS];
+    __shared__ __attribute__((aligned(16))) float2 hb[S::NSEQ == 1 ? S::SLOTS : 1];  // conj(He_a + i He_b)
+    stft2_bwd_body<N>(a, threadIdx.x, blockIdx.x, gridDim.x, blockIdx.y, buf, hb);
+}
+
+// Round 5: the 512- and the 2048-point backward in ONE launch.  Both walk strips of four hop blocks (L512 = L2048 = 4), and 2048-point
+// blocks are four times as long: the 4096 samples of 2048-point strip g are exactly the 512-point strips 4 g .. 4 g + 3.  A 256-lane
+// workgroup first runs those four 512-point strips, one per wave (no workgroup barrier in that part), then - behind one barrier that
+// also drains its stores - the 2048-point strip, which read-modify-writes the samples the same workgroup has just written: no second
+// launch, and the re-read comes out of this CU's own cache levels.  LDS and registers are the 2048-point kernel's (4 x 9 KB = 36 KB,
+// <= 128): four workgroups per CU as before.  Needs whole strips: (n / 1024) % 4 == 0 (stft2_bwd_can_fuse).
+__global__ __launch_bounds__(256, MST_STFT2_W2048_BWD) void k_stft2_bwd_512_2048(StftArgs a512, StftArgs a2048) {
+    using S5 = FftShape<512>;
+    using S2 = FftShape<2048>;
+    __shared__ __attribute__((aligned(16))) float2 lds[2 * S2::SLOTS];
+    static_assert(8 * S5::SLOTS <= 2 * S2::SLOTS, "four waves' 512-point buffers fit the 2048-point kernel's");
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    stft2_bwd_body<512>(a512, tid & 63, 4 * blockIdx.x + wave, 4 * gridDim.x, blockIdx.y,
+                        reinterpret_cast<float2(*)[S5::SLOTS]>(lds + 2 * wave * S5::SLOTS), lds + (2 * wave + 1) * S5::SLOTS);
+    __syncthreads();  // s_waitcnt vmcnt(0) + barrier: the four strips' stores have left before any lane of the workgroup reads them back
+    stft2_bwd_body<2048>(a2048, tid, blockIdx.x, gridDim.x, blockIdx.y, reinterpret_cast<float2(*)[S2::SLOTS]>(lds), lds + S2::SLOTS);
+}
+bool stft2_bwd_can_fuse(int64_t n) { return MST_STFT2_BWD_L512 == MST_STFT2_BWD_L2048 && n % 1024 == 0 && (n / 1024) % MST_STFT2_BWD_L2048 == 0; }
+void launch_stft2_bwd_512_2048(const StftArgs& a512, const StftArgs& a2048, int rows, hipStream_t stream) {
+    const int G = stft2_bwd_groups(2048, a2048.r.n_frames, rows);
+    hipLaunchKernelGGL(k_stft2_bwd_512_2048, dim3(G, rows), dim3(256), 0, stream, a512, a2048);
 }
 
 int stft2_bwd_groups(int n_fft, int n_frames, int rows) {

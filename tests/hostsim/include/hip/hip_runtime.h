@@ -249,5 +249,7 @@ static inline float __builtin_amdgcn_fmed3f(float a, float b, float c) { return 
 static inline float __builtin_amdgcn_sqrtf(float x) { return sqrtf(x); }
 static inline float __builtin_amdgcn_rsqf(float x) { return 1.0f / sqrtf(x); }
 static inline float __fdividef(float a, float b) { return a / b; }
+static inline long long __double_as_longlong(double d) { long long v; memcpy(&v, &d, 8); return v; }
+static inline double __longlong_as_double(long long v) { double d; memcpy(&d, &v, 8); return d; }
 static inline float __int_as_float(int v) { float f; memcpy(&f, &v, 4); return f; }
 static inline int __float_as_int(float f) { int v; memcpy(&v, &f, 4); return v; }
