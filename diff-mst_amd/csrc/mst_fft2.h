@@ -27,6 +27,12 @@
 #ifndef MST_FFT2_SWIZZLE
 #define MST_FFT2_SWIZZLE 0
 #endif
+#ifndef MST_FFT2_PAD64
+#define MST_FFT2_PAD64 0  // A/B switch: 1 = the load-conflict-free images described at FftShape::slot1 (round 5).  Measured and NOT taken: the
+                          // bench kernels are unchanged (k_stft3_fwd 72.4 vs 72.4 us, k_stft2_bwd_512_2048 71.7 vs 71.7) and the engine alone
+                          // (tools/ubench/wf512.hip, 4 / 8 waves per SIMD) runs 846 / 776 cycles per transform against 823 / 743 - the two-way
+                          // load conflicts the counter reports are not what these kernels wait for
+#endif
 
 namespace mst {
 
@@ -104,6 +110,7 @@ struct FftShape {
     // too and needs no padding - it wins for the 4096-point sequences (8192 forward 40.5 -> 37.3 us, backward 77 -> 72 us) and
     // loses below (2048 forward 27.9 -> 32.7 us, 512 backward 48.9 -> 58.4 us)
     static constexpr bool SWZ = MST_FFT2_SWIZZLE ? true : (M >= 4096);
+    static constexpr bool PAD64 = MST_FFT2_PAD64;
     static constexpr int SLOTS = SWZ ? M : M + M / 8;
     static constexpr int TWSCALE = N / M;          // W_M^e = W_N^(TWSCALE e)
     static_assert(M / 8 == LG, "one radix-8 butterfly per lane and sequence in every pass but the last");
@@ -111,8 +118,21 @@ struct FftShape {
     // of rows swap halves with row bit 3, so that every access pattern of the passes (a column of 16 rows, 8 + 8 lanes into
     // rows 8 apart, 16 / 32 consecutive elements) touches each bank once
     __device__ static __forceinline__ constexpr int slot(int i) {
-        return SWZ ? (i ^ (((i >> 4) & 7) | ((i >> 3) & 8))) : (i + (i >> 3));
+        return SWZ ? (i ^ (((i >> 4) & 7) | ((i >> 3) & 8))) : (PAD64 ? i + ((i >> 6) << 3) : i + (i >> 3));
     }
+    // Round 5 (PAD64, the padded maps only): the pad sits behind every 64 elements (8 slots) instead of behind every 8 (1 slot).  With
+    // one pad slot per 8 elements a run of 32 lane-consecutive elements - every LOAD of the passes, every bin read of the epilogues -
+    // spans 35-36 slots = more than the 64 banks a ds_read_b64 group covers: three lanes wrap onto busy banks and the group takes two
+    // LDS cycles instead of one (SQ_LDS_BANK_CONFLICT 35-40 % of the LDS cycles of the 512- / 2048-point kernels, rounds 2-4).  Runs of 32
+    // never cross a multiple of 64, so now they are 32 consecutive slots.  The stores stay conflict-free: Ns = 8 stores put eight
+    // consecutive lanes on eight consecutive slots and the next eight lanes 72 slots = 8 (mod 16) eight-byte bank units later; the first
+    // exchange, whose stores the one-slot pad was made for (lane j -> 8 j + t), gets its own image - slot1() below.
+    // slot1: the first exchange (pass-1 outputs 8 j + t, read back as j' + t' M / 8) as an 8 x M/8 matrix with rows of M/8 + 4 slots:
+    // stores are lane-linear inside row t, loads take row j' & 7, column (j' >> 3) + t' M / 64 - 32 lanes = 8 rows x 4 columns on
+    // 4 (j' & 7) + (j' >> 3) (mod 32) = 32 distinct bank units.  No address arithmetic beyond a per-lane base either way.
+    static constexpr int ROW1 = M / 8 + 4;
+    __device__ static __forceinline__ constexpr int slot1(int i) { return (SWZ || !PAD64) ? slot(i) : (i & 7) * ROW1 + (i >> 3); }
+    static_assert(SWZ || !PAD64 || 8 * ROW1 <= SLOTS, "the first exchange's image fits the buffer");
 };
 
 // ---- per-lane twiddles, held in registers for the lifetime of the kernel ------------------------------------------
@@ -185,13 +205,14 @@ __device__ __forceinline__ void fft_first(float2* v, float2* __restrict__ buf, i
     using S = FftShape<N>;
     butterfly<8>(v);
 #pragma unroll
-    for (int t = 0; t < 8; ++t) buf[S::slot(lane * 8 + t)] = v[t];
+    for (int t = 0; t < 8; ++t) buf[S::slot1(lane * 8 + t)] = v[t];
 }
-template <int N>
+// FIRST: the loads of pass 2, which read the first exchange's image (slot1)
+template <int N, bool FIRST = false>
 __device__ __forceinline__ void fft_load8(float2* v, const float2* __restrict__ buf, int lane) {
     using S = FftShape<N>;
 #pragma unroll
-    for (int t = 0; t < 8; ++t) v[t] = buf[S::slot(lane + t * (S::M / 8))];
+    for (int t = 0; t < 8; ++t) v[t] = buf[FIRST ? S::slot1(lane + t * (S::M / 8)) : S::slot(lane + t * (S::M / 8))];
 }
 // middle pass P (2 <= P < NP), Ns = 8^(P-1): twiddle + butterfly + store (after fft_load8 and a barrier)
 template <int N, int P>
@@ -225,10 +246,10 @@ __device__ __forceinline__ void fft_run(float2* v, float2 (*o)[FftShape<N>::RL],
     fft_first<N>(v, buf, lane);
     group_lds_sync<S::LG>();
 #ifdef MST_FFT2_FIRST_PASS_ONLY
-    for (int u = 0; u < S::NBL; ++u) for (int t = 0; t < S::RL; ++t) o[u][t] = buf[S::slot(lane + t)];
+    for (int u = 0; u < S::NBL; ++u) for (int t = 0; t < S::RL; ++t) o[u][t] = buf[S::slot1(lane + t)];
     return;
 #endif
-    fft_load8<N>(v, buf, lane);
+    fft_load8<N, true>(v, buf, lane);
     group_lds_sync<S::LG>();
     fft_mid_store<N, 2>(v, buf, tw, lane);
     group_lds_sync<S::LG>();
@@ -250,8 +271,8 @@ __device__ __forceinline__ void fft_run2(float2* va, float2* vb, float2 (*oa)[Ff
     fft_first<N>(va, bufa, lane);
     fft_first<N>(vb, bufb, lane);
     group_lds_sync<S::LG>();
-    fft_load8<N>(va, bufa, lane);
-    fft_load8<N>(vb, bufb, lane);
+    fft_load8<N, true>(va, bufa, lane);
+    fft_load8<N, true>(vb, bufb, lane);
     group_lds_sync<S::LG>();
     fft_mid_store<N, 2>(va, bufa, tw, lane);
     fft_mid_store<N, 2>(vb, bufb, tw, lane);
