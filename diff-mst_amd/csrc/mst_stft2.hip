@@ -6,6 +6,9 @@
 #ifndef MST_STFT2_ABLATE
 #define MST_STFT2_ABLATE 0  // timing diagnostics only (wrong results): 1 = no epilogue math, 2 = no global sample loads, 4 = first pass only
 #endif
+#ifndef MST_STFT2_HALF_REUSE
+#define MST_STFT2_HALF_REUSE 1  // prefetching kernels (n_fft <= 2048): a frame's first half is taken from the previous frame's registers, not re-fetched
+#endif
 #ifndef MST_STFT2_W8192
 #define MST_STFT2_W8192 4  // min waves per SIMD asked of the 8192 FORWARD kernel: 2 workgroups of 512 lanes per CU (128 VGPRs, no spill)
 #endif
@@ -128,8 +131,10 @@ __device__ __forceinline__ void stft2_fwd_body(const StftArgs& a, const int lane
 #pragma unroll
             for (int t = 0; t < PTS; ++t) cur[t] = nxt[t];
             if (f + 1 < f1) {
+                // hop = n_fft / 2: the next frame's first half IS this frame's second half, element for element in the same lane
+                // (the reflection at the row ends is a function of the sample index, so it agrees too): four new pairs per frame
 #pragma unroll
-                for (int t = 0; t < PTS; ++t) nxt[t] = fetch(f + 1, t);
+                for (int t = 0; t < PTS; ++t) nxt[t] = (MST_STFT2_HALF_REUSE && t < PTS / 2) ? cur[t + PTS / 2] : fetch(f + 1, t);
             }
             L::transform([&](int t) { return cur[t]; }, win, buf, tw, wl, lane);
         } else {
@@ -417,7 +422,7 @@ __device__ __forceinline__ void stft2_bwd_body(const StftArgs& a, const int lane
                     for (int t = 0; t < 8; ++t) cur[t] = nxt[t];
                     if (f + 1 < F1) {
 #pragma unroll
-                        for (int t = 0; t < 8; ++t) nxt[t] = fetch(f + 1, t);
+                        for (int t = 0; t < 8; ++t) nxt[t] = (MST_STFT2_HALF_REUSE && t < 4) ? cur[t + 4] : fetch(f + 1, t);  // see stft2_fwd_body
                     }
                 } else {
 #pragma unroll
