@@ -434,3 +434,23 @@ def test_fx_bus_golden(dev, golden_dir, record):
     assert rep["g_tp"] < 5e-3 and rep["g_fp"] < 5e-3 and rep["g_mp"] < 5e-3
     assert torch.equal(fpd["reverberation"]["mix"].cpu(), torch.ones(bs))
     assert torch.allclose(fpd["reverberation"]["band3_decay"].detach().cpu(), t("band3_decay"), rtol=1e-6)
+
+
+def test_param_ranges_edited_between_calls(dev):
+    """The console's descriptor is cached per call signature (round 5) - but `param_ranges` is still read on every call, like the
+    reference's denormalize_parameters does (mst/modules.py:79-97): editing a range between two calls must change the second mix."""
+    from mst.modules import AdvancedMixConsole
+
+    torch.manual_seed(5)
+    c = AdvancedMixConsole(44100)
+    tracks = (0.1 * torch.randn(1, 2, 16384)).to(dev)
+    tp, fp, mp = torch.rand(1, 2, 27, device=dev), torch.rand(1, 25, device=dev), torch.rand(1, 26, device=dev)
+    lin = dict(FULL, use_track_eq=False, use_track_compressor=False, use_master_bus=False, use_output_fader=False)
+    with torch.no_grad():
+        m0 = c(tracks, tp, fp, mp, **lin)[1].clone()
+        m1 = c(tracks, tp, fp, mp, **lin)[1].clone()
+        assert torch.equal(m0, m1)  # cached descriptor, same result
+        lo, hi = c.param_ranges["input_fader"]["gain_db"]
+        c.param_ranges["input_fader"]["gain_db"] = (lo + 6.0, hi + 6.0)  # every fader 6 dB up
+        m2 = c(tracks, tp, fp, mp, **lin)[1]
+    assert rel(m2, m0 * 10 ** (6.0 / 20.0)) < 1e-5
