@@ -36,6 +36,9 @@ struct LossArgs {
     int world;              // ranks that contributed to gtotals (1 when null)
 };
 // fold of one row's strip partials of one resolution (fp64, fixed order) by one wave; lane = 0..63
+// AGENT: the four sums are written as two 8-byte agent-scope (write-through) stores - the publishing half of the fence-free hand-over to
+// the last-arriving workgroup of k_mrstft_finish (mst_stft.hip); later LAUNCHES read them with plain loads either way
+template <bool AGENT = false>
 __device__ __forceinline__ void mrstft_rowsum(const LossArgs& a, int row, int res, int tid) {
     const float* p = a.part + a.part_off[res] + (int64_t)row * a.n_groups[res] * 4;
     double s[4] = {0, 0, 0, 0};
@@ -56,8 +59,26 @@ __device__ __forceinline__ void mrstft_rowsum(const LossArgs& a, int row, int re
     for (int q = 0; q < 4; ++q) s[q] = wave_sum_f64(s[q]);
     if (tid == 0) {
         float* o = a.sums + ((int64_t)res * a.rows + row) * 4;
-        o[0] = (float)s[0]; o[1] = (float)s[1]; o[2] = (float)s[2]; o[3] = (float)s[3];
+        if (AGENT) {
+            unsigned long long* o8 = reinterpret_cast<unsigned long long*>(o);
+            const unsigned long long lo = ((unsigned long long)(unsigned)__float_as_int((float)s[1]) << 32) | (unsigned)__float_as_int((float)s[0]);
+            const unsigned long long hi = ((unsigned long long)(unsigned)__float_as_int((float)s[3]) << 32) | (unsigned)__float_as_int((float)s[2]);
+            __hip_atomic_store(o8, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(o8 + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            o[0] = (float)s[0]; o[1] = (float)s[1]; o[2] = (float)s[2]; o[3] = (float)s[3];
+        }
     }
+}
+// one (resolution, row) entry of the row sums; AGENT: with 8-byte agent-scope loads (see mrstft_rowsum)
+template <bool AGENT>
+__device__ __forceinline__ float4 mrstft_load_sums(const float* sums, int64_t i) {
+    if (!AGENT) return *reinterpret_cast<const float4*>(sums + i * 4);
+    const unsigned long long* p = reinterpret_cast<const unsigned long long*>(sums + i * 4);
+    const unsigned long long lo = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long hi = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_float4(__int_as_float((int)(unsigned)lo), __int_as_float((int)(unsigned)(lo >> 32)), __int_as_float((int)(unsigned)hi),
+                       __int_as_float((int)(unsigned)(hi >> 32)));
 }
 __device__ __forceinline__ void write_coef(const LossArgs& a, int i, int res, double c_sc) {
     float* c = a.coef + (int64_t)i * 4;
@@ -69,7 +90,7 @@ __device__ __forceinline__ void write_coef(const LossArgs& a, int i, int res, do
 // loss scalar + per-row backward coefficients by ONE wave (tid = 0..63; BLOCK_SYNC: that wave is the whole workgroup and the
 // phases are separated by __syncthreads, otherwise by the wave's own LDS ordering).  rs / ratio / srow: LDS scratch; can_stage:
 // ratio and srow hold kMaxRes * 64 entries each.
-template <bool BLOCK_SYNC = true>
+template <bool BLOCK_SYNC = true, bool AGENT = false>
 __device__ __forceinline__ void mrstft_final_body(const LossArgs& a, int tid, double (*rs)[4], double* ratio, float4* srow, bool can_stage) {
     auto sync = [] {
         if (BLOCK_SYNC) __syncthreads();
@@ -80,7 +101,7 @@ __device__ __forceinline__ void mrstft_final_body(const LossArgs& a, int tid, do
     // reads LDS and keeps its fixed order (bitwise the same loss).
     const bool staged = can_stage && a.n_res * a.rows <= kMaxRes * 64;
     for (int i = tid; i < a.n_res * a.rows; i += 64) {
-        const float4 sm = *reinterpret_cast<const float4*>(a.sums + (int64_t)i * 4);
+        const float4 sm = mrstft_load_sums<AGENT>(a.sums, i);
         if (staged) srow[i] = sm;
         if (a.sc_per_example) {
             const double s0 = sqrt((double)sm.x), s1 = sqrt((double)sm.y);
@@ -96,7 +117,7 @@ __device__ __forceinline__ void mrstft_final_body(const LossArgs& a, int tid, do
         double tot[4] = {0, 0, 0, 0}, sc_acc = 0.0;
         for (int row = 0; row < a.rows; ++row) {
             const int i = res * a.rows + row;
-            const float4 sm = staged ? srow[i] : *reinterpret_cast<const float4*>(a.sums + (int64_t)i * 4);
+            const float4 sm = staged ? srow[i] : mrstft_load_sums<AGENT>(a.sums, i);
             tot[0] += (double)sm.x; tot[1] += (double)sm.y; tot[2] += (double)sm.z; tot[3] += (double)sm.w;
             if (a.sc_per_example) sc_acc += staged ? ratio[i] : sqrt((double)sm.x) / sqrt((double)sm.y);  // same roots, same quotient
         }

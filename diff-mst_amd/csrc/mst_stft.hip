@@ -591,7 +591,7 @@ __global__ void k_stft_tables(float* tables, ResInfo r, int win_length) {
 // (One merged 1024-lane launch measured 15.5-21.6 us against 5.0 + 6.7 us for these two: sixteen waves on one CU walking three
 // pairs each lose more to their serial fp64 chains than the second launch costs.)
 // stage 1: one 64-lane workgroup per (row, resolution) folds that row's strip partials (fp64, fixed order)
-__global__ __launch_bounds__(64) void k_mrstft_rowsums(LossArgs a) { mrstft_rowsum(a, blockIdx.x, blockIdx.y, threadIdx.x); }
+__global__ __launch_bounds__(64) void k_mrstft_rowsums(LossArgs a) { mrstft_rowsum<false>(a, blockIdx.x, blockIdx.y, threadIdx.x); }
 // stage 2: loss scalar + per-row backward coefficients (without dL/dloss, applied by k_scale_coef)
 __global__ __launch_bounds__(64) void k_mrstft_final(LossArgs a) {
     __shared__ double rs[kMaxRes][4];
@@ -608,6 +608,11 @@ __global__ __launch_bounds__(64) void k_mrstft_finish(LossArgs a, unsigned* tick
     __shared__ double ratio[kMaxRes * 64];
     __shared__ float4 srow[kMaxRes * 64];
     __shared__ unsigned mine;
+#ifndef MST_FINISH_FENCES
+#define MST_FINISH_FENCES 0  // 1: the textbook __threadfence() pair around the ticket (rounds 4: two L2 write-back / L1 invalidate
+                             // rounds, ~2 x 2-3.5 us of a 9.5 us launch)
+#endif
+#if MST_FINISH_FENCES
     mrstft_rowsum(a, blockIdx.x, blockIdx.y, threadIdx.x);
     __threadfence();
     if (threadIdx.x == 0) mine = atomicAdd(ticket, 1u);
@@ -615,6 +620,20 @@ __global__ __launch_bounds__(64) void k_mrstft_finish(LossArgs a, unsigned* tick
     if (mine != gridDim.x * gridDim.y - 1) return;
     __threadfence();
     mrstft_final_body(a, threadIdx.x, rs, ratio, srow, true);
+#else
+    // Round 5, no fence: the row sums travel as 8-byte agent-scope atomics on BOTH sides (write-through stores, L1-bypassing loads:
+    // one of the valid hand-over forms of MI355X_MICROARCH.md), the writer drains its stores before it takes the ticket.
+    mrstft_rowsum<true>(a, blockIdx.x, blockIdx.y, threadIdx.x);
+    if (threadIdx.x == 0) {
+#if defined(__clang__)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        mine = atomicAdd(ticket, 1u);
+    }
+    __syncthreads();
+    if (mine != gridDim.x * gridDim.y - 1) return;
+    mrstft_final_body<true, true>(a, threadIdx.x, rs, ratio, srow, true);
+#endif
 }
 // sharded evaluation only: this rank's totals per resolution, fixed order over the rows
 __global__ __launch_bounds__(64) void k_mrstft_totals(LossArgs a) {
