@@ -166,6 +166,9 @@ struct StftArgs {
     int seam_frames, seam_groups, seam_hop;
     // forward, first launch of a call: workgroup (0, 0) zeroes the ticket of k_mrstft_finish (null: nothing to arm)
     unsigned* tickets;
+    // round-2 kernels, round 5: the target's clamped magnitudes sqrt(max(|Y|^2, eps)), (rows, n_frames, n_fft / 2 + 1) - written by the
+    // forward, read by the backward, which then transforms the prediction alone (null in the forward: not kept)
+    float* ymag;
 };
 
 // the three forward transforms of the reference's resolutions in one launch (mst_stft2.hip: k_stft3_fwd).  a[0] / a[1] / a[2] =

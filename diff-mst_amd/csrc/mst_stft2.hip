@@ -152,6 +152,8 @@ __device__ __forceinline__ void stft2_fwd_body(const StftArgs& a, const int lane
             L::split(buf, k, X, Y);
             const float xm = mag_sqrt(fmaxf(X.x * X.x + X.y * X.y, a.eps));
             const float ym = mag_sqrt(fmaxf(Y.x * Y.x + Y.y * Y.y, a.eps));
+            // round 5: the target's magnitudes are what the backward needs of the target - kept, so that it transforms the prediction alone
+            if (a.ymag) a.ymag[((int64_t)row * r.n_frames + f) * (N / 2 + 1) + k] = ym;
             const float d = ym - xm;
             s1 = fmaf(d, d, s1);
             s2 = fmaf(ym, ym, s2);
@@ -245,6 +247,18 @@ __global__ __launch_bounds__(512, MST_STFT2_W8192) void k_stft3_fwd(Stft3Args p)
 // A[k] = H[k] + conj(H[M-k]), Bq[k] = (H[k] - conj(H[M-k])) conj(W_N^k), M = 4096 - the same 8 x 8 x 8 x 8 plan as the
 // even / odd halves of the forward transform.
 // =====================================================================================================================
+// cotangent of the prediction's bin X given the target's saved magnitude ym (= sqrt(clamp(|Y|^2, eps)), written by the forward)
+__device__ __forceinline__ float2 cotangent_xy(float2 X, float ym, float eps, const float* coef) {
+    const float p2 = X.x * X.x + X.y * X.y;
+    const float xm = mag_sqrt(fmaxf(p2, eps));
+    float g = coef[0] * (xm - ym);
+    const float dl = __builtin_amdgcn_logf(xm) - __builtin_amdgcn_logf(ym);
+    const float rx = mag_rcp(xm);
+    g += coef[1] * ((dl > 0.f) - (dl < 0.f)) * rx;
+    g += coef[2] * ((xm > ym) - (xm < ym));
+    const float s = (p2 >= eps) ? g * rx : 0.0f;  // through sqrt(clamp(|X|^2, eps)): zero below the clamp
+    return make_float2(s * X.x, s * X.y);
+}
 template <int N>
 __device__ __forceinline__ float2 cotangent(const float2 (*buf)[FftShape<N>::SLOTS], int k, float eps, const float* coef) {
     float2 X, Y;
@@ -399,7 +413,101 @@ __device__ __forceinline__ void stft2_bwd_body(const StftArgs& a, const int lane
         return make_float2(x[i], y[i]);
     };
 
-    if constexpr (PAIR) {
+#ifndef MST_STFT2_BWD_SAVED_MAG_8192
+#define MST_STFT2_BWD_SAVED_MAG_8192 0  // ... for the 8192-point resolution as well (the frame as a REAL transform through one 4096-point complex one).
+                                        // Built, -17 us more (8192-point backward 49 -> ~27 us: two sequences per frame instead of three, eight 8-byte loads,
+                                        // two workgroups per CU) - and NOT taken: X[k] = E[k] + W^k O[k] cancels two terms of the size of X[k + 4096],
+                                        // and on the near-zero bins of frame 0 the log-magnitude adjoint lands 5-15x further from float64 than the
+                                        // fp32 reference does on half of the seeds (tools/dbg_logmag2.py); the paired transform below does not
+                                        // (equal to rounds 2-4 on targets independent of the prediction)
+#endif
+#ifndef MST_STFT2_BWD_SAVED_MAG
+#define MST_STFT2_BWD_SAVED_MAG 1  // 0: rounds 2-4 - every frame's (prediction + i target) transform is recomputed in the backward
+#endif
+    // Round 5: the forward keeps |Y| (a.ymag: one float per bin and frame), which is all the cotangent needs of the target.  The
+    // backward then transforms the PREDICTION alone, and two real frames share one complex transform exactly as they share the
+    // inverse: z = w (x_a + i x_b), X_a / X_b by the Hermitian split.  Per pair of frames: one forward + one inverse transform instead
+    // of two + one; consecutive frames overlap by half, so a pair needs two new half frames of ONE signal (8 loads per lane, was 32).
+    if constexpr (PAIR && MST_STFT2_BWD_SAVED_MAG) {
+        constexpr int NB = N / 2 + 1, NK = (NB + LG - 1) / LG;  // bins per frame / cotangent-loop trips per lane
+        const float* ymrow = a.ymag + (int64_t)row * r.n_frames * NB;
+        auto fetchx = [&](int f, int t) { return x[reflect_i32(f * H - H + lane + LG * t, nrow)]; };
+        // Frame 0 of a row goes ALONE (its partner is an all-zero virtual frame -1): it is even about its centre (reflect padding under a
+        // symmetric window), so its spectrum is (-1)^k R[k] with R real - it crosses zero between bins, and those bins' 1 / |X| carries
+        // the rounding error of the whole log-magnitude adjoint.  Sharing a transform with frame 1 would put frame 1's round-off onto
+        // exactly those bins; what fp32 leaves in the imaginary part of frame 0's spectrum is error only and is dropped (the exact value).
+        const int fstart = F0 == 0 ? -1 : F0;
+        float xa1[4];  // first half of frame fa (elements lane + LG t, t < 4)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) xa1[t] = fstart >= 0 ? fetchx(fstart, t) : 0.0f;
+        for (int fa = fstart; fa < F1; fa += 2) {
+            const bool have_a = fa >= 0, have_b = fa + 1 < F1;
+            float xa2[4], xb2[4], ya[NK], yb[NK];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                xa2[t] = fetchx(fa + 1, t);                       // second half of frame fa = first half of frame fa + 1 (fa + 1 <= B always)
+                xb2[t] = have_b ? fetchx(fa + 1, t + 4) : 0.0f;   // = the first half of frame fa + 2
+            }
+#pragma unroll
+            for (int i = 0; i < NK; ++i) {  // requested here, used behind the transform
+                const int k = lane + LG * i;
+                ya[i] = (k < NB && have_a) ? ymrow[(int64_t)fa * NB + k] : 1.0f;
+                yb[i] = (k < NB && have_b) ? ymrow[(int64_t)(fa + 1) * NB + k] : 1.0f;
+            }
+            {
+                float2 v[8], o[S::NBL][S::RL];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    v[t] = make_float2(have_a ? win[t] * xa1[t] : 0.0f, have_b ? win[t] * xa2[t] : 0.0f);
+                    v[t + 4] = make_float2(have_a ? win[t + 4] * xa2[t] : 0.0f, win[t + 4] * xb2[t]);
+                }
+                fft_run<N>(v, o, buf[0], tw, lane);
+                group_lds_sync<LG>();
+#pragma unroll
+                for (int u = 0; u < S::NBL; ++u)
+#pragma unroll
+                    for (int t = 0; t < S::RL; ++t) buf[0][S::slot(lane + u * LG + t * (S::M / S::RL))] = o[u][t];
+                group_lds_sync<LG>();
+            }
+#pragma unroll
+            for (int i = 0; i < NK; ++i) {
+                const int k = lane + LG * i;
+                if (k < NB) {
+                    float2 Xa, Xb;
+                    L::split(buf, k, Xa, Xb);
+                    if (fa == -1) Xb.y = 0.0f;  // frame 0: real spectrum (above)
+                    const float2 Ga = have_a ? cotangent_xy(Xa, ya[i], a.eps, coef) : make_float2(0.f, 0.f);
+                    const float2 Gb = have_b ? cotangent_xy(Xb, yb[i], a.eps, coef) : make_float2(0.f, 0.f);
+                    const int sk = S::slot(k), sn = S::slot((N - k) & (N - 1));
+                    // conj(He_a + i He_b):  He[k] = G / 2, He[N - k] = conj(G) / 2; the real bins 0 and N / 2 carry G.x whole
+                    if (k == 0 || k == N / 2) {
+                        hb[sk] = make_float2(Ga.x, -Gb.x);
+                    } else {
+                        hb[sk] = make_float2(0.5f * (Ga.x - Gb.y), -0.5f * (Ga.y + Gb.x));
+                        hb[sn] = make_float2(0.5f * (Ga.x + Gb.y), 0.5f * (Ga.y - Gb.x));
+                    }
+                }
+            }
+            group_lds_sync<LG>();  // hb is complete, the spectrum has been consumed
+            float2 v[8], o[S::NBL][S::RL];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) v[t] = hb[S::slot(lane + LG * t)];
+            fft_run<N>(v, o, buf[0], tw, lane);
+            float fa1[4], fa2[4], fb1[4], fb2[4];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float2 R = S::RL == 8 ? o[0][q] : o[q & 1][q >> 1];  // element lane + LG q
+                const float ra = win[q] * R.x, rb = -win[q] * R.y;
+                if (q < 4) { fa1[q] = ra; fb1[q] = rb; }
+                else { fa2[q - 4] = ra; fb2[q - 4] = rb; }
+            }
+            group_lds_sync<LG>();  // the inverse has left buf[0]: emit() may use it as mirror scratch, the next transform as work space
+            if (have_a) emit(fa, fa1, fa2);
+            if (have_b) emit(fa + 1, fb1, fb2);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) xa1[t] = xb2[t];
+        }
+    } else if constexpr (PAIR) {
 #ifndef MST_STFT2_BWD2048_PREFETCH
 #define MST_STFT2_BWD2048_PREFETCH 0  // the 2048-point backward fetches each frame when it needs it: 16 registers less = 127, i.e. four
                                       // workgroups per CU instead of three, which is what lets 1024 five-frame strips run in one round
@@ -464,6 +572,107 @@ __device__ __forceinline__ void stft2_bwd_body(const StftArgs& a, const int lane
             group_lds_sync<LG>();  // the inverse has left buf[0]: emit() may use it as mirror scratch, the next transform as work space
             emit(fa, fa1, fa2);
             if (have_b) emit(fa + 1, fb1, fb2);
+        }
+    } else if constexpr (MST_STFT2_BWD_SAVED_MAG && MST_STFT2_BWD_SAVED_MAG_8192) {
+        // 8192, round 5: the prediction's frame alone, as a REAL transform - z[m] = x[2m] + i x[2m+1] through one 4096-point complex
+        // transform, X[k] = E[k] + W_N^k O[k], X[M - k] = conj(E[k] - W_N^k O[k]) with E / O the Hermitian split of Z at (k, M - k) - the
+        // exact mirror of the half-size inverse below.  Two 4096-point transforms per frame instead of three, eight 8-byte loads per lane
+        // instead of 32 four-byte ones, one sequence in flight instead of two (registers: two workgroups per CU).
+        constexpr int M = S::M, NB = N / 2 + 1;                    // 4096, 4097
+        const float2 we = twg[2 * lane], wo = twg[2 * lane + 1];
+        const float* ymrow = a.ymag + (int64_t)row * r.n_frames * NB;
+        // periodic Hann window of samples 2m, 2m + 1 (m = lane + 512 t): 0.5 - 0.5 Re(W_N^(2 lane + c) W_8^t)
+        auto hann2 = [&](int t, float& he, float& ho) {
+            const float2 w8 = t == 0 ? make_float2(1.f, 0.f) : (t == 1 ? make_float2(0.70710678118654752f, -0.70710678118654752f)
+                            : (t == 2 ? make_float2(0.f, -1.f) : (t == 3 ? make_float2(-0.70710678118654752f, -0.70710678118654752f)
+                            : (t == 4 ? make_float2(-1.f, 0.f) : (t == 5 ? make_float2(-0.70710678118654752f, 0.70710678118654752f)
+                            : (t == 6 ? make_float2(0.f, 1.f) : make_float2(0.70710678118654752f, 0.70710678118654752f)))))));
+            he = 0.5f - 0.5f * (we.x * w8.x - we.y * w8.y);
+            ho = 0.5f - 0.5f * (wo.x * w8.x - wo.y * w8.y);
+        };
+        for (int f = F0; f < F1; ++f) {
+            const int base = f * H - H;
+            const bool interior = base >= 0 && base + N <= nrow;  // no reflection in this frame (workgroup-uniform)
+            const float* ymf = ymrow + (int64_t)f * NB;
+            float2 v[8], o[1][8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int m2 = base + 2 * (lane + LG * t);
+                float2 p;
+                if (interior) p = *reinterpret_cast<const float2*>(x + m2);
+                else p = make_float2(x[reflect_i32(m2, nrow)], x[reflect_i32(m2 + 1, nrow)]);
+                float he, ho;
+                hann2(t, he, ho);
+                v[t] = make_float2(he * p.x, ho * p.y);
+            }
+            float yk[4], ymk[4];  // the target's magnitudes at this lane's bin pairs (k, M - k), requested ahead of the transform
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                yk[i] = ymf[lane + LG * i];
+                ymk[i] = ymf[M - (lane + LG * i)];
+            }
+            const float yh = ymf[M / 2];
+            fft_run<N>(v, o, buf[0], tw, lane);  // Z[lane + 512 t]
+            group_lds_sync<LG>();
+#pragma unroll
+            for (int t = 0; t < 8; ++t) buf[0][S::slot(lane + LG * t)] = o[0][t];
+            group_lds_sync<LG>();
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                if (i == 4 && lane != 0) break;
+                const int k = i == 4 ? M / 2 : lane + LG * i;
+                const float2 Zk = buf[0][S::slot(k)], Zm = buf[0][S::slot((M - k) & (M - 1))];
+                const float2 w = twg[k];  // W_N^k ; W_N^(M-k) = -conj(W_N^k)
+                float2 Xk, Xm;
+                if (k == 0) {  // bins 0 and N / 2: both real
+                    Xk = make_float2(Zk.x + Zk.y, 0.f);
+                    Xm = make_float2(Zk.x - Zk.y, 0.f);
+                } else {
+                    const float2 E = make_float2(0.5f * (Zk.x + Zm.x), 0.5f * (Zk.y - Zm.y));
+                    const float2 O = make_float2(0.5f * (Zk.y + Zm.y), -0.5f * (Zk.x - Zm.x));
+                    const float2 WO = cmul(w, O);
+                    Xk = cadd(E, WO);
+                    Xm = cconj(csub(E, WO));
+                }
+                // Frame 0 of a row is x[-p] = x[p] under a window that is symmetric about the same point: X[k] = (-1)^k R[k] with R REAL, which
+                // crosses zero between bins - the bins whose 1 / |X| carries the whole rounding error of the log-magnitude adjoint.  The
+                // imaginary part any fp32 transform leaves there is error only; it is dropped (the exact value), as the real-even structure says.
+                if (f == 0) { Xk.y = 0.0f; Xm.y = 0.0f; }
+                float2 Hk = cotangent_xy(Xk, i == 4 ? yh : yk[i < 4 ? i : 0], a.eps, coef);
+                float2 Hm = cotangent_xy(Xm, i == 4 ? yh : ymk[i < 4 ? i : 0], a.eps, coef);
+                float2 vk, vm;
+                if (k == 0) {
+                    vk = make_float2(Hk.x + Hm.x, -(Hk.x - Hm.x));  // V[0] = (H0 + HM) + i (H0 - HM), both real; conj
+                    vm = vk;
+                } else {
+                    Hk = make_float2(0.5f * Hk.x, 0.5f * Hk.y);
+                    Hm = make_float2(0.5f * Hm.x, 0.5f * Hm.y);
+                    const float2 Ak = make_float2(Hk.x + Hm.x, Hk.y - Hm.y);
+                    const float2 Bk = cmul(make_float2(Hk.x - Hm.x, Hk.y + Hm.y), make_float2(w.x, -w.y));
+                    vk = make_float2(Ak.x - Bk.y, -(Ak.y + Bk.x));
+                    const float2 Am = make_float2(Hm.x + Hk.x, Hm.y - Hk.y);
+                    const float2 Bm = cmul(make_float2(Hm.x - Hk.x, Hm.y + Hk.y), make_float2(-w.x, -w.y));
+                    vm = make_float2(Am.x - Bm.y, -(Am.y + Bm.x));
+                }
+                buf[1][S::slot(k)] = vk;
+                if (k != 0 && k != M / 2) buf[1][S::slot(M - k)] = vm;
+            }
+            group_lds_sync<LG>();
+#pragma unroll
+            for (int t = 0; t < 8; ++t) v[t] = buf[1][S::slot(lane + LG * t)];
+            // (the first pass of the inverse stores into buf[0], which nobody reads any more: no barrier needed here)
+            fft_run<N>(v, o, buf[0], tw, lane);  // = conj(y_even + i y_odd) at m = lane + 512 t
+            float h1[8], h2[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                float he, ho;
+                hann2(t, he, ho);
+                const float ye = he * o[0][t].x, yo = -ho * o[0][t].y;
+                if (t < 4) { h1[2 * t] = ye; h1[2 * t + 1] = yo; }
+                else { h2[2 * (t - 4)] = ye; h2[2 * (t - 4) + 1] = yo; }
+            }
+            group_lds_sync<LG>();
+            emit(f, h1, h2);
         }
     } else {
         constexpr int M = S::M;                                    // 4096
