@@ -413,6 +413,12 @@ __device__ __forceinline__ void stft2_bwd_body(const StftArgs& a, const int lane
         return make_float2(x[i], y[i]);
     };
 
+#ifndef MST_STFT2_BWD_PAIR_8192
+#define MST_STFT2_BWD_PAIR_8192 0  // ... and for the 8192-point resolution as pairs of frames in the full-size transform.  Built and NOT taken: 46.1 us against
+                                   // 49.6 (the two inverses of a pair run one after the other, each with its own set of barriers: 1.5 instead of 2 barrier
+                                   // sets per frame), and the interior log-magnitude adjoint moves from 0.8e-3 to 2.1e-3 from float64 (fp32 reference
+                                   // 0.8e-3; test_mrstft_log_magnitude_adjoint_away_from_the_clamp[2-65536] fails its 2x bound)
+#endif
 #ifndef MST_STFT2_BWD_SAVED_MAG_8192
 #define MST_STFT2_BWD_SAVED_MAG_8192 0  // ... for the 8192-point resolution as well (the frame as a REAL transform through one 4096-point complex one).
                                         // Built, -17 us more (8192-point backward 49 -> ~27 us: two sequences per frame instead of three, eight 8-byte loads,
@@ -673,6 +679,122 @@ __device__ __forceinline__ void stft2_bwd_body(const StftArgs& a, const int lane
             }
             group_lds_sync<LG>();
             emit(f, h1, h2);
+        }
+    } else if constexpr (MST_STFT2_BWD_SAVED_MAG && MST_STFT2_BWD_PAIR_8192) {
+        // 8192, round 5: two PREDICTION frames per 8192-point complex transform (as for 512 / 2048 above; the target is present through
+        // its saved magnitudes), each with its own half-size inverse: two 4096-point sequences per frame instead of three, 16 new
+        // 4-byte loads per pair of frames instead of 64.  The transform buffers are destroyed by the first inverse, so the second
+        // frame's inverse input waits in registers (28: the kernel runs at two waves per SIMD, where 256 are free).
+        constexpr int M = S::M, NB = N / 2 + 1;                    // 4096, 4097
+        const float2 we = twg[2 * lane], wo = twg[2 * lane + 1];
+        const float* ymrow = a.ymag + (int64_t)row * r.n_frames * NB;
+        auto fetchx = [&](int f, int t) { return x[reflect_i32(f * H - H + lane + LG * t, nrow)]; };
+        // V[k], V[M - k] of the half-size inverse from the cotangents at bins k and M - k (the algebra of the one-frame path below)
+        auto v_pair = [&](int k, float2 Hk, float2 Hm, float2& vk, float2& vm) {
+            if (k == 0) {
+                vk = make_float2(Hk.x + Hm.x, -(Hk.x - Hm.x));  // V[0] = (H0 + HM) + i (H0 - HM), both real; conj
+                vm = vk;
+                return;
+            }
+            Hk = make_float2(0.5f * Hk.x, 0.5f * Hk.y);
+            Hm = make_float2(0.5f * Hm.x, 0.5f * Hm.y);
+            const float2 w = twg[k];  // W_N^k ; W_N^(M-k) = -conj(W_N^k)
+            const float2 Ak = make_float2(Hk.x + Hm.x, Hk.y - Hm.y);
+            const float2 Bk = cmul(make_float2(Hk.x - Hm.x, Hk.y + Hm.y), make_float2(w.x, -w.y));
+            vk = make_float2(Ak.x - Bk.y, -(Ak.y + Bk.x));
+            const float2 Am = make_float2(Hm.x + Hk.x, Hm.y - Hk.y);
+            const float2 Bm = cmul(make_float2(Hm.x - Hk.x, Hm.y + Hk.y), make_float2(-w.x, -w.y));
+            vm = make_float2(Am.x - Bm.y, -(Am.y + Bm.x));
+        };
+        const int fstart = F0 == 0 ? -1 : F0;  // frame 0 alone (virtual all-zero partner -1): see the 512 / 2048 path
+        float xa1[8];  // first half of frame fa (elements lane + 512 t, t < 8)
+#pragma unroll
+        for (int t = 0; t < 8; ++t) xa1[t] = fstart >= 0 ? fetchx(fstart, t) : 0.0f;
+        for (int fa = fstart; fa < F1; fa += 2) {
+            const bool have_a = fa >= 0, have_b = fa + 1 < F1;
+            const float* ya = ymrow + (int64_t)(have_a ? fa : 0) * NB;
+            const float* yb = ymrow + (int64_t)(have_b ? fa + 1 : 0) * NB;
+            float xa2[8], xb2[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                xa2[t] = fetchx(fa + 1, t);                       // second half of frame fa = first half of frame fa + 1
+                xb2[t] = have_b ? fetchx(fa + 1, t + 8) : 0.0f;   // = the first half of frame fa + 2
+            }
+            int li = lane;
+            asm volatile("" : "+v"(li));
+            const float2 wlf = twg[li];
+            L::transform([&](int t) {
+                return make_float2(have_a ? (t < 8 ? xa1[t < 8 ? t : 0] : xa2[t >= 8 ? t - 8 : 0]) : 0.0f,
+                                   have_b ? (t < 8 ? xa2[t < 8 ? t : 0] : xb2[t >= 8 ? t - 8 : 0]) : 0.0f);
+            }, win, buf, tw, wlf, lane);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) xa1[t] = xb2[t];
+            // cotangents of both frames at the bin pair (k, M - k) -> the two frames' (V[k], V[M - k])
+            auto both = [&](int k, float2& ak, float2& am, float2& bk, float2& bm) {
+                float2 Xa, Xb, Ya, Yb;
+                L::split(buf, k, Xa, Xb);
+                L::split(buf, M - k, Ya, Yb);
+                if (fa == -1) { Xb.y = 0.0f; Yb.y = 0.0f; }  // frame 0: real spectrum
+                const float2 z0 = make_float2(0.f, 0.f);
+                v_pair(k, have_a ? cotangent_xy(Xa, ya[k], a.eps, coef) : z0, have_a ? cotangent_xy(Ya, ya[M - k], a.eps, coef) : z0, ak, am);
+                v_pair(k, have_b ? cotangent_xy(Xb, yb[k], a.eps, coef) : z0, have_b ? cotangent_xy(Yb, yb[M - k], a.eps, coef) : z0, bk, bm);
+            };
+            static_assert(M / 4 == 2 * LG, "two odd and two even pairs per lane (plus k = M/2 on lane 0)");
+            // odd pairs first (their bins live in buf[1], which then becomes the inverse's input buffer), both frames into registers
+            float2 Oak[2], Oam[2], Pbk[5], Pbm[5];  // Pb: frame b's pairs, parked until frame a's inverse has run (0, 1 odd; 2 .. 4 even)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) both(2 * (lane + i * LG) + 1, Oak[i], Oam[i], Pbk[i], Pbm[i]);
+            group_lds_sync<LG>();  // every lane has read its odd bins: buf[1] is free
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                Pbk[2 + i] = Pbm[2 + i] = make_float2(0.f, 0.f);
+                if (i == 2 && lane != 0) break;
+                const int k = i == 2 ? M / 2 : 2 * (lane + i * LG);
+                float2 vk, vm;
+                both(k, vk, vm, Pbk[2 + i], Pbm[2 + i]);
+                buf[1][S::slot(k)] = vk;
+                if (k != 0 && k != M / 2) buf[1][S::slot(M - k)] = vm;
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int k = 2 * (lane + i * LG) + 1;
+                buf[1][S::slot(k)] = Oak[i];
+                buf[1][S::slot(M - k)] = Oam[i];
+            }
+            // half-size inverse of what sits in buf[1] (passes in buf[0]), window, overlap-add
+            auto inverse_emit = [&](int f) {
+                group_lds_sync<LG>();
+                float2 v[8], o[1][8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) v[t] = buf[1][S::slot(lane + LG * t)];
+                fft_run<N>(v, o, buf[0], tw, lane);  // = conj(y_even + i y_odd) at m = lane + 512 t
+                float h1[8], h2[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const float2 w8 = t == 0 ? make_float2(1.f, 0.f) : (t == 1 ? make_float2(0.70710678118654752f, -0.70710678118654752f)
+                                    : (t == 2 ? make_float2(0.f, -1.f) : (t == 3 ? make_float2(-0.70710678118654752f, -0.70710678118654752f)
+                                    : (t == 4 ? make_float2(-1.f, 0.f) : (t == 5 ? make_float2(-0.70710678118654752f, 0.70710678118654752f)
+                                    : (t == 6 ? make_float2(0.f, 1.f) : make_float2(0.70710678118654752f, 0.70710678118654752f)))))));
+                    const float ce = we.x * w8.x - we.y * w8.y, co = wo.x * w8.x - wo.y * w8.y;  // cos(2 pi i / N), i = 2m, 2m + 1
+                    const float ye = (0.5f - 0.5f * ce) * o[0][t].x, yo = -(0.5f - 0.5f * co) * o[0][t].y;
+                    if (t < 4) { h1[2 * t] = ye; h1[2 * t + 1] = yo; }
+                    else { h2[2 * (t - 4)] = ye; h2[2 * (t - 4) + 1] = yo; }
+                }
+                group_lds_sync<LG>();
+                emit(f, h1, h2);
+            };
+            if (have_a) inverse_emit(fa);
+            if (have_b) {
+                group_lds_sync<LG>();  // (frame a's inverse input has been read by every lane)
+#pragma unroll
+                for (int i = 0; i < 5; ++i) {
+                    if (i == 4 && lane != 0) break;
+                    const int k = i < 2 ? 2 * (lane + i * LG) + 1 : (i == 4 ? M / 2 : 2 * (lane + (i - 2) * LG));
+                    buf[1][S::slot(k)] = Pbk[i];
+                    if (k != 0 && k != M / 2) buf[1][S::slot(M - k)] = Pbm[i];
+                }
+                inverse_emit(fa + 1);
+            }
         }
     } else {
         constexpr int M = S::M;                                    // 4096
