@@ -176,14 +176,16 @@ def cpu_baseline():
         model = "unknown"
     default_threads = torch.get_num_threads()
     legs = {}
-    # every host cpu (os.cpu_count()) AND one thread; 16 threads is the measured optimum of these batched
-    # 2^19-point FFTs on the EPYC hosts and is timed as well
-    for threads in (host, 16, 1):
+    # all cores AND one thread; 16 threads is the measured optimum of these batched 2^19-point FFTs on the EPYC
+    # hosts and is timed as well
+    # "all cores" = torch's own default thread count = the physical cores (128 on the 256-cpu EPYC hosts; the other 128 cpus are their SMT
+    # siblings, and on all 256 these 2^19-point FFT batches over-subscribe to 0.01 mixes/s = 100 s per run, measured in round 5)
+    allc = default_threads
+    for threads in (allc, 16, 1):
         if threads > host or threads in legs:
             continue
         torch.set_num_threads(threads)
-        # every-cpu leg: 2^19-point FFT batches over-subscribe badly (0.01 mixes/s on 256 threads): bounded to ~30 s, however few runs that is
-        med, k = _time_cpu(_oracle_step(T, N, "mrstft", FLAGS), 5, 30.0 if threads == host else 15.0, min_runs=1 if threads == host else 3)
+        med, k = _time_cpu(_oracle_step(T, N, "mrstft", FLAGS), 5, 30.0 if threads == allc else 15.0, min_runs=1 if threads == allc else 3)
         legs[threads] = (1.0 / med, k)
     best = max(legs, key=lambda t: legs[t][0])
     torch.set_num_threads(best)
@@ -197,8 +199,9 @@ def cpu_baseline():
         "sample": f"cfg #2: 1 mix (8 tracks x 262144) console fwd+bwd + MR-STFT, fp32, median of {legs[best][1]} runs after 2 warm-ups, "
                   f"best of the thread settings below on {host} host cpus ({model})",
         "by_threads": {str(t): {"value": v, "unit": "mixes/s", "runs": k} for t, (v, k) in legs.items()},
-        "all_cores": {"value": legs[host][0], "unit": "mixes/s", "cores": host, "runs": legs[host][1],
-                      "note": "torch.set_num_threads(os.cpu_count()), the setting BASELINE.md section 3 names"},
+        "all_cores": {"value": legs[allc][0], "unit": "mixes/s", "cores": allc, "runs": legs[allc][1],
+                      "note": "torch's default thread count = the physical cores of the host (BASELINE.md section 3 'all cores'; os.cpu_count() "
+                              "counts their SMT siblings too, where this workload over-subscribes to 0.01 mixes/s)"},
         "cfg3": {"value": 1.0 / med3, "unit": "mixes/s", "cores": best,
                  "sample": "1 mix of 16 tracks x 262144, console fwd+bwd + AudioFeatureLoss"},
         "cfg1": {"value": 1.0 / med1, "unit": "mixes/s", "cores": best,
