@@ -595,6 +595,11 @@ __device__ __forceinline__ void stft2_bwd_body(const StftArgs& a, const int lane
                             : (t == 6 ? make_float2(0.f, 1.f) : make_float2(0.70710678118654752f, 0.70710678118654752f)))))));
             he = 0.5f - 0.5f * (we.x * w8.x - we.y * w8.y);
             ho = 0.5f - 0.5f * (wo.x * w8.x - wo.y * w8.y);
+#ifdef MST_STFT2_REAL8192_TABLE_WINDOW  // experiment: the exactly rounded table values (torch.hann_window's) instead of the twiddle products
+            const float2 wt = *reinterpret_cast<const float2*>(a.tables + r.win_off + 2 * (lane + LG * t));
+            he = wt.x;
+            ho = wt.y;
+#endif
         };
         for (int f = F0; f < F1; ++f) {
             const int base = f * H - H;
