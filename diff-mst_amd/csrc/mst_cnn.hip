@@ -4,6 +4,11 @@
 // MIOpen in the reference) in forward, data-gradient and weight-gradient form.  gfx950 only:
 //   bf16 operands  v_mfma_f32_16x16x32_bf16  (8 bf16 of K per lane and operand, fp32 accumulate)      - the production path
 //   fp32 operands  v_mfma_f32_16x16x4_f32    (exact fp32 FMA chain at the vector rate)                - the parity path
+//   bf16x3         fp32 operands in memory and LDS, split on the way into the matrix pipe: x = hi + lo with hi = bf16(x),
+//                  lo = bf16(x - hi) (both round-to-nearest-even, v_cvt_pk_bf16_f32), x y ~ hi hi + hi lo + lo hi in the fp32
+//                  accumulators - three v_mfma_f32_16x16x32_bf16 (48 matrix-pipe cycles per 16 x 16 x 32 block) where the fp32
+//                  instruction needs eight v_mfma_f32_16x16x4_f32 (256).  Dropped: lo lo and the rounding of lo, ~2^-17 of a
+//                  product - below the fp32 rounding of a K-term accumulation from K ~ 100 on.  (precision code 2)
 //
 // k_conv_igemm   implicit GEMM  D[co][pixel] = sum_(tap, ci) W[co][tap][ci] X[pixel + tap][ci]:
 //                the WEIGHTS are the MFMA's A operand (rows = output channels) and the activations its B operand (columns =
@@ -32,6 +37,12 @@ namespace mst {
 #ifndef MST_CONV_ABLATE
 #define MST_CONV_ABLATE 0
 #endif
+#ifndef MST_CONV_X3_STAGES
+#define MST_CONV_X3_STAGES 2  // LDS stages of the bf16x3 implicit GEMM
+#endif
+#ifndef MST_CONV_X3_BK
+#define MST_CONV_X3_BK 32     // K per staged tile of the bf16x3 implicit GEMM (32 | 64)
+#endif
 #ifndef MST_CONV_LDS_STAGES
 #define MST_CONV_LDS_STAGES 2  // A/B switch: 1 = one LDS stage, two barriers per K step
 #endif
@@ -51,6 +62,62 @@ template <typename T> __device__ __forceinline__ float to_f32(T v);
 template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) { return bf2f(v); }
 
+// bf16x3 operand split of eight consecutive-K fp32 values (2.5 VALU instructions per value: two packed converts, the widening
+// shift / mask of hi, one packed subtract per pair)
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split8(const float (&x)[8], bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const f32x2_t v = {x[2 * j], x[2 * j + 1]};
+        const bf16x2_t h = __builtin_convertvector(v, bf16x2_t);
+        const f32x2_t r = v - __builtin_convertvector(h, f32x2_t);
+        const bf16x2_t l = __builtin_convertvector(r, bf16x2_t);
+        hi[2 * j] = h[0]; hi[2 * j + 1] = h[1];
+        lo[2 * j] = l[0]; lo[2 * j + 1] = l[1];
+    }
+}
+// three-term split x = hi + mid + lo (24 bits of significand: every fp32 value exactly, up to the rounding of lo at 2^-26) for bf16x6
+__device__ __forceinline__ void split8(const float (&x)[8], bf16x8& hi, bf16x8& mid, bf16x8& lo) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const f32x2_t v = {x[2 * j], x[2 * j + 1]};
+        const bf16x2_t h = __builtin_convertvector(v, bf16x2_t);
+        const f32x2_t r1 = v - __builtin_convertvector(h, f32x2_t);
+        const bf16x2_t m = __builtin_convertvector(r1, bf16x2_t);
+        const f32x2_t r2 = r1 - __builtin_convertvector(m, f32x2_t);
+        const bf16x2_t l = __builtin_convertvector(r2, bf16x2_t);
+        hi[2 * j] = h[0]; hi[2 * j + 1] = h[1];
+        mid[2 * j] = m[0]; mid[2 * j + 1] = m[1];
+        lo[2 * j] = l[0]; lo[2 * j + 1] = l[1];
+    }
+}
+// the operand pieces of one fragment: TERMS = 3 (hi, lo) | 6 (hi, mid, lo)
+template <int TERMS> struct Pieces {
+    bf16x8 h, m, l;  // m unused for TERMS = 3
+    __device__ __forceinline__ void set(const float (&x)[8]) {
+        if constexpr (TERMS == 6) split8(x, h, m, l);
+        else split8(x, h, l);
+    }
+};
+#define MST_MMA(A, B, C) C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B, C, 0, 0, 0)
+// acc += a b over the kept terms, small terms first.  3: hi lo + lo hi + hi hi (dropped from 2^-16 of the product on);
+// 6: every term down to 2^-16 x 2^-8 (lo hi, hi lo, mid mid, mid hi, hi mid, hi hi; dropped: 2^-24 of the product and below)
+template <int TERMS>
+__device__ __forceinline__ f32x4 mma_split(const Pieces<TERMS>& a, const Pieces<TERMS>& b, f32x4 acc) {
+    if constexpr (TERMS == 6) {
+        MST_MMA(a.l, b.h, acc);
+        MST_MMA(a.h, b.l, acc);
+        MST_MMA(a.m, b.m, acc);
+        MST_MMA(a.m, b.h, acc);
+        MST_MMA(a.h, b.m, acc);
+    } else {
+        MST_MMA(a.l, b.h, acc);
+        MST_MMA(a.h, b.l, acc);
+    }
+    MST_MMA(a.h, b.h, acc);
+    return acc;
+}
 template <typename T, int BK> struct Mma;
 // EPC: elements per 16-byte chunk; BK: K extent of one staged tile; LDK: LDS row pitch (elements); off(): element offset of chunk
 // kc of row `row`.  bf16: 64 of K per tile (two MFMA K steps between barriers) in 128-byte rows whose eight 16-byte slots are
@@ -65,8 +132,8 @@ template <int BK> struct Mma<bf16_t, BK> {
     __device__ static __forceinline__ int off(int row, int kc) { return row * LDK + ((kc ^ ((row >> 1) & (BK / 8 - 1))) << 3); }
 };
 template <int BK> struct Mma<float, BK> {
-    static constexpr int EPC = 4, LDK = 36;
-    static_assert(BK == 32, "fp32 tiles hold 32 of K");
+    static constexpr int EPC = 4, LDK = BK + 4;
+    static_assert(BK == 32 || BK == 64, "fp32 tiles hold 32 of K (64: the bf16x3 form, two matrix-pipe steps per staged tile)");
     __device__ static __forceinline__ int off(int row, int kc) { return row * LDK + kc * 4; }
 };
 
@@ -81,13 +148,13 @@ __device__ __forceinline__ void store4(float* p, f32x4 v) { *reinterpret_cast<fl
 int conv_pixel_tiles(int N, int H, int W) { return (int)(((int64_t)N * H * W + kConvPix - 1) / kConvPix); }
 
 // =====================================================================================================================
-template <typename T, int BC, int BK>
+template <typename T, int BC, int BK, int X3 = 0>
 __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs a) {  // 2: up to 256 registers - at the default budget hipcc parks the staging registers in AGPRs (104 v_accvgpr moves per 32 MFMAs)
     using MM = Mma<T, BK>;
     constexpr int BP = kConvPix, EPC = MM::EPC, LDK = MM::LDK, RC = BK / EPC;
     constexpr int WCH = BC * RC / 256, XCH = BP * RC / 256, MT = BC / 32, NT = 4;
     // two LDS stages: tile s + 1 is stored while tile s is multiplied - ONE barrier per K step
-    constexpr int NB = MST_CONV_LDS_STAGES;
+    constexpr int NB = X3 ? MST_CONV_X3_STAGES : MST_CONV_LDS_STAGES;
     __shared__ __attribute__((aligned(16))) T sWb[NB][BC * LDK];
     __shared__ __attribute__((aligned(16))) T sXb[NB][BP * LDK];
     __shared__ float red[2][BC][2];
@@ -174,6 +241,26 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs a) {  // 2: up t
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
                     for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bfr[n], acc[m][n], 0, 0, 0);
+            }
+        } else if constexpr (X3) {
+            // bf16x3: lane (g, li) holds K = 8 g .. 8 g + 7 of row li - two 16-byte LDS reads per fragment (the 144-byte pitch puts the
+            // sixteen rows of a read on sixteen different 16-byte bank groups), split into (hi, lo), three MFMAs per 16 x 16 block
+            auto frag = [&](const float* p, Pieces<X3>& f) {
+                const float4 v0 = *reinterpret_cast<const float4*>(p), v1 = *reinterpret_cast<const float4*>(p + 4);
+                const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                f.set(x);
+            };
+#pragma unroll
+            for (int ks = 0; ks < BK / 32; ++ks) {
+                Pieces<X3> af[MT], bf[NT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) frag(&sW[(wy * (BC / 2) + m * 16 + li) * LDK + ks * 32 + g * 8], af[m]);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) frag(&sX[(wx * 64 + n * 16 + li) * LDK + ks * 32 + g * 8], bf[n]);
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) acc[m][n] = mma_split<X3>(af[m], bf[n], acc[m][n]);
             }
         } else {
 #pragma unroll
@@ -755,11 +842,15 @@ int launch_conv3x3(int precision, ConvArgs a, hipStream_t s, float* kpart, size_
         const dim3 grid(tiles, a.Cout / 128, gz);
         if (precision == 0 && conv3_enabled()) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_igemm3<128, 128, MST_CONV_GLDS_STAGES>), grid, dim3(256), 0, s, a);
         else if (precision == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_igemm<bf16_t, 128, 64>), grid, dim3(256), 0, s, a);
+        else if (precision == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_igemm<float, 128, MST_CONV_X3_BK, 3>), grid, dim3(256), 0, s, a);
+        else if (precision == 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_igemm<float, 128, MST_CONV_X3_BK, 6>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_igemm<float, 128, 32>), grid, dim3(256), 0, s, a);
     } else {
         const dim3 grid(tiles, a.Cout / 64, gz);
         if (precision == 0 && conv3_enabled()) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_igemm3<64, 128, MST_CONV_GLDS_STAGES>), grid, dim3(256), 0, s, a);
         else if (precision == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_igemm<bf16_t, 64, 32>), grid, dim3(256), 0, s, a);
+        else if (precision == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_igemm<float, 64, MST_CONV_X3_BK, 3>), grid, dim3(256), 0, s, a);
+        else if (precision == 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_igemm<float, 64, MST_CONV_X3_BK, 6>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_igemm<float, 64, 32>), grid, dim3(256), 0, s, a);
     }
     if (a.csplit) {
@@ -778,7 +869,7 @@ template <typename T> struct WgPitch;
 template <> struct WgPitch<bf16_t> { static constexpr int PAD = 2; };   // (C + 2) * 2 bytes = 4 (mod 16): k-groups 8 rows apart land 32 bytes apart
 template <> struct WgPitch<float> { static constexpr int PAD = 16; };   // C * 4 + 64 bytes: consecutive rows fill the two halves of the 32 banks
 
-template <typename T, int BCO, int BCI, bool FIRST>
+template <typename T, int BCO, int BCI, bool FIRST, int X3 = 0>
 __global__ __launch_bounds__(256, 2) void k_conv_wgrad(WgradArgs a) {
     constexpr int BKP = kWgradPix, EPC = Mma<T, 32>::EPC, PY = BCO + WgPitch<T>::PAD, PX = BCI + WgPitch<T>::PAD;
     constexpr int YCH = BKP * (BCO / EPC), XCH = FIRST ? 0 : BKP * (BCI / EPC);  // 16-byte chunks per tile
@@ -887,6 +978,28 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(WgradArgs a) {
             for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bfr[n], acc[m][n], 0, 0, 0);
+        } else if constexpr (X3) {
+            // bf16x3 (see k_conv_igemm): K = the 32 staged pixels, lane (g, li) gathers pixels 8 g .. 8 g + 7 of its channel column
+            static_assert(BKP == 32, "one 16x16x32 step per staged tile");
+            Pieces<X3> af[MT], bf[NT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                float x[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] = sY[(8 * g + j) * PY + wy * WCO + m * 16 + li];
+                af[m].set(x);
+            }
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                float x[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] = sX[(8 * g + j) * PX + wx * WCI + n * 16 + li];
+                bf[n].set(x);
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[m][n] = mma_split<X3>(af[m], bf[n], acc[m][n]);
         } else {
 #pragma unroll
             for (int kk = 0; kk < BKP / 4; ++kk) {
@@ -1227,18 +1340,24 @@ void launch_conv_wgrad(int precision, const WgradArgs& a, hipStream_t s) {
     if (a.Cin == 1) {
         const dim3 grid(a.Cout / 64, 1, a.splits);
         if (precision == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_wgrad<bf16_t, 64, 16, true>), grid, dim3(256), 0, s, a);
+        else if (precision == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_wgrad<float, 64, 16, true, 3>), grid, dim3(256), 0, s, a);
+        else if (precision == 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_wgrad<float, 64, 16, true, 6>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_wgrad<float, 64, 16, true>), grid, dim3(256), 0, s, a);
     } else if (a.Cin % 128 == 0 && a.Cout % 128 == 0) {
         const dim3 grid((a.Cout / 128) * (a.Cin / 128), 9, a.splits);
         const dim3 grid3((a.Cout / 128) * (a.Cin / 128) * 9 * ((a.splits + 7) / 8) * 8);
         if (precision == 0 && conv3_enabled()) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_wgrad3<128, 128, MST_CONV_GLDS_STAGES>), grid3, dim3(256), 0, s, a);
         else if (precision == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_wgrad<bf16_t, 128, 128, false>), grid, dim3(256), 0, s, a);
+        else if (precision == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_wgrad<float, 128, 128, false, 3>), grid, dim3(256), 0, s, a);
+        else if (precision == 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_wgrad<float, 128, 128, false, 6>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_wgrad<float, 128, 128, false>), grid, dim3(256), 0, s, a);
     } else {
         const dim3 grid((a.Cout / 64) * (a.Cin / 64), 9, a.splits);
         const dim3 grid3((a.Cout / 64) * (a.Cin / 64) * 9 * ((a.splits + 7) / 8) * 8);
         if (precision == 0 && conv3_enabled()) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_wgrad3<64, 64, MST_CONV_GLDS_STAGES>), grid3, dim3(256), 0, s, a);
         else if (precision == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_wgrad<bf16_t, 64, 64, false>), grid, dim3(256), 0, s, a);
+        else if (precision == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_wgrad<float, 64, 64, false, 3>), grid, dim3(256), 0, s, a);
+        else if (precision == 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_wgrad<float, 64, 64, false, 6>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_wgrad<float, 64, 64, false>), grid, dim3(256), 0, s, a);
     }
 }

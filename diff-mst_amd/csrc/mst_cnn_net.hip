@@ -671,7 +671,7 @@ static int64_t wgrad_part_floats(int precision, int W, int64_t P, int Cin, int C
 }
 static CnnPlan cnn_plan(const mst_cnn14_desc* d) {
     CnnPlan p{};
-    if (!d || d->n <= 0 || d->frames < 64 || d->bins < 256 || d->embed_dim <= 0 || (d->precision != 0 && d->precision != 1)) return p;
+    if (!d || d->n <= 0 || d->frames < 64 || d->bins < 256 || d->embed_dim <= 0 || (d->precision < 0 || d->precision > 3)) return p;
     p.n = d->n;
     p.esz = d->precision == 0 ? 2 : 4;
     p.H[0] = d->frames;

@@ -59,6 +59,11 @@ static constexpr bool fuse_eq_zs() {
 }
 
 extern "C" int mst_abi_version(void) { return 7; }
+#ifdef MST_DEV_PROBE  // developer probe (tools/sidestream_probe.py): an event recorded in the middle of the forward's launch sequence
+static hipEvent_t g_probe_ev = nullptr;
+static int g_probe_where = 0;
+extern "C" void mst_debug_set_mid_event(void* ev, int where) { g_probe_ev = (hipEvent_t)ev; g_probe_where = where; }
+#endif
 
 extern "C" size_t mst_console_fx_tables_bytes(void) { return (size_t)8192 * 2 * sizeof(float); }
 extern "C" int mst_console_fx_init_tables(void* tables, void* stream) {
@@ -122,6 +127,9 @@ extern "C" int mst_console_forward(const mst_console_desc* d, const float* track
         pa.pf_n = n;
     }
     launch_prep(pa, stream);
+#ifdef MST_DEV_PROBE
+    if (g_probe_ev && g_probe_where == 0) (void)hipEventRecord(g_probe_ev, stream);
+#endif
 
     // ---- tracks: EQ (zs -> carry scan -> run), compressor smoother (zs -> scan), apply + pan + bus sum
     // L.eq1: the carries are scanned inside the zs / run kernels (the run kernel reads the zs kernel's states directly)
@@ -156,6 +164,9 @@ extern "C" int mst_console_forward(const mst_console_desc* d, const float* track
                       busp, bus_stride, mixed_tracks, fx_on ? ws + L.fx_in : nullptr,
                       L.T, L.ncC_pad, d->track_lookahead, t_comp ? 1 : 0, n, aligned};
     launch_apply_tracks(ta, L.bs, stream);
+#ifdef MST_DEV_PROBE
+    if (g_probe_ev && g_probe_where == 1) (void)hipEventRecord(g_probe_ev, stream);
+#endif
     // ---- fx bus: reverberate the send bus and add it to the stereo bus (reference mst/modules.py:275-284)
     if (fx_on) launch_fx_forward(fx_plan(L), fx->noise, fx->filters, (const float*)fx->tables, ws, busp, bus_stride, stream);
 

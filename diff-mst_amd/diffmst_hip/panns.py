@@ -26,13 +26,17 @@ _CHANNELS = (64, 128, 256, 512, 1024, 2048)
 POOL_SIZES = ((2, 2), (4, 4), (4, 2), (4, 2), (4, 2), (2, 2))
 
 
+# descriptor codes (include/diffmst_hip.h, mst_cnn14_desc::precision)
+PRECISIONS = {"bf16": 0, "fp32": 1, "bf16x3": 2, "bf16x6": 3}
+
+
 def default_precision() -> str:
     """The encoder precision of a model built without the keyword: fp32 like the reference, unless the environment opts in."""
     import os
 
     p = os.environ.get("MST_ENCODER_PRECISION", "fp32")
-    if p not in ("bf16", "fp32"):
-        raise ValueError("MST_ENCODER_PRECISION must be 'bf16' or 'fp32'")
+    if p not in PRECISIONS:
+        raise ValueError("MST_ENCODER_PRECISION must be 'bf16', 'bf16x3', 'bf16x6' or 'fp32'")
     return p
 
 
@@ -139,7 +143,7 @@ class _Cnn14Function(torch.autograd.Function):
                     raise RuntimeError(f"Cnn14 with SyncBatchNorm: every rank must feed the same number of signals per call (got {got}); "
                                        "pad the batch or use drop_last=True")
                 seen.add((id(group), n))
-        desc = _cabi.Cnn14Desc(n, frames, bins, module.fc.out_features, 0 if module.precision == "bf16" else 1, int(training),
+        desc = _cabi.Cnn14Desc(n, frames, bins, module.fc.out_features, PRECISIONS[module.precision], int(training),
                                float(module.conv_block1.bn1.eps), world)
         nbytes = lib.mst_cnn14_workspace_bytes(ctypes.byref(desc))
         if nbytes == 0:
@@ -211,8 +215,8 @@ class Cnn14(nn.Module):
         precision = default_precision() if precision is None else precision
         if n_inputs != 1:
             raise NotImplementedError("n_inputs = 1 (the reference's SpectrogramEncoder default) is what the first-layer kernel is built for")
-        if precision not in ("bf16", "fp32"):
-            raise ValueError("precision must be 'bf16' or 'fp32'")
+        if precision not in PRECISIONS:
+            raise ValueError("precision must be 'bf16', 'bf16x3', 'bf16x6' or 'fp32'")
         self.precision = precision
         c_in = n_inputs
         for i, c_out in enumerate(_CHANNELS, start=1):

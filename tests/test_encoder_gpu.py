@@ -61,7 +61,7 @@ def test_spectrogram_front_end(dev, golden_dir, record):
     assert e_gold < 1e-5 and l2 < 1e-6 and e_f64 < 1e-5
 
 
-@pytest.mark.parametrize("precision,tol_embed,tol_grad", [("fp32", 1e-4, 1e-2), ("bf16", 3e-2, None)])
+@pytest.mark.parametrize("precision,tol_embed,tol_grad", [("fp32", 1e-4, 1e-2), ("bf16x6", 1e-4, 1e-2), ("bf16x3", 1e-4, 1e-2), ("bf16", 3e-2, None)])
 def test_encoder_against_the_real_classes(precision, tol_embed, tol_grad, dev, golden_dir, record):
     from mst.modules import SpectrogramEncoder
 
@@ -111,7 +111,8 @@ def test_encoder_against_the_real_classes(precision, tol_embed, tol_grad, dev, g
     assert int(enc.model.conv_block1.bn1.num_batches_tracked) == 1
 
 
-def test_encoder_gradients_three_way(dev, record):
+@pytest.mark.parametrize("precision", ["fp32", "bf16x6", "bf16x3"])
+def test_encoder_gradients_three_way(precision, dev, record):
     """ReLU masks make the gradient a discontinuous function of the activations: ONE element whose pre-activation lands on the
     other side of zero moves the gradient of a 2.6e5-element layer by 1/sqrt(N) ~ 2e-3, for any two fp32 evaluations.  So the
     gradients are judged three-way: the HIP encoder (fp32 MFMA) must be no further from a float64 evaluation than torch's own
@@ -120,7 +121,7 @@ def test_encoder_gradients_three_way(dev, record):
     from oracle import encoder_restated as oe
 
     bs, n = 2, 65536
-    enc = encoder_setup(SpectrogramEncoder, 81, 82, precision="fp32")
+    enc = encoder_setup(SpectrogramEncoder, 81, 82, precision=precision)
     sd0 = {k: v.detach().clone() for k, v in enc.state_dict().items()}
     torch.manual_seed(83)
     wave = 0.1 * torch.randn(bs, 1, n)
@@ -144,20 +145,24 @@ def test_encoder_gradients_three_way(dev, record):
     for k in hip:
         t = (rel(hip[k], g32[k]), rel(hip[k], g64[k]), rel(g32[k], g64[k]))
         rep["g." + k.replace("model.", "").replace("conv_block", "b")] = t
-        if t[1] > 3 * t[2] + 3e-3:  # 3e-3: what one or two flipped ReLU masks move a layer's gradient by (either path can draw them)
+        # 3e-3: what one or two flipped ReLU masks move a layer's gradient by (either path can draw them).  bf16x6 is held to the fp32 bound.
+        # bf16x3 carries ~2^-17 per product (fp32: 2^-24 per accumulation) through BatchNorm layers that normalise over 8 values per channel
+        # at this clip length: measured 4e-3 .. 9e-3 from float64 on the early layers (fp32: 4e-5 .. 4e-4, bf16: 0.2 .. 0.5) - an absolute bound
+        if (t[1] > 2e-2) if precision == "bf16x3" else (t[1] > 3 * t[2] + 3e-3):
             bad.append((k, t))
-    print("\n[encoder three-way] (hip vs ref32, hip vs f64, ref32 vs f64)")
+    print(f"\n[encoder three-way {precision}] (hip vs ref32, hip vs f64, ref32 vs f64)")
     for k, v in rep.items():
         print(f"   {k:28s} {v[0]:.2e} {v[1]:.2e} {v[2]:.2e}")
     record(**rep)
     assert rep["embed"][1] < 1e-4
     assert not bad, bad
     # the last block's gradients involve no mask decision of an earlier layer: fp32 round-off only
-    assert all(v[1] < 5e-5 for k, v in rep.items() if k.startswith("g.b6.") or k.startswith("g.fc"))
+    last = max(v[1] for k, v in rep.items() if k.startswith("g.b6.") or k.startswith("g.fc"))
+    assert last < (1e-3 if precision == "bf16x3" else 5e-5), last
 
 
-@pytest.mark.parametrize("precision,tol", [("fp32", 2e-4), ("bf16", 6e-2)])
-def test_encoder_frozen_batchnorm_gradients(precision, tol, dev, record):
+@pytest.mark.parametrize("precision,tol,tol_grad", [("fp32", 2e-4, 8e-4), ("bf16x6", 2e-4, 8e-4), ("bf16x3", 2e-4, 6e-3), ("bf16", 6e-2, 0.24)])
+def test_encoder_frozen_batchnorm_gradients(precision, tol, tol_grad, dev, record):
     """Eval mode (running statistics: BatchNorm is a fixed affine map, nothing divides by an 8-sample variance): forward and
     every parameter gradient against the oracle in float64.  This is the check of the bf16 MFMA kernels proper - in training
     mode at this clip length the last block normalises over 8 pixels per channel and amplifies any rounding of its input."""
@@ -191,7 +196,9 @@ def test_encoder_frozen_batchnorm_gradients(precision, tol, dev, record):
         worst = (k, e) if e > worst[1] else worst
     print(f"\n[encoder eval-mode {precision}] embed {rep['embed']:.2e}; worst gradient {worst[0]} {worst[1]:.2e}")
     record(**rep)
-    assert rep["embed"] < tol and worst[1] < 4 * tol, (rep["embed"], worst)
+    # bf16x3: ~2^-17 per product instead of fp32's 2^-24 per accumulation - the weight gradients (sums over every pixel, heavy cancellation)
+    # land 4-10x further from float64 than the fp32 path's; bf16x6 keeps every product term down to 2^-24 and is held to the fp32 bound
+    assert rep["embed"] < tol and worst[1] < tol_grad, (rep["embed"], worst)
     for k, v in sd0.items():  # eval mode leaves the statistics alone
         if "running" in k:
             assert torch.equal(enc.state_dict()[k].cpu(), v)
