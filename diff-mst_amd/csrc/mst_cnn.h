@@ -36,7 +36,7 @@ struct WgradArgs {
 constexpr int kConvPix = 128;   // pixels per workgroup of the implicit-GEMM convolution
 constexpr int kWgradPix = 32;   // pixels per K step of the weight-gradient GEMM
 
-// all launchers: precision 0 = bf16 operands, 1 = fp32 operands, 2 = fp32 storage with the bf16x3 operand split (mst_cnn14_desc::precision)
+// all launchers: precision 0 = bf16 operands, 1 = fp32 operands, 2 / 3 = fp32 storage with the bf16x3 / bf16x6 operand split (mst_cnn14_desc::precision)
 // returns the number of pixel tiles whose statistics it wrote to a.part (the kernels differ in tile size)
 int launch_conv3x3(int precision, ConvArgs a, hipStream_t s, float* kpart, size_t kpart_bytes);
 size_t conv_splitk_bytes(int N, int H, int W, int Cin, int Cout);

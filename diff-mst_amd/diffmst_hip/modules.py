@@ -537,7 +537,7 @@ class SpectrogramEncoder(torch.nn.Module):
 
     The STFT runs on the register-radix FFT engine of the loss kernels (``mst_spectrogram_forward``), the CNN on the matrix
     cores (``diffmst_hip.panns.Cnn14``); same constructor keywords, same ``window`` buffer and ``model.*`` parameter names as
-    the reference, so its checkpoints load.  ``precision`` ("fp32" = the reference's arithmetic, the default | "bf16", opt-in) is an
+    the reference, so its checkpoints load.  ``precision`` ("fp32" = the reference's arithmetic, the default | "bf16x6" | "bf16x3" | "bf16", opt-in) is an
     extra keyword (see ``Cnn14``; ``MST_ENCODER_PRECISION`` sets the default for an unmodified YAML).
 
     The waveform is NOT differentiated through (the reference's ``torch.stft`` is): nothing in the reference asks for that gradient -

@@ -9,7 +9,10 @@ reverse mode; autograd sees ONE function.
 
 ``precision``: ``"fp32"`` (default, the reference's ``precision: 32``, configs/config.yaml:42) - fp32 operands on the fp32 MFMA;
 ``"bf16"`` (opt-in: constructor keyword, or ``MST_ENCODER_PRECISION=bf16`` in the environment for an unmodified YAML) - bf16 operands and
-activations, fp32 accumulation / statistics / gradients: 2x faster, training-mode weight gradients 20-40 % from the fp32 ones.
+activations, fp32 accumulation / statistics / gradients: 5x faster, training-mode weight gradients 20-40 % from the fp32 ones (DESIGN 9.3);
+``"bf16x6"`` / ``"bf16x3"`` - fp32 tensors everywhere, the convolutions' operands split into bf16 (hi, mid, lo) / (hi, lo) pieces in
+registers and multiplied term by term on the bf16 MFMA with fp32 accumulation: bf16x6 keeps every product term down to 2^-24 and passes
+the fp32 path's parity bounds at 0.84x its time; bf16x3 (~2^-17 per product) runs at 0.68x.
 """
 from __future__ import annotations
 

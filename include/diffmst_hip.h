@@ -247,7 +247,9 @@ typedef struct mst_cnn14_desc {
     int32_t embed_dim;  /* num_classes of the final Linear(2048, embed_dim) */
     int32_t precision;  /* 0: bf16 operands, fp32 accumulate (v_mfma_f32_16x16x32_bf16); 1: fp32 operands (v_mfma_f32_16x16x4_f32);
                          * 2: "bf16x3" - fp32 tensors everywhere (same buffers and sizes as 1), the convolutions' operands split into
-                         *    bf16 (hi, lo) pairs on the way into the matrix pipe, x y ~ hi hi + hi lo + lo hi with fp32 accumulation */
+                         *    bf16 (hi, lo) pairs on the way into the matrix pipe, x y ~ hi hi + hi lo + lo hi with fp32 accumulation
+                         *    (~2^-17 per product); 3: "bf16x6" - the same with (hi, mid, lo) triples and the six product terms down to
+                         *    2^-24: fp32-grade results (passes the parity bounds of precision 1) */
     int32_t training;   /* 1: BatchNorm2d with batch statistics (returned in batch_stats); 0: running statistics */
     float bn_eps;       /* 1e-5 */
     int32_t world;      /* 0 or 1: statistics over this call's signals.  > 1 (with a sync hook, mst_cnn14_forward_sync): BatchNorm statistics
