@@ -169,7 +169,13 @@ struct StftArgs {
     // round-2 kernels, round 5: the target's clamped magnitudes sqrt(max(|Y|^2, eps)), (rows, n_frames, n_fft / 2 + 1) - written by the
     // forward, read by the backward, which then transforms the prediction alone (null in the forward: not kept)
     float* ymag;
+    // 8192-point resolution, round 5: the prediction's spectrum X (float2 per bin and frame, (rows, n_frames, n_fft / 2 + 1)) - written by
+    // the forward, read by the backward, which then runs the inverse transform only (MST_STFT2_BWD_SAVED_SPEC_8192; null: not kept)
+    float* xspec;
 };
+#ifndef MST_STFT2_BWD_SAVED_SPEC_8192
+#define MST_STFT2_BWD_SAVED_SPEC_8192 1  // 0: the 8192-point backward recomputes every frame's (prediction + i target) transform (rounds 2-4)
+#endif
 
 // the three forward transforms of the reference's resolutions in one launch (mst_stft2.hip: k_stft3_fwd).  a[0] / a[1] / a[2] =
 // the 8192- / 2048- / 512-point resolution; groups = strips per row; wg_end = running workgroup counts of the three roles

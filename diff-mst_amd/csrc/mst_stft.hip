@@ -660,6 +660,7 @@ struct Plan {
     // workspace (floats): part | sums | coef | coef_scaled
     int64_t part_total, sums_off, coef_off, coefs_off, seam_off, tick_off, ws_floats;
     int64_t ymag_off[kMaxRes];  // round-2 kernels: the target's magnitudes kept by the forward for the backward (-1: none)
+    int64_t xspec_off[kMaxRes];  // 8192-point resolution on the round-2 kernels: the prediction's spectrum kept for the backward (-1: none)
     int seam_res;  // index of the one seam-mode resolution whose seams are handed to a halo-mode launch, or -1
     bool ok;
 };
@@ -741,9 +742,14 @@ Plan make_plan(const mst_mrstft_desc* d) {
     }
     for (int i = 0; i < d->n_res; ++i) {
         p.ymag_off[i] = -1;
+        p.xspec_off[i] = -1;
         if (p.engine2[i]) {
             p.ymag_off[i] = p.ws_floats;
             p.ws_floats += round_up((int64_t)d->rows * p.res[i].n_frames * p.res[i].n_bins, 64);
+            if (MST_STFT2_BWD_SAVED_SPEC_8192 && p.res[i].n_fft == 8192) {
+                p.xspec_off[i] = p.ws_floats;
+                p.ws_floats += round_up((int64_t)d->rows * p.res[i].n_frames * p.res[i].n_bins * 2, 64);
+            }
         }
     }
     p.ok = true;
@@ -852,6 +858,7 @@ static int mrstft_forward_stages(const mst_mrstft_desc* d, const float* pred, co
             a.n = d->n_samples;
             a.eps = d->eps;
             a.ymag = p.ymag_off[i] >= 0 ? ws + p.ymag_off[i] : nullptr;
+            a.xspec = p.xspec_off[i] >= 0 ? ws + p.xspec_off[i] : nullptr;
             q.groups[w] = p.n_groups[i];
         }
         q.rows = d->rows;
@@ -873,6 +880,7 @@ static int mrstft_forward_stages(const mst_mrstft_desc* d, const float* pred, co
         a.n = d->n_samples;
         a.eps = d->eps;
         a.ymag = p.ymag_off[i] >= 0 ? ws + p.ymag_off[i] : nullptr;
+        a.xspec = p.xspec_off[i] >= 0 ? ws + p.xspec_off[i] : nullptr;
         if (fuse && i == 0) a.tickets = reinterpret_cast<unsigned*>(ws + p.tick_off);
         const dim3 grid(p.n_groups[i], d->rows);
 #define MST_LAUNCH_FWD(NF) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stft_fwd<NF>), grid, dim3(stft_threads(NF)), 0, stream, a)
@@ -959,6 +967,7 @@ extern "C" int mst_mrstft_backward(const mst_mrstft_desc* d, const float* pred, 
                 a.n = d->n_samples;
                 a.eps = d->eps;
                 a.ymag = ws + p.ymag_off[i];
+                a.xspec = p.xspec_off[i] >= 0 ? ws + p.xspec_off[i] : nullptr;
                 a.accumulate = (pass == 1 && written) ? 1 : 0;
                 if (handover && (pass == 0 || pending)) {
                     const ResInfo& sr = p.res[p.seam_res];

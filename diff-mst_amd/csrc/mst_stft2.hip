@@ -13,7 +13,9 @@
 #define MST_STFT2_W8192 4  // min waves per SIMD asked of the 8192 FORWARD kernel: 2 workgroups of 512 lanes per CU (128 VGPRs, no spill)
 #endif
 #ifndef MST_STFT2_W8192_BWD
-#define MST_STFT2_W8192_BWD 2  // the backward kernel needs ~170 registers: at 128 it spills 71 (measured 102 us vs 77 us with one workgroup per CU)
+// the recomputing backward needs ~170 registers: at 128 it spills 71 (measured 102 us vs 77 us with one workgroup per CU); the
+// saved-spectrum backward spills 47 at 128 as well (72.7 us against 30.2 at one workgroup per CU)
+#define MST_STFT2_W8192_BWD 2
 #endif
 
 namespace mst {
@@ -154,6 +156,9 @@ __device__ __forceinline__ void stft2_fwd_body(const StftArgs& a, const int lane
             const float ym = mag_sqrt(fmaxf(Y.x * Y.x + Y.y * Y.y, a.eps));
             // round 5: the target's magnitudes are what the backward needs of the target - kept, so that it transforms the prediction alone
             if (a.ymag) a.ymag[((int64_t)row * r.n_frames + f) * (N / 2 + 1) + k] = ym;
+            if constexpr (N == 8192 && MST_STFT2_BWD_SAVED_SPEC_8192) {  // ... and of the prediction its spectrum: the backward runs the inverse only
+                if (a.xspec) reinterpret_cast<float2*>(a.xspec)[((int64_t)row * r.n_frames + f) * (N / 2 + 1) + k] = X;
+            }
             const float d = ym - xm;
             s1 = fmaf(d, d, s1);
             s2 = fmaf(ym, ym, s2);
@@ -800,6 +805,81 @@ __device__ __forceinline__ void stft2_bwd_body(const StftArgs& a, const int lane
                 }
                 inverse_emit(fa + 1);
             }
+        }
+    } else if constexpr (MST_STFT2_BWD_SAVED_SPEC_8192) {
+        // 8192, round 5: NO forward transform in the backward.  The forward launch kept the prediction's spectrum X and the target's clamped
+        // magnitudes (a.xspec, a.ymag: 12 bytes per bin and frame, 51 MB at cfg #2) - the very values the recomputation below would
+        // produce - so a frame is: cotangents at the bin pairs (k, M - k) -> V of the half-size inverse -> one 4096-point transform ->
+        // window -> overlap-add.  One sequence per frame instead of three, no sample loads; 128 registers = two workgroups per CU.
+        constexpr int M = S::M, NB = N / 2 + 1;                    // 4096, 4097
+        const float2 we = twg[2 * lane], wo = twg[2 * lane + 1];
+        const float2* xrow = reinterpret_cast<const float2*>(a.xspec) + (int64_t)row * r.n_frames * NB;
+        const float* ymrow = a.ymag + (int64_t)row * r.n_frames * NB;
+        static_assert(M / 2 == 4 * LG, "four bin pairs per lane (plus k = M/2 on lane 0)");
+        float2 xk[4], xm[4];
+        float yk[4], ymk[4];
+        auto request = [&](int f) {
+            const float2* xf = xrow + (int64_t)f * NB;
+            const float* yf = ymrow + (int64_t)f * NB;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int k = lane + LG * i;
+                xk[i] = xf[k]; xm[i] = xf[M - k];
+                yk[i] = yf[k]; ymk[i] = yf[M - k];
+            }
+        };
+#ifndef MST_STFT2_BWD_SPEC_PREFETCH
+#define MST_STFT2_BWD_SPEC_PREFETCH 1  // the next frame's spectrum is requested behind the current frame's cotangents: 27.2 against 30.6 us (24 registers, free at two waves per SIMD)
+#endif
+        if (MST_STFT2_BWD_SPEC_PREFETCH) request(F0);
+        for (int f = F0; f < F1; ++f) {
+            if (!MST_STFT2_BWD_SPEC_PREFETCH) request(f);
+            const float2 xh = xrow[(int64_t)f * NB + M / 2];
+            const float yh = ymrow[(int64_t)f * NB + M / 2];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                if (i == 4 && lane != 0) break;
+                const int k = i == 4 ? M / 2 : lane + LG * i;
+                float2 Hk = cotangent_xy(i == 4 ? xh : xk[i < 4 ? i : 0], i == 4 ? yh : yk[i < 4 ? i : 0], a.eps, coef);
+                float2 Hm = cotangent_xy(i == 4 ? xh : xm[i < 4 ? i : 0], i == 4 ? yh : ymk[i < 4 ? i : 0], a.eps, coef);
+                float2 vk, vm;
+                if (k == 0) {
+                    vk = make_float2(Hk.x + Hm.x, -(Hk.x - Hm.x));  // V[0] = (H0 + HM) + i (H0 - HM), both real; conj
+                    vm = vk;
+                } else {
+                    Hk = make_float2(0.5f * Hk.x, 0.5f * Hk.y);
+                    Hm = make_float2(0.5f * Hm.x, 0.5f * Hm.y);
+                    const float2 w = twg[k];  // W_N^k ; W_N^(M-k) = -conj(W_N^k)
+                    const float2 Ak = make_float2(Hk.x + Hm.x, Hk.y - Hm.y);
+                    const float2 Bk = cmul(make_float2(Hk.x - Hm.x, Hk.y + Hm.y), make_float2(w.x, -w.y));
+                    vk = make_float2(Ak.x - Bk.y, -(Ak.y + Bk.x));
+                    const float2 Am = make_float2(Hm.x + Hk.x, Hm.y - Hk.y);
+                    const float2 Bm = cmul(make_float2(Hm.x - Hk.x, Hm.y + Hk.y), make_float2(-w.x, -w.y));
+                    vm = make_float2(Am.x - Bm.y, -(Am.y + Bm.x));
+                }
+                buf[1][S::slot(k)] = vk;
+                if (k != 0 && k != M / 2) buf[1][S::slot(M - k)] = vm;
+            }
+            if (MST_STFT2_BWD_SPEC_PREFETCH && f + 1 < F1) request(f + 1);  // the next frame's 48 bytes per pair fly behind this frame's transform
+            group_lds_sync<LG>();
+            float2 v[8], o[1][8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) v[t] = buf[1][S::slot(lane + LG * t)];
+            fft_run<N>(v, o, buf[0], tw, lane);  // = conj(y_even + i y_odd) at m = lane + 512 t
+            float h1[8], h2[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const float2 w8 = t == 0 ? make_float2(1.f, 0.f) : (t == 1 ? make_float2(0.70710678118654752f, -0.70710678118654752f)
+                                : (t == 2 ? make_float2(0.f, -1.f) : (t == 3 ? make_float2(-0.70710678118654752f, -0.70710678118654752f)
+                                : (t == 4 ? make_float2(-1.f, 0.f) : (t == 5 ? make_float2(-0.70710678118654752f, 0.70710678118654752f)
+                                : (t == 6 ? make_float2(0.f, 1.f) : make_float2(0.70710678118654752f, 0.70710678118654752f)))))));
+                const float ce = we.x * w8.x - we.y * w8.y, co = wo.x * w8.x - wo.y * w8.y;  // cos(2 pi i / N), i = 2m, 2m + 1
+                const float ye = (0.5f - 0.5f * ce) * o[0][t].x, yo = -(0.5f - 0.5f * co) * o[0][t].y;
+                if (t < 4) { h1[2 * t] = ye; h1[2 * t + 1] = yo; }
+                else { h2[2 * (t - 4)] = ye; h2[2 * (t - 4) + 1] = yo; }
+            }
+            group_lds_sync<LG>();
+            emit(f, h1, h2);
         }
     } else {
         constexpr int M = S::M;                                    // 4096
