@@ -176,6 +176,12 @@ struct StftArgs {
 #ifndef MST_STFT2_BWD_SAVED_SPEC_8192
 #define MST_STFT2_BWD_SAVED_SPEC_8192 1  // 0: the 8192-point backward recomputes every frame's (prediction + i target) transform (rounds 2-4)
 #endif
+#ifndef MST_STFT2_BWD_SAVED_SPEC_SMALL
+#define MST_STFT2_BWD_SAVED_SPEC_SMALL 1  // the same for the 512- / 2048-point resolutions (0: their backward transforms the prediction's frames in pairs)
+#endif
+__host__ __device__ constexpr bool stft2_keeps_spectrum(int n_fft) {
+    return n_fft == 8192 ? MST_STFT2_BWD_SAVED_SPEC_8192 != 0 : ((n_fft == 512 || n_fft == 2048) && MST_STFT2_BWD_SAVED_SPEC_SMALL != 0);
+}
 
 // the three forward transforms of the reference's resolutions in one launch (mst_stft2.hip: k_stft3_fwd).  a[0] / a[1] / a[2] =
 // the 8192- / 2048- / 512-point resolution; groups = strips per row; wg_end = running workgroup counts of the three roles

@@ -746,7 +746,7 @@ Plan make_plan(const mst_mrstft_desc* d) {
         if (p.engine2[i]) {
             p.ymag_off[i] = p.ws_floats;
             p.ws_floats += round_up((int64_t)d->rows * p.res[i].n_frames * p.res[i].n_bins, 64);
-            if (MST_STFT2_BWD_SAVED_SPEC_8192 && p.res[i].n_fft == 8192) {
+            if (stft2_keeps_spectrum(p.res[i].n_fft)) {
                 p.xspec_off[i] = p.ws_floats;
                 p.ws_floats += round_up((int64_t)d->rows * p.res[i].n_frames * p.res[i].n_bins * 2, 64);
             }

@@ -155,9 +155,20 @@ __device__ __forceinline__ void stft2_fwd_body(const StftArgs& a, const int lane
             const float xm = mag_sqrt(fmaxf(X.x * X.x + X.y * X.y, a.eps));
             const float ym = mag_sqrt(fmaxf(Y.x * Y.x + Y.y * Y.y, a.eps));
             // round 5: the target's magnitudes are what the backward needs of the target - kept, so that it transforms the prediction alone
-            if (a.ymag) a.ymag[((int64_t)row * r.n_frames + f) * (N / 2 + 1) + k] = ym;
-            if constexpr (N == 8192 && MST_STFT2_BWD_SAVED_SPEC_8192) {  // ... and of the prediction its spectrum: the backward runs the inverse only
-                if (a.xspec) reinterpret_cast<float2*>(a.xspec)[((int64_t)row * r.n_frames + f) * (N / 2 + 1) + k] = X;
+#ifndef MST_STFT2_NT_STORES
+#define MST_STFT2_NT_STORES 0  // non-temporal stores of the kept planes: forward 86.5 -> 85.8 us, but the backward then reads them from HBM (43.2 -> 49.0, 27.5 -> 30.3): off
+#endif
+            if (a.ymag) {
+                float* q = a.ymag + ((int64_t)row * r.n_frames + f) * (N / 2 + 1) + k;
+                if (MST_STFT2_NT_STORES) __builtin_nontemporal_store(ym, q);
+                else *q = ym;
+            }
+            if constexpr (stft2_keeps_spectrum(N)) {  // ... and of the prediction its spectrum: the backward runs the inverse only
+                if (a.xspec) {
+                    float* q = a.xspec + 2 * (((int64_t)row * r.n_frames + f) * (N / 2 + 1) + k);
+                    if (MST_STFT2_NT_STORES) { __builtin_nontemporal_store(X.x, q); __builtin_nontemporal_store(X.y, q + 1); }
+                    else *reinterpret_cast<float2*>(q) = X;
+                }
             }
             const float d = ym - xm;
             s1 = fmaf(d, d, s1);
@@ -439,7 +450,59 @@ __device__ __forceinline__ void stft2_bwd_body(const StftArgs& a, const int lane
     // backward then transforms the PREDICTION alone, and two real frames share one complex transform exactly as they share the
     // inverse: z = w (x_a + i x_b), X_a / X_b by the Hermitian split.  Per pair of frames: one forward + one inverse transform instead
     // of two + one; consecutive frames overlap by half, so a pair needs two new half frames of ONE signal (8 loads per lane, was 32).
-    if constexpr (PAIR && MST_STFT2_BWD_SAVED_MAG) {
+    if constexpr (PAIR && stft2_keeps_spectrum(N)) {
+        // Round 5, second step: no forward transform in the backward at all - the forward launch kept the prediction's spectrum next to the
+        // target's magnitudes (12 bytes per bin and frame).  Per pair of frames: cotangents of both -> conj(He_a + i He_b) -> ONE inverse.
+        constexpr int NB = N / 2 + 1, NK = (NB + LG - 1) / LG;  // bins per frame / trips per lane
+        const float2* xrow = reinterpret_cast<const float2*>(a.xspec) + (int64_t)row * r.n_frames * NB;
+        const float* ymrow = a.ymag + (int64_t)row * r.n_frames * NB;
+        for (int fa = F0; fa < F1; fa += 2) {
+            const bool have_b = fa + 1 < F1;
+            float2 xa[NK], xb[NK];
+            float ya[NK], yb[NK];
+#pragma unroll
+            for (int i = 0; i < NK; ++i) {
+                const int k = lane + LG * i;
+                const bool in = k < NB;
+                xa[i] = in ? xrow[(int64_t)fa * NB + k] : make_float2(0.f, 0.f);
+                ya[i] = in ? ymrow[(int64_t)fa * NB + k] : 1.0f;
+                xb[i] = (in && have_b) ? xrow[(int64_t)(fa + 1) * NB + k] : make_float2(0.f, 0.f);
+                yb[i] = (in && have_b) ? ymrow[(int64_t)(fa + 1) * NB + k] : 1.0f;
+            }
+#pragma unroll
+            for (int i = 0; i < NK; ++i) {
+                const int k = lane + LG * i;
+                if (k < NB) {
+                    const float2 Ga = cotangent_xy(xa[i], ya[i], a.eps, coef);
+                    const float2 Gb = have_b ? cotangent_xy(xb[i], yb[i], a.eps, coef) : make_float2(0.f, 0.f);
+                    const int sk = S::slot(k), sn = S::slot((N - k) & (N - 1));
+                    // conj(He_a + i He_b):  He[k] = G / 2, He[N - k] = conj(G) / 2; the real bins 0 and N / 2 carry G.x whole
+                    if (k == 0 || k == N / 2) {
+                        hb[sk] = make_float2(Ga.x, -Gb.x);
+                    } else {
+                        hb[sk] = make_float2(0.5f * (Ga.x - Gb.y), -0.5f * (Ga.y + Gb.x));
+                        hb[sn] = make_float2(0.5f * (Ga.x + Gb.y), 0.5f * (Ga.y - Gb.x));
+                    }
+                }
+            }
+            group_lds_sync<LG>();  // hb is complete
+            float2 v[8], o[S::NBL][S::RL];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) v[t] = hb[S::slot(lane + LG * t)];
+            fft_run<N>(v, o, buf[0], tw, lane);
+            float fa1[4], fa2[4], fb1[4], fb2[4];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float2 R = S::RL == 8 ? o[0][q] : o[q & 1][q >> 1];  // element lane + LG q
+                const float ra = win[q] * R.x, rb = -win[q] * R.y;
+                if (q < 4) { fa1[q] = ra; fb1[q] = rb; }
+                else { fa2[q - 4] = ra; fb2[q - 4] = rb; }
+            }
+            group_lds_sync<LG>();  // the inverse has left buf[0] (emit() may use it as mirror scratch); every lane has read hb
+            emit(fa, fa1, fa2);
+            if (have_b) emit(fa + 1, fb1, fb2);
+        }
+    } else if constexpr (PAIR && MST_STFT2_BWD_SAVED_MAG) {
         constexpr int NB = N / 2 + 1, NK = (NB + LG - 1) / LG;  // bins per frame / cotangent-loop trips per lane
         const float* ymrow = a.ymag + (int64_t)row * r.n_frames * NB;
         auto fetchx = [&](int f, int t) { return x[reflect_i32(f * H - H + lane + LG * t, nrow)]; };
