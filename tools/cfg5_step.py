@@ -14,7 +14,7 @@ dev = torch.device("cuda:0")
 torch.manual_seed(3001)
 model = MixStyleTransferModel(SpectrogramEncoder(embed_dim=512), SpectrogramEncoder(embed_dim=512),
                               TransformerController(512, 27, 25, 26, num_layers=12, nhead=8,
-                                                    graphed=os.environ.get("MST_GRAPHED", "1") == "1",
+                                                    graphed=os.environ.get("MST_GRAPHED", "0") == "1",
                                                     native=os.environ.get("MST_NATIVE", "1") == "1")).to(dev).train()
 step = CommonStep(model, AdvancedMixConsole(bench.SR, materialize_mixed_tracks=False, validate="deferred", param_dicts="lazy"), naive_random_mix,
                   AudioFeatureLoss(bench.AF_WEIGHTS, bench.SR), generate_mix=True, active_eq_epoch=0, active_compressor_epoch=0,

@@ -109,11 +109,13 @@ def summary():
            "| secondary line | ms per step (median) | mixes/s (encoder line: signals/s) |", "|---|---:|---:|"]
     for s_ in b.get("secondary", []):
         rate = s_.get("mixes_per_s", s_.get("signals_per_s", 0.0))
+        peak_name = {"bf16": "bf16 MFMA peak", "bf16x3": "bf16 MFMA peak / 3 (three matrix instructions per block)",
+                     "bf16x6": "bf16 MFMA peak / 6 (six matrix instructions per block)"}.get(s_.get("precision"), "fp32 MFMA peak")
         extra = (f" ({s_['conv_TFLOPs_per_s']:.0f} TFLOP/s of convolution = {100 * s_['frac_of_dense_mfma_peak_of_that_dtype']:.1f} % of the dense "
-                 f"{'bf16' if s_.get('precision') == 'bf16' else 'fp32'} MFMA peak)") if "conv_TFLOPs_per_s" in s_ else ""
+                 f"{peak_name})") if "conv_TFLOPs_per_s" in s_ else ""
         if "hipgraph_replay" in s_:
             extra += f" (replayed as one hipGraph: {s_['hipgraph_replay']['ms_per_step_median']:.4f} ms)"
-        out.append(f"| {s_['workload'][:150]}{extra} | {s_['ms_per_step_median']:.3f} | {rate:.0f} |")
+        out.append(f"| {s_['workload'][:150]}{' [' + (s_.get('precision') or s_.get('encoder_precision')) + ']' if (s_.get('precision') or s_.get('encoder_precision')) else ''}{extra} | {s_['ms_per_step_median']:.3f} | {rate:.0f} |")
     cb = b.get("cpu_baseline") or {}
     if cb:
         out += ["", f"CPU baseline (oracle, `kind: {cb.get('kind')}`): {cb.get('value'):.2f} mixes/s on {cb.get('cores')} threads; by thread count: "
