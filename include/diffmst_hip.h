@@ -172,7 +172,10 @@ typedef struct mst_mrstft_desc {
 /* Twiddle + window tables: built once per descriptor into caller memory, read-only afterwards. */
 size_t mst_mrstft_tables_bytes(const mst_mrstft_desc* d);
 int mst_mrstft_init_tables(const mst_mrstft_desc* d, void* tables, void* stream);
-/* Per-call scratch; forward leaves what backward needs in it. */
+/* Per-call scratch; forward leaves what backward needs in it: the partial sums and coefficients, and - for the reference's
+ * resolutions (512 / 2048 / 8192 points, hop = n_fft / 2) - the prediction's spectrum and the target's clamped magnitudes of every
+ * bin and frame (12 bytes each; ~9.6 MB per row of 262144 samples): the backward reads them instead of transforming again, and
+ * touches `pred` / `target` only on the generic path (other resolutions). */
 size_t mst_mrstft_workspace_bytes(const mst_mrstft_desc* d);
 /* loss: one fp32 on the device. */
 int mst_mrstft_forward(const mst_mrstft_desc* d, const float* pred, const float* target, const void* tables,
