@@ -309,7 +309,8 @@ __device__ __forceinline__ float2 w16(int t) {
 // On return (the caller adds ONE barrier) Z[2m] = bufe[slot(m)], Z[2m + 1] = bufo[slot(m)].  tw = LaneTw<8192>, wl = W_8192^lane.
 // RAW_IN_LDS: raw() reads the transform's own LDS buffers (the previous transform's output, modified in place) - a barrier
 // separates the last read from the first pass's stores, so that callers need not park 16 values in registers.
-template <bool WINDOW, bool RAW_IN_LDS = false, typename F>
+// HALF: the window carries a factor 1/2 (an exact scaling: the spectrum is the same bits, halved - see FrameLoader::split)
+template <bool WINDOW, bool RAW_IN_LDS = false, bool HALF = false, typename F>
 __device__ __forceinline__ void fft8192_from(F&& raw, float2* __restrict__ bufe, float2* __restrict__ bufo, const LaneTw<8192>& tw,
                                              float2 wl, int lane) {
     using S = FftShape<8192>;
@@ -317,7 +318,8 @@ __device__ __forceinline__ void fft8192_from(F&& raw, float2* __restrict__ bufe,
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
         const float2 w = cmul(wl, w16(t));
-        const float h0 = WINDOW ? 0.5f - 0.5f * w.x : 1.0f, h1 = WINDOW ? 0.5f + 0.5f * w.x : 1.0f;
+        constexpr float hc = HALF ? 0.25f : 0.5f;
+        const float h0 = WINDOW ? hc - hc * w.x : 1.0f, h1 = WINDOW ? hc + hc * w.x : 1.0f;
         const float2 za = raw(t), zb = raw(t + 8);
         const float2 a = make_float2(h0 * za.x, h0 * za.y), b = make_float2(h1 * zb.x, h1 * zb.y);
         e[t] = cadd(a, b);

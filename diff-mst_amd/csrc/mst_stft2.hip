@@ -35,7 +35,8 @@ struct FrameLoader {
     // raw(t) -> unwindowed (pred, target) sample pair of element lane + LG t; win[t] = its window value (NSEQ = 1);
     // the 8192-point transform forms its window from the radix-2 twiddle it needs anyway:
     //   W_N^i = wl W_16^t (i = lane + 512 t),  hann(i) = 0.5 - 0.5 Re W_N^i,  hann(i + N/2) = 0.5 + 0.5 Re W_N^i
-    template <typename F>
+    // HALF: the window values handed in (NSEQ = 1) / formed here (8192) carry a factor 1/2: split<true> then skips its own
+    template <bool HALF = false, typename F>
     __device__ static __forceinline__ void transform(F&& raw, const float* win, float2 (*buf)[S::SLOTS],
                                                      const LaneTw<N>& tw, float2 wl, int lane) {
         if constexpr (S::NSEQ == 1) {
@@ -52,7 +53,7 @@ struct FrameLoader {
 #pragma unroll
                 for (int t = 0; t < S::RL; ++t) buf[0][S::slot(lane + u * LG + t * (S::M / S::RL))] = o[u][t];
         } else {
-            fft8192_from<true>(raw, buf[0], buf[1], tw, wl, lane);
+            fft8192_from<true, false, HALF>(raw, buf[0], buf[1], tw, wl, lane);
         }
         group_lds_sync<LG>();
     }
@@ -61,10 +62,18 @@ struct FrameLoader {
         if constexpr (S::NSEQ == 1) return buf[0][S::slot(k)];
         else return buf[k & 1][S::slot(k >> 1)];
     }
+    // HALF: the transform ran on a window scaled by 1/2 (transform<true>): Z is half the packed spectrum - exactly, a power-of-two
+    // scaling commutes with every rounding - and the four multiplications by 1/2 below are not needed: the same X, Y to the bit
+    template <bool HALF = false>
     __device__ static __forceinline__ void split(const float2 (*buf)[S::SLOTS], int k, float2& X, float2& Y) {
         const float2 zk = bin(buf, k), zn = bin(buf, (N - k) & (N - 1));
-        X = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
-        Y = make_float2(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
+        if constexpr (HALF) {
+            X = make_float2(zk.x + zn.x, zk.y - zn.y);
+            Y = make_float2(zk.y + zn.y, zn.x - zk.x);
+        } else {
+            X = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
+            Y = make_float2(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
+        }
     }
 };
 
@@ -107,6 +116,14 @@ __device__ __forceinline__ void stft2_fwd_body(const StftArgs& a, const int lane
     const float2 wl = twg[lane];
     float win[S::NSEQ == 1 ? PTS : 1];
     if constexpr (S::NSEQ == 1) load_window<N>(win, a.tables + r.win_off, lane);
+#ifndef MST_STFT2_FWD_HALF_WINDOW
+#define MST_STFT2_FWD_HALF_WINDOW 1  // the forward's window carries the 1/2 of the Hermitian split (FrameLoader::split<true>): four multiplications per bin less, same bits
+#endif
+    constexpr bool HW = MST_STFT2_FWD_HALF_WINDOW;
+    if constexpr (S::NSEQ == 1 && HW) {
+#pragma unroll
+        for (int t = 0; t < PTS; ++t) win[t] *= 0.5f;
+    }
     const float* x = a.pred + (int64_t)row * a.n;
     const float* y = a.target + (int64_t)row * a.n;
     int f0, f1;
@@ -138,7 +155,7 @@ __device__ __forceinline__ void stft2_fwd_body(const StftArgs& a, const int lane
 #pragma unroll
                 for (int t = 0; t < PTS; ++t) nxt[t] = (MST_STFT2_HALF_REUSE && t < PTS / 2) ? cur[t + PTS / 2] : fetch(f + 1, t);
             }
-            L::transform([&](int t) { return cur[t]; }, win, buf, tw, wl, lane);
+            L::template transform<HW>([&](int t) { return cur[t]; }, win, buf, tw, wl, lane);
         } else {
             // 8192: W_N^lane is re-fetched per frame (an L1 hit) instead of living in two registers across the epilogue - the
             // kernel sits exactly at the 128-register edge that lets two 512-lane workgroups share a CU, and a spilled register
@@ -146,29 +163,20 @@ __device__ __forceinline__ void stft2_fwd_body(const StftArgs& a, const int lane
             int li = lane;
             asm volatile("" : "+v"(li));
             const float2 wlf = twg[li];
-            L::transform([&](int t) { return fetch(f, t); }, win, buf, tw, wlf, lane);
+            L::template transform<HW>([&](int t) { return fetch(f, t); }, win, buf, tw, wlf, lane);
         }
 #pragma unroll 2
         for (int k = lane; k <= ((MST_STFT2_ABLATE & 1) ? lane : N / 2); k += LG) {
             float2 X, Y;
-            L::split(buf, k, X, Y);
+            L::template split<HW>(buf, k, X, Y);
             const float xm = mag_sqrt(fmaxf(X.x * X.x + X.y * X.y, a.eps));
             const float ym = mag_sqrt(fmaxf(Y.x * Y.x + Y.y * Y.y, a.eps));
             // round 5: the target's magnitudes are what the backward needs of the target - kept, so that it transforms the prediction alone
-#ifndef MST_STFT2_NT_STORES
-#define MST_STFT2_NT_STORES 0  // non-temporal stores of the kept planes: forward 86.5 -> 85.8 us, but the backward then reads them from HBM (43.2 -> 49.0, 27.5 -> 30.3): off
-#endif
-            if (a.ymag) {
-                float* q = a.ymag + ((int64_t)row * r.n_frames + f) * (N / 2 + 1) + k;
-                if (MST_STFT2_NT_STORES) __builtin_nontemporal_store(ym, q);
-                else *q = ym;
-            }
+            // (non-temporal stores of the two kept planes were measured: forward 86.5 -> 85.8 us, but the backward then reads them from HBM
+            // instead of the Infinity Cache - 43.2 -> 49.0 and 27.5 -> 30.3 us; plain stores)
+            if (a.ymag) a.ymag[((int64_t)row * r.n_frames + f) * (N / 2 + 1) + k] = ym;
             if constexpr (stft2_keeps_spectrum(N)) {  // ... and of the prediction its spectrum: the backward runs the inverse only
-                if (a.xspec) {
-                    float* q = a.xspec + 2 * (((int64_t)row * r.n_frames + f) * (N / 2 + 1) + k);
-                    if (MST_STFT2_NT_STORES) { __builtin_nontemporal_store(X.x, q); __builtin_nontemporal_store(X.y, q + 1); }
-                    else *reinterpret_cast<float2*>(q) = X;
-                }
+                if (a.xspec) reinterpret_cast<float2*>(a.xspec)[((int64_t)row * r.n_frames + f) * (N / 2 + 1) + k] = X;
             }
             const float d = ym - xm;
             s1 = fmaf(d, d, s1);
