@@ -58,7 +58,7 @@ static constexpr bool fuse_eq_zs() {
 #endif
 }
 
-extern "C" int mst_abi_version(void) { return 7; }
+extern "C" int mst_abi_version(void) { return 8; }
 #ifdef MST_DEV_PROBE  // developer probe (tools/sidestream_probe.py): an event recorded in the middle of the forward's launch sequence
 static hipEvent_t g_probe_ev = nullptr;
 static int g_probe_where = 0;
@@ -92,10 +92,10 @@ extern "C" size_t mst_console_workspace_bytes(const mst_console_desc* d) {
     return (size_t)make_layout(d).total * sizeof(float);
 }
 
-extern "C" int mst_console_forward(const mst_console_desc* d, const float* tracks, const float* track_params,
-                                   const float* fx_bus_params, const float* master_bus_params, const mst_console_fx* fx,
-                                   float* mix, float* mixed_tracks, int32_t* status, void* workspace, size_t workspace_bytes,
-                                   void* stream_) {
+static int console_forward_impl(const mst_console_desc* d, const float* tracks, const float* track_params,
+                                const float* fx_bus_params, const float* master_bus_params, const mst_console_fx* fx,
+                                float* mix, float* mixed_tracks, int32_t* status, void* workspace, size_t workspace_bytes,
+                                void* stream_, int32_t* status_host, void* status_event) {
     if (int e = check_desc(d)) return e;
     const Layout L = make_layout(d);
     if (!workspace || workspace_bytes < (size_t)L.total * sizeof(float) || ((uintptr_t)workspace & 255)) return hipErrorInvalidValue;
@@ -114,6 +114,10 @@ extern "C" int mst_console_forward(const mst_console_desc* d, const float* track
         BasicArgs ba{tracks, track_params, fx_bus_params, master_bus_params, mix, mixed_tracks, status, nullptr, nullptr, nullptr, nullptr, nullptr,
                      ws + L.cp_t, *d};
         launch_basic_forward(ba, stream);
+        if (status_host) {  // (see below: the verdict of the range check, mirrored to the host)
+            (void)hipMemcpyAsync(status_host, status, sizeof(int32_t), hipMemcpyDeviceToHost, stream);
+            if (status_event) (void)hipEventRecord((hipEvent_t)status_event, stream);
+        }
         return (int)hipGetLastError();
     }
 
@@ -127,6 +131,12 @@ extern "C" int mst_console_forward(const mst_console_desc* d, const float* track
         pa.pf_n = n;
     }
     launch_prep(pa, stream);
+    // the range check is complete when k_prep is: its verdict travels to the host NOW, behind k_prep and ahead of the rest of the forward
+    // (mst_console_forward_mirrored) - a caller that wants the reference's immediate ValueError waits for this copy, not for the mix
+    if (status_host && status) {
+        (void)hipMemcpyAsync(status_host, status, sizeof(int32_t), hipMemcpyDeviceToHost, stream);
+        if (status_event) (void)hipEventRecord((hipEvent_t)status_event, stream);
+    }
 #ifdef MST_DEV_PROBE
     if (g_probe_ev && g_probe_where == 0) (void)hipEventRecord(g_probe_ev, stream);
 #endif
@@ -196,6 +206,22 @@ extern "C" int mst_console_forward(const mst_console_desc* d, const float* track
 
 // carry scan of the all-pole bank's chunk states: every row, or - when the forward's master-bus run already carried the track rows'
 // (Layout::apscan_fwd) - the master rows only
+extern "C" int mst_console_forward(const mst_console_desc* d, const float* tracks, const float* track_params,
+                                   const float* fx_bus_params, const float* master_bus_params, const mst_console_fx* fx,
+                                   float* mix, float* mixed_tracks, int32_t* status, void* workspace, size_t workspace_bytes,
+                                   void* stream) {
+    return console_forward_impl(d, tracks, track_params, fx_bus_params, master_bus_params, fx, mix, mixed_tracks, status, workspace,
+                                workspace_bytes, stream, nullptr, nullptr);
+}
+extern "C" int mst_console_forward_mirrored(const mst_console_desc* d, const float* tracks, const float* track_params,
+                                            const float* fx_bus_params, const float* master_bus_params, const mst_console_fx* fx,
+                                            float* mix, float* mixed_tracks, int32_t* status, void* workspace, size_t workspace_bytes,
+                                            void* stream, int32_t* status_host, void* status_event) {
+    if (!status || !status_host) return hipErrorInvalidValue;
+    return console_forward_impl(d, tracks, track_params, fx_bus_params, master_bus_params, fx, mix, mixed_tracks, status, workspace,
+                                workspace_bytes, stream, status_host, status_event);
+}
+
 static void allpole_scan(const Layout& L, float* ws, int nsig_all, hipStream_t stream) {
     if (L.apscan_fwd && fuse_allpole()) {
         // nothing up front: the track rows' scans rode on the forward's master-bus run, the master rows' ride on the backward's adjoint run

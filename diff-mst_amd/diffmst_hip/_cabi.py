@@ -24,7 +24,7 @@ DEV_MULTIPASS_EQ = 0x200
 NO_RANGE_CHECK = 0x400
 BWD_PREPARED = 0x800
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class ConsoleDesc(C.Structure):
@@ -121,6 +121,7 @@ SIGNATURES = {
     "mst_console_fx_tables_bytes": (C.c_size_t, []),
     "mst_console_fx_init_tables": (C.c_int, [_P, _P]),
     "mst_console_forward": (C.c_int, [C.POINTER(ConsoleDesc), _P, _P, _P, _P, C.POINTER(ConsoleFx), _P, _P, _P, _P, C.c_size_t, _P]),
+    "mst_console_forward_mirrored": (C.c_int, [C.POINTER(ConsoleDesc), _P, _P, _P, _P, C.POINTER(ConsoleFx), _P, _P, _P, _P, C.c_size_t, _P, _P, _P]),
     "mst_console_backward": (C.c_int, [C.POINTER(ConsoleDesc), _P, _P, _P, _P, C.POINTER(ConsoleFx), _P, _P, _P, _P, _P, _P, _P, _P,
                                        C.c_size_t, _P]),
     "mst_console_backward_prepare": (C.c_int, [C.POINTER(ConsoleDesc), _P, C.c_size_t, _P]),

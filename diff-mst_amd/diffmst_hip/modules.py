@@ -155,14 +155,25 @@ class _ConsoleFunction(torch.autograd.Function):
         mix = torch.empty(bs, 2, n, dtype=torch.float32, device=dev)
         mixed = torch.empty(bs, 2, n_tracks, n, dtype=torch.float32, device=dev) if want_mixed else None
         status = console._status_word(dev)
+        mirror = console._status_mirror(dev) if console.validate == "sync" and not torch.cuda.is_current_stream_capturing() else None
         with torch.cuda.device(dev):
-            rc = lib.mst_console_forward(
-                ctypes.byref(desc), _cabi.ptr(rows), _cabi.ptr(tp), _cabi.ptr(fp), _cabi.ptr(mp),
-                ctypes.byref(fx) if fx is not None else None, _cabi.ptr(mix),
-                _cabi.ptr(mixed), _cabi.ptr(status), _cabi.ptr(ws), nbytes, _hip.current_stream_ptr(dev),
-            )
+            if mirror is not None:
+                # validate="sync": the range check's verdict is copied to pinned host memory right behind the launch that forms it, the
+                # rest of the forward is enqueued behind that copy, and the host waits for the COPY - not for the mix
+                rc = lib.mst_console_forward_mirrored(
+                    ctypes.byref(desc), _cabi.ptr(rows), _cabi.ptr(tp), _cabi.ptr(fp), _cabi.ptr(mp),
+                    ctypes.byref(fx) if fx is not None else None, _cabi.ptr(mix),
+                    _cabi.ptr(mixed), _cabi.ptr(status), _cabi.ptr(ws), nbytes, _hip.current_stream_ptr(dev),
+                    ctypes.c_void_p(mirror[0].data_ptr()), ctypes.c_void_p(mirror[1].cuda_event),
+                )
+            else:
+                rc = lib.mst_console_forward(
+                    ctypes.byref(desc), _cabi.ptr(rows), _cabi.ptr(tp), _cabi.ptr(fp), _cabi.ptr(mp),
+                    ctypes.byref(fx) if fx is not None else None, _cabi.ptr(mix),
+                    _cabi.ptr(mixed), _cabi.ptr(status), _cabi.ptr(ws), nbytes, _hip.current_stream_ptr(dev),
+                )
         _hip.check(rc, "mst_console_forward")
-        console._note_status(status)
+        console._note_status(status, mirror)
         ctx.prep_event = None
         if need_grad and console.overlap_backward_prepare and not torch.cuda.is_current_stream_capturing():
             # The first 15 us of the backward (all-pole carry scan) depend only on what forward saved: queue them on a side stream
@@ -314,6 +325,7 @@ class AdvancedMixConsole(torch.nn.Module):
         self.supports_fx_bus = True
         self._fx_cache = {}
         self._status = {}
+        self._mirror = {}
         self._affine_cache = {}
         self._desc_cache = {}
         self._multipass_eq = False  # test switch: EQ carries through the separate carry-scan kernel at any length
@@ -328,9 +340,26 @@ class AdvancedMixConsole(torch.nn.Module):
             t = self._status[key] = torch.zeros(1, dtype=torch.int32, device=device)
         return t
 
-    def _note_status(self, status: torch.Tensor):
+    def _status_mirror(self, device):
+        """(pinned int32, event) per device: where `mst_console_forward_mirrored` puts the range check's verdict (validate="sync")."""
+        key = str(device)
+        m = self._mirror.get(key)
+        if m is None:
+            ev = torch.cuda.Event()
+            with torch.cuda.device(device):
+                ev.record()  # creates the underlying hipEvent_t, which the library records from now on
+            m = self._mirror[key] = (torch.zeros(1, dtype=torch.int32).pin_memory(), ev)
+        return m
+
+    def _note_status(self, status: torch.Tensor, mirror=None):
         if self.validate == "sync":
-            code = int(status.item())
+            if mirror is not None:
+                # the copy sits right behind the parameter check (20 us into the call): range errors raise HERE, like the reference's; a code
+                # raised by a LATER launch of this call (exchange time-out) stays in the sticky device word and raises at the next check
+                mirror[1].synchronize()
+                code = int(mirror[0][0])
+            else:
+                code = int(status.item())
             if code:
                 status.zero_()
                 raise _desc.status_to_error(code)

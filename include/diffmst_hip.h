@@ -127,6 +127,16 @@ int mst_console_forward(const mst_console_desc* d, const float* tracks, const fl
                         const float* fx_bus_params, const float* master_bus_params, const mst_console_fx* fx,
                         float* mix, float* mixed_tracks, int32_t* status, void* workspace, size_t workspace_bytes,
                         void* stream);
+/* The same call (ABI v8) with the verdict of the range check MIRRORED to the host as soon as it exists: the parameters are checked by
+ * the first launch of the forward; right behind it - ahead of every other launch - *status is copied to `status_host` (pinned host
+ * memory, one int32) and `status_event` (a hipEvent_t, may be NULL) is recorded.  A caller that wants the reference's immediate
+ * ValueError (mst/modules.py:86-89) enqueues the whole forward, then waits for THAT event - 20 us into the call - instead of for the
+ * mix: the device never idles behind the host.  Codes raised by later launches of the call (MST_STATUS_EXCHANGE_TIMEOUT) are not in
+ * the mirrored value; the device word is sticky and the next mirrored call (or any read of *status) sees them. */
+int mst_console_forward_mirrored(const mst_console_desc* d, const float* tracks, const float* track_params,
+                                 const float* fx_bus_params, const float* master_bus_params, const mst_console_fx* fx,
+                                 float* mix, float* mixed_tracks, int32_t* status, void* workspace, size_t workspace_bytes,
+                                 void* stream, int32_t* status_host, void* status_event);
 
 /* Reverse-mode of the above (what autograd does through the reference's op graph).
  * `workspace` must be the buffer a forward call with MST_SAVE_FOR_BACKWARD filled, untouched.

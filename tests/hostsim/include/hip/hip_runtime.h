@@ -50,6 +50,7 @@ static inline hipError_t hipGetLastError() { return 0; }
 static inline hipError_t hipPeekAtLastError() { return 0; }
 static inline const char* hipGetErrorString(hipError_t) { return "hostsim"; }
 static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return 0; }
+enum { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3 };
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { memcpy(d, s, n); return 0; }
 #define hipMemcpyDeviceToDevice 3
 typedef void* hipEvent_t;

@@ -28,14 +28,18 @@ def params():
             torch.rand(bs, 26, device=dev, requires_grad=True))
 flags = dict(use_track_input_fader=True, use_track_eq=True, use_track_compressor=True, use_track_panner=True,
              use_fx_bus=False, use_master_bus=True, use_output_fader=True)
-# validate="sync": the forward itself raises
+# validate="sync": the host reads the status word as mirrored right behind the parameter check (ABI v8) - a time-out of a LATER launch of
+# the same call is in the sticky device word and raises at the next call at the latest
 tp, fp, mp = params()
 c = AdvancedMixConsole(44100)
-try:
-    c(tracks, tp, fp, mp, **flags)
-    print("SYNC no-raise")
-except RuntimeError as e:
-    print("SYNC RuntimeError", "timed out" in str(e))
+raised = None
+for attempt in range(2):
+    try:
+        c(tracks, tp, fp, mp, **flags)
+    except RuntimeError as e:
+        raised = (attempt, "timed out" in str(e))
+        break
+print("SYNC RuntimeError", raised is not None and raised[1], "attempt", None if raised is None else raised[0])
 # validate="deferred": the call returns (poisoned), check_parameters() raises; the status word is cleared by the read
 c = AdvancedMixConsole(44100, validate="deferred")
 tp, fp, mp = params()
@@ -68,7 +72,7 @@ def test_timed_out_exchange_raises():
     out = subprocess.run([sys.executable, "-c", SCRIPT], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = out.stdout.strip().splitlines()
-    assert "SYNC RuntimeError True" in lines, out.stdout
+    assert any(l.startswith("SYNC RuntimeError True") for l in lines), out.stdout
     assert "DEFERRED finite False" in lines, out.stdout  # the poisoned call is visibly poisoned ...
     assert "DEFERRED RuntimeError True" in lines, out.stdout  # ... and the deferred check raises
     assert "BACKWARD RuntimeError True" in lines, out.stdout
