@@ -231,18 +231,29 @@ __global__ __launch_bounds__(512, MST_STFT2_W8192) void k_stft3_fwd(Stft3Args p)
     if (!(MST_STFT3_ROLES & 1) && b < p.wg_end[0]) return;
     if (!(MST_STFT3_ROLES & 2) && b >= p.wg_end[0] && b < p.wg_end[1]) return;
     if (!(MST_STFT3_ROLES & 4) && b >= p.wg_end[1]) return;
+#ifndef MST_STFT3_XCD
+#define MST_STFT3_XCD 1  // neighbouring strips of a row on ONE XCD (they share half a frame of samples): see xcd_chunk below
+#endif
+    // Workgroup ids go round-robin over the eight XCDs, each with an L2 of its own: strips u, u + 1 of a row - which read the same half
+    // frame - landed on two L2s and the overlap was fetched twice from the fabric (FETCH_SIZE of this launch: 4.3x its unique input).
+    // Within a role, XCD j takes the j-th contiguous eighth of the (row, strip) sequence instead.
+    auto xcd_chunk = [](int u, int n) {
+        if (!MST_STFT3_XCD) return u;
+        const int q = n >> 3, r = n & 7, x = u & 7, idx = u >> 3;
+        return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + idx;
+    };
     if (b < p.wg_end[0]) {
-        const int G = p.groups[0];
-        stft2_fwd_body<8192>(p.a[0], tid, b % G, G, b / G, true, reinterpret_cast<float2(*)[FftShape<8192>::SLOTS]>(lds), red);
+        const int G = p.groups[0], u = xcd_chunk(b, p.wg_end[0]);
+        stft2_fwd_body<8192>(p.a[0], tid, u % G, G, u / G, true, reinterpret_cast<float2(*)[FftShape<8192>::SLOTS]>(lds), red);
     } else if (b < p.wg_end[1]) {
-        const int u = b - p.wg_end[0], G = p.groups[1], sub = __builtin_amdgcn_readfirstlane(tid >> 8);  // wave-uniform: keep it scalar
+        const int u = xcd_chunk(b - p.wg_end[0], p.wg_end[1] - p.wg_end[0]), G = p.groups[1], sub = __builtin_amdgcn_readfirstlane(tid >> 8);  // wave-uniform: keep it scalar
         const int row = 2 * (u / G) + sub;
         const bool live = row < p.rows;
         stft2_fwd_body<2048>(p.a[1], tid & 255, u % G, G, live ? row : p.rows - 1, live,
                              reinterpret_cast<float2(*)[FftShape<2048>::SLOTS]>(lds + sub * FftShape<2048>::SLOTS), red + 4 * sub);
     } else {
         const int G = p.groups[2], wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-        const int u = (b - p.wg_end[1]) * 8 + wave;
+        const int u = xcd_chunk(b - p.wg_end[1], p.wg_end[2] - p.wg_end[1]) * 8 + wave;
         if (u < G * p.rows)
             stft2_fwd_body<512>(p.a[2], tid & 63, u % G, G, u / G, true,
                                 reinterpret_cast<float2(*)[FftShape<512>::SLOTS]>(lds + wave * FftShape<512>::SLOTS), red + wave);
