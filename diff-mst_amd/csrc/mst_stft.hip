@@ -702,11 +702,13 @@ Plan make_plan(const mst_mrstft_desc* d) {
 #endif
         if (p.engine2[i]) {
             // balanced strips of ~8 / 4 / 2 frames (one workgroup each): consecutive frames share half their samples
+            // fused forward with the kept spectra (one box, us): (4, 4) 83.8; (3, 4) 80.0; (3, 6) 79.6; (3, 7) 80.0; (4, 6) 78.6 vs 81.5; (6, 4) 83.6 vs
+            // 81.5; (2, 4) 81.5 vs 85.0 - short one-wave 512-point strips fill the launch's tail, long 2048-point strips amortise their prologue
 #ifndef MST_STFT2_STRIP_512
-#define MST_STFT2_STRIP_512 4
+#define MST_STFT2_STRIP_512 3
 #endif
 #ifndef MST_STFT2_STRIP_2048
-#define MST_STFT2_STRIP_2048 4
+#define MST_STFT2_STRIP_2048 6
 #endif
             // at cfg #2 (16 rows x 262144): 4100 one-wave / 1024 four-wave / 512 eight-wave workgroups = one resident round each
 #ifndef MST_STFT2_STRIP_8192
