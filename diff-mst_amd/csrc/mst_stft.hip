@@ -802,8 +802,11 @@ extern "C" int mst_mrstft_init_tables(const mst_mrstft_desc* d, void* tables, vo
 // stages: 1 = transforms + row sums (+ totals when asked for), 2 = loss + backward coefficients
 static int mrstft_forward_stages(const mst_mrstft_desc* d, const float* pred, const float* target, const void* tables, float* loss,
                                  double* totals, const double* gtotals, int world, int stages, void* workspace,
-                                 size_t workspace_bytes, void* stream_) {
-    const Plan p = make_plan(d);
+                                 size_t workspace_bytes, void* stream_, bool keep = true) {
+    Plan p = make_plan(d);
+    if (!keep) {  // evaluation only (mst_mrstft_forward_eval): nothing is kept for a backward, the planes are not written
+        for (int i = 0; i < kMaxRes; ++i) p.ymag_off[i] = p.xspec_off[i] = -1;
+    }
     if (!p.ok || !workspace) return hipErrorInvalidValue;
     if ((stages & 1) && (!pred || !target || !tables)) return hipErrorInvalidValue;
     if ((stages & 2) && (!loss || world < 1)) return hipErrorInvalidValue;
@@ -908,6 +911,10 @@ static int mrstft_forward_stages(const mst_mrstft_desc* d, const float* pred, co
 extern "C" int mst_mrstft_forward(const mst_mrstft_desc* d, const float* pred, const float* target, const void* tables,
                                   float* loss, void* workspace, size_t workspace_bytes, void* stream) {
     return mrstft_forward_stages(d, pred, target, tables, loss, nullptr, nullptr, 1, 3, workspace, workspace_bytes, stream);
+}
+extern "C" int mst_mrstft_forward_eval(const mst_mrstft_desc* d, const float* pred, const float* target, const void* tables,
+                                       float* loss, void* workspace, size_t workspace_bytes, void* stream) {
+    return mrstft_forward_stages(d, pred, target, tables, loss, nullptr, nullptr, 1, 3, workspace, workspace_bytes, stream, false);
 }
 extern "C" int mst_mrstft_forward_partial(const mst_mrstft_desc* d, const float* pred, const float* target, const void* tables,
                                           double* totals, void* workspace, size_t workspace_bytes, void* stream) {

@@ -129,6 +129,7 @@ SIGNATURES = {
     "mst_mrstft_init_tables": (C.c_int, [C.POINTER(MrstftDesc), _P, _P]),
     "mst_mrstft_workspace_bytes": (C.c_size_t, [C.POINTER(MrstftDesc)]),
     "mst_mrstft_forward": (C.c_int, [C.POINTER(MrstftDesc), _P, _P, _P, _P, _P, C.c_size_t, _P]),
+    "mst_mrstft_forward_eval": (C.c_int, [C.POINTER(MrstftDesc), _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "mst_mrstft_forward_partial": (C.c_int, [C.POINTER(MrstftDesc), _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "mst_mrstft_forward_finish": (C.c_int, [C.POINTER(MrstftDesc), _P, C.c_int32, _P, _P, C.c_size_t, _P]),
     "mst_mrstft_backward": (C.c_int, [C.POINTER(MrstftDesc), _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),

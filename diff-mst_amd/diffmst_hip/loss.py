@@ -90,11 +90,14 @@ class _MrstftFunction(torch.autograd.Function):
                                                          _cabi.ptr(loss), _cabi.ptr(ws), nbytes, _hip.current_stream_ptr(dev)),
                            "mst_mrstft_forward_finish")
         else:
+            # no gradient asked for (torch.no_grad(), a detached prediction): the value only - the forward then keeps no spectra
+            fwd = lib.mst_mrstft_forward if ctx.needs_input_grad[0] else lib.mst_mrstft_forward_eval
             with torch.cuda.device(dev):
-                _hip.check(lib.mst_mrstft_forward(ctypes.byref(desc), _cabi.ptr(x), _cabi.ptr(y), _cabi.ptr(tables), _cabi.ptr(loss),
-                                                  _cabi.ptr(ws), nbytes, _hip.current_stream_ptr(dev)), "mst_mrstft_forward")
-        ctx.desc, ctx.nbytes, ctx.shape = desc, nbytes, pred.shape
-        ctx.save_for_backward(x, y, tables, ws)
+                _hip.check(fwd(ctypes.byref(desc), _cabi.ptr(x), _cabi.ptr(y), _cabi.ptr(tables), _cabi.ptr(loss),
+                               _cabi.ptr(ws), nbytes, _hip.current_stream_ptr(dev)), "mst_mrstft_forward")
+        if ctx.needs_input_grad[0]:
+            ctx.desc, ctx.nbytes, ctx.shape = desc, nbytes, pred.shape
+            ctx.save_for_backward(x, y, tables, ws)
         return loss.reshape(())
 
     @staticmethod

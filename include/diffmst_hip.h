@@ -190,6 +190,11 @@ size_t mst_mrstft_workspace_bytes(const mst_mrstft_desc* d);
 /* loss: one fp32 on the device. */
 int mst_mrstft_forward(const mst_mrstft_desc* d, const float* pred, const float* target, const void* tables,
                        float* loss, void* workspace, size_t workspace_bytes, void* stream);
+/* The same loss with NOTHING kept for a backward (ABI v8): the spectra / magnitude planes are not written (153 MB per call at BASELINE
+ * cfg #2), the workspace afterwards holds no valid backward state - for callers that only want the value (validation loops,
+ * torch.no_grad()).  Same workspace size. */
+int mst_mrstft_forward_eval(const mst_mrstft_desc* d, const float* pred, const float* target, const void* tables,
+                            float* loss, void* workspace, size_t workspace_bytes, void* stream);
 /* Sharded evaluation (the batch rows are split over ranks, one process per GPU; reference: DDP over the batch axis,
  * configs/config.yaml:34-42).  Every term of the loss is a mean over rows except the batch-global spectral-convergence
  * ratio (sc_per_example = 0), whose two squared norms must be summed over ALL ranks before the division:

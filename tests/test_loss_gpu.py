@@ -192,6 +192,27 @@ def test_mrstft_known_answers(dev):
     assert torch.isfinite(x.grad).all()
 
 
+def test_mrstft_value_only_call(dev):
+    """No gradient asked for (torch.no_grad(), or a prediction that does not require grad): `mst_mrstft_forward_eval` - the same launches
+    without the kept spectra - returns the bit-identical loss, and a later differentiable call is unaffected."""
+    torch.manual_seed(5)
+    x = (0.1 * torch.randn(2, 2, 65536)).to(dev)
+    y = (0.1 * torch.randn(2, 2, 65536)).to(dev)
+    f = make_loss()
+    xg = x.clone().requires_grad_(True)
+    l_grad = f(xg, y)
+    with torch.no_grad():
+        l_eval = f(xg, y)
+    l_detached = f(x, y)
+    assert not l_eval.requires_grad and not l_detached.requires_grad
+    assert torch.equal(l_eval, l_grad.detach()) and torch.equal(l_detached, l_grad.detach())
+    l_grad.backward()
+    g1 = xg.grad.clone()
+    xg.grad = None
+    f(xg, y).backward()
+    assert torch.equal(g1, xg.grad) and torch.isfinite(g1).all()
+
+
 def test_mrstft_odd_configuration(dev):
     """auraloss default-like resolutions: hop not dividing n_fft, win_length < n_fft, odd length."""
     from oracle import loss_restated as ol
