@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 out=$R/gpurun_out/cfg5_prof; rm -rf $out
 rocprofv3 --kernel-trace -d $out -o r --output-format csv -- python $R/tools/cfg5_step.py 3 > $out.log 2>&1
-grep "cfg5 step" $out.log
+grep "cfg5 step\|pipelined" $out.log
 python - <<PY
 import csv, glob, collections
 f = glob.glob("$out/**/r_kernel_trace.csv", recursive=True)[0]
