@@ -163,8 +163,12 @@ class CommonStep(torch.nn.Module):
         if self.use_mix_loss:
             mix_loss = self.loss(pred_mix_b, ref_mix_b)
             if type(mix_loss) == dict:
+                # reference: `loss += val.mean()` from `loss = 0`.  The mean of a 0-dim value IS the value and 0 + v IS v, to the bit: for
+                # the five 0-dim terms of AudioFeatureLoss that is 6 tiny launches forward and 5 backward less per step (cfg #5 is
+                # launch-bound at the bf16 precision: profiles/round5_cfg5.md)
                 for key, val in mix_loss.items():
-                    loss += val.mean()
+                    term = val if val.dim() == 0 else val.mean()
+                    loss = term if isinstance(loss, int) else loss + term
                 terms = mix_loss
             else:
                 loss += mix_loss
