@@ -712,7 +712,10 @@ Plan make_plan(const mst_mrstft_desc* d) {
 #endif
             // at cfg #2 (16 rows x 262144): 4100 one-wave / 1024 four-wave / 512 eight-wave workgroups = one resident round each
 #ifndef MST_STFT2_STRIP_8192
-#define MST_STFT2_STRIP_8192 1  // one frame per workgroup: 1040 workgroups walk the 512 resident slots without the three-frame stragglers of two-frame strips (fused forward 72.6 -> 68.5 us)
+// Frames per 8192-point forward strip.  Without the kept spectra one frame per workgroup was best (fused forward 72.6 -> 68.5 us: 1040 workgroups
+// walk the 512 resident slots without the stragglers of two-frame strips); with them - a heavier epilogue, the strips of a row on one XCD - the
+// prologue is worth amortising again (one box, us): 1: 78.3; 2: 73.9; 3: 73.6; 4: 71.0; 5: 70.7 / 69.3; 6: 72.6; 8: 83.3; 11: 114
+#define MST_STFT2_STRIP_8192 5
 #endif
             const int target = nf == 512 ? MST_STFT2_STRIP_512 : (nf == 2048 ? MST_STFT2_STRIP_2048 : MST_STFT2_STRIP_8192);
             p.n_groups[i] = r.n_frames / target > 0 ? r.n_frames / target : 1;
