@@ -320,7 +320,10 @@ __device__ __forceinline__ float2 cotangent(const float2 (*buf)[FftShape<N>::SLO
 #ifndef MST_STFT2_W2048_BWD
 #define MST_STFT2_W2048_BWD 1  // min waves per SIMD asked of the 2048-point backward (A/B switch; uncapped it takes 144 registers)
 #endif
-constexpr int kStft2Bwd8192Slots = 256;  // resident workgroups of k_stft2_bwd<8192> on the 256 CUs
+#ifndef MST_STFT2_BWD8192_SLOTS
+#define MST_STFT2_BWD8192_SLOTS 256
+#endif
+constexpr int kStft2Bwd8192Slots = MST_STFT2_BWD8192_SLOTS;  // resident workgroups of k_stft2_bwd<8192> on the 256 CUs
 // one strip of one row by a group of LG lanes (lane = 0 .. LG - 1); buf / hb: the group's LDS (hb: n_fft <= 2048 only)
 template <int N>
 __device__ __forceinline__ void stft2_bwd_body(const StftArgs& a, const int lane, const int strip, const int nstrips, const int row,
