@@ -327,7 +327,7 @@ constexpr int kStft2Bwd8192Slots = MST_STFT2_BWD8192_SLOTS;  // resident workgro
 // one strip of one row by a group of LG lanes (lane = 0 .. LG - 1); buf / hb: the group's LDS (hb: n_fft <= 2048 only)
 template <int N>
 __device__ __forceinline__ void stft2_bwd_body(const StftArgs& a, const int lane, const int strip, const int nstrips, const int row,
-                                               float2 (*buf)[FftShape<N>::SLOTS], float2* hb) {
+                                               float2 (*buf)[FftShape<N>::SLOTS], float2* hb, const int blk0 = -1, const int blk1 = -1) {
     using S = FftShape<N>;
     using L = FrameLoader<N>;
     constexpr int LG = S::LG, H = N / 2;
@@ -352,6 +352,7 @@ __device__ __forceinline__ void stft2_bwd_body(const StftArgs& a, const int lane
     } else {
         int b0, b1;
         strip_range(strip, nstrips, B, b0, b1);
+        if (blk0 >= 0) { b0 = blk0; b1 = blk1; }  // the caller's own split of the row (k_stft2_bwd_512_2048)
         F0 = b0;
         F1 = b1 + 1;
     }
@@ -1078,19 +1079,26 @@ __global__ __launch_bounds__(FftPlan<N>::LG, (N == 8192 ? MST_STFT2_W8192_BWD : 
 // workgroup first runs those four 512-point strips, one per wave (no workgroup barrier in that part), then - behind one barrier that
 // also drains its stores - the 2048-point strip, which read-modify-writes the samples the same workgroup has just written: no second
 // launch, and the re-read comes out of this CU's own cache levels.  LDS and registers are the 2048-point kernel's (4 x 9 KB = 36 KB,
-// <= 128): four workgroups per CU as before.  Needs whole strips: (n / 1024) % 4 == 0 (stft2_bwd_can_fuse).
+// <= 128): four workgroups per CU as before.  Strips are balanced (lengths may differ by one block); other strip lengths measured with
+// the kept spectra (us): L = 3: 51.9, 4: 44.4, 5: 47.9, 6: 51.0 - a strip is a dependent chain, fewer inverses per row do not pay for a longer one.
 __global__ __launch_bounds__(256, MST_STFT2_W2048_BWD) void k_stft2_bwd_512_2048(StftArgs a512, StftArgs a2048) {
     using S5 = FftShape<512>;
     using S2 = FftShape<2048>;
     __shared__ __attribute__((aligned(16))) float2 lds[2 * S2::SLOTS];
     static_assert(8 * S5::SLOTS <= 2 * S2::SLOTS, "four waves' 512-point buffers fit the 2048-point kernel's");
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // the 2048-point strip's hop blocks [B0, B1) are the 512-point blocks [4 B0, 4 B1): a quarter of them per wave (balanced strips may differ
+    // in length by one block - the quarters follow their own strip, not a split of the whole row)
+    int B0, B1;
+    strip_range(blockIdx.x, gridDim.x, (int)(a2048.n / 1024), B0, B1);
+    const int q = B1 - B0;
     stft2_bwd_body<512>(a512, tid & 63, 4 * blockIdx.x + wave, 4 * gridDim.x, blockIdx.y,
-                        reinterpret_cast<float2(*)[S5::SLOTS]>(lds + 2 * wave * S5::SLOTS), lds + (2 * wave + 1) * S5::SLOTS);
+                        reinterpret_cast<float2(*)[S5::SLOTS]>(lds + 2 * wave * S5::SLOTS), lds + (2 * wave + 1) * S5::SLOTS,
+                        4 * B0 + wave * q, 4 * B0 + (wave + 1) * q);
     __syncthreads();  // s_waitcnt vmcnt(0) + barrier: the four strips' stores have left before any lane of the workgroup reads them back
     stft2_bwd_body<2048>(a2048, tid, blockIdx.x, gridDim.x, blockIdx.y, reinterpret_cast<float2(*)[S2::SLOTS]>(lds), lds + S2::SLOTS);
 }
-bool stft2_bwd_can_fuse(int64_t n) { return MST_STFT2_BWD_L512 == MST_STFT2_BWD_L2048 && n % 1024 == 0 && (n / 1024) % MST_STFT2_BWD_L2048 == 0; }
+bool stft2_bwd_can_fuse(int64_t n) { return MST_STFT2_BWD_L512 == MST_STFT2_BWD_L2048 && n % 1024 == 0 && n / 1024 >= 2 * MST_STFT2_BWD_L2048; }
 void launch_stft2_bwd_512_2048(const StftArgs& a512, const StftArgs& a2048, int rows, hipStream_t stream) {
     const int G = stft2_bwd_groups(2048, a2048.r.n_frames, rows);
     hipLaunchKernelGGL(k_stft2_bwd_512_2048, dim3(G, rows), dim3(256), 0, stream, a512, a2048);
