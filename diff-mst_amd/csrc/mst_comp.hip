@@ -15,6 +15,22 @@ namespace mst {
 
 constexpr int CC = kCompChunk;
 
+// developer timeline (-DMST_CBR_STAMPS, tools/cbr_timeline.py): wave 0 of every track workgroup of k_comp_bwd_run stamps the 100 MHz
+// wall clock at its phase boundaries; mst_debug_read_cbr_stamps copies the table out
+#ifdef MST_CBR_STAMPS
+constexpr int kStampSlots = 12, kStampWGs = 16384;
+__device__ unsigned long long g_cbr_stamps[kStampWGs * kStampSlots];
+#define CBR_STAMP(k)                                                                                         \
+    do {                                                                                                     \
+        if (!MASTER && threadIdx.x == 0) {                                                                   \
+            const int wg_ = blockIdx.x + gridDim.x * blockIdx.y;                                             \
+            if (wg_ < kStampWGs) g_cbr_stamps[wg_ * kStampSlots + (k)] = wall_clock64();                     \
+        }                                                                                                    \
+    } while (0)
+#else
+#define CBR_STAMP(k) do {} while (0)
+#endif
+
 __device__ __forceinline__ void ld8(const float* row, int64_t i, int64_t n, float* v) {
     const float4 a = load4(row, i, n), b = load4(row, i + 4, n);
     v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
@@ -623,6 +639,7 @@ __device__ __forceinline__ void comp_bwd_run_body(const CompBwdArgs& a, int row,
     for (int i = 0; i < CP_COUNT; ++i) p[i] = 0.0f;
     float gl[CC], gr[CC], du0[CC], du1[CC];
     float xu[CC], xu1[MASTER ? CC : 1];  // the compressor input of this lane's samples, kept for the fused coefficient-gradient pass
+    CBR_STAMP(0);
     load_gy<MASTER, FAST>(a, row, rc, i0, gl, gr);
     CgStates cgs = {0.f, 0.f, 0.f, 0.f}, cgs1 = {0.f, 0.f, 0.f, 0.f};  // all-pole entry states of the coefficient walk, when requested early
     bool have_cgs = false;
@@ -698,10 +715,12 @@ __device__ __forceinline__ void comp_bwd_run_body(const CompBwdArgs& a, int row,
         }
         const float ac = rc[RC_ALPHA_C], l2a = rc[RC_LOG2A_C];
         gran_t* gq = a.gran ? a.gran + (int64_t)row * gridDim.x : nullptr;
+        CBR_STAMP(1);
         if (gq) {
             const float agg = block_aggregate<true>(zq, l2a, red[0], tid);
             if (tid == 0) gran_publish(gq + blk, a.gran_near, agg);
         }
+        CBR_STAMP(2);
         // look-ahead branch: du[i] += gy[i+L] * G[i+L].  Folded to one (two: master) value per sample right after the loads -
         // three arrays less are alive across the block scan (the kernel ran at 152 registers = 3 waves per SIMD)
         float fwd0[CC], fwd1[MASTER ? CC : 1];
@@ -718,6 +737,7 @@ __device__ __forceinline__ void comp_bwd_run_body(const CompBwdArgs& a, int row,
                 if (MASTER) fwd1[i] = liveF ? pr * grF[i] * GF : 0.0f;
             }
         }
+        CBR_STAMP(3);
         if (!(MST_CBR_EARLY & 2)) {
             LD8<FAST>(u0, i0, a.n, x0);
             if (MASTER) LD8<FAST>(u1, i0, a.n, x1);
@@ -739,6 +759,7 @@ __device__ __forceinline__ void comp_bwd_run_body(const CompBwdArgs& a, int row,
         float Q0 = 0.0f, W = 0.0f;
         block_enter_split<true>(zq, ac, l2a, red[0], tid, Q0, W);
         const gran_t peek = gq ? carry_peek<true>(gq, a.gran_near, blk, gridDim.x, tid) : 0ull;
+        CBR_STAMP(4);
         // q[i] = zs[i] + pw[i] Q with zs the zero-entry recurrence over this lane's samples and pw[i] = alpha^(CC - i):
         //   alpha += q A;  kappa += oma q Fv;  thr -= oma q Kp;  knee += oma q Kw;  du = oma q E + look-ahead branch
         // pairs (zero-state part, homogeneous part): one packed multiply-add per sum and sample
@@ -780,8 +801,10 @@ __device__ __forceinline__ void comp_bwd_run_body(const CompBwdArgs& a, int row,
             db[i] = zp.y * cE;
             if (MST_CBR_SCHED & 2) __builtin_amdgcn_sched_barrier(0);
         }
+        CBR_STAMP(5);
         const float S = gq ? block_carry_g<true>(gq, a.gran_near, peek, blk, gridDim.x, l2a, red[0], tid, a.status)
                            : block_carry<true>(a.s0 + (int64_t)row * gridDim.x, blk, gridDim.x, l2a, red[0], tid);
+        CBR_STAMP(6);
         const float Q = fmaf(W, S, Q0);
 #pragma unroll
         for (int i = 0; i < CC; ++i) {
@@ -880,11 +903,13 @@ __device__ __forceinline__ void comp_bwd_run_body(const CompBwdArgs& a, int row,
         ST8<FAST>(a.du + (int64_t)(row * NCH) * a.stride, i0, a.n, du0);
         if (MASTER) ST8<FAST>(a.du + (int64_t)(row * NCH + 1) * a.stride, i0, a.n, du1);
     }
+    CBR_STAMP(7);
     if (a.ep) {  // signal rows: tracks = row, master = 2 row + channel
         coefgrad_fused<FAST>(a, blk, row * NCH, rc, i0, xu, du0, cg_u, cg_g, have_cgs, cgs);
         if (MASTER) coefgrad_fused<FAST>(a, blk, row * NCH + 1, rc, i0, xu1, du1, cg_u, cg_g, have_cgs, cgs1);
     }
 
+    CBR_STAMP(8);
     const int wave = tid >> 6, lane = tid & 63;
 #pragma unroll
     for (int i = 0; i < CP_COUNT; ++i) {
@@ -900,6 +925,7 @@ __device__ __forceinline__ void comp_bwd_run_body(const CompBwdArgs& a, int row,
             for (int w = 0; w < kCompWaves; ++w) t += red[w][tid];
         a.part[((int64_t)row * gridDim.x + blk) * CP_COUNT + tid] = t;
     }
+    CBR_STAMP(9);
 }
 #ifndef MST_COMP_BWD_W
 #define MST_COMP_BWD_W 1  // min waves per SIMD asked of the compressor backward (A/B switch)
@@ -936,6 +962,7 @@ __global__ __launch_bounds__(kWG, (!MASTER && !FXS) ? MST_COMP_BWD_WT : MST_COMP
         }
     }
     if (light) {
+        CBR_STAMP(10);
         const int j = row;
         const int64_t i0 = ((int64_t)blk * kWG + threadIdx.x) * CC;
         const bool fast = a.aligned && (int64_t)(blk + 1) * kWG * CC <= a.n;
@@ -949,6 +976,7 @@ __global__ __launch_bounds__(kWG, (!MASTER && !FXS) ? MST_COMP_BWD_WT : MST_COMP
             ld8(a.cg2_du + (int64_t)j * a.stride, i0, a.n, du);
             coefgrad_fused<false>(a, blk, main_rows + j, a.cg2_rc + (int64_t)(j >> 1) * RC_STRIDE, i0, xu, du, cg_u, cg_g);
         }
+        CBR_STAMP(11);
         return;
     }
     if (a.gran) {
@@ -985,3 +1013,10 @@ void launch_comp_bwd(bool master, bool run, const CompBwdArgs& a, int rows, hipS
 }
 
 }  // namespace mst
+
+#ifdef MST_CBR_STAMPS
+extern "C" int mst_debug_read_cbr_stamps(void* host, size_t bytes) {
+    if (bytes > sizeof(mst::g_cbr_stamps)) bytes = sizeof(mst::g_cbr_stamps);
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(mst::g_cbr_stamps), bytes, 0, hipMemcpyDeviceToHost);
+}
+#endif
