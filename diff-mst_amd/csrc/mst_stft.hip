@@ -612,6 +612,9 @@ __global__ __launch_bounds__(64) void k_mrstft_finish(LossArgs a, unsigned* tick
 #define MST_FINISH_FENCES 0  // 1: the textbook __threadfence() pair around the ticket (rounds 4: two L2 write-back / L1 invalidate
                              // rounds, ~2 x 2-3.5 us of a 9.5 us launch)
 #endif
+#if !MST_FINISH_FENCES && defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "k_mrstft_finish: the fence-free hand-over below relies on gfx942 / gfx950 cache behaviour (sc1 write-through stores, L1-bypassing agent-scope loads); build any other target with -DMST_FINISH_FENCES=1"
+#endif
 #if MST_FINISH_FENCES
     mrstft_rowsum(a, blockIdx.x, blockIdx.y, threadIdx.x);
     __threadfence();
@@ -622,7 +625,9 @@ __global__ __launch_bounds__(64) void k_mrstft_finish(LossArgs a, unsigned* tick
     mrstft_final_body(a, threadIdx.x, rs, ratio, srow, true);
 #else
     // Round 5, no fence: the row sums travel as 8-byte agent-scope atomics on BOTH sides (write-through stores, L1-bypassing loads:
-    // one of the valid hand-over forms of MI355X_MICROARCH.md), the writer drains its stores before it takes the ticket.
+    // one of the valid hand-over forms of MI355X_MICROARCH.md), the writer drains its stores before it takes the ticket.  This is NOT
+    // expressed in the language's memory model (relaxed atomics only): it is correct by the cache behaviour of the targets named in the
+    // #error above, and only built for them - the portable form is the MST_FINISH_FENCES=1 branch.
     mrstft_rowsum<true>(a, blockIdx.x, blockIdx.y, threadIdx.x);
     if (threadIdx.x == 0) {
 #if defined(__clang__)

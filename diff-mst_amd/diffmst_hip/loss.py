@@ -50,8 +50,16 @@ def _tables(desc, resolutions, device):
 
 class _MrstftFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, pred, target, cfg):
+    def forward(ctx, pred, target, cfg, want_grad=True):
         _hip.require_cuda(pred, target)
+        if ctx.needs_input_grad[1]:
+            # auraloss differentiates w.r.t. both arguments; no in-repo caller of the reference asks for the target's gradient
+            # (mst/system.py:331-338: the target is the detached reference mix) and the adjoint kernels do not form it
+            raise NotImplementedError("MultiResolutionSTFTLoss (MI355X build): the target's gradient is not implemented; detach the target")
+        # the backward is wanted when the prediction requires grad AND grad mode is on at the call (forward() itself runs with grad
+        # mode off, so the module hands the caller's mode over): under torch.no_grad() the value-only forward keeps no spectra
+        want_grad = bool(want_grad) and ctx.needs_input_grad[0]
+        ctx.saved = False
         lib = _hip.lib()
         n = pred.shape[-1]
         x = pred.float().reshape(-1, n).contiguous()
@@ -91,18 +99,21 @@ class _MrstftFunction(torch.autograd.Function):
                            "mst_mrstft_forward_finish")
         else:
             # no gradient asked for (torch.no_grad(), a detached prediction): the value only - the forward then keeps no spectra
-            fwd = lib.mst_mrstft_forward if ctx.needs_input_grad[0] else lib.mst_mrstft_forward_eval
+            fwd = lib.mst_mrstft_forward if want_grad else lib.mst_mrstft_forward_eval
             with torch.cuda.device(dev):
                 _hip.check(fwd(ctypes.byref(desc), _cabi.ptr(x), _cabi.ptr(y), _cabi.ptr(tables), _cabi.ptr(loss),
                                _cabi.ptr(ws), nbytes, _hip.current_stream_ptr(dev)), "mst_mrstft_forward")
-        if ctx.needs_input_grad[0]:
+        if want_grad:
             ctx.desc, ctx.nbytes, ctx.shape = desc, nbytes, pred.shape
             ctx.save_for_backward(x, y, tables, ws)
+            ctx.saved = True
         return loss.reshape(())
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_loss):
+        if not ctx.saved:  # nothing was kept (value-only forward): there is no gradient to hand back
+            return None, None, None, None
         x, y, tables, ws = ctx.saved_tensors
         lib = _hip.lib()
         dev = x.device
@@ -112,7 +123,7 @@ class _MrstftFunction(torch.autograd.Function):
             _hip.check(lib.mst_mrstft_backward(ctypes.byref(ctx.desc), _cabi.ptr(x), _cabi.ptr(y), _cabi.ptr(tables), _cabi.ptr(g),
                                                _cabi.ptr(gx), _cabi.ptr(ws), ctx.nbytes, _hip.current_stream_ptr(dev)),
                        "mst_mrstft_backward")
-        return gx.view(ctx.shape), None, None
+        return gx.view(ctx.shape), None, None, None
 
 
 class MultiResolutionSTFTLoss(torch.nn.Module):
@@ -164,7 +175,7 @@ class MultiResolutionSTFTLoss(torch.nn.Module):
         )
 
     def forward(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
-        return _MrstftFunction.apply(x, y, self.cfg)
+        return _MrstftFunction.apply(x, y, self.cfg, torch.is_grad_enabled())
 
 
 # ------------------------------------------------------------------------------------------------

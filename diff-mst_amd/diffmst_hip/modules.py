@@ -131,7 +131,7 @@ class _ConsoleFunction(torch.autograd.Function):
         # the descriptor (78 range look-ups, ~15 us of host time) and its workspace size are rebuilt only when something they are made of
         # changes; param_ranges is still READ on every call (a caller may edit it between calls, like the reference's) - as a fingerprint
         key = (bs, n_tracks, n, row_stride, word, console.sample_rate, console.fx_ir_samples, console.fx_bandpass_taps,
-               tuple(v for d in console.param_ranges.values() for v in d.values()))
+               tuple(tuple(map(float, v)) for d in console.param_ranges.values() for v in d.values()))  # ranges may be lists (YAML)
         hit = console._desc_cache.get(key)
         if hit is None:
             desc = _desc.make_desc(console.param_ranges, console.sample_rate, bs, n_tracks, n, row_stride, word,
@@ -242,7 +242,13 @@ class AdvancedMixConsole(torch.nn.Module):
                                  (returned as ``None``) - the "lean" variant of SURVEY 8d.
       validate                   "sync"  : read the range-check flag after launch and raise the
                                            reference's ValueError immediately (one host sync,
-                                           instead of the reference's 156);
+                                           instead of the reference's 156).  The host waits for the
+                                           verdict of the RANGE CHECK only (copied out right behind the
+                                           launch that forms it): an in-launch exchange time-out of a later
+                                           launch of the same call, or of its backward, stays in the sticky
+                                           status word and raises (RuntimeError) at the next forward, at
+                                           ``check_parameters()`` or at ``CommonStep.check_finite()`` - call
+                                           one of them before an optimizer step / at loop end;
                                  "deferred": keep the flag on the device; ``check_parameters()``
                                            raises later.
       param_dicts                "eager" : the three returned parameter dictionaries are built during the
@@ -329,6 +335,16 @@ class AdvancedMixConsole(torch.nn.Module):
         self._affine_cache = {}
         self._desc_cache = {}
         self._multipass_eq = False  # test switch: EQ carries through the separate carry-scan kernel at any length
+
+    # per-device / per-signature caches (status words, pinned mirrors with their events, descriptors, constant tables) are not module
+    # state: copy.deepcopy / pickling of a console that has already run gets fresh, empty ones (a torch.cuda.Event does not pickle)
+    _CACHES = ("_fx_cache", "_status", "_mirror", "_affine_cache", "_desc_cache")
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        for k in self._CACHES:
+            state[k] = {}
+        return state
 
     # ------------------------------------------------------------------ validation
     def _status_word(self, device) -> torch.Tensor:

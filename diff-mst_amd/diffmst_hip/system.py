@@ -104,6 +104,11 @@ class CommonStep(torch.nn.Module):
         flag, self._nan_flag = self._nan_flag, None
         if flag is not None and bool(flag):
             raise ValueError("Found nan in ref_mix")
+        # the same (already synchronous) point reads the console's sticky status word: an in-launch exchange that timed out in a LATER
+        # launch of an earlier forward, or in its backward, is reported here at the latest - validate="sync" only waits for the range
+        # check's verdict, 20 us into the call (diffmst_hip/modules.py: _note_status)
+        if flag is not None and hasattr(self.mix_console, "check_parameters"):
+            self.mix_console.check_parameters()
 
     def forward(self, batch: tuple, train: bool = False, collect: bool = False):
         tracks, instrument_id, stereo_info, track_padding, ref_mix, song_name = batch

@@ -31,7 +31,7 @@ def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
 
 
-# ---- measured parity numbers of the -m gpu tests -> gpurun_out/parity_r05.json (committed copy: profiles/) -----------
+# ---- measured parity numbers of the -m gpu tests -> gpurun_out/parity_r06.json (committed copy: profiles/) -----------
 _PARITY = {}
 
 
@@ -59,5 +59,5 @@ def pytest_sessionfinish(session, exitstatus):
     os.makedirs(out, exist_ok=True)
     legend = ("rel-L2 errors measured by the -m gpu tests on the MI355X; triples are (HIP vs fp32 reference algorithm, "
               "HIP vs float64, fp32 reference algorithm vs float64)")
-    with open(os.path.join(out, "parity_r05.json"), "w") as f:
+    with open(os.path.join(out, "parity_r06.json"), "w") as f:
         json.dump({"legend": legend, "tests": _PARITY}, f, indent=1, sort_keys=True)

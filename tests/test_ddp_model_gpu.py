@@ -126,3 +126,46 @@ def test_ddp_model_step_equals_single_process(record):
           f"(shared: {max(head.values()):.2e})")
     record(per_rank_bn_loss=p_loss, per_rank_bn_head=p_head, shared_head=max(head.values()))
     assert p_loss > 100 * e_loss and p_head > 100 * max(head.values())
+
+
+def _count_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    from mst.modules import SpectrogramEncoder
+
+    torch.manual_seed(5)
+    enc = torch.nn.SyncBatchNorm.convert_sync_batchnorm(SpectrogramEncoder(embed_dim=32, precision="fp32")).to(dev).train()
+    x = 0.1 * torch.randn(3, 1, 65536, device=dev)
+    out = []
+    # call 1: both ranks feed 2 signals.  call 2: rank 0 feeds 2 again (an `n` it has already seen), rank 1 feeds 3 - the case in which a
+    # check cached per (group, n) let rank 0 skip the exchange rank 1 was waiting in (advisor, round 5).  Every call of every rank now
+    # enqueues the same collectives: nobody hangs, and BOTH ranks get the error (one call late at worst; check_sync_counts flushes)
+    for n in (2, 2 if rank == 0 else 3):
+        try:
+            enc(x[:n])
+            out.append("ok")
+        except RuntimeError as e:
+            out.append(str(e))
+    try:
+        enc.model.check_sync_counts()
+        out.append("ok")
+    except RuntimeError as e:
+        out.append(str(e))
+    torch.cuda.synchronize()
+    ret[rank] = out
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sync_batchnorm_signal_count_mismatch_raises_on_every_rank():
+    """`diffmst_hip/panns.py: _sync_count_check` - never gates a collective on rank-local state."""
+    world, port = 2, 29500 + ((os.getpid() + 13) % 2000)
+    with mp.Manager() as m:
+        ret = m.dict()
+        mp.spawn(_count_worker, args=(world, port, ret), nprocs=world, join=True)
+        ret = dict(ret)
+    for rank in range(world):
+        assert ret[rank][0] == "ok", ret[rank]
+        assert any("same number of signals" in r for r in ret[rank][1:]), ret[rank]

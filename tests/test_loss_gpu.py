@@ -133,6 +133,110 @@ def test_mrstft_log_magnitude_adjoint_away_from_the_clamp(bs, n, seed, dev, reco
     assert float(xd.grad[..., :4096].abs().max()) == 0.0 and float(xd.grad[..., -4096:].abs().max()) == 0.0  # silence below the clamp: no gradient
 
 
+def _ill_posed_atoms(x64_row, res, tau_rel):
+    """The time-domain atoms d X[t, k] / d x (real and imaginary part) of every bin of ONE row whose magnitude is below tau_rel x the
+    row's rms bin magnitude at that resolution - the bins where the sign() / |X| adjoint of the log-magnitude term amplifies the
+    transform's own round-off by 1 / |X| in ANY fp32 evaluation - plus every bin within a factor 4 of the 1e-8 clamp.  Returns
+    (B (n, 2 * bins) float64, number of bins).  Reflect padding is folded back onto the row, as torch.stft(center=True) does."""
+    n = x64_row.numel()
+    cols, count = [], 0
+    for n_fft, hop, win in res:
+        w = torch.hann_window(win, dtype=torch.float64)
+        X = torch.stft(x64_row[None], n_fft, hop, win, w, return_complex=True)[0]  # (bins, frames)
+        p2 = X.real**2 + X.imag**2
+        tau2 = tau_rel**2 * p2.mean()
+        bad = (p2 < tau2) | ((p2 > 0.25e-8) & (p2 < 4e-8))
+        ks, ts = torch.nonzero(bad, as_tuple=True)
+        if ks.numel() == 0:
+            continue
+        m = torch.arange(n_fft, dtype=torch.float64)
+        pos = torch.arange(n_fft)
+        for k, t in zip(ks.tolist(), ts.tolist()):
+            idx = t * hop + pos - n_fft // 2           # sample index before reflection
+            idx = torch.where(idx < 0, -idx, idx)
+            idx = torch.where(idx >= n, 2 * (n - 1) - idx, idx)
+            ang = 2.0 * math.pi * k * m / n_fft
+            for comp in (w * torch.cos(ang), -w * torch.sin(ang)):
+                a = torch.zeros(n, dtype=torch.float64)
+                a.index_add_(0, idx, comp)
+                cols.append(a)
+        count += ks.numel()
+    return (torch.stack(cols, 1) if cols else torch.zeros(n, 0, dtype=torch.float64)), count
+
+
+def _project_out(d_row, B):
+    """d_row (n,) minus its least-squares projection onto the columns of B (n, m)."""
+    if not B.shape[1]:
+        return d_row
+    # the atoms are not independent (DC / Nyquist bins have no imaginary part, frame 0's spectrum is real): SVD-based solver; the
+    # default (gelsy) cuts the rank at ~60 of ~1300 columns and projects almost nothing out
+    return d_row - B @ torch.linalg.lstsq(B, d_row[:, None], rcond=1e-10, driver="gelsd").solution[:, 0]
+
+
+@pytest.mark.parametrize("case,bs,n,seed", [("tracking", 2, 32768, 31), ("tracking", 1, 65536, 33), ("independent", 2, 32768, 34),
+                                            ("independent", 1, 65536, 35), ("frame0", 2, 32768, 36)])
+def test_mrstft_gradient_every_draw_off_the_ill_posed_bins(case, bs, n, seed, dev, record):
+    """A deterministic bound on EVERY draw of the full MR-STFT gradient (round-5 review, weak 3 / item 5b) - no median, no 10x allowance.
+
+    The gradient is  sum_bins c[t, k] * atom[t, k]  with atom = d X[t, k] / d x and, for the log-magnitude term, c ~ sign(.) / |X|: at a
+    bin with |X| << the row's level BOTH fp32 paths carry the transform's round-off amplified by 1 / |X| (and a bin within rounding of
+    the 1e-8 clamp switches a ~1e4 cotangent on or off), so their error lives in the span of those bins' atoms.  That span is removed
+    - by a least-squares projection in float64, the SAME bins (chosen from the float64 spectra of the prediction: |X| < 0.05 x the row's
+    rms bin magnitude, ~0.25 % of the bins) for HIP and for the fp32 reference - and what is left must satisfy the three-way bound of
+    every other gradient test: HIP no further from float64 than twice the fp32 reference, + 1e-5.  The un-projected numbers are recorded
+    next to them: the projection takes the fp32 reference's own distance down by the same factor, which is the evidence that the
+    complement is where the ill-posedness lives.
+      tracking     target = 0.5 x + noise (the other gradient tests' construction)
+      independent  target independent of the prediction: the saved-magnitude path of the backward (the forward keeps |Y| only) cannot
+                   lean on Y ~ X
+      frame0       energy only in the first 2048 samples: the gradient flows through frame 0 of every row and resolution, whose
+                   reflect-padded real-even spectrum the backward projects onto the real axis, and frames 1..; everything else silent"""
+    from oracle import loss_restated as ol
+
+    torch.manual_seed(seed)
+    x = 0.3 * torch.randn(bs, 2, n)
+    y = 0.5 * x + 0.2 * torch.randn(bs, 2, n) if case != "independent" else 0.3 * torch.randn(bs, 2, n)
+    if case == "frame0":
+        for t in (x, y):
+            t[..., 2048:] = 0.0
+    xd = x.to(dev).requires_grad_(True)
+    loss = make_loss()(xd, y.to(dev))
+    loss.backward()
+    outs = {}
+    for dt in (torch.float32, torch.float64):
+        xo = x.clone().to(dt).requires_grad_(True)
+        lo = ol.mrstft_loss(xo, y.to(dt), RES)
+        lo.backward()
+        outs[dt] = (lo.item(), xo.grad.double().reshape(-1, n))
+    l64, g64 = outs[torch.float64]
+    g32 = outs[torch.float32][1]
+    gh = xd.grad.detach().cpu().double().reshape(-1, n)
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(16, threads))  # the SVD of a tall 32768 x 1400 matrix does not scale to the GPU box's 128 threads
+    # row by row (one row's atoms: n x ~2 % of n doubles - 0.4 GB at n = 32768, 1.4 GB at 65536 - are dropped before the next row's are built)
+    nb, sq_h, sq_r = 0, 0.0, 0.0
+    for i, row in enumerate(x.double().reshape(-1, n)):
+        B, c = _ill_posed_atoms(row, RES, 0.05)
+        nb += c
+        sq_h += _project_out(gh[i] - g64[i], B).norm().item() ** 2
+        sq_r += _project_out(g32[i] - g64[i], B).norm().item() ** 2
+        del B
+    torch.set_num_threads(threads)
+    total_bins = x[..., 0].numel() * sum((1 + n // r[1]) * (r[0] // 2 + 1) for r in RES)
+    norm = g64.norm().item()
+    raw_h, raw_r = (gh - g64).norm().item() / norm, (g32 - g64).norm().item() / norm
+    h, r = math.sqrt(sq_h) / norm, math.sqrt(sq_r) / norm
+    e_loss = abs(loss.item() - l64) / l64
+    print(f"\n[mrstft gradient off the ill-posed bins, {case} {bs}x2x{n} seed {seed}] {nb} of {total_bins} bins projected out "
+          f"({100.0 * nb / total_bins:.2f} %); HIP vs f64 {h:.2e} (raw {raw_h:.2e}), fp32 reference vs f64 {r:.2e} (raw {raw_r:.2e}); loss {e_loss:.1e}")
+    record(bins_projected=nb, bins=total_bins, hip_vs_f64=h, ref32_vs_f64=r, hip_vs_f64_raw=raw_h, ref32_vs_f64_raw=raw_r, loss=e_loss)
+    assert e_loss < 1e-5
+    assert nb < 0.01 * total_bins
+    assert h <= 2 * r + 1e-5, (h, r, raw_h, raw_r)
+    if case == "frame0":  # silence (below the clamp for both) beyond the reach of the frames that hold the burst
+        assert float(xd.grad[..., 2048 + 8192:].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("kw", [dict(w_sc=1.0, w_log_mag=0.0), dict(w_sc=1.0, w_log_mag=0.0, sc_per_example=False)])
 def test_mrstft_well_conditioned_terms(kw, dev):
     """The spectral-convergence term is smooth (no 1/|X| factor, no sign()): its gradient pins the
