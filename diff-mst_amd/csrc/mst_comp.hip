@@ -27,10 +27,22 @@ __device__ unsigned long long g_cbr_stamps[kStampWGs * kStampSlots];
             if (wg_ < kStampWGs) g_cbr_stamps[wg_ * kStampSlots + (k)] = wall_clock64();                     \
         }                                                                                                    \
     } while (0)
+#define CBM_STAMP(k)                                                                                         \
+    do {                                                                                                     \
+        if (threadIdx.x == 0) {                                                                              \
+            const int wg_ = blockIdx.x + gridDim.x * blockIdx.y;                                             \
+            if (wg_ < kStampWGs) g_cbr_stamps[wg_ * kStampSlots + (k)] = wall_clock64();                     \
+        }                                                                                                    \
+    } while (0)
 #else
 #define CBR_STAMP(k) do {} while (0)
+#define CBM_STAMP(k) do {} while (0)
 #endif
 
+// the value is materialised HERE: without it LLVM sinks a whole unrolled loop below the next spin-wait (into the block that uses its
+// results), which serialises the arithmetic behind the wait and keeps every operand of the loop alive across it
+__device__ __forceinline__ void pin(float& x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void pin2(f2& x) { asm volatile("" : "+v"(x)); }
 __device__ __forceinline__ void ld8(const float* row, int64_t i, int64_t n, float* v) {
     const float4 a = load4(row, i, n), b = load4(row, i + 4, n);
     v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
@@ -43,6 +55,12 @@ __device__ __forceinline__ void st8(float* row, int64_t i, int64_t n, const floa
 // Unguarded variants for interior lanes of aligned rows (the overwhelmingly common case): no bounds or
 // alignment tests, two plain 16-byte accesses.
 __device__ __forceinline__ void ld8f(const float* row, int64_t i, float* v) {
+#ifdef MST_NOMEM  // timing diagnostics only (wrong results): the interior blocks' operands are synthesised from the index - no global loads
+    const float base = 0.001f * (float)((int)i & 2047) + 0.01f + 1e-6f * (float)((int)(uintptr_t)row & 0xffff);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = base + 0.0007f * (float)q;
+    return;
+#endif
     const float4 a = *reinterpret_cast<const float4*>(row + i), b = *reinterpret_cast<const float4*>(row + i + 4);
     v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
 }
@@ -799,7 +817,22 @@ __device__ __forceinline__ void comp_bwd_run_body(const CompBwdArgs& a, int row,
             du0[i] = fmaf(zp.x, cE, fwd0[i]);
             if (MASTER) du1[i] = fmaf(zp.x, cE, fwd1[i]);
             db[i] = zp.y * cE;
+#ifndef MST_CBR_PIN
+#define MST_CBR_PIN 1  // 1: the static-curve loop is pinned in front of the granule wait (tools/cbr_timeline.py showed it sunk BEHIND the wait,
+                       // into the block that uses its results: the wait then overlapped nothing)
+#endif
+            if (MST_CBR_PIN) {
+                pin(du0[i]);
+                if (MASTER) pin(du1[i]);
+                pin(db[i]);
+            }
             if (MST_CBR_SCHED & 2) __builtin_amdgcn_sched_barrier(0);
+        }
+        if (MST_CBR_PIN) {
+            pin2(sA);
+            pin2(sF);
+            pin2(sP);
+            pin2(sW);
         }
         CBR_STAMP(5);
         const float S = gq ? block_carry_g<true>(gq, a.gran_near, peek, blk, gridDim.x, l2a, red[0], tid, a.status)
@@ -989,6 +1022,437 @@ __global__ __launch_bounds__(kWG, (!MASTER && !FXS) ? MST_COMP_BWD_WT : MST_COMP
     else comp_bwd_run_body<MASTER, false, FXS>(a, row, blk, cg_u, cg_g);
 }
 
+// ---- backward, tracks, MIX-WISE (round 6): one workgroup = one 2048-sample block of one MIX, looping over (half of) the mix's tracks ----
+// k_comp_bwd_run<tracks> runs one workgroup per (track row, block): 9 workgroup barriers, five dependent load phases and 16 operand tiles
+// per block, of which the bus cotangent (4 tiles) is the same for all the tracks of the mix.  tools/cbr_timeline.py (wall-clock stamps of
+// every workgroup): of a workgroup's 8.6 us, 3.3 us are spent in the barrier / exchange phases, 1.6 us in load phases, and the SIMDs issue
+// 44 % of the time.  Here the tracks of a mix are walked by ONE workgroup (as k_apply_tracks does in the forward):
+//   * the bus cotangent of the block (at i and at i + look-ahead) is loaded once and parked in LDS (lane-private slots);
+//   * the NEXT track's first operands (u at i - L, g_s, the all-pole entry states) are requested while the current track computes;
+//   * ONE workgroup barrier per track: the waves meet only to exchange their zero-entry aggregates of the adjoint smoother (block
+//     aggregate to publish + state entering each wave).  The state entering the block is summed from the other blocks' granules by
+//     every wave on its own (two granules per lane), and every wave walks the coefficient-gradient bank over ITS 512 samples (8 chunks x
+//     6 sections = 48 lanes; tiles are wave-private, wave-level LDS hand-over); the waves' partial sums meet behind the next track's
+//     barrier (double-buffered slots);
+//   * the master channels' coefficient-gradient walks (2048 light workgroups in front of the row-wise grid, 11 us) are one more
+//     short iteration of the workgroups of their mix.
+// Registers: 168 = three waves per SIMD (the row-wise kernel is at 128 without any of the above; with the prefetch it spills 65).  768
+// resident workgroups: the tracks of a mix are dealt to TWO workgroups (halves), 2048 items at cfg #2 = 2.67 rounds of four tracks.
+// Same arithmetic per sample as comp_bwd_run_body (static curve, split adjoint state, packed all-pole walk); the order of the
+// block-level sums differs (fixed, reproducible).  Handles what the bench / training path needs - compressor on, in-launch granules,
+// fused coefficient gradients, no grad_tracks / grad_mixed_tracks / fx bus, look-ahead = one block; everything else keeps the row-wise kernel.
+// MEASURED AND LEFT OFF (round 6, one box, tools/ab_bench.sh): 119 us against 97-99 us for the row-wise kernel.  The premise was
+// wrong: with every bulk operand synthesised in registers instead of loaded (-DMST_NOMEM, wrong results) the row-wise kernel still takes
+// 84 us (64 us without the 64-sample walks) and this one 116 us - both are bound by what they execute, not by what they wait for, and
+// this form executes more (per-wave walks at 48 of 64 lanes, the ride, LDS parking) on three waves per SIMD instead of four.
+#ifndef MST_CBM
+#define MST_CBM 0  // A/B switch: 1 = the mix-wise kernel where it applies, 0 = k_comp_bwd_run<tracks> for every configuration
+#endif
+#ifndef MST_CBM_W
+#define MST_CBM_W 3  // waves per SIMD asked of the mix-wise kernel (3: register cap 168)
+#endif
+#ifndef MST_CBM_PREFETCH
+#define MST_CBM_PREFETCH 1  // 0: the next track's early operands are requested at the END of the track (fewer live registers, exposed latency)
+#endif
+constexpr int kMwChunks = 64 * CC / kEqChunk;     // 64-sample chunks per wave (8)
+constexpr int kMwTile = kMwChunks * kCgPitch;     // floats of one wave's u (or du) tile
+static_assert(kMwChunks == 8 && kCompWaves * kMwTile == kCgTile, "per-wave tiles fill the row-wise kernel's tiles");
+
+__device__ __forceinline__ void park8(float* slot, const float* v) {
+    *reinterpret_cast<float4*>(slot) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(slot + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+// a lane's eight samples into a chunk row of the walk's tile image (sample 8 j + 4 h + e at float 32 h + 4 j + e: coefgrad_fused)
+__device__ __forceinline__ void tile8(float* at, const float* v) {
+    *reinterpret_cast<float4*>(at) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(at + 32) = make_float4(v[4], v[5], v[6], v[7]);
+}
+__device__ __forceinline__ void fetch8(const float* slot, float* v) {
+    const float4 a = *reinterpret_cast<const float4*>(slot), b = *reinterpret_cast<const float4*>(slot + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+// the all-pole walk of one (section, chunk) lane over its wave's tiles; sums over the eight chunk lanes of a section land in sums[5 cs ..]
+__device__ __forceinline__ void mix_walk(const float* __restrict__ rc, const float* __restrict__ my_u, const float* __restrict__ my_g, const CgStates ws,
+                                         const int cs, const int cc, float* __restrict__ sums) {
+    const float ka1 = rc[RC_SOS + 5 * cs + 3], ka2 = rc[RC_SOS + 5 * cs + 4];
+    const float kc1 = rc[RC_AP + 3 * cs], kc2 = rc[RC_AP + 3 * cs + 1], kib0 = rc[RC_AP + 3 * cs + 2];
+    const float* mu = &my_u[cc * kCgPitch];
+    const float* mg = &my_g[cc * kCgPitch];
+    float db0 = 0.f;
+    f2 w1 = {ws.wb1, ws.wa1}, w2 = {ws.wb2, ws.wa2}, acc1 = {0.f, 0.f}, acc2 = {0.f, 0.f};
+    const f2 nk1 = {-kc1, -ka1}, nk2 = {-kc2, -ka2};
+#pragma unroll 2
+    for (int i4 = 0; i4 < kEqChunk; i4 += 4) {
+        const int at = ((i4 >> 2) & 1) * 32 + (i4 >> 3) * 4;
+        const float4 xv = *reinterpret_cast<const float4*>(&mu[at]);
+        const float4 gv = *reinterpret_cast<const float4*>(&mg[at]);
+        const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, gsv[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f2 xx = {xs[q], xs[q]}, gg = {gsv[q], -gsv[q]};
+            const f2 wn = f2_fma(nk2, w2, f2_fma(nk1, w1, xx));
+            db0 = fmaf(gsv[q], wn.x, db0);
+            acc1 = f2_fma(gg, w1, acc1);
+            acc2 = f2_fma(gg, w2, acc2);
+            w2 = w1;
+            w1 = wn;
+        }
+    }
+    float e[5] = {db0 * kib0, acc1.x * kib0, acc2.x * kib0, acc1.y, acc2.y};
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {  // sum over the eight chunk lanes of the section
+        float s = e[i];
+        s = dpp_add<0xb1, 0xf>(s);   // quad_perm [1,0,3,2]
+        s = dpp_add<0x4e, 0xf>(s);   // quad_perm [2,3,0,1]
+        s = dpp_add<0x141, 0xf>(s);  // row_half_mirror
+        e[i] = s;
+    }
+    if (cc == 0) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) sums[5 * cs + i] = e[i];
+    }
+}
+
+struct MixSlots {  // small LDS exchange slots of the mix-wise kernel (one copy for both template instantiations of the body)
+    float agg[2][kCompWaves];
+    float p[2][kCompWaves][CP_COUNT];
+    float e[2][kCompWaves][EP_COUNT];
+    float r[2][kCompWaves][EP_COUNT];
+};
+// tracks [t_lo, t_hi) of mix b; ride = the master channels whose coefficient-gradient walk this workgroup carries: [ride_lo, ride_hi) of {0, 1}
+template <bool FAST>
+__device__ __forceinline__ void comp_bwd_mix_body(const CompBwdArgs& a, const int b, const int blk, const int t_lo, const int t_hi, const int ride_lo,
+                                                  const int ride_hi, const int sig0, float* __restrict__ cg_u, float* __restrict__ cg_g,
+                                                  float* __restrict__ park, MixSlots& sl) {
+    float (*sc_agg)[kCompWaves] = sl.agg;             // zero-entry wave aggregates of the adjoint smoother (by track parity)
+    float (*sc_p)[kCompWaves][CP_COUNT] = sl.p;       // per-wave compressor partial sums
+    float (*sc_e)[kCompWaves][EP_COUNT] = sl.e;       // per-wave coefficient-gradient partial sums
+    float (*sc_r)[kCompWaves][EP_COUNT] = sl.r;       // ... of the master channels that ride here
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nblk = gridDim.x;
+    const int64_t i0 = ((int64_t)blk * kWG + tid) * CC;
+    const int L = a.lookahead;
+    CBM_STAMP(9);
+    // ---- once per workgroup: the bus cotangent of this block and of the next block, parked in lane-private LDS slots
+    float* pkL = park + tid * CC;
+    float* pkR = pkL + kWG * CC;
+    float* pkLF = pkR + kWG * CC;
+    float* pkRF = pkLF + kWG * CC;
+    {
+        const float* gL = a.gup + ((int64_t)b * 2 + 0) * a.gup_stride;
+        const float* gR = a.gup + ((int64_t)b * 2 + 1) * a.gup_stride;
+        float v0[CC], v1[CC], v2[CC], v3[CC];
+        LD8S<FAST>(gL, i0, a.n, v0);
+        LD8S<FAST>(gR, i0, a.n, v1);
+        LD8S<FAST>(gL, i0 + L, a.n, v2);
+        LD8S<FAST>(gR, i0 + L, a.n, v3);
+        park8(pkL, v0);
+        park8(pkR, v1);
+        park8(pkLF, v2);
+        park8(pkRF, v3);
+    }
+    // coefficient-gradient walk of this lane: section cs, chunk cc of the wave's eight
+    const int cs = lane >> 3, cc = lane & 7;
+    const bool walker = cs < kSections;
+    auto load_states = [&](int sig) {
+        CgStates w = {0.f, 0.f, 0.f, 0.f};
+        if (walker) {
+            const int64_t base = ((int64_t)sig * 24 + 4 * cs) * a.ap_nc_pad + (int64_t)blk * kCgChunks + wave * kMwChunks + cc;
+            w.wa1 = a.ap_s0[base];
+            w.wa2 = a.ap_s0[base + a.ap_nc_pad];
+            w.wb1 = a.ap_s0[base + 2 * (int64_t)a.ap_nc_pad];
+            w.wb2 = a.ap_s0[base + 3 * (int64_t)a.ap_nc_pad];
+        }
+        return w;
+    };
+    const int row0 = b * a.T;
+    float xd[CC], g[CC], gprev;
+    CgStates ws;
+    {   // first track's early operands
+        const float* u0 = a.u + (int64_t)(row0 + t_lo) * a.stride;
+        const float* gs0 = a.gs + (int64_t)(row0 + t_lo) * a.stride;
+        LD8S<FAST>(u0, i0 - L, a.n, xd);
+        LD8<FAST>(gs0, i0, a.n, g);
+        gprev = (i0 > 0 && i0 - 1 < a.n) ? gs0[i0 - 1] : 0.0f;
+        ws = load_states(row0 + t_lo);
+    }
+    float* my_u = cg_u + wave * kMwTile;
+    float* my_g = cg_g + wave * kMwTile;
+    float* tile_at_u = &my_u[(lane >> 3) * kCgPitch + 4 * (lane & 7)];  // row image of coefgrad_fused: sample 8 j + 4 h + e at float 32 h + 4 j + e
+    float* tile_at_g = &my_g[(lane >> 3) * kCgPitch + 4 * (lane & 7)];
+    const int rl = 63 - lane, rw = kCompWaves - 1 - wave;  // position in the adjoint recursion's order (it runs from the row's end)
+
+    // ---- the master channels that ride here: all that is left of their backward is the all-pole walk over (master EQ output, its
+    // cotangent).  Their waves' sums are folded behind the first track's barrier.
+    for (int ch = ride_lo; ch < ride_hi; ++ch) {
+        const int j = 2 * b + ch, sig = sig0 + j;
+        float xu[CC], dv[CC];
+        LD8<FAST>(a.cg2_u + (int64_t)j * a.stride, i0, a.n, xu);
+        LD8<FAST>(a.cg2_du + (int64_t)j * a.stride, i0, a.n, dv);
+        const CgStates wm = load_states(sig);
+        if (!FAST) {
+#pragma unroll
+            for (int i = 0; i < CC; ++i) dv[i] = (i0 + i < a.n) ? dv[i] : 0.0f;
+        }
+        tile8(tile_at_u, xu);
+        tile8(tile_at_g, dv);
+        wave_lds_sync();
+        if (walker) mix_walk(a.cg2_rc + (int64_t)b * RC_STRIDE, my_u, my_g, wm, cs, cc, sc_r[ch][wave]);
+        wave_lds_sync();
+    }
+
+    CBM_STAMP(11);
+    for (int t = t_lo; t < t_hi; ++t) {
+        const int row = row0 + t, par = (t - t_lo) & 1;
+        const bool stamp = t == t_lo + 1;
+        if (stamp) CBM_STAMP(0);
+        const float* rc = a.rc + (int64_t)row * RC_STRIDE;
+        const float* urow = a.u + (int64_t)row * a.stride;
+        const float* gsrow = a.gs + (int64_t)row * a.stride;
+        const CompK k = load_comp(rc);
+        const float pl = rc[RC_PANL], pr = rc[RC_PANR];
+        const float ac = rc[RC_ALPHA_C], l2a = rc[RC_LOG2A_C];
+        // (1) this track's late operands: compressor input of the block, smoothed gain one block ahead
+        float x0[CC], gF[CC];
+        LD8<FAST>(urow, i0, a.n, x0);
+        LD8S<FAST>(gsrow, i0 + L, a.n, gF);
+        // (2) cotangent of the smoothed gain, zero-entry end value of the adjoint smoother over the lane's samples, pan / make-up sums
+        float p[CP_COUNT];
+#pragma unroll
+        for (int i = 0; i < CP_COUNT; ++i) p[i] = 0.0f;
+        float dgsv[CC];
+        float zq = 0.0f;
+        {
+            // (the slot offset is laundered once per track: the parked values are loop-invariant, and hoisted out of the loop they are
+            // the 32 registers the parking was for)
+            int po = 0;
+            asm volatile("" : "+v"(po));
+            float gl[CC], gr[CC];
+            fetch8(pkL + po, gl);
+            fetch8(pkR + po, gr);
+#pragma unroll
+            for (int i = CC - 1; i >= 0; --i) {
+                const float Gi = lin_gain(g[i], k);
+                const float yv = xd[i] * Gi;
+                dgsv[i] = (FAST || i0 + i < a.n) ? (pl * gl[i] + pr * gr[i]) * yv * kLn10Over20 : 0.0f;
+                pin(dgsv[i]);
+                zq = fmaf(k.alpha, zq, dgsv[i]);
+                if (FAST || i0 + i < a.n) {
+                    p[CP_MAKEUP] += dgsv[i];
+                    p[CP_PANL] = fmaf(gl[i], yv, p[CP_PANL]);
+                    p[CP_PANR] = fmaf(gr[i], yv, p[CP_PANR]);
+                }
+            }
+            pin(p[CP_MAKEUP]);
+            pin(p[CP_PANL]);
+            pin(p[CP_PANR]);
+        }
+        if (stamp) CBM_STAMP(1);
+        // (3) in-wave scan (from the last lane down), wave aggregates through LDS: the ONE workgroup barrier of the track
+        float v = zq, pw = ac;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const float o = __shfl_down(v, d);
+            if (rl >= d) v = fmaf(pw, o, v);
+            pw *= pw;
+        }
+        if (lane == 0) sc_agg[par][wave] = v;  // zero-entry aggregate of this wave (pw == a^64 now)
+        float ex = __shfl_down(v, 1);
+        if (rl == 0) ex = 0.0f;
+        lds_barrier();
+        if (stamp) CBM_STAMP(2);
+        float sw = 0.0f;  // zero-entry state entering this wave: the waves behind it in time come first
+        for (int w = kCompWaves - 1; w > wave; --w) sw = fmaf(pw, sw, sc_agg[par][w]);
+        gran_t* gq = a.gran + (int64_t)row * nblk;
+        if (tid == 0) {  // block aggregate = state leaving the block towards earlier time with zero entering it
+            float agg = 0.0f;
+            for (int w = kCompWaves - 1; w >= 0; --w) agg = fmaf(pw, agg, sc_agg[par][w]);
+            gran_publish(gq + blk, a.gran_near, agg);
+        }
+        const float Q0 = fmaf(__builtin_amdgcn_exp2f((float)rl * l2a), sw, ex);
+        const float W = __builtin_amdgcn_exp2f((float)(rl + 64 * rw) * l2a);
+        // the partial sums of the PREVIOUS track (first track: of the riding master channels): complete behind the barrier above
+        if (t == t_lo) {
+            for (int ch = ride_lo; ch < ride_hi; ++ch) {
+                if (tid >= 64 && tid < 64 + EP_COUNT) {
+                    const int q = tid - 64;
+                    const float s = (sc_r[ch][0][q] + sc_r[ch][1][q]) + (sc_r[ch][2][q] + sc_r[ch][3][q]);
+                    a.ep[((int64_t)(sig0 + 2 * b + ch) * nblk + blk) * EP_COUNT + q] = s;
+                }
+            }
+        }
+        if (t > t_lo) {
+            if (tid < CP_COUNT) {
+                const float s = (sc_p[par ^ 1][0][tid] + sc_p[par ^ 1][1][tid]) + (sc_p[par ^ 1][2][tid] + sc_p[par ^ 1][3][tid]);
+                a.part[((int64_t)(row - 1) * nblk + blk) * CP_COUNT + tid] = s;
+            } else if (tid >= 64 && tid < 64 + EP_COUNT) {
+                const int q = tid - 64;
+                const float s = (sc_e[par ^ 1][0][q] + sc_e[par ^ 1][1][q]) + (sc_e[par ^ 1][2][q] + sc_e[par ^ 1][3][q]);
+                a.ep[((int64_t)(row - 1) * nblk + blk) * EP_COUNT + q] = s;
+            }
+        }
+        // (4) the next track's early operands, in flight behind everything below
+        float xdn[CC], gn[CC], gprevn = 0.0f;
+        CgStates wsn = {0.f, 0.f, 0.f, 0.f};
+        if (MST_CBM_PREFETCH && t + 1 < t_hi) {
+            const float* un = urow + a.stride;
+            const float* gsn = gsrow + a.stride;
+            LD8S<FAST>(un, i0 - L, a.n, xdn);
+            LD8<FAST>(gsn, i0, a.n, gn);
+            gprevn = (i0 > 0 && i0 - 1 < a.n) ? gsn[i0 - 1] : 0.0f;
+            wsn = load_states(row + 1);
+        }
+        // first look at the later blocks' aggregates of this row (one per lane now, a second round of 64 behind the arithmetic)
+        const int j0 = blk + 1 + lane;
+        const gran_t peek0 = j0 < nblk ? gran_load(gq + j0 + (MST_GRAN_NEAR ? a.gran_near : 0)) : 0ull;
+        // (5) look-ahead branch: du[i] += (pl gl + pr gr)[i + L] G[i + L]
+        float fwd[CC];
+        {
+            int po = 0;
+            asm volatile("" : "+v"(po));
+            float fl[CC], fr[CC];
+            fetch8(pkLF + po, fl);
+            fetch8(pkRF + po, fr);
+#pragma unroll
+            for (int i = 0; i < CC; ++i) {
+                const bool liveF = FAST || i0 + i + L < a.n;
+                fwd[i] = liveF ? (pl * fl[i] + pr * fr[i]) * lin_gain(gF[i], k) : 0.0f;
+#if defined(MST_CBM_DBG) && MST_CBM_DBG == 1
+                fwd[i] = 0.0f;
+#endif
+                pin(fwd[i]);
+            }
+        }
+        if (stamp) CBM_STAMP(3);
+        // (6) the compressor input goes to the wave's u tile
+        tile8(tile_at_u, x0);
+        __builtin_amdgcn_sched_barrier(0);
+        // (7) static curve; every q-dependent quantity as (zero-state part, homogeneous part) of q[i] = zs[i] + alpha^(CC - i) Q
+        f2 zp = {0.0f, 1.0f}, sA = {0.f, 0.f}, sF = {0.f, 0.f}, sP = {0.f, 0.f}, sW = {0.f, 0.f};
+        const float kinvw = k.kappa * k.invw, kw2 = k.kappa * k.inv2w * k.invw, ke = k.oma * 8.685889638065035f;
+        float du[CC], db[CC];
+#pragma unroll
+        for (int i = CC - 1; i >= 0; --i) {
+            const bool live = FAST || i0 + i < a.n;
+            const float side = x0[i];
+            float tc;
+            const float fval = curve_f(curve_t(side, k), k, tc);
+            const float gp = (i > 0) ? g[i - 1] : gprev;
+            const float kp = tc * kinvw;
+            const float cKw = tc * (k.knee - tc) * kw2;
+            const float cA = live ? fmaf(-k.kappa, fval, gp) : 0.0f;
+            const float cE = (fabsf(side) >= kCompEps) ? kp * ke * __builtin_amdgcn_rcpf(side) : 0.0f;
+            zp.x = fmaf(k.alpha, zp.x, dgsv[i]);
+            zp.y *= k.alpha;
+            sA = f2_fma(zp, f2{cA, cA}, sA);
+            sF = f2_fma(zp, f2{fval, fval}, sF);
+            sP = f2_fma(zp, f2{kp, kp}, sP);
+            sW = f2_fma(zp, f2{cKw, cKw}, sW);
+            du[i] = fmaf(zp.x, cE, fwd[i]);
+            db[i] = zp.y * cE;
+            pin(du[i]);
+            pin(db[i]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        pin2(sA);
+        pin2(sF);
+        pin2(sP);
+        pin2(sW);
+        if (stamp) CBM_STAMP(4);
+        // (8) state entering the block from later time: sum of the later blocks' aggregates, formed by every wave on its own
+        float acc = 0.0f;
+        {
+            bool first = true;
+            for (int j = j0; j < nblk; j += 64, first = false) {
+                const float vj = (first && (peek0 >> 32) == 1) ? __int_as_float((int)(unsigned)peek0) : gran_wait(gq + j, a.gran_near, a.status);
+                acc += __builtin_amdgcn_exp2f((float)(j - blk - 1) * (float)kWG * l2a) * vj;
+            }
+        }
+        const float S = wave_sum(acc);
+        if (stamp) CBM_STAMP(5);
+        const float Q = fmaf(W, S, Q0);
+#pragma unroll
+        for (int i = 0; i < CC; ++i) du[i] = (FAST || i0 + i < a.n) ? fmaf(Q, db[i], du[i]) : 0.0f;
+        p[CP_ALPHA] = fmaf(Q, sA.y, sA.x);
+        p[CP_KAPPA] = k.oma * fmaf(Q, sF.y, sF.x);
+        p[CP_THR] = -k.oma * fmaf(Q, sP.y, sP.x);
+        p[CP_KNEE] = k.oma * fmaf(Q, sW.y, sW.x);
+        // (9) cotangent of the EQ output to the wave's tile, then the all-pole walk of (section cs, chunk cc)
+#if defined(MST_CBM_DBG) && MST_CBM_DBG == 2
+#pragma unroll
+        for (int i = 0; i < CC; ++i) du[i] = 1.0f;
+#endif
+        tile8(tile_at_g, du);
+        wave_lds_sync();
+        if (stamp) CBM_STAMP(6);
+        if (walker) mix_walk(rc, my_u, my_g, ws, cs, cc, sc_e[par][wave]);
+        if (stamp) CBM_STAMP(7);
+        // (10) compressor partial sums of the wave
+#pragma unroll
+        for (int i = 0; i < CP_COUNT; ++i) {
+            const float s = wave_sum(p[i]);
+            if (lane == 0) sc_p[par][wave][i] = s;
+        }
+        wave_lds_sync();  // the tiles are rewritten by the next track's stores
+        if (!MST_CBM_PREFETCH && t + 1 < t_hi) {
+            const float* un = urow + a.stride;
+            const float* gsn = gsrow + a.stride;
+            LD8S<FAST>(un, i0 - L, a.n, xdn);
+            LD8<FAST>(gsn, i0, a.n, gn);
+            gprevn = (i0 > 0 && i0 - 1 < a.n) ? gsn[i0 - 1] : 0.0f;
+            wsn = load_states(row + 1);
+        }
+        if (stamp) CBM_STAMP(8);
+        // rotate
+#pragma unroll
+        for (int i = 0; i < CC; ++i) {
+            xd[i] = xdn[i];
+            g[i] = gn[i];
+        }
+        gprev = gprevn;
+        ws = wsn;
+    }
+    lds_barrier();
+    CBM_STAMP(10);
+    {   // the last track's sums
+        const int par = (t_hi - 1 - t_lo) & 1, row = row0 + t_hi - 1;
+        if (tid < CP_COUNT) {
+            const float s = (sc_p[par][0][tid] + sc_p[par][1][tid]) + (sc_p[par][2][tid] + sc_p[par][3][tid]);
+            a.part[((int64_t)row * nblk + blk) * CP_COUNT + tid] = s;
+        } else if (tid >= 64 && tid < 64 + EP_COUNT) {
+            const int q = tid - 64;
+            const float s = (sc_e[par][0][q] + sc_e[par][1][q]) + (sc_e[par][2][q] + sc_e[par][3][q]);
+            a.ep[((int64_t)row * nblk + blk) * EP_COUNT + q] = s;
+        }
+    }
+}
+
+// grid (nblk, bs x mw_split): one workgroup per (mix, block, part of the tracks); the blocks of a mix on one XCD and walked from the row's
+// end (a block waits for LATER blocks of its row only: they carry lower workgroup ids)
+__global__ __launch_bounds__(kWG, MST_CBM_W) void k_comp_bwd_mix(CompBwdArgs a) {
+    static_assert(kCompWaves == 4, "the mix-wise kernel is written for four-wave workgroups");
+    __shared__ __attribute__((aligned(16))) float cg_u[kCgTile], cg_g[kCgTile];
+    __shared__ __attribute__((aligned(16))) float park[4 * kWG * CC];
+    __shared__ MixSlots sl;
+    const int nsplit = a.mw_split, bs = (int)gridDim.y / nsplit;
+    int rid, step;
+    row_block_xcd(rid, step, 1, (int)gridDim.y, 0);
+    const int b = rid % bs, h = rid / bs;  // part h of mix b: with bs % 8 == 0 both parts of a mix sit on XCD b % 8
+    const int blk = gridDim.x - 1 - step;
+    const int per = (a.T + nsplit - 1) / nsplit, t_lo = h * per, t_hi = min(a.T, t_lo + per);
+    int ride_lo = 0, ride_hi = 0;
+    if (a.cg2_rows) {
+        ride_lo = nsplit == 2 ? h : 0;
+        ride_hi = nsplit == 2 ? h + 1 : 2;
+    }
+    if (t_lo >= t_hi) return;
+#ifdef MST_CBM_FASTONLY  // register-pressure diagnostics: the interior body alone
+    comp_bwd_mix_body<true>(a, b, blk, t_lo, t_hi, ride_lo, ride_hi, bs * a.T, cg_u, cg_g, park, sl);
+#else
+    if (block_interior(a.n, a.lookahead, a.aligned, blk)) comp_bwd_mix_body<true>(a, b, blk, t_lo, t_hi, ride_lo, ride_hi, bs * a.T, cg_u, cg_g, park, sl);
+    else comp_bwd_mix_body<false>(a, b, blk, t_lo, t_hi, ride_lo, ride_hi, bs * a.T, cg_u, cg_g, park, sl);
+#endif
+}
+
 // ---- launch helpers ---------------------------------------------------------------------------------
 void launch_comp_zs(int nch, const float* u, int64_t stride, const float* rc, float* zs, int nc_pad, int64_t n, int rows,
                     hipStream_t stream) {
@@ -1009,6 +1473,12 @@ void launch_comp_bwd(bool master, bool run, const CompBwdArgs& a, int rows, hipS
     else if (master && run) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_comp_bwd_run<true>), grid, block, 0, stream, a);
     else if (!master && !run) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_comp_bwd_zs<false>), grid, block, 0, stream, a);
     else if (a.gfx) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_comp_bwd_run<false, true>), grid, block, 0, stream, a);
+    else if (MST_CBM && kWG == 256 && a.comp_on && a.gran && a.ep && !a.du && !a.gmixed && a.T > 0 && rows % a.T == 0 && a.lookahead == kWG * CC &&
+             (a.cg2_rows == 0 || a.cg2_rows == 2 * (rows / a.T))) {
+        CompBwdArgs m = a;  // one workgroup per (mix, block, half of the tracks)
+        m.mw_split = (a.T >= 4 && a.T % 2 == 0) ? 2 : 1;
+        hipLaunchKernelGGL(k_comp_bwd_mix, dim3(a.nc_pad / kWG, (rows / a.T) * m.mw_split), block, 0, stream, m);
+    }
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_comp_bwd_run<false>), grid, block, 0, stream, a);
 }
 

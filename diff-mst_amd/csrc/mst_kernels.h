@@ -191,6 +191,7 @@ struct CompBwdArgs {
     gran_t* gran;         // (rows, nblk) zeroed granules (+ near copies gran_near granules later): the run pass publishes / awaits the block aggregates itself (no zs launch); null = read s0
     int64_t gran_near;
     int32_t* status;      // raised to kStatusExchangeTimeout when an exchange wait gives up (may be null)
+    int mw_split;         // k_comp_bwd_mix only (set by launch_comp_bwd): workgroups the tracks of one mix are dealt to (1 or 2)
 };
 void launch_comp_zs(int nch, const float* u, int64_t stride, const float* rc, float* zs, int nc_pad, int64_t n, int rows,
                     hipStream_t stream);
