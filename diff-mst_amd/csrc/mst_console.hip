@@ -58,7 +58,7 @@ static constexpr bool fuse_eq_zs() {
 #endif
 }
 
-extern "C" int mst_abi_version(void) { return 8; }
+extern "C" int mst_abi_version(void) { return 9; }
 #ifdef MST_DEV_PROBE  // developer probe (tools/sidestream_probe.py): an event recorded in the middle of the forward's launch sequence
 static hipEvent_t g_probe_ev = nullptr;
 static int g_probe_where = 0;
@@ -87,8 +87,34 @@ static FxPlan fx_plan(const Layout& L) {
     return p;
 }
 
+// MST_SPLIT_BATCH (ABI v9): the mixes of a call are dealt to two halves that run as two independent console calls - the first on the
+// caller's stream, the second on a side stream the caller lends (mst_console_overlap) - each over its own part of the workspace.  The
+// two halves' launches interleave on the device: the first half's latency-bound stretches (k_prep's fp64 chains, the lone-wave master
+// chain, the single-workgroup tails) run beside the second half's occupancy-full track kernels and vice versa.  Same kernels, same
+// arithmetic per mix: results are bit-identical to the unsplit call.
+static bool split_on(const mst_console_desc* d) {
+    return (d->flags & MST_SPLIT_BATCH) && d->bs >= 2 && !(d->flags & MST_USE_FX_BUS) && !basic_path(d);
+}
+struct Halves {
+    mst_console_desc da, db;
+    int64_t ws_b;  // float offset of the second half's workspace
+    int64_t total;
+};
+static Halves make_halves(const mst_console_desc* d) {
+    Halves h{*d, *d, 0, 0};
+    h.da.bs = d->bs / 2;
+    h.db.bs = d->bs - h.da.bs;
+    h.da.flags &= ~MST_SPLIT_BATCH;
+    h.db.flags &= ~MST_SPLIT_BATCH;
+    h.ws_b = make_layout(&h.da).total;
+    h.total = h.ws_b + make_layout(&h.db).total;
+    return h;
+}
+static bool overlap_ok(const mst_console_overlap* ov) { return ov && ov->side_stream && ov->fork_event && ov->join_event; }
+
 extern "C" size_t mst_console_workspace_bytes(const mst_console_desc* d) {
     if (check_desc(d) != hipSuccess) return 0;
+    if (split_on(d)) return (size_t)make_halves(d).total * sizeof(float);
     return (size_t)make_layout(d).total * sizeof(float);
 }
 
@@ -210,14 +236,46 @@ extern "C" int mst_console_forward(const mst_console_desc* d, const float* track
                                    const float* fx_bus_params, const float* master_bus_params, const mst_console_fx* fx,
                                    float* mix, float* mixed_tracks, int32_t* status, void* workspace, size_t workspace_bytes,
                                    void* stream) {
+    if (d && (d->flags & MST_SPLIT_BATCH)) return hipErrorInvalidValue;  // the split form needs the side stream: mst_console_forward_overlapped
     return console_forward_impl(d, tracks, track_params, fx_bus_params, master_bus_params, fx, mix, mixed_tracks, status, workspace,
                                 workspace_bytes, stream, nullptr, nullptr);
+}
+extern "C" int mst_console_forward_overlapped(const mst_console_desc* d, const float* tracks, const float* track_params,
+                                              const float* fx_bus_params, const float* master_bus_params, const mst_console_fx* fx,
+                                              float* mix, float* mixed_tracks, int32_t* status, void* workspace, size_t workspace_bytes,
+                                              void* stream, const mst_console_overlap* ov) {
+    if (int e = check_desc(d)) return e;
+    if (!split_on(d))
+        return console_forward_impl(d, tracks, track_params, fx_bus_params, master_bus_params, fx, mix, mixed_tracks, status, workspace,
+                                    workspace_bytes, stream, nullptr, nullptr);
+    if (!overlap_ok(ov) || ov->side_stream == stream) return hipErrorInvalidValue;
+    const Halves h = make_halves(d);
+    if (!workspace || workspace_bytes < (size_t)h.total * sizeof(float) || ((uintptr_t)workspace & 255)) return hipErrorInvalidValue;
+    if (!tracks || !track_params || !fx_bus_params || !master_bus_params || !mix || !status) return hipErrorInvalidValue;
+    hipStream_t main_s = (hipStream_t)stream, side = (hipStream_t)ov->side_stream;
+    const int64_t ba = h.da.bs, T = d->n_tracks, n = d->n_samples;
+    if (int e = (int)hipEventRecord((hipEvent_t)ov->fork_event, main_s)) return e;
+    if (int e = (int)hipStreamWaitEvent(side, (hipEvent_t)ov->fork_event, 0)) return e;
+    float* ws = (float*)workspace;
+    // the second half first: its stream has just been released and its k_prep is the first thing the device can start beside the main stream's
+    int e = console_forward_impl(&h.db, tracks + ba * T * d->track_row_stride, track_params + ba * T * MST_NUM_TRACK_PARAMS,
+                                 fx_bus_params + ba * MST_NUM_FX_PARAMS, master_bus_params + ba * MST_NUM_MASTER_PARAMS, nullptr, mix + ba * 2 * n,
+                                 mixed_tracks ? mixed_tracks + ba * 2 * T * n : nullptr, status, ws + h.ws_b,
+                                 (size_t)(h.total - h.ws_b) * sizeof(float), side, nullptr, nullptr);
+    if (!e)
+        e = console_forward_impl(&h.da, tracks, track_params, fx_bus_params, master_bus_params, nullptr, mix, mixed_tracks, status, ws,
+                                 (size_t)h.ws_b * sizeof(float), main_s, nullptr, nullptr);
+    // always rejoin (also after an error: a captured graph must not end with the side stream forked)
+    (void)hipEventRecord((hipEvent_t)ov->join_event, side);
+    (void)hipStreamWaitEvent(main_s, (hipEvent_t)ov->join_event, 0);
+    return e ? e : (int)hipGetLastError();
 }
 extern "C" int mst_console_forward_mirrored(const mst_console_desc* d, const float* tracks, const float* track_params,
                                             const float* fx_bus_params, const float* master_bus_params, const mst_console_fx* fx,
                                             float* mix, float* mixed_tracks, int32_t* status, void* workspace, size_t workspace_bytes,
                                             void* stream, int32_t* status_host, void* status_event) {
     if (!status || !status_host) return hipErrorInvalidValue;
+    if (d && (d->flags & MST_SPLIT_BATCH)) return hipErrorInvalidValue;  // the mirrored verdict is formed by ONE k_prep: no split form
     return console_forward_impl(d, tracks, track_params, fx_bus_params, master_bus_params, fx, mix, mixed_tracks, status, workspace,
                                 workspace_bytes, stream, status_host, status_event);
 }
@@ -235,7 +293,7 @@ extern "C" int mst_console_backward_prepare(const mst_console_desc* d, void* wor
     if (int e = check_desc(d)) return e;
     const Layout L = make_layout(d);
     if (!workspace || workspace_bytes < (size_t)L.total * sizeof(float) || ((uintptr_t)workspace & 255)) return hipErrorInvalidValue;
-    if (!(d->flags & MST_SAVE_FOR_BACKWARD)) return hipErrorInvalidValue;
+    if (!(d->flags & MST_SAVE_FOR_BACKWARD) || (d->flags & MST_SPLIT_BATCH)) return hipErrorInvalidValue;
     float* ws = (float*)workspace;
     const int64_t Ns = row_stride(L.N);
     const int nsig_all = L.R + ((d->flags & MST_USE_MASTER_BUS) ? 2 * L.bs : 0);
@@ -244,11 +302,11 @@ extern "C" int mst_console_backward_prepare(const mst_console_desc* d, void* wor
     return (int)hipGetLastError();
 }
 
-extern "C" int mst_console_backward(const mst_console_desc* d, const float* tracks, const float* track_params,
-                                    const float* fx_bus_params, const float* master_bus_params, const mst_console_fx* fx,
-                                    const float* grad_mix, const float* grad_mixed_tracks, float* grad_track_params,
-                                    float* grad_fx_params, float* grad_master_params, float* grad_tracks, int32_t* status,
-                                    void* workspace, size_t workspace_bytes, void* stream_) {
+static int console_backward_impl(const mst_console_desc* d, const float* tracks, const float* track_params,
+                                 const float* fx_bus_params, const float* master_bus_params, const mst_console_fx* fx,
+                                 const float* grad_mix, const float* grad_mixed_tracks, float* grad_track_params,
+                                 float* grad_fx_params, float* grad_master_params, float* grad_tracks, int32_t* status,
+                                 void* workspace, size_t workspace_bytes, void* stream_) {
     if (int e = check_desc(d)) return e;
     const Layout L = make_layout(d);
     if (!workspace || workspace_bytes < (size_t)L.total * sizeof(float) || ((uintptr_t)workspace & 255)) return hipErrorInvalidValue;
@@ -377,4 +435,44 @@ extern "C" int mst_console_backward(const mst_console_desc* d, const float* trac
                    (gran_t*)(ws + L.gran_b), L.gran_nb};
     launch_prep_bwd(pb, stream);
     return (int)hipGetLastError();
+}
+
+extern "C" int mst_console_backward(const mst_console_desc* d, const float* tracks, const float* track_params,
+                                    const float* fx_bus_params, const float* master_bus_params, const mst_console_fx* fx,
+                                    const float* grad_mix, const float* grad_mixed_tracks, float* grad_track_params,
+                                    float* grad_fx_params, float* grad_master_params, float* grad_tracks, int32_t* status,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
+    if (d && (d->flags & MST_SPLIT_BATCH)) return hipErrorInvalidValue;  // mst_console_backward_overlapped
+    return console_backward_impl(d, tracks, track_params, fx_bus_params, master_bus_params, fx, grad_mix, grad_mixed_tracks, grad_track_params,
+                                 grad_fx_params, grad_master_params, grad_tracks, status, workspace, workspace_bytes, stream);
+}
+extern "C" int mst_console_backward_overlapped(const mst_console_desc* d, const float* tracks, const float* track_params,
+                                               const float* fx_bus_params, const float* master_bus_params, const mst_console_fx* fx,
+                                               const float* grad_mix, const float* grad_mixed_tracks, float* grad_track_params,
+                                               float* grad_fx_params, float* grad_master_params, float* grad_tracks, int32_t* status,
+                                               void* workspace, size_t workspace_bytes, void* stream, const mst_console_overlap* ov) {
+    if (int e = check_desc(d)) return e;
+    if (!split_on(d))
+        return console_backward_impl(d, tracks, track_params, fx_bus_params, master_bus_params, fx, grad_mix, grad_mixed_tracks, grad_track_params,
+                                     grad_fx_params, grad_master_params, grad_tracks, status, workspace, workspace_bytes, stream);
+    if (!overlap_ok(ov) || ov->side_stream == stream || (d->flags & MST_BWD_PREPARED)) return hipErrorInvalidValue;
+    const Halves h = make_halves(d);
+    if (!workspace || workspace_bytes < (size_t)h.total * sizeof(float) || ((uintptr_t)workspace & 255)) return hipErrorInvalidValue;
+    if (!track_params || !master_bus_params || !grad_mix || !grad_track_params || !grad_master_params) return hipErrorInvalidValue;
+    hipStream_t main_s = (hipStream_t)stream, side = (hipStream_t)ov->side_stream;
+    const int64_t ba = h.da.bs, T = d->n_tracks, n = d->n_samples;
+    if (int e = (int)hipEventRecord((hipEvent_t)ov->fork_event, main_s)) return e;
+    if (int e = (int)hipStreamWaitEvent(side, (hipEvent_t)ov->fork_event, 0)) return e;
+    float* ws = (float*)workspace;
+    int e = console_backward_impl(&h.db, tracks ? tracks + ba * T * d->track_row_stride : nullptr, track_params + ba * T * MST_NUM_TRACK_PARAMS,
+                                  fx_bus_params ? fx_bus_params + ba * MST_NUM_FX_PARAMS : nullptr, master_bus_params + ba * MST_NUM_MASTER_PARAMS, nullptr,
+                                  grad_mix + ba * 2 * n, grad_mixed_tracks ? grad_mixed_tracks + ba * 2 * T * n : nullptr,
+                                  grad_track_params + ba * T * MST_NUM_TRACK_PARAMS, nullptr, grad_master_params + ba * MST_NUM_MASTER_PARAMS,
+                                  grad_tracks ? grad_tracks + ba * T * n : nullptr, status, ws + h.ws_b, (size_t)(h.total - h.ws_b) * sizeof(float), side);
+    if (!e)
+        e = console_backward_impl(&h.da, tracks, track_params, fx_bus_params, master_bus_params, nullptr, grad_mix, grad_mixed_tracks, grad_track_params,
+                                  nullptr, grad_master_params, grad_tracks, status, ws, (size_t)h.ws_b * sizeof(float), main_s);
+    (void)hipEventRecord((hipEvent_t)ov->join_event, side);
+    (void)hipStreamWaitEvent(main_s, (hipEvent_t)ov->join_event, 0);
+    return e ? e : (int)hipGetLastError();
 }

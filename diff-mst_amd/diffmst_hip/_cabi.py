@@ -23,8 +23,9 @@ SAVE_FOR_BACKWARD = 0x100
 DEV_MULTIPASS_EQ = 0x200
 NO_RANGE_CHECK = 0x400
 BWD_PREPARED = 0x800
+SPLIT_BATCH = 0x1000
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class ConsoleDesc(C.Structure):
@@ -50,6 +51,10 @@ class ConsoleDesc(C.Structure):
 
 class ConsoleFx(C.Structure):  # mirrors mst_console_fx
     _fields_ = [("noise", C.c_void_p), ("filters", C.c_void_p), ("tables", C.c_void_p)]
+
+
+class ConsoleOverlap(C.Structure):  # mirrors mst_console_overlap: the side stream and the two events a split call borrows
+    _fields_ = [("side_stream", C.c_void_p), ("fork_event", C.c_void_p), ("join_event", C.c_void_p)]
 
 
 MAX_RESOLUTIONS = 8
@@ -125,6 +130,10 @@ SIGNATURES = {
     "mst_console_backward": (C.c_int, [C.POINTER(ConsoleDesc), _P, _P, _P, _P, C.POINTER(ConsoleFx), _P, _P, _P, _P, _P, _P, _P, _P,
                                        C.c_size_t, _P]),
     "mst_console_backward_prepare": (C.c_int, [C.POINTER(ConsoleDesc), _P, C.c_size_t, _P]),
+    "mst_console_forward_overlapped": (C.c_int, [C.POINTER(ConsoleDesc), _P, _P, _P, _P, C.POINTER(ConsoleFx), _P, _P, _P, _P, C.c_size_t, _P,
+                                                 C.POINTER(ConsoleOverlap)]),
+    "mst_console_backward_overlapped": (C.c_int, [C.POINTER(ConsoleDesc), _P, _P, _P, _P, C.POINTER(ConsoleFx), _P, _P, _P, _P, _P, _P, _P, _P,
+                                                  C.c_size_t, _P, C.POINTER(ConsoleOverlap)]),
     "mst_mrstft_tables_bytes": (C.c_size_t, [C.POINTER(MrstftDesc)]),
     "mst_mrstft_init_tables": (C.c_int, [C.POINTER(MrstftDesc), _P, _P]),
     "mst_mrstft_workspace_bytes": (C.c_size_t, [C.POINTER(MrstftDesc)]),

@@ -48,7 +48,7 @@ def range_vectors(param_ranges: dict, index):
     return lo, hi
 
 
-def flag_word(save_for_backward: bool = False, multipass_eq: bool = False, **flags) -> int:
+def flag_word(save_for_backward: bool = False, multipass_eq: bool = False, split_batch: bool = False, **flags) -> int:
     word = 0
     for name, bit in FLAG_BITS.items():
         if flags.get(name, True):
@@ -57,6 +57,8 @@ def flag_word(save_for_backward: bool = False, multipass_eq: bool = False, **fla
         word |= _cabi.SAVE_FOR_BACKWARD
     if multipass_eq:  # test switch (include/diffmst_hip.h MST_DEV_MULTIPASS_EQ): console._multipass_eq = True
         word |= _cabi.DEV_MULTIPASS_EQ
+    if split_batch:  # include/diffmst_hip.h MST_SPLIT_BATCH: two halves of the batch on two streams (mst_console_*_overlapped)
+        word |= _cabi.SPLIT_BATCH
     return word
 
 

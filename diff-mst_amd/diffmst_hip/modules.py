@@ -107,6 +107,26 @@ def _aux_stream(dev):
     return s
 
 
+_OVERLAP = {}
+
+
+def _overlap_handles(dev):
+    """(mst_console_overlap, keep-alive) of a device: the side stream and the two events a split call borrows (include/diffmst_hip.h,
+    MST_SPLIT_BATCH).  One set per device: calls are enqueued one after the other on the caller's stream and every call rejoins before it
+    returns, so two calls never hold the handles at once."""
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    h = _OVERLAP.get(key)
+    if h is None:
+        with torch.cuda.device(dev):
+            side = torch.cuda.Stream(device=dev)
+            fork, join = torch.cuda.Event(), torch.cuda.Event()
+            fork.record()  # creates the underlying hipEvent_t
+            join.record()
+        ov = _cabi.ConsoleOverlap(side.cuda_stream, fork.cuda_event, join.cuda_event)
+        h = _OVERLAP[key] = (ov, (side, fork, join))
+    return h[0]
+
+
 class _ConsoleFunction(torch.autograd.Function):
     """One fused forward / backward pair over the C ABI (mst_console_forward / _backward)."""
 
@@ -125,7 +145,9 @@ class _ConsoleFunction(torch.autograd.Function):
         tp = track_params.float().contiguous()
         fp = fx_bus_params.float().contiguous()
         mp = master_bus_params.float().contiguous()
-        word = _desc.flag_word(save_for_backward=need_grad, multipass_eq=console._multipass_eq, **flags)
+        # two halves of the batch on two streams (opt-in: measured slower at BASELINE cfg #2, see the class docstring)
+        split = bool(console.split_batch) and bs >= 2 and not flags["use_fx_bus"] and console.validate == "deferred" and not console.overlap_backward_prepare
+        word = _desc.flag_word(save_for_backward=need_grad, multipass_eq=console._multipass_eq, split_batch=split, **flags)
         if denormalized:  # forward_mix_console: values arrive denormalised and are NOT range-checked (reference :186-314)
             word |= _cabi.NO_RANGE_CHECK
         # the descriptor (78 range look-ups, ~15 us of host time) and its workspace size are rebuilt only when something they are made of
@@ -166,6 +188,12 @@ class _ConsoleFunction(torch.autograd.Function):
                     _cabi.ptr(mixed), _cabi.ptr(status), _cabi.ptr(ws), nbytes, _hip.current_stream_ptr(dev),
                     ctypes.c_void_p(mirror[0].data_ptr()), ctypes.c_void_p(mirror[1].cuda_event),
                 )
+            elif split:
+                rc = lib.mst_console_forward_overlapped(
+                    ctypes.byref(desc), _cabi.ptr(rows), _cabi.ptr(tp), _cabi.ptr(fp), _cabi.ptr(mp), None, _cabi.ptr(mix),
+                    _cabi.ptr(mixed), _cabi.ptr(status), _cabi.ptr(ws), nbytes, _hip.current_stream_ptr(dev),
+                    ctypes.byref(_overlap_handles(dev)),
+                )
             else:
                 rc = lib.mst_console_forward(
                     ctypes.byref(desc), _cabi.ptr(rows), _cabi.ptr(tp), _cabi.ptr(fp), _cabi.ptr(mp),
@@ -190,6 +218,7 @@ class _ConsoleFunction(torch.autograd.Function):
             ctx.status = status
             ctx.want_mixed = want_mixed
             ctx.fx_on = bool(flags["use_fx_bus"])
+            ctx.split = split
             # the backward needs the engine tables only: the filtered noise and the spectra are already in the workspace
             ctx.save_for_backward(rows, tp, mp, ws, fp, *fx_keep[2:])
         ctx.set_materialize_grads(False)  # an unused mixed_tracks output must not cost a zero (bs,2,T,N) cotangent
@@ -222,12 +251,19 @@ class _ConsoleFunction(torch.autograd.Function):
             desc = prepared
         # fx bus off: the fx parameters never reach the mix - their gradient is None, as in the reference (no zero fill)
         with torch.cuda.device(dev):
-            rc = lib.mst_console_backward(
-                ctypes.byref(desc), _cabi.ptr(rows), _cabi.ptr(tp), _cabi.ptr(fp), _cabi.ptr(mp),
-                ctypes.byref(fx) if fx is not None else None, _cabi.ptr(grad_mix), _cabi.ptr(grad_mixed), _cabi.ptr(g_tp),
-                _cabi.ptr(g_fx) if ctx.fx_on else None, _cabi.ptr(g_mp), _cabi.ptr(g_tracks), _cabi.ptr(ctx.status), _cabi.ptr(ws),
-                ctx.nbytes, _hip.current_stream_ptr(dev),
-            )
+            if ctx.split:
+                rc = lib.mst_console_backward_overlapped(
+                    ctypes.byref(desc), _cabi.ptr(rows), _cabi.ptr(tp), _cabi.ptr(fp), _cabi.ptr(mp), None, _cabi.ptr(grad_mix),
+                    _cabi.ptr(grad_mixed), _cabi.ptr(g_tp), None, _cabi.ptr(g_mp), _cabi.ptr(g_tracks), _cabi.ptr(ctx.status), _cabi.ptr(ws),
+                    ctx.nbytes, _hip.current_stream_ptr(dev), ctypes.byref(_overlap_handles(dev)),
+                )
+            else:
+                rc = lib.mst_console_backward(
+                    ctypes.byref(desc), _cabi.ptr(rows), _cabi.ptr(tp), _cabi.ptr(fp), _cabi.ptr(mp),
+                    ctypes.byref(fx) if fx is not None else None, _cabi.ptr(grad_mix), _cabi.ptr(grad_mixed), _cabi.ptr(g_tp),
+                    _cabi.ptr(g_fx) if ctx.fx_on else None, _cabi.ptr(g_mp), _cabi.ptr(g_tracks), _cabi.ptr(ctx.status), _cabi.ptr(ws),
+                    ctx.nbytes, _hip.current_stream_ptr(dev),
+                )
         _hip.check(rc, "mst_console_backward")
         # no readback here: a backward whose in-launch exchange gave up has raised the (sticky) status word - the next forward's check
         # (validate="sync") or check_parameters() raises; a host sync inside every backward would stall the autograd thread
@@ -254,6 +290,16 @@ class AdvancedMixConsole(torch.nn.Module):
       param_dicts                "eager" : the three returned parameter dictionaries are built during the
                                            call, like the reference (three small affine-map launches);
                                  "lazy"  : read-only mappings computed on first access.
+      split_batch                False   : (default) one call, one stream.
+                                 True    : the call runs as two halves of the batch on two streams
+                                           (``mst_console_forward_overlapped`` / ``_backward_overlapped``, include/diffmst_hip.h; needs
+                                           validate="deferred", no fx bus).  Mixes are independent: results are BIT-identical to the
+                                           unsplit call (tests/test_console_gpu.py).  Measured on MI355X at BASELINE cfg #2: 0.492 ms per
+                                           step against 0.455 ms unsplit (0.483 as a hipGraph: it is not the host).  The kernel trace
+                                           shows why: both halves start together and stay in lockstep - the fp64 design
+                                           chains beside each other, the two lone-wave master chains beside each other, the two
+                                           occupancy-full track kernels sharing the chip - and even a perfect stagger is bounded by
+                                           (first half's latency-bound stages) + (all execution-bound work), which is the unsplit time.
       overlap_backward_prepare   False   : everything on the caller's stream (default).
                                  True    : a forward that saves for backward queues the part of the backward that depends on
                                            nothing but the forward (``mst_console_backward_prepare``, 15 us) on a side stream, where
@@ -284,10 +330,12 @@ class AdvancedMixConsole(torch.nn.Module):
         validate: str = "sync",
         param_dicts: str = "eager",
         overlap_backward_prepare: bool = False,
+        split_batch: bool = False,
     ):
         super().__init__()
         self.sample_rate = sample_rate
         self.overlap_backward_prepare = bool(overlap_backward_prepare)
+        self.split_batch = split_batch
         top = (sample_rate // 2) - 1000
         eq_freq = {
             "low_shelf": (20, 2000), "band0": (80, 2000), "band1": (2000, 8000),

@@ -49,6 +49,10 @@ extern "C" {
                                        caller passes lo = 0, hi = 1 so that the map v*(hi-lo)+lo is the identity and the
                                        returned gradients are w.r.t. the denormalised values */
 #define MST_BWD_PREPARED 0x800u     /* mst_console_backward only: mst_console_backward_prepare has already run on this workspace */
+#define MST_SPLIT_BATCH 0x1000u     /* ABI v9, mst_console_forward_overlapped / _backward_overlapped: run the call as two halves of the
+                                       batch on two streams (see mst_console_overlap); must be set - or not - in BOTH calls over a
+                                       workspace, it selects the workspace layout.  Ignored (both calls alike) when bs < 2, with
+                                       MST_USE_FX_BUS and on the gain + pan fast path */
 #define MST_DEV_MULTIPASS_EQ 0x200u /* developer/test switch: keep the EQ carry scan in its own kernel (zero-state pass,
                                        carry scan, run) even when a row is short enough (<= 262144 samples) for the
                                        in-wave scans of the two-kernel path; longer rows always take three kernels */
@@ -138,6 +142,25 @@ int mst_console_forward_mirrored(const mst_console_desc* d, const float* tracks,
                                  float* mix, float* mixed_tracks, int32_t* status, void* workspace, size_t workspace_bytes,
                                  void* stream, int32_t* status_host, void* status_event);
 
+/* ABI v9: the same forward as two HALVES of the batch that overlap on the device (d->flags & MST_SPLIT_BATCH; without the flag this is
+ * mst_console_forward).  The mixes of a call are independent (reference mst/modules.py:186-314 has no cross-batch term), so mixes
+ * [0, bs / 2) run on `stream` and the rest on `ov->side_stream`, each over its own part of the workspace: the latency-bound stretches of
+ * one half (the fp64 design chains of the first launch, the 2 x bs / 2 master-bus rows at one wave per SIMD) run beside the other half's
+ * occupancy-full track kernels.  Same kernels and arithmetic per mix: the results are bit-identical to the unsplit call.
+ * The library stays stateless: the caller LENDS the side stream and two events (created once, reused by every call, never shared by two
+ * calls in flight); the call records `fork_event` on `stream`, makes the side stream wait for it, and before it returns makes `stream`
+ * wait for `join_event` recorded behind the side stream's last launch - to the caller everything is ordered on `stream` as before
+ * (memory handed to the call may be reused or freed in stream order on `stream`; the pattern is capturable into a hipGraph). */
+typedef struct mst_console_overlap {
+    void* side_stream; /* hipStream_t, not `stream` */
+    void* fork_event;  /* hipEvent_t */
+    void* join_event;  /* hipEvent_t */
+} mst_console_overlap;
+int mst_console_forward_overlapped(const mst_console_desc* d, const float* tracks, const float* track_params,
+                                   const float* fx_bus_params, const float* master_bus_params, const mst_console_fx* fx,
+                                   float* mix, float* mixed_tracks, int32_t* status, void* workspace, size_t workspace_bytes,
+                                   void* stream, const mst_console_overlap* ov);
+
 /* Reverse-mode of the above (what autograd does through the reference's op graph).
  * `workspace` must be the buffer a forward call with MST_SAVE_FOR_BACKWARD filled, untouched.
  *   grad_mix           (bs, 2, n_samples)
@@ -153,6 +176,12 @@ int mst_console_backward(const mst_console_desc* d, const float* tracks, const f
                          const float* grad_mix, const float* grad_mixed_tracks, float* grad_track_params,
                          float* grad_fx_params, float* grad_master_params, float* grad_tracks, int32_t* status,
                          void* workspace, size_t workspace_bytes, void* stream);
+/* ... over a workspace that mst_console_forward_overlapped filled with the same d->flags (MST_SPLIT_BATCH included) */
+int mst_console_backward_overlapped(const mst_console_desc* d, const float* tracks, const float* track_params,
+                                    const float* fx_bus_params, const float* master_bus_params, const mst_console_fx* fx,
+                                    const float* grad_mix, const float* grad_mixed_tracks, float* grad_track_params,
+                                    float* grad_fx_params, float* grad_master_params, float* grad_tracks, int32_t* status,
+                                    void* workspace, size_t workspace_bytes, void* stream, const mst_console_overlap* ov);
 /* status (ABI v7; may be null): the forward's status word, raised to MST_STATUS_EXCHANGE_TIMEOUT by a backward launch whose
  * in-launch exchange gave up - the gradients of that call are poisoned. */
 

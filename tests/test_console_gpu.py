@@ -499,3 +499,43 @@ def test_second_backward_over_the_same_forward(console, dev):
     mix2.backward(g2)
     assert torch.equal(second[0], a2.grad) and torch.equal(second[1], b2.grad)
     assert not torch.equal(first[0], second[0])
+
+
+@pytest.mark.parametrize("bs,T,n,materialize", [(3, 4, 65536, True), (2, 8, 262144, False), (5, 2, 20000, True)])
+def test_split_batch_is_bit_identical(bs, T, n, materialize, dev):
+    """Round 6: `split_batch` runs the call as two halves of the batch on two streams (mst_console_forward_overlapped /
+    _backward_overlapped, include/diffmst_hip.h).  The mixes of a call are independent (reference mst/modules.py:186-314), the halves run
+    the same kernels over their own part of the workspace: every output and every gradient must be BIT-equal to the unsplit call - odd
+    batch sizes (halves of different size), ragged lengths, with and without `mixed_tracks` and its cotangent, twice in a row (the side
+    stream and its events are reused by every call)."""
+    from mst.modules import AdvancedMixConsole
+
+    torch.manual_seed(bs * 1000 + T)
+    tracks = (0.1 * torch.randn(bs, T, n)).to(dev)
+    tp, fp, mp = torch.rand(bs, T, 27), torch.rand(bs, 25), torch.rand(bs, 26)
+    gmix, gmixed = torch.randn(bs, 2, n).to(dev), torch.randn(bs, 2, T, n).to(dev)
+
+    def run(split):
+        c = AdvancedMixConsole(44100, validate="deferred", materialize_mixed_tracks=materialize, split_batch=split)
+        outs = []
+        for _ in range(2):
+            tr = tracks.clone().requires_grad_(True)
+            a, b = tp.to(dev).requires_grad_(True), mp.to(dev).requires_grad_(True)
+            mixed, mix, *_ = c(tr, a, fp.to(dev), b, **FULL)
+            loss = (mix * gmix).sum()
+            if materialize:
+                loss = loss + (mixed * gmixed).sum()
+            loss.backward()
+            torch.cuda.synchronize()
+            c.check_parameters()
+            outs.append((mix.detach(), mixed.detach() if materialize else None, a.grad, b.grad, tr.grad))
+        return outs
+
+    plain, split = run(False), run(True)
+    for rep in range(2):
+        for name, p, q in zip(("mix", "mixed_tracks", "grad_track_params", "grad_master_params", "grad_tracks"), plain[0], split[rep]):
+            if p is None:
+                assert q is None
+                continue
+            assert torch.isfinite(q).all(), name
+            assert torch.equal(p, q), (rep, name, float((p - q).abs().max()))
