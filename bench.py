@@ -54,7 +54,7 @@ FLOPS_PER_MIX = 0.63e9 + 0.26e9
 def committed_profile():
     """Numbers that need the profiler (bench.py cannot run rocprofv3 on itself): HBM bytes per step from the PMC passes
     and VALU instructions per step from the SQ passes of this same command, committed under profiles/."""
-    for name in ("round5_traffic.json", "round4_traffic.json", "round3_traffic.json", "round2_traffic.json", "round1_traffic.json"):
+    for name in ("round6_traffic.json", "round5_traffic.json", "round4_traffic.json", "round3_traffic.json", "round2_traffic.json", "round1_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 d = json.load(f)

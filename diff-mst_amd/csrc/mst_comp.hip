@@ -41,8 +41,15 @@ __device__ unsigned long long g_cbr_stamps[kStampWGs * kStampSlots];
 
 // the value is materialised HERE: without it LLVM sinks a whole unrolled loop below the next spin-wait (into the block that uses its
 // results), which serialises the arithmetic behind the wait and keeps every operand of the loop alive across it
+#if defined(__clang__)
 __device__ __forceinline__ void pin(float& x) { asm volatile("" : "+v"(x)); }
 __device__ __forceinline__ void pin2(f2& x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void pin_int(int& x) { asm volatile("" : "+v"(x)); }
+#else  // host-side build of these sources (tests/hostsim): no code motion to guard against
+inline void pin(float&) {}
+inline void pin2(f2&) {}
+inline void pin_int(int&) {}
+#endif
 __device__ __forceinline__ void ld8(const float* row, int64_t i, int64_t n, float* v) {
     const float4 a = load4(row, i, n), b = load4(row, i + 4, n);
     v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
@@ -1225,7 +1232,7 @@ __device__ __forceinline__ void comp_bwd_mix_body(const CompBwdArgs& a, const in
             // (the slot offset is laundered once per track: the parked values are loop-invariant, and hoisted out of the loop they are
             // the 32 registers the parking was for)
             int po = 0;
-            asm volatile("" : "+v"(po));
+            pin_int(po);
             float gl[CC], gr[CC];
             fetch8(pkL + po, gl);
             fetch8(pkR + po, gr);
@@ -1308,7 +1315,7 @@ __device__ __forceinline__ void comp_bwd_mix_body(const CompBwdArgs& a, const in
         float fwd[CC];
         {
             int po = 0;
-            asm volatile("" : "+v"(po));
+            pin_int(po);
             float fl[CC], fr[CC];
             fetch8(pkLF + po, fl);
             fetch8(pkRF + po, fr);
@@ -1438,7 +1445,7 @@ __global__ __launch_bounds__(kWG, MST_CBM_W) void k_comp_bwd_mix(CompBwdArgs a) 
     row_block_xcd(rid, step, 1, (int)gridDim.y, 0);
     const int b = rid % bs, h = rid / bs;  // part h of mix b: with bs % 8 == 0 both parts of a mix sit on XCD b % 8
     const int blk = gridDim.x - 1 - step;
-    const int per = (a.T + nsplit - 1) / nsplit, t_lo = h * per, t_hi = min(a.T, t_lo + per);
+    const int per = (a.T + nsplit - 1) / nsplit, t_lo = h * per, t_hi = t_lo + per < a.T ? t_lo + per : a.T;
     int ride_lo = 0, ride_hi = 0;
     if (a.cg2_rows) {
         ride_lo = nsplit == 2 ? h : 0;
