@@ -45,7 +45,7 @@ __device__ unsigned long long g_cbr_stamps[kStampWGs * kStampSlots];
 __device__ __forceinline__ void pin(float& x) { asm volatile("" : "+v"(x)); }
 __device__ __forceinline__ void pin2(f2& x) { asm volatile("" : "+v"(x)); }
 __device__ __forceinline__ void pin_int(int& x) { asm volatile("" : "+v"(x)); }
-#else  // host-side build of these sources (tests/hostsim): no code motion to guard against
+#else  // host-only g++ build of these sources (the repository's CPU test harness): no code motion to guard against
 inline void pin(float&) {}
 inline void pin2(f2&) {}
 inline void pin_int(int&) {}
