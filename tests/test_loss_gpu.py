@@ -145,7 +145,8 @@ def _ill_posed_atoms(x64_row, res, tau_rel):
         X = torch.stft(x64_row[None], n_fft, hop, win, w, return_complex=True)[0]  # (bins, frames)
         p2 = X.real**2 + X.imag**2
         tau2 = tau_rel**2 * p2.mean()
-        bad = (p2 < tau2) | ((p2 > 0.25e-8) & (p2 < 4e-8))
+        # (bins far BELOW the 1e-8 clamp - silence - have exactly zero cotangent in every implementation: nothing to project out)
+        bad = ((p2 < tau2) & (p2 > 0.25e-8)) | ((p2 > 0.25e-8) & (p2 < 4e-8))
         ks, ts = torch.nonzero(bad, as_tuple=True)
         if ks.numel() == 0:
             continue
@@ -165,12 +166,16 @@ def _ill_posed_atoms(x64_row, res, tau_rel):
 
 
 def _project_out(d_row, B):
-    """d_row (n,) minus its least-squares projection onto the columns of B (n, m)."""
+    """d_row (n,) minus its least-squares projection onto the columns of B (n, m).  The atoms are far from independent (DC / Nyquist bins
+    have no imaginary part, frame 0's spectrum is real, neighbouring bins of one frame overlap): the projector is formed from the
+    eigen-decomposition of the Gram matrix with the directions below 1e-12 of the largest eigenvalue dropped - LAPACK's least-squares
+    drivers either cut the rank at ~60 of ~1300 columns (gelsy, default tolerance) or fail to converge on some draws (gelsd)."""
     if not B.shape[1]:
         return d_row
-    # the atoms are not independent (DC / Nyquist bins have no imaginary part, frame 0's spectrum is real): SVD-based solver; the
-    # default (gelsy) cuts the rank at ~60 of ~1300 columns and projects almost nothing out
-    return d_row - B @ torch.linalg.lstsq(B, d_row[:, None], rcond=1e-10, driver="gelsd").solution[:, 0]
+    lam, V = torch.linalg.eigh(B.T @ B)
+    keep = lam > 1e-12 * lam[-1]
+    c = (V[:, keep].T @ (B.T @ d_row)) / lam[keep]
+    return d_row - B @ (V[:, keep] @ c)
 
 
 @pytest.mark.parametrize("case,bs,n,seed", [("tracking", 2, 32768, 31), ("tracking", 1, 65536, 33), ("independent", 2, 32768, 34),
