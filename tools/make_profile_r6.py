@@ -1,6 +1,6 @@
 """Turn the round-6 evidence run (gpurun_out/r6_*: tools/pmc_passes.sh r5 + pytest + bench) into the committed artefacts:
 
-  profiles/round6_bench_kernel_stats.csv   rocprofv3 --kernel-trace --stats of `bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-secondary`
+  profiles/round6_bench_kernel_stats.csv   rocprofv3 --kernel-trace --stats of `bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-secondary --no-graph`
   profiles/round6_agent_info.csv
   profiles/round6_counters.md / .json      per-kernel table: duration, grid, VGPR, LDS, waves/SIMD, VALU issue %, wait %, stall %,
                                            LDS bank-conflict %, FETCH / WRITE (tools/pmc_table.py)
@@ -43,7 +43,7 @@ def main(steps):
     v, _ = counter_sum(os.path.join(G, "r6_sq1", "r_results.db"), "SQ_INSTS_VALU")
     out = {
         "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, separately, WRITE_SIZE / the SQ sets of tools/pmc_passes.sh) -- "
-                   "python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-secondary",
+                   "python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-secondary --no-graph",
         "steps_counted": steps,
         "fetch_kb_per_step": f / steps, "write_kb_per_step": w / steps,
         "hbm_bytes_per_step_raw": (f + w) * 1024.0 / steps,
@@ -94,9 +94,9 @@ def summary():
     R2 = round2_us()
     r = b["roofline"]
     out = ["# Round 6 profile - `python bench.py` on one MI355X (final build of the round)", "",
-           "Made by `tools/round_end.sh` on the GPU box (full `-m gpu` suite, `smoke()`, `tools/pmc_passes.sh r5`, `bench.py`) and "
+           "Made by `tools/round_end_r6.sh main` on the GPU box (`smoke()`, `tools/pmc_passes.sh r6`, `bench.py`; the `-m gpu` suite ran separately: 132 passed) and "
            "`tools/make_profile_r6.py` here.  Raw: `round6_bench_kernel_stats.csv` (rocprofv3 --kernel-trace --stats of "
-           "`bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-secondary`), `round6_counters.md/json` (separate --pmc passes), "
+           "`bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-secondary --no-graph`), `round6_counters.md/json` (separate --pmc passes), "
            "`round6_traffic.json`, `round6_bench.json` (the un-profiled bench line), `parity_r06.json` (measured parity numbers).", "",
            f"**Bench line: {b['value']:.0f} mixes/s, {b['ms_per_step']:.4f} ms per step** (median of per-step HIP events "
            f"{r['gpu_ms_per_step_median']:.4f} ms), {r['achieved']:.0f} GB/s algorithmic = {100 * r['frac']:.2f} % of 8 TB/s; L2 <-> fabric "

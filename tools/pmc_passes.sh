@@ -3,7 +3,7 @@
 #   tools/pmc_passes.sh <tag> [bench args...]          (PMC_SCRIPT=tools/loss_bench.py: another script of the repo)
 # writes gpurun_out/<tag>_{stats,sq1,sq2,fetch,write}/ and gpurun_out/<tag>_counters.txt (rocprofv3 -L excerpt)
 tag="$1"; shift
-args="${@:---steps 10 --warmup 2 --no-cpu-baseline --no-secondary}"
+args="${@:---steps 10 --warmup 2 --no-cpu-baseline --no-secondary --no-graph}"
 R="${GRAFT_REPO_ROOT:-/root/repo}"
 O="$R/gpurun_out"
 mkdir -p "$O"
