@@ -1055,6 +1055,7 @@ __global__ __launch_bounds__(kWG, (!MASTER && !FXS) ? MST_COMP_BWD_WT : MST_COMP
 #ifndef MST_CBM
 #define MST_CBM 0  // A/B switch: 1 = the mix-wise kernel where it applies, 0 = k_comp_bwd_run<tracks> for every configuration
 #endif
+#if MST_CBM  // the whole kernel is compiled only into -DMST_CBM=1 builds (make BUILD=build_cbm OUT=../lib/cbm.so EXTRA=-DMST_CBM=1)
 #ifndef MST_CBM_W
 #define MST_CBM_W 3  // waves per SIMD asked of the mix-wise kernel (3: register cap 168)
 #endif
@@ -1460,6 +1461,8 @@ __global__ __launch_bounds__(kWG, MST_CBM_W) void k_comp_bwd_mix(CompBwdArgs a) 
 #endif
 }
 
+#endif  // MST_CBM
+
 // ---- launch helpers ---------------------------------------------------------------------------------
 void launch_comp_zs(int nch, const float* u, int64_t stride, const float* rc, float* zs, int nc_pad, int64_t n, int rows,
                     hipStream_t stream) {
@@ -1480,12 +1483,14 @@ void launch_comp_bwd(bool master, bool run, const CompBwdArgs& a, int rows, hipS
     else if (master && run) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_comp_bwd_run<true>), grid, block, 0, stream, a);
     else if (!master && !run) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_comp_bwd_zs<false>), grid, block, 0, stream, a);
     else if (a.gfx) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_comp_bwd_run<false, true>), grid, block, 0, stream, a);
+#if MST_CBM
     else if (MST_CBM && kWG == 256 && a.comp_on && a.gran && a.ep && !a.du && !a.gmixed && a.T > 0 && rows % a.T == 0 && a.lookahead == kWG * CC &&
              (a.cg2_rows == 0 || a.cg2_rows == 2 * (rows / a.T))) {
         CompBwdArgs m = a;  // one workgroup per (mix, block, half of the tracks)
         m.mw_split = (a.T >= 4 && a.T % 2 == 0) ? 2 : 1;
         hipLaunchKernelGGL(k_comp_bwd_mix, dim3(a.nc_pad / kWG, (rows / a.T) * m.mw_split), block, 0, stream, m);
     }
+#endif
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_comp_bwd_run<false>), grid, block, 0, stream, a);
 }
 
