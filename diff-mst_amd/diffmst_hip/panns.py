@@ -17,7 +17,6 @@ the fp32 path's parity bounds at 0.84x its time; bf16x3 (~2^-17 per product) run
 from __future__ import annotations
 
 import ctypes
-import weakref
 
 import torch
 import torch.nn as nn
@@ -98,34 +97,31 @@ def sync_group_of(module: "Cnn14"):
     return (group, world) if world > 1 else (None, 1)
 
 
-_SYNC_PENDING = weakref.WeakKeyDictionary()  # Cnn14 module -> [(all-reduced [max n, max -n], this rank's n, event)]
+_COUNT_STREAMS = {}
 
 
-def _sync_count_check(module, group, n: int, dev, flush: bool = False):
-    """The cross-rank statistics count ``world x n`` signals (torch's SyncBatchNorm exchanges the counts; these kernels assume them
-    equal).  EVERY training call of EVERY rank enqueues the same tiny collective - an all-reduce (MAX) of ``[n, -n]`` - so that no
-    collective is ever gated on rank-local state (a per-``n`` cache would let a rank that has seen its ``n`` skip the exchange its
-    peer is waiting in: advisor, round 5).  The verdict is read without stalling the host: finished exchanges are examined at the next
-    call (``Event.query``), at most eight stay pending, and ``Cnn14.check_sync_counts()`` / ``flush=True`` examines all of them.  A
-    mismatch (drop_last=False, a variable track count) therefore raises one call late at worst - instead of silently wrong statistics."""
+def _sync_count_check(group, n: int, dev):
+    """The cross-rank statistics count ``world x n`` signals and the per-layer exchanges are sized by ``n`` (torch's SyncBatchNorm
+    exchanges the counts; these kernels assume them equal): ranks that feed different ``n`` - a short last batch with drop_last=False, a
+    variable track count - must not reach the statistics exchange at all (gloo aborts on the size mismatch, RCCL hangs or corrupts).
+    EVERY training call of EVERY rank therefore runs the same tiny collective first - an all-reduce (MAX) of ``[n, -n]`` - and reads its
+    verdict before anything else is enqueued.  No collective is gated on rank-local state (a per-``n`` cache let a rank that had seen its
+    ``n`` skip the exchange its peer was waiting in: advisor, round 5), and the verdict is a function of the reduced values only
+    (max n != min n): every rank raises, at the same call, in front of the same collective.  The exchange runs on a stream of its own,
+    so the host waits for one collective's latency, not for the compute stream's backlog."""
     import torch.distributed as dist
 
-    pending = _SYNC_PENDING.setdefault(module, [])  # not module state: events do not pickle / deepcopy
-    if n is not None:
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    side = _COUNT_STREAMS.get(key)
+    if side is None:
+        side = _COUNT_STREAMS[key] = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(side):
         t = torch.tensor([n, -n], dtype=torch.int64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
-        ev = torch.cuda.Event()
-        ev.record()
-        pending.append((t, n, ev))
-    while pending and (flush or len(pending) > 8 or pending[0][2].query()):
-        t, mine, ev = pending.pop(0)
-        ev.synchronize()
         hi, neg_lo = (int(v) for v in t.tolist())
-        if hi != mine or -neg_lo != mine:
-            pending.clear()
-            raise RuntimeError(f"Cnn14 with SyncBatchNorm: every rank must feed the same number of signals per call (this rank {mine}, "
-                               f"ranks between {-neg_lo} and {hi}); pad the batch or use drop_last=True")
-
+    if hi != -neg_lo:
+        raise RuntimeError(f"Cnn14 with SyncBatchNorm: every rank must feed the same number of signals per call (this rank {n}, "
+                           f"ranks between {-neg_lo} and {hi}); pad the batch or use drop_last=True")
 
 class _StatSync:
     """The ``mst_sync_fn`` of one kernel call: all-reduces (SUM) a span of the call's workspace over the process group."""
@@ -162,7 +158,7 @@ class _Cnn14Function(torch.autograd.Function):
         n, frames, bins = spec.shape
         group, world = sync_group_of(module) if training else (None, 1)
         if world > 1:
-            _sync_count_check(module, group, n, dev)
+            _sync_count_check(group, n, dev)
         desc = _cabi.Cnn14Desc(n, frames, bins, module.fc.out_features, PRECISIONS[module.precision], int(training),
                                float(module.conv_block1.bn1.eps), world)
         nbytes = lib.mst_cnn14_workspace_bytes(ctypes.byref(desc))
@@ -250,12 +246,6 @@ class Cnn14(nn.Module):
 
     def _bns(self):
         return [bn for b in self._blocks() for bn in (b.bn1, b.bn2)]
-
-    def check_sync_counts(self):
-        """SyncBatchNorm only: examine every pending signal-count exchange now (they are otherwise examined, one call late, as they
-        finish - `_sync_count_check`).  Call before an optimizer step or at loop end; a no-op without a process group."""
-        if _SYNC_PENDING.get(self):
-            _sync_count_check(self, None, None, None, flush=True)
 
     def _parameters_in_abi_order(self):
         blocks = self._blocks()
