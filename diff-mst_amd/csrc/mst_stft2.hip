@@ -368,22 +368,50 @@ __device__ __forceinline__ void stft2_bwd_body(const StftArgs& a, const int lane
     };
     auto put = [&](int block, const float* v, bool rmw) {  // write one complete block
         float* g = gx + block * H;
+        // 8192-point kernel (round 6): every load of the block before its first store.  Written as  *p = *p + v  per element the compiler
+        // cannot prove the addresses distinct and emits load - wait - store four times, each wait (vmcnt(0): loads and stores share the
+        // counter on gfx9) also draining the previous store - four dependent round trips per block instead of one (27.3 -> 25.9 us).
+        // Same sums, same order.
         if constexpr (PAIR) {
+            // (uncapped, the K temporaries of the batched form take the fused 512 / 2048-point kernel from 128 to 144 registers = three waves
+            // per SIMD instead of four, 43.7 -> 51.4 us: it is built with a 128-register cap - MST_STFT2_W512_2048_BWD - and fits without spills)
+#ifndef MST_STFT2_PUT_BATCH
+#define MST_STFT2_PUT_BATCH 1  // A/B: 0 = the element-wise form (43.5 against 43.0 us for the fused 512 / 2048-point launch)
+#endif
             if (parked(block * H)) {  // workgroup-uniform
                 const float* sc = a.seam + (int64_t)row * a.n + block * H;
+                if (MST_STFT2_PUT_BATCH) {
+                    float o[K], p[K];
+#pragma unroll
+                    for (int q = 0; q < K; ++q) {
+                        o[q] = rmw ? g[pos(q)] : 0.0f;
+                        p[q] = sc[pos(q)];
+                    }
+#pragma unroll
+                    for (int q = 0; q < K; ++q) g[pos(q)] = o[q] + p[q] + v[q];
+                    return;
+                }
 #pragma unroll
                 for (int q = 0; q < K; ++q) g[pos(q)] = (rmw ? g[pos(q)] : 0.0f) + sc[pos(q)] + v[q];
+                return;
+            }
+            if (MST_STFT2_PUT_BATCH && rmw) {
+                float o[K];
+#pragma unroll
+                for (int q = 0; q < K; ++q) o[q] = g[pos(q)];
+#pragma unroll
+                for (int q = 0; q < K; ++q) g[pos(q)] = o[q] + v[q];
                 return;
             }
 #pragma unroll
             for (int q = 0; q < K; ++q) g[pos(q)] = rmw ? g[pos(q)] + v[q] : v[q];
         } else {
+            float2 o[4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                float2* p = reinterpret_cast<float2*>(g + 2 * lane + 1024 * t);
-                const float2 o = rmw ? *p : make_float2(0.f, 0.f);
-                *p = make_float2(o.x + v[2 * t], o.y + v[2 * t + 1]);
-            }
+            for (int t = 0; t < 4; ++t) o[t] = rmw ? *reinterpret_cast<const float2*>(g + 2 * lane + 1024 * t) : make_float2(0.f, 0.f);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                *reinterpret_cast<float2*>(g + 2 * lane + 1024 * t) = make_float2(o[t].x + v[2 * t], o[t].y + v[2 * t + 1]);
         }
     };
     // SEAM mode: one of the two contributions to a block shared with a neighbour strip.  `opening` = the first half of this
@@ -1081,7 +1109,10 @@ __global__ __launch_bounds__(FftPlan<N>::LG, (N == 8192 ? MST_STFT2_W8192_BWD : 
 // launch, and the re-read comes out of this CU's own cache levels.  LDS and registers are the 2048-point kernel's (4 x 9 KB = 36 KB,
 // <= 128): four workgroups per CU as before.  Strips are balanced (lengths may differ by one block); other strip lengths measured with
 // the kept spectra (us): L = 3: 51.9, 4: 44.4, 5: 47.9, 6: 51.0 - a strip is a dependent chain, fewer inverses per row do not pay for a longer one.
-__global__ __launch_bounds__(256, MST_STFT2_W2048_BWD) void k_stft2_bwd_512_2048(StftArgs a512, StftArgs a2048) {
+#ifndef MST_STFT2_W512_2048_BWD
+#define MST_STFT2_W512_2048_BWD 4  // waves per SIMD asked of the fused launch (128 registers, no spills)
+#endif
+__global__ __launch_bounds__(256, MST_STFT2_W512_2048_BWD) void k_stft2_bwd_512_2048(StftArgs a512, StftArgs a2048) {
     using S5 = FftShape<512>;
     using S2 = FftShape<2048>;
     __shared__ __attribute__((aligned(16))) float2 lds[2 * S2::SLOTS];
