@@ -974,7 +974,11 @@ template <bool MASTER, bool FXS = false>
 #ifndef MST_COMP_BWD_WT
 #define MST_COMP_BWD_WT 4
 #endif
-__global__ __launch_bounds__(kWG, (!MASTER && !FXS) ? MST_COMP_BWD_WT : MST_COMP_BWD_W) void k_comp_bwd_run(CompBwdArgs a) {  // tracks without fx: 130 registers uncapped, two short of four waves per SIMD
+#ifndef MST_COMP_BWD_WM
+#define MST_COMP_BWD_WM 4  // master rows (round 6): 137 registers uncapped = three waves per SIMD = 1.33 rounds of its 1024 workgroups at cfg #2;
+                           // capped at 128 (8 spilled, also in the path with the coefficient-gradient walks that cfg #2 does not take) one round: 18.5 -> 17.9 us
+#endif
+__global__ __launch_bounds__(kWG, (!MASTER && !FXS) ? MST_COMP_BWD_WT : (MASTER ? MST_COMP_BWD_WM : MST_COMP_BWD_W)) void k_comp_bwd_run(CompBwdArgs a) {  // tracks without fx: 130 registers uncapped, two short of four waves per SIMD
     __shared__ __attribute__((aligned(16))) float cg_u[kCgTile], cg_g[kCgTile];  // one copy for both bodies
     // a.gran: the blocks a workgroup waits for (LATER in time: the adjoint smoother runs backwards) must have been dispatched before
     // it, so the grid walks the row from its end
