@@ -151,7 +151,12 @@ static int console_forward_impl(const mst_console_desc* d, const float* tracks, 
                 ws + L.powF_t, ws + L.powF_m, ws + L.powA_t, ws + L.powA_m, ws + L.powP_t, ws + L.powP_m,
                 ws + L.pow1F_t, ws + L.pow1F_m, ws + L.pow1A_t, ws + L.pow1A_m, ws + L.wzF_t, ws + L.wzF_m, ws + L.wzA_t, ws + L.wzA_m, fx_on ? ws + L.fx_rc : nullptr, fx_on ? ws + L.fx_mix : nullptr, status, L.R, L.bs, L.KE,
                 L.eq1, *d, (gran_t*)(ws + L.gran_f), L.gran_nf + L.gran_nb, nullptr, 0, 0};
-    if (n % 4 == 0 && d->track_row_stride % 4 == 0 && !((uintptr_t)tracks & 15)) {
+#ifndef MST_PREP_RIDER_MAX_BYTES
+#define MST_PREP_RIDER_MAX_BYTES (128ll << 20)  // the riders pull the track rows through the 256 MB Infinity Cache for the launch that follows:
+                                                // only while the rows fit it (cfg #2: 67 MB).  At cfg #3 (537 MB) they were 120 us of k_prep
+                                                // for rows that were gone again before the EQ pass read them
+#endif
+    if (n % 4 == 0 && d->track_row_stride % 4 == 0 && !((uintptr_t)tracks & 15) && (int64_t)L.R * n * 4 <= MST_PREP_RIDER_MAX_BYTES) {
         pa.pf_src = tracks;
         pa.pf_stride = d->track_row_stride;
         pa.pf_n = n;
