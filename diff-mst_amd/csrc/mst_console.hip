@@ -188,7 +188,10 @@ static int console_forward_impl(const mst_console_desc* d, const float* tracks, 
     const ZsIn zi_m{ws + L.wzF_m, (gran_t*)(ws + L.eqg_f) + (int64_t)L.R * kMaxTiles1 * kStates, L.eqg_nf, status};
     // tracks: only while (almost) every tile of the launch is resident at once - with many rounds of workgroups (cfg #3: 32768 tiles, 8
     // rounds) the stand-alone zero-state launch streams the rows at the HBM rate and the merged form measured 0.6 % slower
-    const bool zsin_t = zsin && t_comp && (int64_t)L.R * L.ntE <= 8192;
+#ifndef MST_ZSIN_MAX_TILES
+#define MST_ZSIN_MAX_TILES 8192
+#endif
+    const bool zsin_t = zsin && t_comp && (int64_t)L.R * L.ntE <= MST_ZSIN_MAX_TILES;
     if (zsin_t) {}
     else if (L.eq1 && mfma_zs()) launch_eq_zs_mfma(EQ_FWD, tracks, d->track_row_stride, ws + L.wzF_t, L.R, ws + L.zE_t, L.ncE_pad, n, L.R, stream, p1F_t, L.ntE, ws + L.aggF_t);
     else launch_cascade(EQ_FWD, false, tracks, d->track_row_stride, nullptr, 0, ws + L.rc_t, L.R, nullptr, ws + L.zE_t, L.ncE_pad, n, L.R, stream, p1F_t, L.ntE, ws + L.aggF_t);
